@@ -1,0 +1,156 @@
+"""
+TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by running the REFERENCE's own code
+(/root/reference, imported read-only through oracle/ref_fixture.py) on seeded synthetic weights
+and PCM (libreasr_amd/synth.py).  Run in the authoring container:
+
+    python -m oracle.make_golden
+
+The fixtures travel to the GPU box; /root/reference does not.  Everything stored is an OUTPUT of
+the reference (features, encoder/predictor activations, joint logits, token ids); inputs are
+regenerated from seeds on both sides.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_fixture as rf          # noqa: E402
+from libreasr_amd import synth                # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def t(x):
+    return torch.as_tensor(np.asarray(x))
+
+
+def golden_frontend():
+    x_tfm, s_tfm, AT = rf.ref_transforms()
+    pcm = synth.synth_pcm(2, 16000 + 937, seed=7)            # ragged length on purpose
+    out = {}
+    import libreasr.lib.transforms as T
+    tt = [f for f in x_tfm.fs if isinstance(f, T.TransformTime)][0]
+    for s in range(2):
+        spec = tt(AT(t(pcm[s][None]), 16000))[0].numpy()     # [T,128]
+        out[f"logmel_{s}"] = spec.astype(np.float32)
+        feats = x_tfm(AT(t(pcm[s][None]), 16000))[0, :, :, 0].numpy()
+        out[f"feats_{s}"] = feats.astype(np.float32)
+    # silence -> log(1e-6)
+    out["logmel_zero"] = tt(AT(torch.zeros(1, 3840), 16000))[0].numpy().astype(np.float32)
+    # streaming front-end: api-server.py:83-115 window + x_tfm_stream, 80 ms chunks
+    chunks = synth.stream_chunks(pcm[0], 1280, lead=1, tail=2)
+    frames, outs, pattern = [], [], []
+    for c in chunks:
+        frames.append(t(c[None]))
+        if len(frames) != 3:
+            continue
+        aud = torch.cat(frames, dim=1)
+        del frames[0]
+        o = s_tfm(AT(aud, 16000))
+        pattern.append(0 if o is None else 1)
+        if o is not None:
+            outs.append(o[:, :, 0].numpy())
+    out["stream_pattern"] = np.array(pattern, dtype=np.int32)
+    out["stream_feats"] = np.stack(outs).astype(np.float32)   # [n_calls, 2, 1280]
+    np.savez_compressed(os.path.join(OUT, "frontend.npz"), **out)
+    print("frontend:", {k: v.shape for k, v in out.items()})
+
+
+def golden_model(name, n_sec, n_streams, store_acts):
+    cfg = synth.model_cfg(name)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    m = rf.ref_transducer(cfg, sd)
+    x_tfm, s_tfm, AT = rf.ref_transforms()
+    pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
+    out = {}
+    with torch.no_grad():
+        for s in range(n_streams):
+            feats = x_tfm(AT(t(pcm[s][None]), 16000))[0]                 # [T',1280,1]
+            # offline greedy (models.py:369-455)
+            txt, neg_logp, metrics, extra = m.decode_greedy(feats)
+            toks = [int(v) for v in txt.split()] if txt else []
+            out[f"off_tokens_{s}"] = np.array(toks, dtype=np.int32)
+            out[f"off_neglogp_{s}"] = np.float64(neg_logp)
+            out[f"off_align_{s}"] = np.float64(metrics["alignment_score"])
+            out[f"off_iters_{s}"] = np.array(extra["iters"], dtype=np.int32)
+            lp = torch.stack([o.reshape(-1) for o in extra["outs"]]).numpy()   # log-softmax rows
+            out[f"off_logp_first_{s}"] = lp[:6].astype(np.float32)
+            if store_acts and s == 0:
+                enc, st = m.encoder(feats[None], return_state=True)
+                out["enc_out_0"] = enc[0].numpy().astype(np.float32)
+                out["enc_h_0"] = np.stack([a[0][0, 0].numpy() for a in st]).astype(np.float32)
+                out["enc_c_0"] = np.stack([a[1][0, 0].numpy() for a in st]).astype(np.float32)
+                hp, ps = m.predictor(torch.LongTensor([[m.bos]]))
+                hp2, ps2 = m.predictor(torch.LongTensor([[5]]), state=ps)
+                out["pred_bos"] = hp[0, 0].numpy().astype(np.float32)
+                out["pred_bos_5"] = hp2[0, 0].numpy().astype(np.float32)
+                j = m.joint(hp2[None], enc[0, 3][None, None, None])
+                out["joint_logits"] = j.reshape(-1).numpy().astype(np.float32)
+            # streaming (api-server.py:83-135 + models.py:457-577), 80 ms chunks, api-client.py:32-47
+            s_tfm.fs[-1].saved.clear()
+            chunks = synth.stream_chunks(pcm[s], 1280, lead=1, tail=10)
+
+            def gen():
+                frames = []
+                for c in chunks:
+                    frames.append(t(c[None]))
+                    if len(frames) != 3:
+                        continue
+                    aud = torch.cat(frames, dim=1)
+                    del frames[0]
+                    yield s_tfm(AT(aud, 16000))
+
+            per_chunk, y_all = [], []
+            for y, y_one, reset_fn in m.transcribe_stream(gen(), m.lang.denumericalize):
+                per_chunk.append(len(y) - len(y_all))
+                y_all = list(y)
+            out[f"st_tokens_{s}"] = np.array(y_all, dtype=np.int32)
+            out[f"st_counts_{s}"] = np.array(per_chunk, dtype=np.int32)
+            nb = sum(1 for v in extra["iters"] for _ in range(1))
+            print(f"  {name} s{s}: T'={feats.shape[0]} offline tokens={len(toks)} "
+                  f"evals={int(np.sum(extra['iters']))} stream tokens={len(y_all)} calls={len(per_chunk)}")
+    np.savez_compressed(os.path.join(OUT, f"model_{name}.npz"), **out)
+
+
+def golden_flac():
+    """Known-answer artefact in the tree: demo FLAC STREAMINFO MD5 of the decoded PCM."""
+    p = os.path.join(rf.REF_ROOT, "demo", "3729-6852-0035.flac")
+    if not os.path.exists(p):
+        return
+    from libreasr_amd import flac
+    pcm, sr, md5_ok = flac.decode(p)
+    feats = None
+    x_tfm, _, AT = rf.ref_transforms()
+    feats = x_tfm(AT(t(pcm[None]), sr))[0, :, :, 0].numpy()
+    np.savez_compressed(os.path.join(OUT, "demo_flac.npz"), n_samples=np.int64(len(pcm)), sr=np.int32(sr),
+                        md5_ok=np.bool_(md5_ok), feats_first=feats[:4].astype(np.float32),
+                        feats_last=feats[-2:].astype(np.float32), n_frames=np.int32(feats.shape[0]),
+                        pcm_head=pcm[:4096].astype(np.float32), pcm_sum=np.float64(pcm.astype(np.float64).sum()))
+    print("flac:", len(pcm), sr, md5_ok, feats.shape)
+
+
+if __name__ == "__main__":
+    assert rf.available(), "/root/reference is required to generate goldens"
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["frontend", "tiny", "tiny_lstm", "cfg2", "cfg2_lstm", "flac"]
+    if "frontend" in which:
+        golden_frontend()
+    if "tiny" in which:
+        golden_model("tiny", 3.0, 3, True)
+    if "tiny_lstm" in which:
+        golden_model("tiny_lstm", 3.0, 2, True)
+    if "cfg2" in which:
+        golden_model("cfg2", 4.0, 2, True)
+    if "cfg2_lstm" in which:
+        golden_model("cfg2_lstm", 2.0, 1, True)
+    if "flac" in which:
+        try:
+            golden_flac()
+        except ImportError as e:
+            print("flac golden skipped:", e)

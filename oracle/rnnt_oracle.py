@@ -1,0 +1,311 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  A CPU (numpy, float32) restatement of the reference's
+streaming RNN-T inference path.  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import this; the product (libreasr_amd/) never does.
+
+Parity status: PINNED for everything whose source is in /root/reference -- tests/test_oracle.py
+checks this file against golden vectors produced by the reference's own code
+(oracle/make_golden.py, via oracle/ref_fixture.py) -- and "parity unpinned" only for the one
+un-vendored numeric dependency, torchaudio==0.6.0 `MelSpectrogram` (restated from its published
+algorithm; call site transforms.py:290-296,310), and for beam search, which the reference does not
+have (models.py:8 imports PriorityQueue and never uses it).
+
+Each function cites the reference file:line it follows (paths relative to /root/reference).
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------- front-end
+def hann_periodic(n):
+    # torch.hann_window(n) (periodic=True), used by torchaudio MelSpectrogram 0.6.0
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n, dtype=np.float64) / n)).astype(F32)
+
+
+def htk_filterbank(n_freqs=513, f_min=0.0, f_max=8000.0, n_mels=128, sr=16000):
+    # torchaudio 0.6.0 functional.create_fb_matrix: HTK mel scale, triangular, no area norm.
+    all_freqs = np.linspace(0, sr // 2, n_freqs)
+    m_min = 2595.0 * np.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * np.log10(1.0 + f_max / 700.0)
+    m_pts = np.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return np.maximum(0.0, np.minimum(down, up)).astype(F32)  # [n_freqs, n_mels]
+
+
+def logmel(pcm, n_fft=1024, win=400, hop=160, n_mels=128, sr=16000):
+    """TransformTime.encodes (transforms.py:306-323) with melkwargs {n_fft:1024,n_mels:128}
+    (config/testing.yaml:133-135), win 0.025 s, hop 0.01 s (transforms.py:288-289), deltas 0:
+    MelSpectrogram (center=True, reflect pad n_fft/2, periodic Hann(win) zero-padded centred to
+    n_fft, one-sided, power 2) then log(x + 1e-6) (transforms.py:311-313), permuted to [T, n_mels].
+    pcm: [N] float32 -> [T, n_mels], T = 1 + N // hop."""
+    pcm = np.asarray(pcm, dtype=F32)
+    n = pcm.shape[0]
+    pad = n_fft // 2
+    xp = np.pad(pcm, (pad, pad), mode="reflect")
+    w = np.zeros(n_fft, dtype=F32)
+    off = (n_fft - win) // 2
+    w[off:off + win] = hann_periodic(win)
+    T = 1 + n // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(T)[:, None]
+    frames = xp[idx] * w[None, :]
+    spec = np.fft.rfft(frames.astype(np.float64), axis=1)
+    power = (spec.real ** 2 + spec.imag ** 2).astype(F32)
+    mel = power @ htk_filterbank(n_fft // 2 + 1, 0.0, sr / 2.0, n_mels, sr)
+    return np.log(mel + F32(1e-6)).astype(F32)
+
+
+def stream_postprocess(spec, n_stack=10):
+    """StreamPostprocess.encodes (transforms.py:335-342): l = T//3; keep frames [l+1, l+1+n_stack)."""
+    a = spec.shape[0] // 3 + 1
+    return spec[a:][:n_stack]
+
+
+def stack_downsample(spec, n_stack=10, downsample=8):
+    """StackDownsample.encodes (transforms.py:436-441): unfold(-2, n_stack, downsample) then view:
+    feat[t', m*n_stack + k] = spec[downsample*t' + k, m]  (mel-major, frame-minor)."""
+    T, M = spec.shape
+    if T < n_stack:
+        return np.zeros((0, M * n_stack), dtype=F32)
+    Tp = (T - n_stack) // downsample + 1
+    idx = downsample * np.arange(Tp)[:, None] + np.arange(n_stack)[None, :]   # [Tp, k]
+    uf = spec[idx]                       # [Tp, k, M]
+    return np.ascontiguousarray(uf.transpose(0, 2, 1)).reshape(Tp, M * n_stack).astype(F32)
+
+
+def features_offline(pcm, n_stack=10, downsample=8):
+    """x_tfm pipeline (config/testing.yaml:341-356; api-server.py:74-75): [N] -> [T', 1280]."""
+    return stack_downsample(logmel(pcm), n_stack, downsample)
+
+
+class StreamFrontend:
+    """Per-stream restatement of the servicer's 3-chunk window (api-server.py:83-115,
+    BUFFER_N_FRAMES=3 :26) + x_tfm_stream (testing.yaml:358-374) incl. Buffer(n_buffer)
+    (transforms.py:455-471).  push(chunk) -> None or [n_buffer*T', 1280]."""
+
+    def __init__(self, n_stack=10, downsample=8, n_buffer=2, n_window=3):
+        self.n_stack, self.downsample, self.n_buffer, self.n_window = n_stack, downsample, n_buffer, n_window
+        self.frames, self.saved = [], []
+
+    def push(self, chunk):
+        self.frames.append(np.asarray(chunk, dtype=F32))
+        self.called = False                      # did this push reach the transform pipeline?
+        if len(self.frames) != self.n_window:
+            return None
+        self.called = True
+        aud = np.concatenate(self.frames)
+        del self.frames[0]
+        spec = stream_postprocess(logmel(aud), self.n_stack)
+        st = stack_downsample(spec, self.n_stack, self.downsample)
+        self.saved.append(st)
+        if len(self.saved) == self.n_buffer:
+            cat = np.concatenate(self.saved, axis=0)
+            self.saved = []
+            return cat
+        return None
+
+
+# ----------------------------------------------------------------------------- model pieces
+def sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x.astype(F32)))).astype(F32)
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    # nn.LayerNorm(feature_sz) (models.py:84,107): biased variance over the last dim
+    x = x.astype(F32)
+    mu = x.mean(-1, keepdims=True, dtype=F32)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True, dtype=F32)
+    return ((x - mu) / np.sqrt(var + F32(eps)) * w + b).astype(F32)
+
+
+def bn_eval(x, p, eps=1e-5):
+    # BatchNorm1d in eval mode over the channel (= hidden) dim (custom_rnn.py:122-126,210-213)
+    return ((x - p["running_mean"]) / np.sqrt(p["running_var"] + F32(eps)) * p["weight"] + p["bias"]).astype(F32)
+
+
+def lstm_step(x, h, c, p):
+    """torch.nn.LSTM cell, gate order i,f,g,o (custom_rnn.py:36-42,172; in-tree statement
+    haste/lstm.py:34-68 with the weight map haste/lstm.py:181-187).  x [B,I], h,c [B,H]."""
+    g = x @ p["weight_ih_l0"].T + p["bias_ih_l0"] + h @ p["weight_hh_l0"].T + p["bias_hh_l0"]
+    H = h.shape[-1]
+    i, f, gg, o = g[:, :H], g[:, H:2 * H], g[:, 2 * H:3 * H], g[:, 3 * H:]
+    c2 = sigmoid(f) * c + sigmoid(i) * np.tanh(gg)
+    h2 = sigmoid(o) * np.tanh(c2)
+    return h2.astype(F32), c2.astype(F32)
+
+
+def nbrc_step(x, h, p):
+    """NBRCScript (haste/nbrc.py:30-64): Wx = x K + b; Rh = h R + rb; layout z,r,g;
+    g = tanh(Wx_g + r * Rh_g); h' = z h + (1 - z) g.  zoneout = 0 => branch dead (:57-61)."""
+    H = h.shape[-1]
+    Wx = x @ p["kernel"] + p["bias"]
+    Rh = h @ p["recurrent_kernel"] + p["recurrent_bias"]
+    z = sigmoid(Wx[:, :H] + Rh[:, :H])
+    r = sigmoid(Wx[:, H:2 * H] + Rh[:, H:2 * H])
+    g = np.tanh(Wx[:, 2 * H:] + r * Rh[:, 2 * H:])
+    return (z * h + (F32(1.0) - z) * g).astype(F32)
+
+
+def _sub(sd, prefix):
+    n = len(prefix)
+    return {k[n:]: np.asarray(v, dtype=F32) for k, v in sd.items() if k.startswith(prefix)}
+
+
+class OracleTransducer:
+    """Restatement of Encoder / Predictor / Joint / Transducer.decode_greedy / transcribe_stream
+    (models.py:68-187, 369-455, 457-577) + CustomRNN (custom_rnn.py:140-232)."""
+
+    def __init__(self, sd, cfg, blank=0, bos=2):
+        self.cfg = cfg
+        self.blank, self.bos = blank, bos  # models.py:203,225,227
+        self.Le, self.Lp, self.H = cfg["enc_layers"], cfg["pred_layers"], cfg["hidden"]
+        self.pred_lstm = cfg["pred_cell"] == "LSTM"
+        self.ln_w = np.asarray(sd["encoder.input_norm.weight"], F32)
+        self.ln_b = np.asarray(sd["encoder.input_norm.bias"], F32)
+        self.enc = [dict(rnn=_sub(sd, f"encoder.rnn_stack.rnns.{i}."),
+                         bn=_sub(sd, f"encoder.rnn_stack.bns.{i}."),
+                         hs=np.asarray(sd[f"encoder.rnn_stack.hs.{i}"], F32)) for i in range(self.Le)]
+        self.pred = [dict(rnn=_sub(sd, f"predictor.rnn_stack.rnns.{i}."),
+                          bn=_sub(sd, f"predictor.rnn_stack.bns.{i}."),
+                          hs=np.asarray(sd[f"predictor.rnn_stack.hs.{i}"], F32)) for i in range(self.Lp)]
+        self.embed = np.asarray(sd["predictor.embed.weight"], F32)
+        self.ffn_w = np.asarray(sd["predictor.ffn.weight"], F32) if "predictor.ffn.weight" in sd else None
+        self.ffn_b = np.asarray(sd["predictor.ffn.bias"], F32) if "predictor.ffn.bias" in sd else None
+        self.j0_w = np.asarray(sd["joint.joint.0.weight"], F32)
+        self.j0_b = np.asarray(sd["joint.joint.0.bias"], F32)
+        self.j2_w = np.asarray(sd["joint.joint.2.weight"], F32)
+        self.j2_b = np.asarray(sd["joint.joint.2.bias"], F32)
+
+    # -- encoder -------------------------------------------------------------------------
+    def enc_init_state(self, B):
+        # learned initial state broadcast over the batch (custom_rnn.py:152-158)
+        return [(np.repeat(l["hs"][0, 0], B, 0).copy(), np.repeat(l["hs"][1, 0], B, 0).copy())
+                for l in self.enc]
+
+    def encoder(self, x, state=None):
+        """Encoder.forward (models.py:105-113).  x [B,T,F] -> ([B,T,H], state)."""
+        B, T, _ = x.shape
+        x = layer_norm(x.reshape(B, T, -1), self.ln_w, self.ln_b)   # models.py:107
+        if state is None:
+            state = self.enc_init_state(B)
+        new_state = []
+        for l, (h, c) in zip(self.enc, state):
+            ys = np.empty((B, T, self.H), F32)
+            for t in range(T):
+                h, c = lstm_step(x[:, t], h, c, l["rnn"])
+                ys[:, t] = h
+            x = bn_eval(ys, l["bn"])                                 # custom_rnn.py:210-213
+            new_state.append((h, c))
+        return x, new_state                                          # dropout(eval)=id, linear=id
+
+    # -- predictor -----------------------------------------------------------------------
+    def pred_init_state(self, B=1):
+        if self.pred_lstm:
+            return [(np.repeat(l["hs"][0, 0], B, 0).copy(), np.repeat(l["hs"][1, 0], B, 0).copy())
+                    for l in self.pred]
+        return [np.repeat(l["hs"][0, 0], B, 0).copy() for l in self.pred]
+
+    def predictor(self, tok, state=None):
+        """Predictor.forward (models.py:181-187) for one token per row.  tok [B] -> ([B,H], state)."""
+        tok = np.asarray(tok).reshape(-1)
+        x = self.embed[tok]                                          # models.py:182
+        if self.ffn_w is not None:
+            x = (x @ self.ffn_w.T + self.ffn_b).astype(F32)          # models.py:183
+        if state is None:
+            state = self.pred_init_state(len(tok))
+        new_state = []
+        for l, s in zip(self.pred, state):
+            if self.pred_lstm:
+                h, c = lstm_step(x, s[0], s[1], l["rnn"])
+                new_state.append((h, c))
+            else:
+                h = nbrc_step(x, s, l["rnn"])
+                new_state.append(h)
+            x = bn_eval(h, l["bn"])
+        return x, new_state
+
+    # -- joint ---------------------------------------------------------------------------
+    def joint_logp(self, h_pred, h_enc):
+        """Joint.forward 'concat' (models.py:132-140; cat order pred, enc :136) + log_softmax
+        (models.py:418).  h_pred, h_enc [B,H] -> log-probs [B,V]."""
+        x = np.concatenate([h_pred, h_enc], axis=-1)
+        a = np.tanh(x @ self.j0_w.T + self.j0_b).astype(F32)
+        z = (a @ self.j2_w.T + self.j2_b).astype(F32)
+        m = z.max(-1, keepdims=True)
+        lse = m + np.log(np.exp(z - m).sum(-1, keepdims=True, dtype=F32))
+        return (z - lse).astype(F32), z
+
+    # -- decoders ------------------------------------------------------------------------
+    def decode_greedy(self, feats, max_iters=3, return_logits=False):
+        """Transducer.decode_greedy (models.py:369-455).  feats [T',F] (one utterance).
+        Returns (tokens, neg_log_p, alignment_score, iters[, logits_per_eval])."""
+        enc, _ = self.encoder(feats[None])
+        enc = enc[0]
+        h_pred, pstate = self.predictor([self.bos])                  # models.py:397-398
+        y, log_p, iters_all, outs = [], 0.0, [], []
+        for t in range(enc.shape[0]):
+            iters = 0
+            while iters < max_iters:                                 # models.py:408
+                iters += 1
+                lp, z = self.joint_logp(h_pred, enc[t][None])
+                if return_logits:
+                    outs.append(z[0].copy())
+                pred = int(lp[0].argmax())
+                log_p += float(lp[0, pred])                          # models.py:420-422
+                if pred == self.blank:
+                    break
+                y.append(pred)
+                h_pred, pstate = self.predictor([pred], pstate)      # models.py:437
+            iters_all.append(iters)
+        align = np.array(iters_all)
+        s = align.sum()
+        ones = int((align == 1).sum())
+        score = (s - ones) / (s + 1e-4)                              # models.py:447-453
+        res = (y, -log_p, float(score), iters_all)
+        return res + (outs,) if return_logits else res
+
+    def stream_decoder(self, max_iters=10):
+        """Transducer.transcribe_stream (models.py:457-577) as a push-style object: call
+        .step(chunk[T,F]) per non-None chunk -> new tokens of that chunk; .reset() = reset()."""
+        return _StreamDecoder(self, max_iters)
+
+
+class _StreamDecoder:
+    def __init__(self, m, max_iters):
+        self.m, self.max_iters = m, max_iters
+        self.y = []
+        self.reset()
+
+    def reset(self):                                                  # models.py:480-500
+        self.enc_state = None
+        self.h_pred, self.pstate = self.m.predictor([self.m.bos])
+
+    def step(self, chunk, return_logits=False):
+        m = self.m
+        enc, self.enc_state = m.encoder(chunk[None], self.enc_state)  # models.py:517-522
+        enc = enc[0]
+        y_seq, outs = [], []
+        for t in range(enc.shape[0]):
+            iters = 0
+            while iters < self.max_iters:
+                iters += 1
+                lp, z = m.joint_logp(self.h_pred, enc[t][None])
+                if return_logits:
+                    outs.append(z[0].copy())
+                pred = int(lp[0].argmax())
+                if pred == m.blank:
+                    break
+                y_seq.append(pred)
+                self.h_pred, self.pstate = m.predictor([pred], self.pstate)
+        self.y = self.y + y_seq
+        return (y_seq, outs) if return_logits else y_seq
+
+
+# ----------------------------------------------------------------------------- servicer policy
+def should_reset(steps, downsample=8, n_buffer=2, thresh=4000):
+    """api-server.py:44-50."""
+    return int(10.0 * downsample * n_buffer * steps) >= thresh

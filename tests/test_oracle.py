@@ -1,0 +1,94 @@
+"""Pins the numpy oracle (oracle/rnnt_oracle.py) against golden vectors produced by the
+REFERENCE's own code (oracle/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from libreasr_amd import synth
+from oracle import rnnt_oracle as O
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_logmel_matches_reference(golden_dir):
+    g = load(golden_dir, "frontend.npz")
+    pcm = synth.synth_pcm(2, 16000 + 937, seed=7)
+    for s in range(2):
+        lm = O.logmel(pcm[s])
+        assert lm.shape == g[f"logmel_{s}"].shape
+        np.testing.assert_allclose(lm, g[f"logmel_{s}"], atol=2e-4, rtol=0)
+        feats = O.features_offline(pcm[s])
+        np.testing.assert_allclose(feats, g[f"feats_{s}"], atol=2e-4, rtol=0)
+    z = O.logmel(np.zeros(3840, np.float32))
+    np.testing.assert_allclose(z, g["logmel_zero"], atol=1e-6)
+    assert np.allclose(z, np.log(np.float32(1e-6)))
+
+
+def test_stack_layout_is_mel_major_frame_minor():
+    spec = np.arange(30 * 128, dtype=np.float32).reshape(30, 128)
+    st = O.stack_downsample(spec)
+    assert st.shape == (3, 1280)
+    for t in range(3):
+        for m in (0, 5, 127):
+            for k in (0, 9):
+                assert st[t, m * 10 + k] == spec[8 * t + k, m]
+
+
+def test_stream_frontend_matches_reference(golden_dir):
+    g = load(golden_dir, "frontend.npz")
+    pcm = synth.synth_pcm(2, 16000 + 937, seed=7)
+    fe = O.StreamFrontend()
+    pattern, outs = [], []
+    for c in synth.stream_chunks(pcm[0], 1280, lead=1, tail=2):
+        o = fe.push(c)
+        if not fe.called:           # window not yet full: the servicer does not call the pipeline
+            continue
+        pattern.append(0 if o is None else 1)
+        if o is not None:
+            outs.append(o)
+    assert pattern == list(g["stream_pattern"])
+    np.testing.assert_allclose(np.stack(outs), g["stream_feats"], atol=2e-4, rtol=0)
+
+
+@pytest.mark.parametrize("name,n_sec,n_streams", [("tiny", 3.0, 3), ("tiny_lstm", 3.0, 2),
+                                                   ("cfg2", 4.0, 2), ("cfg2_lstm", 2.0, 1)])
+def test_model_matches_reference(golden_dir, name, n_sec, n_streams):
+    g = load(golden_dir, f"model_{name}.npz")
+    cfg = synth.model_cfg(name)
+    m = O.OracleTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
+    pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
+    for s in range(n_streams):
+        feats = O.features_offline(pcm[s])
+        if s == 0:
+            enc, st = m.encoder(feats[None])
+            np.testing.assert_allclose(enc[0], g["enc_out_0"], atol=2e-4)
+            np.testing.assert_allclose(np.stack([a[0][0] for a in st]), g["enc_h_0"], atol=1e-4)
+            np.testing.assert_allclose(np.stack([a[1][0] for a in st]), g["enc_c_0"], atol=2e-4)
+            hp, ps = m.predictor([m.bos])
+            np.testing.assert_allclose(hp[0], g["pred_bos"], atol=1e-4)
+            hp2, _ = m.predictor([5], ps)
+            np.testing.assert_allclose(hp2[0], g["pred_bos_5"], atol=1e-4)
+            _, z = m.joint_logp(hp2, enc[0, 3][None])
+            np.testing.assert_allclose(z[0], g["joint_logits"], atol=1e-3)
+        toks, neg_logp, score, iters, outs = m.decode_greedy(feats, return_logits=True)
+        assert toks == list(g[f"off_tokens_{s}"])
+        assert iters == list(g[f"off_iters_{s}"])
+        assert abs(neg_logp - float(g[f"off_neglogp_{s}"])) < 1e-2
+        assert abs(score - float(g[f"off_align_{s}"])) < 1e-9
+        # streaming: api-server window + Buffer + transcribe_stream
+        fe, dec = O.StreamFrontend(), m.stream_decoder()
+        counts = []
+        for c in synth.stream_chunks(pcm[s], 1280, lead=1, tail=10):
+            o = fe.push(c)
+            if o is not None:
+                counts.append(len(dec.step(o)))
+        assert dec.y == list(g[f"st_tokens_{s}"])
+        assert counts == list(g[f"st_counts_{s}"])
+
+
+def test_should_reset_policy():
+    # api-server.py:44-50: 10 ms * downsample 8 * n_buffer 2 * steps >= 4000 ms
+    assert not O.should_reset(24) and O.should_reset(25)
