@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""
+bench.py -- audio-sec/sec of the streaming RNN-T hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): 64 concurrent 16 kHz streams per GPU, 4x1024 uni-LSTM encoder,
+2xNBRC predictor (the reference's shipped predictor cell), J=1024, V=2048, greedy decode, fp32,
+reference-faithful streaming call pattern: 80 ms client chunks, 3-chunk sliding window, 2-frame
+Buffer => the model runs every second chunk on 2 stacked frames (api-server.py:83-115,
+transforms.py:326-342,455-471, models.py:457-577).
+
+A "step" = one 80 ms chunk pushed for every stream of the rank (lasr_push_pcm + lasr_step_stream,
+tokens fetched to the host).  Synthetic PCM is resident in HBM before the timed region.
+Streams are independent: rank r owns streams [64 r, 64 r + 64), there is no data-path collective
+("scaling": "weak"); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STREAMS_PER_GPU = 64
+CHUNK = 1280                 # 80 ms at 16 kHz
+SR = 16000
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def dist_init(world, use_cuda):
+    """One process per GPU; backend "nccl" is RCCL on ROCm, gloo for the CPU self-test."""
+    if world == 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+    return dist
+
+
+def shard_streams(total_streams, world, rank):
+    """Contiguous block partition: stream s -> rank s // (total/world)."""
+    per = total_streams // world
+    return list(range(rank * per, (rank + 1) * per))
+
+
+def aggregate(dist, elapsed_local, units_local, device):
+    """max-over-ranks wall time, sum-over-ranks units.  Returns (elapsed_max, units_total)."""
+    if dist is None:
+        return elapsed_local, units_local
+    import torch
+    t = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+    u = torch.tensor([units_local], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def cell_flops(cfg, layer, rows):
+    H = cfg["hidden"]
+    I = cfg["feat"] if layer == 0 else H
+    return 2.0 * rows * 4 * H * (I + H)
+
+
+def cpu_baseline(cfg, sd, pcm_rows, n_chunks):
+    """The oracle (numpy restatement of the reference's CPU path) timed on the host cores on a
+    bounded sample of the same workload: `len(pcm_rows)` streams x n_chunks 80 ms chunks through the
+    reference-faithful streaming pipeline (window -> log-mel -> Buffer -> encoder -> greedy)."""
+    from oracle import rnnt_oracle as O      # baseline leg only; never on the product path
+    m = O.OracleTransducer(sd, cfg)
+    B = len(pcm_rows)
+    fes = [O.StreamFrontend() for _ in range(B)]
+    decs = [m.stream_decoder() for _ in range(B)]
+    t0 = time.perf_counter()
+    for k in range(n_chunks):
+        for b in range(B):
+            o = fes[b].push(pcm_rows[b][k * CHUNK:(k + 1) * CHUNK])
+            if o is not None:
+                decs[b].step(o)
+    dt = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": round(B * n_chunks * CHUNK / SR / dt, 2), "unit": "audio-sec/sec",
+            "cores": int(cores), "kind": "port",
+            "sample": f"{B} streams x {n_chunks} chunks of 80 ms, numpy oracle, batch 1 per stream (as the reference serves)",
+            "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="cfg2")
+    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-streams", type=int, default=8)
+    ap.add_argument("--cpu-chunks", type=int, default=100)
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="CPU-only: exercise sharding + aggregation over gloo (no GPU work)")
+    args = ap.parse_args()
+
+    rank, world, local = dist_env()
+    if args.selftest_dist:
+        import torch
+        dist = dist_init(world, use_cuda=False)
+        mine = shard_streams(args.streams * world, world, rank)
+        el, units = aggregate(dist, 1.0 + 0.5 * rank, float(len(mine)), torch.device("cpu"))
+        if rank == 0:
+            print(json.dumps({"selftest": True, "world": world, "elapsed_max": el, "units_total": units,
+                              "first_stream_rank0": mine[0], "n_local": len(mine)}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    import torch
+    from libreasr_amd import synth
+    from libreasr_amd.engine import Engine
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = dist_init(world, use_cuda=True)
+
+    cfg = synth.model_cfg(args.model)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    B = args.streams
+    eng = Engine(sd, cfg, max_streams=B, device=local)
+    my_streams = shard_streams(B * world, world, rank)
+    K, W = args.steps, args.warmup
+    n_chunks = K + W + 4
+    # synthetic PCM for this rank's streams (seeded per global stream id), resident in HBM,
+    # laid out [chunk][stream][1280] so that one step reads one contiguous block
+    pcm_host = np.stack([synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in my_streams])
+    pcm_dev = torch.as_tensor(pcm_host.reshape(B, n_chunks, CHUNK).transpose(1, 0, 2).copy()).to(device)
+    slots = [eng.open() for _ in range(B)]
+    assert slots == list(range(B))
+
+    def one_step(k):
+        eng.push(slots, pcm_dev[k])
+        ran = eng.step(slots)
+        ntok = 0
+        if ran:
+            for s in slots:
+                ntok += len(eng.fetch(s, cap=256)[0])
+        return ran, ntok
+
+    for k in range(W):
+        one_step(k)
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    eng.set_profiling(True)
+    lat, lat_model, enc_ms, dec_ms, fe_ms, iters, tokens = [], [], [], [], [], [], 0
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        t1 = time.perf_counter()
+        ran, ntok = one_step(k)
+        dt = time.perf_counter() - t1
+        lat.append(dt)
+        tokens += ntok
+        if ran:
+            lat_model.append(dt)
+            st = eng.stats()
+            enc_ms.append(st["encoder_ms"]); dec_ms.append(st["decode_ms"]); fe_ms.append(st["frontend_ms"])
+            iters.append(st["decode_iters"])
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(False)
+
+    audio_local = K * B * CHUNK / SR
+    elapsed_max, audio_total = aggregate(dist, elapsed, audio_local, device)
+
+    if rank == 0:
+        # dominant kernel: the fused LSTM-cell GEMM (k_gemm<EpiLSTM>), measured live with HIP
+        # events on the engine's stream: `iters` back-to-back launches of layer 1, all rows active
+        cell_us = eng.bench_cell(layer=1, iters=300)
+        flops = cell_flops(cfg, 1, B)
+        achieved = flops / (cell_us * 1e-6) / 1e12
+        n_cells = cfg["enc_layers"] * 2
+        out = {
+            "metric": "audio-sec/sec/GPU (16 kHz streaming RNN-T) + p50 per-chunk latency",
+            "value": round(audio_total / elapsed_max, 1),
+            "unit": "audio-sec/sec",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(1e3 * elapsed_max / K, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: {B} concurrent 16 kHz streams/GPU, 4x1024 uni-LSTM encoder, "
+                                   "2xNBRC predictor, J=1024, V=2048, greedy, fp32, 80 ms chunks, "
+                                   "3-chunk window, 2-frame buffer (model every 160 ms)",
+                       "streams_per_gpu": B, "chunk_ms": 80, "parallelism": f"dp{world} (independent streams, no collective)"},
+            "per_gpu_value": round(audio_total / elapsed_max / world, 1),
+            "latency_ms": {"p50_chunk": round(1e3 * float(np.median(lat)), 4),
+                           "p50_model_chunk": round(1e3 * float(np.median(lat_model)), 4) if lat_model else None,
+                           "p95_model_chunk": round(1e3 * float(np.percentile(lat_model, 95)), 4) if lat_model else None,
+                           "p50_per_40ms_equiv": round(0.5e3 * float(np.median(lat_model)), 4) if lat_model else None},
+            "stage_ms_per_model_step": {"frontend": round(float(np.mean(fe_ms)), 4) if fe_ms else None,
+                                        "encoder": round(float(np.mean(enc_ms)), 4) if enc_ms else None,
+                                        "decode": round(float(np.mean(dec_ms)), 4) if dec_ms else None,
+                                        "decode_iters": round(float(np.mean(iters)), 2) if iters else None},
+            "tokens_per_frame": round(tokens / max(1, K * B), 4),
+            "roofline": {"bound": "mfma", "kernel": "k_gemm<EpiLSTM> (encoder LSTM cell, layer 1, 64 rows)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launch_us": round(cell_us, 3), "flops_per_launch": flops,
+                         "weight_bytes_per_launch": 4.0 * 4 * cfg["hidden"] * 2 * cfg["hidden"],
+                         "in_situ_encoder_us_per_cell": round(1e3 * float(np.mean(enc_ms)) / n_cells, 3) if enc_ms else None},
+        }
+        if not args.no_cpu_baseline:
+            rows = [pcm_host[i] for i in range(min(args.cpu_streams, B))]
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, rows, args.cpu_chunks)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

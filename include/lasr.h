@@ -1,0 +1,168 @@
+/*
+ * lasr.h -- C ABI of liblasr_hip.so: the MI355X (gfx950) streaming RNN-Transducer inference path.
+ *
+ * The reference (iceychris/LibreASR) has NO FFI / plugin / operator interface: its hot path is a
+ * Python call surface over torch CPU ops.  This header is therefore the boundary a maintainer
+ * binds with ctypes (INTEGRATION.md shows the stub); each entry point names the reference
+ * interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns LASR_OK (0) or a negative LASR_E* code; nothing throws or aborts;
+ *     lasr_last_error() gives a human-readable message for the last failure on that ctx.
+ *   - the caller owns every buffer it passes; the ctx owns all device memory it allocates.
+ *   - a ctx is single-caller (one scheduler thread per GPU); all work is enqueued on the
+ *     hipStream_t given at creation (pass torch.cuda.current_stream().cuda_stream, or NULL).
+ *   - "row" == stream slot: slot s occupies batch row s of every device buffer, so there is no
+ *     state gather/scatter; rows that do not take part in a call are masked.
+ *   - pointers documented "host or device" are classified with hipPointerGetAttributes.
+ */
+#ifndef LASR_H
+#define LASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LASR_OK 0
+#define LASR_EINVAL (-1)   /* bad argument / unsupported shape          */
+#define LASR_ENOMEM (-2)   /* device or host allocation failed          */
+#define LASR_EHIP (-3)     /* a HIP runtime call failed                 */
+#define LASR_ESTATE (-4)   /* call not valid in the slot's/ctx's state  */
+#define LASR_EFULL (-5)    /* no free stream slot / output buffer small */
+
+typedef struct lasr_ctx lasr_ctx;
+
+/* Model + front-end description.  Mirrors config/testing.yaml:202-229 (model) and :133-143,
+ * :350-374 (front-end), and Transducer.__init__ (libreasr/lib/models.py:190-234). */
+typedef struct {
+    int32_t feat;        /* feature_sz = n_mels * n_stack (1280)                       */
+    int32_t hidden;      /* hidden_sz == out_sz (encoder.linear / predictor.linear = id) */
+    int32_t enc_layers;  /* encoder LSTM layers                                          */
+    int32_t pred_layers; /* predictor layers                                             */
+    int32_t pred_cell;   /* 0 = NBRC/GRU cell (haste/nbrc.py), 1 = LSTM                  */
+    int32_t embed;       /* embed_sz; if embed != hidden a Linear(embed,hidden) follows  */
+    int32_t joint;       /* joint_sz                                                     */
+    int32_t vocab;       /* vocab_sz                                                     */
+    int32_t blank;       /* 0   (models.py:203)                                          */
+    int32_t bos;         /* 2   (models.py:227)                                          */
+    int32_t n_fft;       /* 1024 */
+    int32_t win;         /* 400  */
+    int32_t hop;         /* 160  */
+    int32_t n_mels;      /* 128  */
+    int32_t n_stack;     /* 10   */
+    int32_t stride;      /* 8  (StackDownsample.downsample)                              */
+    int32_t n_buffer;    /* 2  (Buffer.n_buffer, transforms.py:455-471)                  */
+    int32_t n_window;    /* 3  (BUFFER_N_FRAMES, api-server.py:26)                       */
+    int32_t chunk;       /* client chunk length in samples (1280 = 80 ms)                */
+    int32_t sample_rate; /* 16000 */
+    int32_t dtype;       /* 0 = f32 (bf16 reserved)                                      */
+    int32_t max_streams; /* number of stream slots (= batch rows)                        */
+    int32_t max_iters_offline; /* 3  (decode_greedy default, models.py:369)             */
+    int32_t max_iters_stream;  /* 10 (transcribe_stream default, models.py:458)         */
+    int32_t beam;        /* 1 = greedy (the only decode the reference has)               */
+} lasr_model_desc;
+
+/* Fills `d` with the reference defaults listed above (4x1024 encoder, 2xNBRC predictor). */
+void lasr_default_desc(lasr_model_desc* d);
+
+/* Number of float32 values lasr_create expects in `weights` for `d` (0 if d is invalid).
+ * The blob is the reference state_dict flattened in this order, every tensor in its reference
+ * layout:
+ *   encoder.input_norm.{weight,bias}
+ *   per encoder layer i: rnn_stack.hs.i [2,H] (h0,c0); bns.i.{weight,bias,running_mean,running_var};
+ *                        rnns.i.{weight_ih_l0 [4H,I], weight_hh_l0 [4H,H], bias_ih_l0, bias_hh_l0}
+ *   predictor.embed.weight [V,E]; if E != H: predictor.ffn.{weight [H,E], bias}
+ *   per predictor layer i: hs.i [S,H] (S=1 NBRC, 2 LSTM); bns.i.* (as above);
+ *        NBRC: rnns.i.{kernel [I,3H], recurrent_kernel [H,3H], bias [3H], recurrent_bias [3H]}
+ *        LSTM: rnns.i.{weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0}
+ *   joint.joint.0.{weight [J,2H], bias}; joint.joint.2.{weight [V,J], bias}                  */
+size_t lasr_weight_count(const lasr_model_desc* d);
+
+/* Replaces: load_stuff / Transducer.from_config + load_asr_model (libreasr/lib/inference.py:18-51,
+ * models.py:236-259, model_utils.py:61-95).  Packs the weights into MFMA-fragment order, folds
+ * BatchNorm(eval) into scale/shift, builds the predictor input tables, uploads everything. */
+int lasr_create(int device, const lasr_model_desc* d, const float* weights, size_t n_weights,
+                void* hip_stream, lasr_ctx** out);
+void lasr_destroy(lasr_ctx* c);
+const char* lasr_last_error(const lasr_ctx* c);
+
+/* ---- stream slots: per-stream state lives on the device (replaces the Python closure state of
+ * Transducer.transcribe_stream, models.py:466-500, the Buffer transform's `saved` list,
+ * transforms.py:461-471, and the servicer's 3-chunk `frames` list, api-server.py:85-102). */
+int lasr_stream_open(lasr_ctx* c, int* slot);
+/* what: 1 = encoder state, 2 = predictor (re-run on BOS), 4 = lm (no-op: no LM), 8 = front-end
+ * window + frame buffer; OR-able.  reset() of models.py:494-497 == 1|2|4. */
+int lasr_stream_reset(lasr_ctx* c, int slot, int what);
+int lasr_stream_close(lasr_ctx* c, int slot);
+
+/* ---- streaming hot path, batched over n slots ------------------------------------------------
+ * lasr_push_pcm: one client chunk of `chunk` float32 samples per listed slot (replaces
+ * tensorize + the window cat of api-server.py:88-102).  pcm: [n, chunk] host or device.
+ * lasr_step_stream: for every listed slot whose window is full, computes the log-mel frames of
+ * the window's middle (TransformTime + StreamPostprocess + StackDownsample, transforms.py:
+ * 306-342,436-441), buffers them (Buffer), and for slots whose buffer reached n_buffer runs
+ * encoder + greedy decode with carried state (models.py:506-575).  Blocks until the tokens of
+ * this step are on the host.  n_ran (optional) = number of slots the model ran for. */
+int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm);
+int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran);
+
+/* ---- offline path (Transcribe RPC, api-server.py:64-80 -> Transducer.transcribe,
+ * models.py:365-455): whole utterances, fresh state, max_iters_offline.
+ * pcm: concatenated samples of the n utterances (host or device), n_samples[i] each (>= 2400).
+ * Results are fetched with lasr_fetch on the same slots. */
+int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm,
+                        const int64_t* n_samples);
+/* Same, starting from stacked features [sum(n_frames), feat] row-major (x_tfm output). */
+int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* feats,
+                          const int32_t* n_frames);
+
+/* New tokens of `slot` since the last fetch (int32 ids incl. nothing for blanks).
+ * neg_logp / align (optional): offline metrics of the last lasr_transcribe_* call
+ * (-sum log p of every decision, models.py:420-422,455; alignment_score, models.py:445-453). */
+int lasr_fetch(lasr_ctx* c, int slot, int32_t* tokens, int cap, int* n_new, double* neg_logp,
+               double* align);
+
+/* ---- op-level entry points (parity tests and roofline micro-benchmarks).  Device pointers
+ * unless noted; all enqueue on the ctx stream and return without synchronising. -------------- */
+/* log-mel of whole signals: pcm [B, N] -> logmel [B, T, n_mels], T = 1 + N / hop. */
+int lasr_logmel(lasr_ctx* c, const float* pcm, int B, int64_t N, float* logmel);
+/* stacked features [B, T', feat] from logmel [B, T, n_mels] (StackDownsample). */
+int lasr_stack(lasr_ctx* c, const float* logmel, int B, int T, float* feats, int* Tp);
+/* Encoder.forward with fresh (learned) initial state: feats [B, T', feat] -> out [B, T', hidden]
+ * (B <= max_streams).  h_out/c_out optional [enc_layers, B, hidden]. */
+int lasr_encoder(lasr_ctx* c, const float* feats, int B, int Tp, float* out, float* h_out,
+                 float* c_out);
+/* Predictor on a token sequence per row from the learned initial state: tok [B, U] (host int32)
+ * -> out [B, hidden] after the last token. */
+int lasr_predictor(lasr_ctx* c, const int32_t* tok, int B, int U, float* out);
+/* Joint + log-softmax: h_pred, h_enc [B, hidden] -> logits [B, vocab] (pre-softmax),
+ * logp_max [B], argmax [B] (device). */
+int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, float* logits,
+               float* logp_max, int32_t* argmax);
+
+/* ---- timing / introspection ------------------------------------------------------------------ */
+typedef struct {
+    double frontend_ms, encoder_ms, decode_ms; /* HIP-event time of the last step's stages     */
+    int32_t decode_iters;                      /* joint evaluations rounds in the last step    */
+    int32_t frames;                            /* encoder frames (T) of the last step          */
+    double cell_ms;                            /* sum over the LSTM-cell launches of last step */
+    int32_t cell_launches;
+} lasr_step_stats;
+int lasr_get_stats(lasr_ctx* c, lasr_step_stats* s);
+/* enable per-stage HIP-event timing (costs a few us per step) */
+int lasr_set_profiling(lasr_ctx* c, int on);
+/* hipStreamSynchronize on the ctx stream */
+int lasr_sync(lasr_ctx* c);
+
+/* Roofline micro-benchmark of the dominant kernel (one encoder LSTM-cell launch: all rows active,
+ * layer `layer`), `iters` back-to-back launches timed with HIP events on the ctx stream.
+ * Returns average microseconds per launch in *us. */
+int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LASR_H */

@@ -1,0 +1,86 @@
+"""
+ctypes binding of liblasr_hip.so (include/lasr.h).  There is NO CPU fallback: if the HIP
+library is missing or cannot be loaded this module raises, loudly.
+
+torch is imported first on purpose: its bundled libamdhip64.so (SONAME libamdhip64.so.7) is then
+already mapped, so liblasr_hip.so binds to the SAME HIP runtime and device pointers / streams are
+interchangeable with PyTorch-ROCm tensors.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblasr_hip.so")
+
+LASR_OK, LASR_EINVAL, LASR_ENOMEM, LASR_EHIP, LASR_ESTATE, LASR_EFULL = 0, -1, -2, -3, -4, -5
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "feat", "hidden", "enc_layers", "pred_layers", "pred_cell", "embed", "joint", "vocab",
+        "blank", "bos", "n_fft", "win", "hop", "n_mels", "n_stack", "stride", "n_buffer",
+        "n_window", "chunk", "sample_rate", "dtype", "max_streams", "max_iters_offline",
+        "max_iters_stream", "beam")]
+
+
+class StepStats(C.Structure):
+    _fields_ = [("frontend_ms", C.c_double), ("encoder_ms", C.c_double), ("decode_ms", C.c_double),
+                ("decode_iters", C.c_int32), ("frames", C.c_int32), ("cell_ms", C.c_double),
+                ("cell_launches", C.c_int32)]
+
+
+# every symbol include/lasr.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("lasr_default_desc", None, [C.POINTER(ModelDesc)]),
+    ("lasr_weight_count", C.c_size_t, [C.POINTER(ModelDesc)]),
+    ("lasr_create", C.c_int, [C.c_int, C.POINTER(ModelDesc), _P, C.c_size_t, _P, C.POINTER(_P)]),
+    ("lasr_destroy", None, [_P]),
+    ("lasr_last_error", C.c_char_p, [_P]),
+    ("lasr_stream_open", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("lasr_stream_reset", C.c_int, [_P, C.c_int, C.c_int]),
+    ("lasr_stream_close", C.c_int, [_P, C.c_int]),
+    ("lasr_push_pcm", C.c_int, [_P, _P, C.c_int, _P]),
+    ("lasr_step_stream", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    ("lasr_transcribe_pcm", C.c_int, [_P, _P, C.c_int, _P, _P]),
+    ("lasr_transcribe_feats", C.c_int, [_P, _P, C.c_int, _P, _P]),
+    ("lasr_fetch", C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                             C.POINTER(C.c_double)]),
+    ("lasr_logmel", C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
+    ("lasr_stack", C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int)]),
+    ("lasr_encoder", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    ("lasr_predictor", C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    ("lasr_joint", C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
+    ("lasr_get_stats", C.c_int, [_P, C.POINTER(StepStats)]),
+    ("lasr_set_profiling", C.c_int, [_P, C.c_int]),
+    ("lasr_sync", C.c_int, [_P]),
+    ("lasr_bench_cell", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load liblasr_hip.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  libreasr_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, res, args in SYMBOLS:
+        f = getattr(L, name)       # AttributeError here == the .so does not export the header's symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+class LasrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"liblasr_hip error {code}: {msg}")
+        self.code = code

@@ -1,0 +1,1208 @@
+// lasr_engine.hip -- host side of liblasr_hip.so: weight packing, per-stream device state, the
+// per-chunk step (front-end -> encoder -> greedy decode loop) and the C ABI of include/lasr.h.
+// gfx950 only.  No CPU fallback: every numeric result comes from the kernels in lasr_kernels.hip.h.
+#include "lasr_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lasr.h"
+
+using namespace lasr;
+
+namespace {
+
+constexpr int NW = 8;          // waves per GEMM workgroup (K split)
+constexpr int NCMD = 64;       // ring of host->device command blocks
+
+struct Cell {                  // one recurrent layer (+ its BatchNorm fold and learned initial state)
+    int I = 0;                 // input width
+    float *Wx = nullptr, *Wh = nullptr;   // packed
+    float *bias = nullptr, *rbias = nullptr;
+    float *bn_s = nullptr, *bn_t = nullptr;
+    float *h0 = nullptr, *c0 = nullptr;
+    float *tab = nullptr;      // predictor layer 0: per-token input projection table
+};
+
+}  // namespace
+
+struct lasr_ctx {
+    lasr_model_desc d;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> dev_allocs;
+    std::vector<void*> host_allocs;
+
+    int M = 0, MT = 0;         // padded rows, m-tiles
+    int G_pred = 0;            // gates of the predictor cell (3 NBRC / 4 LSTM)
+
+    // front-end constants
+    float* window = nullptr; float2* tw512 = nullptr; float2* tw1024 = nullptr;
+    int* fb_start = nullptr; int* fb_off = nullptr; float* fb_w = nullptr;
+    float *ln_w = nullptr, *ln_b = nullptr;
+
+    std::vector<Cell> enc, pred;
+    float *W1p = nullptr, *W1e = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
+
+    // recurrent state (row == slot)
+    std::vector<float*> enc_h[2], enc_c, pred_h[2], pred_c, pred_y;
+    int enc_par = 0, pred_par = 0;
+    float *pp = nullptr, *ja = nullptr, *logits = nullptr;
+    DecState ds{};
+    int n_iter_slots = 0;
+    int* T_row_dev = nullptr;       // [M] current step's frames per row (copied from the cmd block)
+
+    // time-series buffers (capacity Tcap frames)
+    int Tcap = 0;
+    float *x0 = nullptr, *ybuf[2] = {nullptr, nullptr}, *pe = nullptr;
+    int tok_cap_alloc = 0;
+
+    // front-end buffers
+    float* win = nullptr; int* ring_pos = nullptr;
+    float* pend = nullptr;          // [M][n_buffer*n_stack][n_mels]
+    float* stage_pcm = nullptr; size_t stage_pcm_floats = 0;
+    float* lm_buf = nullptr; size_t lm_floats = 0;       // offline log-mel
+    float* feat_stage = nullptr; size_t feat_stage_floats = 0;
+
+    // command blocks (pinned host ring + device ring)
+    struct Cmd {
+        int* T_row; int* what; int* src_idx; int* feat_sel; int* row_frames; int* token; int* emit;
+        long long* row_N; long long* row_src_off; long long* row_feat_off;
+    };
+    char* cmd_host = nullptr; char* cmd_dev = nullptr; size_t cmd_bytes = 0; int cmd_next = 0; int cmd_inflight = 0;
+    Cmd hc{}, dc{};
+
+    // host results
+    int* res_host = nullptr;        // pinned: unfinished flag + ntok + tokens + metrics
+    size_t res_bytes = 0;
+
+    // host mirrors
+    std::vector<char> open_;
+    std::vector<int> n_chunks, n_pend;
+    std::vector<std::vector<int32_t>> queue;
+    std::vector<double> neg_logp, align;
+
+    // stats
+    bool profiling = false;
+    hipEvent_t ev[8];
+    bool ev_ok = false;
+    lasr_step_stats stats{};
+};
+
+namespace {
+
+int fail(lasr_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(c, LASR_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T>
+int dalloc(lasr_ctx* c, T** p, size_t n) {
+    void* q = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) return fail(c, LASR_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    c->dev_allocs.push_back(q);
+    *p = (T*)q;
+    return LASR_OK;
+}
+void dfree(lasr_ctx* c, void* p) {
+    if (!p) return;
+    auto it = std::find(c->dev_allocs.begin(), c->dev_allocs.end(), p);
+    if (it != c->dev_allocs.end()) c->dev_allocs.erase(it);
+    (void)hipFree(p);
+}
+template <class T>
+int upload(lasr_ctx* c, T** p, const T* src, size_t n) {
+    int rc = dalloc(c, p, n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return LASR_OK;
+}
+#define RC(x)                \
+    do {                     \
+        int rc_ = (x);       \
+        if (rc_) return rc_; \
+    } while (0)
+
+// dst[(tile*KC + c)*256 + lane*4 + e] = get(tile, ui, k) with ui = lane&15, k = 16c + 4(lane>>4) + e
+template <class F>
+void pack_tiles(std::vector<float>& dst, int n_tiles, int KC, F get) {
+    dst.assign((size_t)n_tiles * KC * 256, 0.f);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int c = 0; c < KC; ++c) {
+            float* o = dst.data() + ((size_t)t * KC + c) * 256;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) o[lane * 4 + e] = get(t, lane & 15, 16 * c + 4 * (lane >> 4) + e);
+        }
+}
+
+bool valid_desc(const lasr_model_desc* d) {
+    if (!d) return false;
+    auto m16 = [](int v) { return v > 0 && v % 16 == 0; };
+    if (!m16(d->feat) || !m16(d->hidden) || !m16(d->embed) || !m16(d->joint) || !m16(d->vocab)) return false;
+    if (d->enc_layers < 1 || d->enc_layers > 16 || d->pred_layers < 1 || d->pred_layers > 8) return false;
+    if (d->pred_cell != 0 && d->pred_cell != 1) return false;
+    if (d->n_fft != 1024 || d->win <= 0 || d->win > d->n_fft || d->hop <= 0) return false;
+    if (d->n_mels <= 0 || d->n_stack <= 0 || d->stride <= 0 || d->feat != d->n_mels * d->n_stack) return false;
+    if (d->feat > 64 * 32) return false;
+    if (d->n_buffer < 1 || d->n_window < 1 || d->chunk <= 0) return false;
+    if (d->max_streams < 1 || d->max_streams > 1024) return false;
+    if (d->max_iters_offline < 1 || d->max_iters_stream < 1) return false;
+    if (d->blank < 0 || d->blank >= d->vocab || d->bos < 0 || d->bos >= d->vocab) return false;
+    if (d->dtype != 0 || d->beam != 1) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------- launch helpers
+struct Ctx2 {};  // (placeholder to keep helper signatures short)
+
+template <class Epi, bool AROW>
+void launch_gemm(lasr_ctx* c, int n_groups, int m_tiles, const GemmArgs& g, const typename Epi::Args& ea) {
+    hipLaunchKernelGGL((k_gemm<Epi, NW, AROW>), dim3(n_groups, m_tiles), dim3(NW * 64), 0, c->stream, g, ea);
+}
+
+int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
+
+// encoder LSTM cell (layer l, step t): x from `xsrc` (fragment-major, K = I)
+void launch_enc_cell(lasr_ctx* c, int l, int t, const float* xsrc, int x_mt_total, float* ydst, int y_mt_total) {
+    const Cell& L = c->enc[l];
+    const int H = c->d.hidden;
+    GemmArgs g{};
+    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / 16; g.W[0] = L.Wx;
+    g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16; g.W[1] = L.Wh;
+    EpiLSTM<false, false>::Args ea{};
+    ea.bias = L.bias; ea.tab = nullptr; ea.token = nullptr; ea.flag = c->T_row_dev; ea.t = t;
+    ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
+    ea.y = ydst; ea.y_mt_total = y_mt_total; ea.y_mt_off = t * c->MT;
+    ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
+    launch_gemm<EpiLSTM<false, false>, false>(c, H / 16, c->MT, g, ea);
+}
+
+// one predictor pass (all layers) for rows with emit != 0; toggles pred_par
+void launch_predictor(lasr_ctx* c) {
+    const int H = c->d.hidden;
+    const int p = c->pred_par;
+    for (int l = 0; l < c->d.pred_layers; ++l) {
+        const Cell& L = c->pred[l];
+        GemmArgs g{};
+        if (l > 0) {
+            g.A[0] = c->pred_y[l - 1]; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = L.Wx;
+        }
+        g.A[1] = c->pred_h[p][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16; g.W[1] = L.Wh;
+        if (c->d.pred_cell == 1) {
+            EpiLSTM<true, true>::Args ea{};   // same Args type for all EpiLSTM instantiations
+            ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
+            ea.c = c->pred_c[l]; ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l];
+            ea.y = c->pred_y[l]; ea.y_mt_total = c->MT; ea.y_mt_off = 0;
+            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
+            if (l == 0) {
+                launch_gemm<EpiLSTM<true, true>, false>(c, H / 16, c->MT, g, ea);
+            } else {
+                EpiLSTM<true, false>::Args eb{};
+                memcpy(&eb, &ea, sizeof(eb));
+                launch_gemm<EpiLSTM<true, false>, false>(c, H / 16, c->MT, g, eb);
+            }
+        } else {
+            EpiNBRC<true>::Args ea{};
+            ea.bias = L.bias; ea.rbias = L.rbias; ea.tab = L.tab; ea.token = c->ds.token; ea.emit = c->ds.emit;
+            ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = c->pred_y[l];
+            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.MT = c->MT;
+            if (l == 0) {
+                launch_gemm<EpiNBRC<true>, false>(c, H / 16, c->MT, g, ea);
+            } else {
+                EpiNBRC<false>::Args eb{};
+                memcpy(&eb, &ea, sizeof(eb));
+                launch_gemm<EpiNBRC<false>, false>(c, H / 16, c->MT, g, eb);
+            }
+        }
+    }
+    c->pred_par ^= 1;
+}
+
+// pp (for emitting rows) and the joint activation ja = tanh(pe[t_idx] + pp) for all rows
+void launch_ppj(lasr_ctx* c) {
+    const int H = c->d.hidden, J = c->d.joint;
+    GemmArgs g{};
+    g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p;
+    EpiPPJ::Args ea{};
+    ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->ds.t_idx; ea.T_row = c->T_row_dev; ea.emit = c->ds.emit;
+    ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT;
+    launch_gemm<EpiPPJ, false>(c, J / 16, c->MT, g, ea);
+}
+
+void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
+    const int J = c->d.joint, V = c->d.vocab;
+    GemmArgs g{};
+    g.A[0] = c->ja; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = J / 16; g.W[0] = c->W2;
+    EpiLinear::Args ea{};
+    ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
+    ea.t_idx = gated ? c->ds.t_idx : nullptr; ea.T_row = c->T_row_dev; ea.M = c->M;
+    launch_gemm<EpiLinear, false>(c, V / 16, (n_rows + 15) / 16, g, ea);
+}
+
+// ---------------------------------------------------------------------------- command blocks
+size_t cmd_layout(lasr_ctx::Cmd& k, char* base, int M) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += (bytes + 15) & ~size_t(15); return p; };
+    k.T_row = (int*)take(sizeof(int) * M); k.what = (int*)take(sizeof(int) * M);
+    k.src_idx = (int*)take(sizeof(int) * M); k.feat_sel = (int*)take(sizeof(int) * M);
+    k.row_frames = (int*)take(sizeof(int) * M); k.token = (int*)take(sizeof(int) * M);
+    k.emit = (int*)take(sizeof(int) * M);
+    k.row_N = (long long*)take(sizeof(long long) * M); k.row_src_off = (long long*)take(sizeof(long long) * M);
+    k.row_feat_off = (long long*)take(sizeof(long long) * M);
+    return o;
+}
+
+// next command block: c->hc (host views) / c->dc (device views); zero-initialised
+int cmd_begin(lasr_ctx* c) {
+    if (c->cmd_inflight >= NCMD - 1) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->cmd_inflight = 0;
+    }
+    const int i = c->cmd_next;
+    c->cmd_next = (i + 1) % NCMD;
+    c->cmd_inflight++;
+    cmd_layout(c->hc, c->cmd_host + (size_t)i * c->cmd_bytes, c->M);
+    cmd_layout(c->dc, c->cmd_dev + (size_t)i * c->cmd_bytes, c->M);
+    memset(c->cmd_host + (size_t)i * c->cmd_bytes, 0, c->cmd_bytes);
+    return LASR_OK;
+}
+int cmd_commit(lasr_ctx* c) {
+    HIPCHK(c, hipMemcpyAsync((char*)c->dc.T_row, (char*)c->hc.T_row, c->cmd_bytes, hipMemcpyHostToDevice, c->stream));
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- buffers that grow
+int ensure_T(lasr_ctx* c, int T) {
+    if (T <= c->Tcap) return LASR_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int M = c->M, H = c->d.hidden, F = c->d.feat, J = c->d.joint;
+    int cap = std::max(T, std::max(2 * c->Tcap, c->d.n_buffer));
+    dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe);
+    dfree(c, c->ds.step_tok); dfree(c, c->ds.unfinished);
+    c->x0 = c->ybuf[0] = c->ybuf[1] = c->pe = nullptr; c->ds.step_tok = nullptr; c->ds.unfinished = nullptr;
+    RC(dalloc(c, &c->x0, (size_t)cap * M * F));
+    RC(dalloc(c, &c->ybuf[0], (size_t)cap * M * H));
+    RC(dalloc(c, &c->ybuf[1], (size_t)cap * M * H));
+    RC(dalloc(c, &c->pe, (size_t)cap * M * J));
+    const int mi = std::max(c->d.max_iters_offline, c->d.max_iters_stream);
+    c->tok_cap_alloc = cap * mi;
+    RC(dalloc(c, &c->ds.step_tok, (size_t)M * c->tok_cap_alloc));
+    c->n_iter_slots = cap * mi + 8;
+    RC(dalloc(c, &c->ds.unfinished, (size_t)c->n_iter_slots));
+    HIPCHK(c, hipMemset(c->ybuf[0], 0, (size_t)cap * M * H * 4));
+    HIPCHK(c, hipMemset(c->ybuf[1], 0, (size_t)cap * M * H * 4));
+    HIPCHK(c, hipMemset(c->x0, 0, (size_t)cap * M * F * 4));
+    // pinned result block: [0] unfinished, then ntok[M], sum_iters[M], n_ones[M], logp[M] (double), tokens
+    if (c->res_host) (void)hipHostFree(c->res_host);
+    c->res_bytes = sizeof(int) * (4 + 3 * (size_t)M) + sizeof(double) * M + sizeof(int) * (size_t)M * c->tok_cap_alloc + 64;
+    HIPCHK(c, hipHostMalloc((void**)&c->res_host, c->res_bytes));
+    c->Tcap = cap;
+    return LASR_OK;
+}
+
+template <class T>
+int ensure_buf(lasr_ctx* c, T** p, size_t* have, size_t need) {
+    if (need <= *have) return LASR_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(c, *p);
+    *p = nullptr;
+    need = need + need / 4;
+    RC(dalloc(c, p, need));
+    *have = need;
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- reset
+// applies c->dc.what (already committed) to the state; runs the predictor on BOS for rows with bit 2
+int apply_reset(lasr_ctx* c, bool any_pred) {
+    ResetArgs a{};
+    a.what = c->dc.what; a.M = c->M; a.MT = c->MT; a.H = c->d.hidden; a.Le = c->d.enc_layers; a.Lp = c->d.pred_layers;
+    a.pred_lstm = c->d.pred_cell; a.bos = c->d.bos;
+    for (int l = 0; l < a.Le; ++l) {
+        a.enc_h[l] = c->enc_h[c->enc_par][l]; a.enc_c[l] = c->enc_c[l];
+        a.enc_h0[l] = c->enc[l].h0; a.enc_c0[l] = c->enc[l].c0;
+    }
+    for (int l = 0; l < a.Lp; ++l) {
+        a.pred_h[l] = c->pred_h[c->pred_par][l]; a.pred_c[l] = c->d.pred_cell ? c->pred_c[l] : nullptr;
+        a.pred_h0[l] = c->pred[l].h0; a.pred_c0[l] = c->pred[l].c0;
+    }
+    a.token = c->ds.token; a.emit = c->ds.emit;
+    hipLaunchKernelGGL(k_reset_rows, dim3(grid1((size_t)c->M * c->d.hidden)), dim3(256), 0, c->stream, a);
+    if (any_pred) {
+        // T_row = 0 for every row: EpiPPJ then only refreshes pp (models.py:489: predictor(BOS))
+        HIPCHK(c, hipMemsetAsync(c->T_row_dev, 0, sizeof(int) * c->M, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->ds.t_idx, 0, sizeof(int) * c->M, c->stream));
+        launch_predictor(c);
+        launch_ppj(c);
+    }
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- encoder + decode
+// Encoder over T_max frames for rows with T_row > 0 (x0 already holds LayerNorm'ed features).
+void run_encoder(lasr_ctx* c, int T_max) {
+    const int L = c->d.enc_layers;
+    const int mt_total = c->Tcap * c->MT;
+    const int par0 = c->enc_par;
+    for (int l = 0; l < L; ++l) {
+        c->enc_par = par0;
+        const float* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
+        float* ydst = c->ybuf[l & 1];
+        for (int t = 0; t < T_max; ++t) {
+            launch_enc_cell(c, l, t, xsrc, mt_total, ydst, mt_total);
+            c->enc_par ^= 1;
+        }
+    }
+    // every layer toggled T_max times from par0; all end at the same parity
+    // encoder half of the joint for all frames: pe[t][r] = W1e * enc[t][r]
+    const int H = c->d.hidden, J = c->d.joint;
+    GemmArgs g{};
+    g.A[0] = c->ybuf[(L - 1) & 1]; g.a_mt_total[0] = mt_total; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1e;
+    EpiLinear::Args ea{};
+    ea.bias = nullptr; ea.out = c->pe; ea.ldo = J; ea.n_rows = T_max * c->M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
+    launch_gemm<EpiLinear, false>(c, J / 16, T_max * c->MT, g, ea);
+}
+
+// fix: every layer must start from the same parity and end on the same parity; with layer-major
+// order the h buffers of layer l toggle T_max times.  enc_h[par][l] is indexed by the parity at
+// launch time, so all layers share c->enc_par (restored to par0 per layer, final = par0 ^ (T_max&1)).
+
+// Greedy decode of the current step (T_row_dev, pe ready).  Blocks until done; fills host queues.
+int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows) {
+    const int M = c->M, J = c->d.joint, V = c->d.vocab;
+    DecState s = c->ds;
+    s.tok_cap = T_max * max_iters;
+    const int total_cap = T_max * max_iters;
+    hipLaunchKernelGGL(k_step_begin, dim3(grid1(std::max(M, c->n_iter_slots))), dim3(256), 0, c->stream, s, M,
+                       c->n_iter_slots, offline ? 1 : 0);
+    hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->ds.t_idx,
+                       c->T_row_dev, c->ja, J, M, c->MT);
+    int iter = 0;
+    int group = offline ? std::min(total_cap, T_max + 16) : std::min(total_cap, T_max + 2);
+    const int next_group = offline ? 32 : 2;
+    int* res = c->res_host;
+    while (iter < total_cap) {
+        const int n = std::min(group, total_cap - iter);
+        for (int q = 0; q < n; ++q, ++iter) {
+            launch_logits(c, c->logits, M, true);
+            hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, max_iters,
+                               c->T_row_dev, s, iter, (float*)nullptr, (int*)nullptr);
+            launch_predictor(c);
+            launch_ppj(c);
+        }
+        HIPCHK(c, hipMemcpyAsync(res, c->ds.unfinished + (iter - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->cmd_inflight = 0;
+        if (res[0] == 0) break;
+        group = next_group;
+    }
+    c->stats.decode_iters = iter;
+    // results
+    int* ntok = res + 4;
+    int* sum_iters = ntok + M;
+    int* n_ones = sum_iters + M;
+    double* logp = (double*)(((uintptr_t)(n_ones + M) + 15) & ~uintptr_t(15));
+    int* toks = (int*)(logp + M);
+    HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(toks, c->ds.step_tok, sizeof(int) * (size_t)M * s.tok_cap, hipMemcpyDeviceToHost, c->stream));
+    if (offline) {
+        HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(n_ones, c->ds.n_ones, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(logp, c->ds.logp_sum, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r : rows) {
+        const int n = std::min(ntok[r], s.tok_cap);
+        for (int q = 0; q < n; ++q) c->queue[r].push_back(toks[(size_t)r * s.tok_cap + q]);
+        if (offline) {
+            c->neg_logp[r] = -logp[r];
+            // alignment_score = (sum(iters) - #frames with 1 iter) / (sum(iters) + 1e-4)  (models.py:447-453)
+            c->align[r] = ((double)sum_iters[r] - (double)n_ones[r]) / ((double)sum_iters[r] + 1e-4);
+        }
+    }
+    return LASR_OK;
+}
+
+void rec(lasr_ctx* c, int i) {
+    if (c->profiling && c->ev_ok) (void)hipEventRecord(c->ev[i], c->stream);
+}
+void collect_stats(lasr_ctx* c, int T) {
+    c->stats.frames = T;
+    if (!(c->profiling && c->ev_ok)) return;
+    float a = 0, b = 0, d = 0;
+    (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
+    c->stats.frontend_ms = a; c->stats.encoder_ms = b; c->stats.decode_ms = d;
+    c->stats.cell_ms = b; c->stats.cell_launches = T * c->d.enc_layers;
+}
+
+int check_slots(lasr_ctx* c, const int* slots, int n, bool need_open) {
+    if (!slots || n < 0 || n > c->d.max_streams) return fail(c, LASR_EINVAL, "bad slot list (n=%d)", n);
+    std::vector<char> seen(c->M, 0);
+    for (int i = 0; i < n; ++i) {
+        const int s = slots[i];
+        if (s < 0 || s >= c->d.max_streams) return fail(c, LASR_EINVAL, "slot %d out of range", s);
+        if (seen[s]) return fail(c, LASR_EINVAL, "slot %d listed twice", s);
+        seen[s] = 1;
+        if (need_open && !c->open_[s]) return fail(c, LASR_ESTATE, "slot %d is not open", s);
+    }
+    return LASR_OK;
+}
+
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
+// HTK mel filterbank (torchaudio 0.6.0 create_fb_matrix semantics), sparse, bin-ascending
+void build_fb(const lasr_model_desc& d, std::vector<int>& start, std::vector<int>& off, std::vector<float>& w) {
+    const int nf = d.n_fft / 2 + 1, nm = d.n_mels;
+    const double fmax = d.sample_rate / 2;
+    auto mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
+    std::vector<double> fpts(nm + 2);
+    const double m0 = mel(0.0), m1 = mel(fmax);
+    for (int i = 0; i < nm + 2; ++i) {
+        const double m = m0 + (m1 - m0) * i / (nm + 1);
+        fpts[i] = 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
+    }
+    start.assign(nm, 0); off.assign(nm + 1, 0); w.clear();
+    for (int m = 0; m < nm; ++m) {
+        int first = -1;
+        std::vector<float> vals;
+        for (int k = 0; k < nf; ++k) {
+            const double f = fmax * k / (nf - 1);
+            const double down = (f - fpts[m]) / (fpts[m + 1] - fpts[m]);
+            const double up = (fpts[m + 2] - f) / (fpts[m + 2] - fpts[m + 1]);
+            const double v = std::max(0.0, std::min(down, up));
+            if (v > 0.0) {
+                if (first < 0) first = k;
+                while ((int)vals.size() < k - first) vals.push_back(0.f);
+                vals.push_back((float)v);
+            }
+        }
+        start[m] = first < 0 ? 0 : first;
+        off[m] = (int)w.size();
+        w.insert(w.end(), vals.begin(), vals.end());
+    }
+    off[nm] = (int)w.size();
+}
+
+// ---------------------------------------------------------------------------- weight loading
+struct Reader {
+    const float* p; size_t left;
+    const float* take(size_t n) {
+        if (n > left) return nullptr;
+        const float* q = p; p += n; left -= n; return q;
+    }
+};
+
+int fold_bn(lasr_ctx* c, Reader& rd, int H, float** s_dev, float** t_dev) {
+    const float* w = rd.take(H); const float* b = rd.take(H); const float* mean = rd.take(H); const float* var = rd.take(H);
+    if (!var) return fail(c, LASR_EINVAL, "weight blob too short (bn)");
+    std::vector<float> s(H), t(H);
+    for (int i = 0; i < H; ++i) {
+        const double sc = (double)w[i] / std::sqrt((double)var[i] + 1e-5);   // BatchNorm1d eps
+        s[i] = (float)sc;
+        t[i] = (float)((double)b[i] - (double)mean[i] * sc);
+    }
+    RC(upload(c, s_dev, s.data(), H));
+    RC(upload(c, t_dev, t.data(), H));
+    return LASR_OK;
+}
+
+// LSTM layer in torch layout: W_ih [4H,I], W_hh [4H,H]; packs tiles (jb, gate)
+int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, std::vector<float>* keep_wih, std::vector<float>* keep_bias) {
+    L.I = I;
+    const float* wih = rd.take((size_t)4 * H * I); const float* whh = rd.take((size_t)4 * H * H);
+    const float* bih = rd.take(4 * H); const float* bhh = rd.take(4 * H);
+    if (!bhh) return fail(c, LASR_EINVAL, "weight blob too short (lstm)");
+    std::vector<float> pk;
+    pack_tiles(pk, (H / 16) * 4, I / 16, [&](int t, int ui, int k) { return wih[((size_t)(t & 3) * H + 16 * (t >> 2) + ui) * I + k]; });
+    RC(upload(c, &L.Wx, pk.data(), pk.size()));
+    pack_tiles(pk, (H / 16) * 4, H / 16, [&](int t, int ui, int k) { return whh[((size_t)(t & 3) * H + 16 * (t >> 2) + ui) * H + k]; });
+    RC(upload(c, &L.Wh, pk.data(), pk.size()));
+    std::vector<float> bias(4 * H);
+    for (int i = 0; i < 4 * H; ++i) bias[i] = bih[i] + bhh[i];
+    RC(upload(c, &L.bias, bias.data(), bias.size()));
+    if (keep_wih) keep_wih->assign(wih, wih + (size_t)4 * H * I);
+    if (keep_bias) *keep_bias = bias;
+    return LASR_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+void lasr_default_desc(lasr_model_desc* d) {
+    if (!d) return;
+    memset(d, 0, sizeof(*d));
+    d->feat = 1280; d->hidden = 1024; d->enc_layers = 4; d->pred_layers = 2; d->pred_cell = 0;
+    d->embed = 512; d->joint = 1024; d->vocab = 2048; d->blank = 0; d->bos = 2;
+    d->n_fft = 1024; d->win = 400; d->hop = 160; d->n_mels = 128; d->n_stack = 10; d->stride = 8;
+    d->n_buffer = 2; d->n_window = 3; d->chunk = 1280; d->sample_rate = 16000; d->dtype = 0;
+    d->max_streams = 64; d->max_iters_offline = 3; d->max_iters_stream = 10; d->beam = 1;
+}
+
+size_t lasr_weight_count(const lasr_model_desc* d) {
+    if (!valid_desc(d)) return 0;
+    const size_t F = d->feat, H = d->hidden, E = d->embed, V = d->vocab, J = d->joint;
+    size_t n = 2 * F;
+    for (int l = 0; l < d->enc_layers; ++l) {
+        const size_t I = l == 0 ? F : H;
+        n += 2 * H + 4 * H + 4 * H * I + 4 * H * H + 8 * H;
+    }
+    n += V * E;
+    if (E != H) n += H * E + H;
+    for (int l = 0; l < d->pred_layers; ++l) {
+        if (d->pred_cell == 1) n += 2 * H + 4 * H + 4 * H * H + 4 * H * H + 8 * H;
+        else n += H + 4 * H + 3 * H * H + 3 * H * H + 6 * H;
+    }
+    n += J * 2 * H + J + V * J + V;
+    return n;
+}
+
+void lasr_destroy(lasr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->dev_allocs) (void)hipFree(p);
+    if (c->cmd_host) (void)hipHostFree(c->cmd_host);
+    if (c->res_host) (void)hipHostFree(c->res_host);
+    for (void* p : c->host_allocs) (void)hipHostFree(p);
+    if (c->ev_ok)
+        for (auto& e : c->ev) (void)hipEventDestroy(e);
+    delete c;
+}
+
+const char* lasr_last_error(const lasr_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
+    const lasr_model_desc& d = c->d;
+    const int F = d.feat, H = d.hidden, E = d.embed, V = d.vocab, J = d.joint;
+    c->M = (d.max_streams + 15) / 16 * 16;
+    c->MT = c->M / 16;
+    const int M = c->M;
+    c->G_pred = d.pred_cell ? 4 : 3;
+    Reader rd{weights, n_weights};
+
+    // ---- front-end constants
+    {
+        std::vector<float> win(d.n_fft, 0.f);
+        const int off = (d.n_fft - d.win) / 2;
+        for (int i = 0; i < d.win; ++i) win[off + i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / d.win));  // periodic Hann
+        RC(upload(c, &c->window, win.data(), win.size()));
+        std::vector<float2> t5(512), t10(513);
+        for (int i = 0; i < 512; ++i) t5[i] = float2{(float)std::cos(2.0 * M_PI * i / 512), (float)-std::sin(2.0 * M_PI * i / 512)};
+        for (int i = 0; i <= 512; ++i) t10[i] = float2{(float)std::cos(2.0 * M_PI * i / 1024), (float)-std::sin(2.0 * M_PI * i / 1024)};
+        RC(upload(c, &c->tw512, t5.data(), t5.size()));
+        RC(upload(c, &c->tw1024, t10.data(), t10.size()));
+        std::vector<int> st, of; std::vector<float> w;
+        build_fb(d, st, of, w);
+        RC(upload(c, &c->fb_start, st.data(), st.size()));
+        RC(upload(c, &c->fb_off, of.data(), of.size()));
+        RC(upload(c, &c->fb_w, w.data(), w.size()));
+    }
+    // ---- encoder
+    {
+        const float* lw = rd.take(F); const float* lb = rd.take(F);
+        if (!lb) return fail(c, LASR_EINVAL, "weight blob too short");
+        RC(upload(c, &c->ln_w, lw, F)); RC(upload(c, &c->ln_b, lb, F));
+    }
+    c->enc.resize(d.enc_layers);
+    for (int l = 0; l < d.enc_layers; ++l) {
+        Cell& L = c->enc[l];
+        const float* hs = rd.take(2 * H);
+        if (!hs) return fail(c, LASR_EINVAL, "weight blob too short");
+        RC(upload(c, &L.h0, hs, H)); RC(upload(c, &L.c0, hs + H, H));
+        RC(fold_bn(c, rd, H, &L.bn_s, &L.bn_t));
+        RC(load_lstm(c, rd, L, l == 0 ? F : H, H, nullptr, nullptr));
+    }
+    // ---- predictor
+    const float* embed = rd.take((size_t)V * E);
+    if (!embed) return fail(c, LASR_EINVAL, "weight blob too short");
+    const float *ffn_w = nullptr, *ffn_b = nullptr;
+    if (E != H) {
+        ffn_w = rd.take((size_t)H * E); ffn_b = rd.take(H);
+        if (!ffn_b) return fail(c, LASR_EINVAL, "weight blob too short");
+    }
+    c->pred.resize(d.pred_layers);
+    std::vector<float> in0_w;      // layer-0 input weights as [G*H][H] (n-major) for the table build
+    std::vector<float> in0_b;
+    for (int l = 0; l < d.pred_layers; ++l) {
+        Cell& L = c->pred[l];
+        L.I = H;
+        const int S = d.pred_cell ? 2 : 1;
+        const float* hs = rd.take((size_t)S * H);
+        if (!hs) return fail(c, LASR_EINVAL, "weight blob too short");
+        RC(upload(c, &L.h0, hs, H));
+        if (S == 2) RC(upload(c, &L.c0, hs + H, H));
+        RC(fold_bn(c, rd, H, &L.bn_s, &L.bn_t));
+        if (d.pred_cell == 1) {
+            RC(load_lstm(c, rd, L, H, H, l == 0 ? &in0_w : nullptr, l == 0 ? &in0_b : nullptr));
+        } else {
+            const float* kx = rd.take((size_t)H * 3 * H); const float* kh = rd.take((size_t)H * 3 * H);
+            const float* b = rd.take(3 * H); const float* rb = rd.take(3 * H);
+            if (!rb) return fail(c, LASR_EINVAL, "weight blob too short (nbrc)");
+            std::vector<float> pk;
+            // haste layout [K][3H], gates z,r,g; tiles (jb, slot)
+            pack_tiles(pk, (H / 16) * 3, H / 16, [&](int t, int ui, int k) { return kx[(size_t)k * 3 * H + (size_t)(t % 3) * H + 16 * (t / 3) + ui]; });
+            RC(upload(c, &L.Wx, pk.data(), pk.size()));
+            pack_tiles(pk, (H / 16) * 3, H / 16, [&](int t, int ui, int k) { return kh[(size_t)k * 3 * H + (size_t)(t % 3) * H + 16 * (t / 3) + ui]; });
+            RC(upload(c, &L.Wh, pk.data(), pk.size()));
+            RC(upload(c, &L.bias, b, 3 * H)); RC(upload(c, &L.rbias, rb, 3 * H));
+            if (l == 0) {
+                in0_w.resize((size_t)3 * H * H);
+                for (int n = 0; n < 3 * H; ++n)
+                    for (int k = 0; k < H; ++k) in0_w[(size_t)n * H + k] = kx[(size_t)k * 3 * H + n];
+                in0_b.assign(b, b + 3 * H);
+            }
+        }
+    }
+    // ---- joint
+    {
+        const float* w0 = rd.take((size_t)J * 2 * H); const float* b0 = rd.take(J);
+        const float* w2 = rd.take((size_t)V * J); const float* b2 = rd.take(V);
+        if (!b2) return fail(c, LASR_EINVAL, "weight blob too short (joint)");
+        if (rd.left != 0) return fail(c, LASR_EINVAL, "weight blob has %zu extra floats", rd.left);
+        std::vector<float> pk;
+        pack_tiles(pk, J / 16, H / 16, [&](int t, int ui, int k) { return w0[(size_t)(16 * t + ui) * 2 * H + k]; });          // pred half (cat order pred, enc: models.py:136)
+        RC(upload(c, &c->W1p, pk.data(), pk.size()));
+        pack_tiles(pk, J / 16, H / 16, [&](int t, int ui, int k) { return w0[(size_t)(16 * t + ui) * 2 * H + H + k]; });
+        RC(upload(c, &c->W1e, pk.data(), pk.size()));
+        pack_tiles(pk, V / 16, J / 16, [&](int t, int ui, int k) { return w2[(size_t)(16 * t + ui) * J + k]; });
+        RC(upload(c, &c->W2, pk.data(), pk.size()));
+        RC(upload(c, &c->b1, b0, J)); RC(upload(c, &c->b2, b2, V));
+    }
+
+    // ---- state + work buffers
+    for (int p = 0; p < 2; ++p) { c->enc_h[p].resize(d.enc_layers); c->pred_h[p].resize(d.pred_layers); }
+    c->enc_c.resize(d.enc_layers); c->pred_c.assign(d.pred_layers, nullptr); c->pred_y.resize(d.pred_layers);
+    for (int l = 0; l < d.enc_layers; ++l) {
+        for (int p = 0; p < 2; ++p) { RC(dalloc(c, &c->enc_h[p][l], (size_t)M * H)); HIPCHK(c, hipMemset(c->enc_h[p][l], 0, (size_t)M * H * 4)); }
+        RC(dalloc(c, &c->enc_c[l], (size_t)M * H)); HIPCHK(c, hipMemset(c->enc_c[l], 0, (size_t)M * H * 4));
+    }
+    for (int l = 0; l < d.pred_layers; ++l) {
+        for (int p = 0; p < 2; ++p) { RC(dalloc(c, &c->pred_h[p][l], (size_t)M * H)); HIPCHK(c, hipMemset(c->pred_h[p][l], 0, (size_t)M * H * 4)); }
+        if (d.pred_cell) { RC(dalloc(c, &c->pred_c[l], (size_t)M * H)); HIPCHK(c, hipMemset(c->pred_c[l], 0, (size_t)M * H * 4)); }
+        RC(dalloc(c, &c->pred_y[l], (size_t)M * H)); HIPCHK(c, hipMemset(c->pred_y[l], 0, (size_t)M * H * 4));
+    }
+    RC(dalloc(c, &c->pp, (size_t)M * J)); HIPCHK(c, hipMemset(c->pp, 0, (size_t)M * J * 4));
+    RC(dalloc(c, &c->ja, (size_t)M * J)); HIPCHK(c, hipMemset(c->ja, 0, (size_t)M * J * 4));
+    RC(dalloc(c, &c->logits, (size_t)M * V));
+    RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, M));
+    RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.step_ntok, M)); RC(dalloc(c, &c->ds.logp_sum, M));
+    RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->T_row_dev, M));
+    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.step_ntok, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev})
+        HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
+    HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
+    RC(dalloc(c, &c->win, (size_t)M * d.n_window * d.chunk)); HIPCHK(c, hipMemset(c->win, 0, (size_t)M * d.n_window * d.chunk * 4));
+    RC(dalloc(c, &c->ring_pos, M)); HIPCHK(c, hipMemset(c->ring_pos, 0, sizeof(int) * M));
+    RC(dalloc(c, &c->pend, (size_t)M * d.n_buffer * d.n_stack * d.n_mels));
+    HIPCHK(c, hipMemset(c->pend, 0, (size_t)M * d.n_buffer * d.n_stack * d.n_mels * 4));
+
+    lasr_ctx::Cmd tmp;
+    c->cmd_bytes = cmd_layout(tmp, nullptr, M);
+    HIPCHK(c, hipHostMalloc((void**)&c->cmd_host, c->cmd_bytes * NCMD));
+    RC(dalloc(c, &c->cmd_dev, c->cmd_bytes * NCMD));
+    RC(ensure_T(c, std::max(d.n_buffer, 4)));
+
+    // ---- predictor input tables (one-time, on device):  EF = ffn(embed);  tab = EF * Wx0^T + b
+    {
+        float* emb_dev = nullptr; float* EF = nullptr;
+        RC(upload(c, &emb_dev, embed, (size_t)V * E));
+        if (E != H) {
+            std::vector<float> pk; float* wf = nullptr; float* bf = nullptr;
+            pack_tiles(pk, H / 16, E / 16, [&](int t, int ui, int k) { return ffn_w[(size_t)(16 * t + ui) * E + k]; });
+            RC(upload(c, &wf, pk.data(), pk.size())); RC(upload(c, &bf, ffn_b, H));
+            RC(dalloc(c, &EF, (size_t)V * H));
+            GemmArgs g{}; g.A[0] = emb_dev; g.a_mt_total[0] = E; g.a_mt_off[0] = 0; g.KC[0] = E / 16; g.W[0] = wf; g.a_rows = V;
+            EpiLinear::Args ea{}; ea.bias = bf; ea.out = EF; ea.ldo = H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
+            launch_gemm<EpiLinear, true>(c, H / 16, V / 16, g, ea);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            dfree(c, wf); dfree(c, bf);
+        } else {
+            EF = emb_dev; emb_dev = nullptr;
+        }
+        const int G = c->G_pred;
+        std::vector<float> pk; float* wt = nullptr; float* bt = nullptr;
+        pack_tiles(pk, G * H / 16, H / 16, [&](int t, int ui, int k) { return in0_w[(size_t)(16 * t + ui) * H + k]; });
+        RC(upload(c, &wt, pk.data(), pk.size())); RC(upload(c, &bt, in0_b.data(), in0_b.size()));
+        RC(dalloc(c, &c->pred[0].tab, (size_t)V * G * H));
+        GemmArgs g{}; g.A[0] = EF; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = wt; g.a_rows = V;
+        EpiLinear::Args ea{}; ea.bias = bt; ea.out = c->pred[0].tab; ea.ldo = G * H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
+        launch_gemm<EpiLinear, true>(c, G * H / 16, V / 16, g, ea);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        dfree(c, wt); dfree(c, bt); dfree(c, EF); dfree(c, emb_dev);
+    }
+
+    c->open_.assign(M, 0); c->n_chunks.assign(M, 0); c->n_pend.assign(M, 0);
+    c->queue.assign(M, {}); c->neg_logp.assign(M, 0.0); c->align.assign(M, 0.0);
+    c->ev_ok = true;
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) c->ev_ok = false;
+    return LASR_OK;
+}
+
+int lasr_create(int device, const lasr_model_desc* d, const float* weights, size_t n_weights, void* hip_stream,
+                lasr_ctx** out) {
+    if (!out) return LASR_EINVAL;
+    *out = nullptr;
+    lasr_ctx* c = new lasr_ctx();
+    if (!valid_desc(d)) { int rc = fail(c, LASR_EINVAL, "invalid model description"); *out = c; return rc; }
+    c->d = *d;
+    c->device = device;
+    *out = c;   // returned even on failure so that lasr_last_error() works; caller destroys it
+    if (!weights || n_weights != lasr_weight_count(d))
+        return fail(c, LASR_EINVAL, "weight blob has %zu floats, expected %zu", n_weights, lasr_weight_count(d));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, LASR_EHIP, "no HIP device available");
+    HIPCHK(c, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(c, LASR_EHIP, "device %d is %s; liblasr_hip is built for gfx950 only", device, prop.gcnArchName);
+    c->stream = (hipStream_t)hip_stream;
+    return create_impl(c, weights, n_weights);
+}
+
+// ---------------------------------------------------------------------------- slots
+int lasr_stream_open(lasr_ctx* c, int* slot) {
+    if (!c || !slot) return LASR_EINVAL;
+    for (int s = 0; s < c->d.max_streams; ++s)
+        if (!c->open_[s]) {
+            c->open_[s] = 1;
+            *slot = s;
+            return lasr_stream_reset(c, s, 1 | 2 | 4 | 8);
+        }
+    return fail(c, LASR_EFULL, "all %d stream slots are open", c->d.max_streams);
+}
+
+int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
+    if (!c) return LASR_EINVAL;
+    if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); }
+    if (what & 3) {
+        RC(cmd_begin(c));
+        c->hc.what[slot] = what & 3;
+        RC(cmd_commit(c));
+        RC(apply_reset(c, (what & 2) != 0));
+    }
+    return LASR_OK;
+}
+
+int lasr_stream_close(lasr_ctx* c, int slot) {
+    if (!c) return LASR_EINVAL;
+    if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
+    c->open_[slot] = 0;
+    c->queue[slot].clear();
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- streaming
+int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
+    if (!c) return LASR_EINVAL;
+    RC(check_slots(c, slots, n, true));
+    if (n == 0) return LASR_OK;
+    if (!pcm) return fail(c, LASR_EINVAL, "pcm is null");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int CH = c->d.chunk;
+    const float* src = pcm;
+    if (!is_device_ptr(pcm)) {
+        RC(ensure_buf(c, &c->stage_pcm, &c->stage_pcm_floats, (size_t)c->M * CH));
+        // pageable host memory: hipMemcpyAsync stages it synchronously, so the caller's buffer is free on return
+        HIPCHK(c, hipMemcpyAsync(c->stage_pcm, pcm, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream));
+        src = c->stage_pcm;
+    }
+    RC(cmd_begin(c));
+    for (int r = 0; r < c->M; ++r) c->hc.src_idx[r] = -1;
+    for (int i = 0; i < n; ++i) c->hc.src_idx[slots[i]] = i;
+    RC(cmd_commit(c));
+    hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, c->dc.src_idx, c->win, c->ring_pos, CH, c->d.n_window);
+    for (int i = 0; i < n; ++i) c->n_chunks[slots[i]]++;
+    if (!is_device_ptr(pcm)) {
+        // the staging buffer is reused by the next push: keep ordering simple
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->cmd_inflight = 0;
+    }
+    return LASR_OK;
+}
+
+int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
+    if (!c) return LASR_EINVAL;
+    if (n_ran) *n_ran = 0;
+    RC(check_slots(c, slots, n, true));
+    HIPCHK(c, hipSetDevice(c->device));
+    const lasr_model_desc& d = c->d;
+    // window geometry (api-server.py:95-102 + TransformTime + StreamPostprocess)
+    const long long N = (long long)d.n_window * d.chunk;
+    const int T = 1 + (int)(N / d.hop);
+    const int a0 = T / 3 + 1;
+    const int nf = std::min(d.n_stack, T - a0);
+    if (nf < d.n_stack) return fail(c, LASR_EINVAL, "chunk of %d samples is too short: window yields %d < n_stack frames", d.chunk, nf);
+    if (N <= d.n_fft / 2) return fail(c, LASR_EINVAL, "window shorter than the reflect padding");
+    RC(cmd_begin(c));
+    std::vector<int> model_rows;
+    bool any_feat = false;
+    for (int r = 0; r < c->M; ++r) c->hc.feat_sel[r] = -1;
+    for (int i = 0; i < n; ++i) {
+        const int s = slots[i];
+        if (c->n_chunks[s] < d.n_window) continue;          // window not full: the servicer does not call the pipeline
+        c->hc.feat_sel[s] = c->n_pend[s] * d.n_stack;
+        any_feat = true;
+        if (++c->n_pend[s] == d.n_buffer) {                  // Buffer.encodes: emit when n_buffer collected
+            c->n_pend[s] = 0;
+            c->hc.T_row[s] = d.n_buffer;
+            model_rows.push_back(s);
+        }
+    }
+    RC(cmd_commit(c));
+    rec(c, 0);
+    if (any_feat) {
+        MelArgs m{};
+        m.window = c->window; m.tw512 = c->tw512; m.tw1024 = c->tw1024; m.fb_start = c->fb_start; m.fb_off = c->fb_off;
+        m.fb_w = c->fb_w; m.n_mels = d.n_mels; m.hop = d.hop; m.pcm = c->win; m.N = N; m.stream = 1;
+        m.ring_head = c->ring_pos; m.chunk = d.chunk; m.n_window = d.n_window; m.row_sel = c->dc.feat_sel; m.frame0 = a0;
+        m.frames_per_row = d.n_stack; m.out = c->pend; m.out_frames = d.n_buffer * d.n_stack;
+        m.row_N = nullptr; m.row_src_off = nullptr; m.row_frames = nullptr;
+        hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), 0, c->stream, m);
+    }
+    if (model_rows.empty()) {
+        HIPCHK(c, hipGetLastError());
+        return LASR_OK;
+    }
+    const int Tm = d.n_buffer;
+    RC(ensure_T(c, Tm));
+    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    {
+        StackLnArgs a{};
+        a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
+        a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
+        a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = Tm;
+        hipLaunchKernelGGL((k_stack_ln<32>), dim3((Tm + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    }
+    rec(c, 1);
+    run_encoder(c, Tm);
+    rec(c, 2);
+    RC(run_decode(c, Tm, d.max_iters_stream, false, model_rows));
+    rec(c, 3);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    collect_stats(c, Tm);
+    if (n_ran) *n_ran = (int)model_rows.size();
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- offline
+static int transcribe_common(lasr_ctx* c, const int* slots, int n, int T_max) {
+    // cmd block (T_row, what) already filled + committed by the caller; x0 holds the features
+    const lasr_model_desc& d = c->d;
+    std::vector<int> rows(slots, slots + n);
+    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    rec(c, 1);
+    run_encoder(c, T_max);
+    rec(c, 2);
+    RC(run_decode(c, T_max, d.max_iters_offline, true, rows));
+    rec(c, 3);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    collect_stats(c, T_max);
+    return LASR_OK;
+}
+
+int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, const int64_t* n_samples) {
+    if (!c) return LASR_EINVAL;
+    RC(check_slots(c, slots, n, true));
+    if (n == 0) return LASR_OK;
+    if (!pcm || !n_samples) return fail(c, LASR_EINVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const lasr_model_desc& d = c->d;
+    long long total = 0; int T_max = 0; int Tmel_max = 0;
+    std::vector<int> Tp(n), Tm(n);
+    for (int i = 0; i < n; ++i) {
+        if (n_samples[i] <= d.n_fft / 2) return fail(c, LASR_EINVAL, "utterance %d too short (%lld samples)", i, (long long)n_samples[i]);
+        Tm[i] = 1 + (int)(n_samples[i] / d.hop);
+        if (Tm[i] < d.n_stack) return fail(c, LASR_EINVAL, "utterance %d yields no stacked frame", i);
+        Tp[i] = (Tm[i] - d.n_stack) / d.stride + 1;
+        T_max = std::max(T_max, Tp[i]); Tmel_max = std::max(Tmel_max, Tm[i]);
+        total += n_samples[i];
+    }
+    RC(ensure_T(c, T_max));
+    const float* src = pcm;
+    if (!is_device_ptr(pcm)) {
+        RC(ensure_buf(c, &c->stage_pcm, &c->stage_pcm_floats, (size_t)total));
+        HIPCHK(c, hipMemcpyAsync(c->stage_pcm, pcm, sizeof(float) * (size_t)total, hipMemcpyHostToDevice, c->stream));
+        src = c->stage_pcm;
+    }
+    RC(ensure_buf(c, &c->lm_buf, &c->lm_floats, (size_t)c->M * Tmel_max * d.n_mels));
+    RC(cmd_begin(c));
+    long long off = 0;
+    for (int i = 0; i < n; ++i) {
+        const int s = slots[i];
+        c->hc.T_row[s] = Tp[i]; c->hc.what[s] = 3; c->hc.row_frames[s] = Tm[i];
+        c->hc.row_N[s] = n_samples[i]; c->hc.row_src_off[s] = off;
+        off += n_samples[i];
+        c->queue[s].clear();
+    }
+    RC(cmd_commit(c));
+    RC(apply_reset(c, true));
+    rec(c, 0);
+    MelArgs m{};
+    m.window = c->window; m.tw512 = c->tw512; m.tw1024 = c->tw1024; m.fb_start = c->fb_start; m.fb_off = c->fb_off;
+    m.fb_w = c->fb_w; m.n_mels = d.n_mels; m.hop = d.hop; m.pcm = src; m.N = 0; m.stream = 0;
+    m.ring_head = nullptr; m.chunk = d.chunk; m.n_window = d.n_window; m.row_sel = nullptr; m.frame0 = 0;
+    m.frames_per_row = Tmel_max; m.out = c->lm_buf; m.out_frames = Tmel_max;
+    m.row_N = c->dc.row_N; m.row_src_off = c->dc.row_src_off; m.row_frames = c->dc.row_frames;
+    hipLaunchKernelGGL(k_logmel, dim3((Tmel_max + 3) / 4, c->M), dim3(256), 0, c->stream, m);
+    StackLnArgs a{};
+    a.src = c->lm_buf; a.mode = 0; a.src_frames = Tmel_max; a.frame_step = d.stride; a.row_off = nullptr;
+    a.T_row = c->dc.T_row; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
+    a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = T_max;
+    hipLaunchKernelGGL((k_stack_ln<32>), dim3((T_max + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    return transcribe_common(c, slots, n, T_max);
+}
+
+int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* feats, const int32_t* n_frames) {
+    if (!c) return LASR_EINVAL;
+    RC(check_slots(c, slots, n, true));
+    if (n == 0) return LASR_OK;
+    if (!feats || !n_frames) return fail(c, LASR_EINVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const lasr_model_desc& d = c->d;
+    long long total = 0; int T_max = 0;
+    for (int i = 0; i < n; ++i) {
+        if (n_frames[i] < 1) return fail(c, LASR_EINVAL, "utterance %d has no frames", i);
+        T_max = std::max(T_max, (int)n_frames[i]); total += n_frames[i];
+    }
+    RC(ensure_T(c, T_max));
+    const float* src = feats;
+    if (!is_device_ptr(feats)) {
+        RC(ensure_buf(c, &c->feat_stage, &c->feat_stage_floats, (size_t)total * d.feat));
+        HIPCHK(c, hipMemcpyAsync(c->feat_stage, feats, sizeof(float) * (size_t)total * d.feat, hipMemcpyHostToDevice, c->stream));
+        src = c->feat_stage;
+    }
+    RC(cmd_begin(c));
+    long long off = 0;
+    for (int i = 0; i < n; ++i) {
+        const int s = slots[i];
+        c->hc.T_row[s] = n_frames[i]; c->hc.what[s] = 3; c->hc.row_feat_off[s] = off;
+        off += n_frames[i];
+        c->queue[s].clear();
+    }
+    RC(cmd_commit(c));
+    RC(apply_reset(c, true));
+    rec(c, 0);
+    StackLnArgs a{};
+    a.src = src; a.mode = 1; a.src_frames = 0; a.frame_step = 0; a.row_off = c->dc.row_feat_off;
+    a.T_row = c->dc.T_row; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
+    a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = T_max;
+    hipLaunchKernelGGL((k_stack_ln<32>), dim3((T_max + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    return transcribe_common(c, slots, n, T_max);
+}
+
+int lasr_fetch(lasr_ctx* c, int slot, int32_t* tokens, int cap, int* n_new, double* neg_logp, double* align) {
+    if (!c || !n_new) return LASR_EINVAL;
+    if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
+    auto& q = c->queue[slot];
+    if ((int)q.size() > cap || (!tokens && !q.empty())) {
+        *n_new = (int)q.size();
+        return fail(c, LASR_EFULL, "token buffer too small: need %d", (int)q.size());
+    }
+    if (!q.empty()) memcpy(tokens, q.data(), sizeof(int32_t) * q.size());
+    *n_new = (int)q.size();
+    q.clear();
+    if (neg_logp) *neg_logp = c->neg_logp[slot];
+    if (align) *align = c->align[slot];
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- op-level entry points
+int lasr_logmel(lasr_ctx* c, const float* pcm, int B, int64_t N, float* logmel) {
+    if (!c || !pcm || !logmel || B < 1 || B > c->M) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    if (N <= c->d.n_fft / 2) return fail(c, LASR_EINVAL, "signal shorter than the reflect padding");
+    HIPCHK(c, hipSetDevice(c->device));
+    const lasr_model_desc& d = c->d;
+    const int T = 1 + (int)(N / d.hop);
+    MelArgs m{};
+    m.window = c->window; m.tw512 = c->tw512; m.tw1024 = c->tw1024; m.fb_start = c->fb_start; m.fb_off = c->fb_off;
+    m.fb_w = c->fb_w; m.n_mels = d.n_mels; m.hop = d.hop; m.pcm = pcm; m.N = N; m.stream = 0;
+    m.ring_head = nullptr; m.chunk = d.chunk; m.n_window = d.n_window; m.row_sel = nullptr; m.frame0 = 0;
+    m.frames_per_row = T; m.out = logmel; m.out_frames = T;
+    m.row_N = nullptr; m.row_src_off = nullptr; m.row_frames = nullptr;
+    hipLaunchKernelGGL(k_logmel, dim3((T + 3) / 4, B), dim3(256), 0, c->stream, m);
+    HIPCHK(c, hipGetLastError());
+    return LASR_OK;
+}
+
+int lasr_stack(lasr_ctx* c, const float* logmel, int B, int T, float* feats, int* Tp) {
+    if (!c || !logmel || !feats || B < 1) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    const lasr_model_desc& d = c->d;
+    const int tp = T < d.n_stack ? 0 : (T - d.n_stack) / d.stride + 1;
+    if (Tp) *Tp = tp;
+    if (tp == 0) return LASR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_stack, dim3(tp, B), dim3(256), 0, c->stream, logmel, T, d.n_mels, d.n_stack, d.stride, feats, tp, d.feat);
+    HIPCHK(c, hipGetLastError());
+    return LASR_OK;
+}
+
+int lasr_encoder(lasr_ctx* c, const float* feats, int B, int Tp, float* out, float* h_out, float* c_out) {
+    if (!c || !feats || !out || B < 1 || B > c->d.max_streams || Tp < 1) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const lasr_model_desc& d = c->d;
+    const int H = d.hidden;
+    RC(ensure_T(c, Tp));
+    RC(cmd_begin(c));
+    for (int r = 0; r < B; ++r) { c->hc.T_row[r] = Tp; c->hc.what[r] = 1; c->hc.row_feat_off[r] = (long long)r * Tp; }
+    RC(cmd_commit(c));
+    RC(apply_reset(c, false));
+    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    StackLnArgs a{};
+    a.src = feats; a.mode = 1; a.row_off = c->dc.row_feat_off; a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b;
+    a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels; a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT;
+    a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = Tp;
+    hipLaunchKernelGGL((k_stack_ln<32>), dim3((Tp + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    run_encoder(c, Tp);
+    hipLaunchKernelGGL(k_enc_out, dim3(grid1((size_t)B * Tp * H)), dim3(256), 0, c->stream,
+                       (const float*)c->ybuf[(d.enc_layers - 1) & 1], c->Tcap * c->MT, c->M, out, B, Tp, H);
+    for (int l = 0; l < d.enc_layers; ++l) {
+        if (h_out)
+            hipLaunchKernelGGL(k_from_frag, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream,
+                               (const float*)c->enc_h[c->enc_par][l], c->MT, 0, h_out + (size_t)l * B * H, H, B, H);
+        if (c_out)
+            hipLaunchKernelGGL(k_c_to_rows, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream,
+                               (const float*)c->enc_c[l], c->M, c_out + (size_t)l * B * H, B, H);
+    }
+    HIPCHK(c, hipGetLastError());
+    return LASR_OK;
+}
+
+int lasr_predictor(lasr_ctx* c, const int32_t* tok, int B, int U, float* out) {
+    if (!c || !tok || !out || B < 1 || B > c->d.max_streams || U < 1) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int H = c->d.hidden;
+    for (int i = 0; i < B * U; ++i)
+        if (tok[i] < 0 || tok[i] >= c->d.vocab) return fail(c, LASR_EINVAL, "token %d out of range", tok[i]);
+    // learned initial state, no implicit BOS
+    RC(cmd_begin(c));
+    for (int r = 0; r < B; ++r) c->hc.what[r] = 2;
+    RC(cmd_commit(c));
+    RC(apply_reset(c, false));
+    for (int u = 0; u < U; ++u) {
+        RC(cmd_begin(c));
+        for (int r = 0; r < B; ++r) { c->hc.token[r] = tok[(size_t)r * U + u]; c->hc.emit[r] = 1; }
+        RC(cmd_commit(c));
+        HIPCHK(c, hipMemcpyAsync(c->ds.token, c->dc.token, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->ds.emit, c->dc.emit, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+        launch_predictor(c);
+    }
+    hipLaunchKernelGGL(k_from_frag, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream,
+                       (const float*)c->pred_y[c->d.pred_layers - 1], c->MT, 0, out, H, B, H);
+    HIPCHK(c, hipGetLastError());
+    return LASR_OK;
+}
+
+int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, float* logits, float* logp_max, int32_t* argmax) {
+    if (!c || !h_pred || !h_enc || !logits || B < 1 || B > c->d.max_streams) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int H = c->d.hidden, J = c->d.joint, V = c->d.vocab;
+    RC(ensure_T(c, 1));
+    {   // pp = h_pred W1p^T + b1 ; pe[0] = h_enc W1e^T   (row-major A)
+        GemmArgs g{}; g.A[0] = h_pred; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p; g.a_rows = B;
+        EpiLinear::Args ea{}; ea.bias = c->b1; ea.out = c->pp; ea.ldo = J; ea.n_rows = B; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
+        launch_gemm<EpiLinear, true>(c, J / 16, (B + 15) / 16, g, ea);
+        g.A[0] = h_enc; g.W[0] = c->W1e; ea.bias = nullptr; ea.out = c->pe;
+        launch_gemm<EpiLinear, true>(c, J / 16, (B + 15) / 16, g, ea);
+    }
+    hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)c->M * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)c->pp,
+                       (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MT);
+    launch_logits(c, logits, B, false);
+    if (logp_max && argmax) {
+        DecState s = c->ds;
+        hipLaunchKernelGGL((k_select<true>), dim3(B), dim3(256), 0, c->stream, (const float*)logits, V, c->d.blank, 1,
+                           (const int*)nullptr, s, 0, logp_max, argmax);
+    }
+    HIPCHK(c, hipGetLastError());
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- stats / bench
+int lasr_get_stats(lasr_ctx* c, lasr_step_stats* s) {
+    if (!c || !s) return LASR_EINVAL;
+    *s = c->stats;
+    return LASR_OK;
+}
+int lasr_set_profiling(lasr_ctx* c, int on) {
+    if (!c) return LASR_EINVAL;
+    c->profiling = on != 0;
+    return LASR_OK;
+}
+int lasr_sync(lasr_ctx* c) {
+    if (!c) return LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cmd_inflight = 0;
+    return LASR_OK;
+}
+
+int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us) {
+    if (!c || !us || layer < 0 || layer >= c->d.enc_layers || iters < 1) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    RC(ensure_T(c, 1));
+    const int H = c->d.hidden, I = c->enc[layer].I, M = c->M;
+    // random (not zero) operands: zero-filled data inflates the clock (DVFS)
+    hipLaunchKernelGGL(k_fill_rand, dim3(grid1((size_t)M * I)), dim3(256), 0, c->stream, layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1], (size_t)M * I, 17u);
+    for (int p = 0; p < 2; ++p)
+        hipLaunchKernelGGL(k_fill_rand, dim3(grid1((size_t)M * H)), dim3(256), 0, c->stream, c->enc_h[p][layer], (size_t)M * H, 23u + p);
+    RC(cmd_begin(c));
+    for (int r = 0; r < c->d.max_streams; ++r) c->hc.T_row[r] = 1;
+    RC(cmd_commit(c));
+    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * M, hipMemcpyDeviceToDevice, c->stream));
+    const float* xsrc = layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1];
+    const int mt_total = c->Tcap * c->MT;
+    for (int i = 0; i < 3; ++i) { launch_enc_cell(c, layer, 0, xsrc, mt_total, c->ybuf[layer & 1], mt_total); c->enc_par ^= 1; }
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) { launch_enc_cell(c, layer, 0, xsrc, mt_total, c->ybuf[layer & 1], mt_total); c->enc_par ^= 1; }
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *us = (double)ms * 1000.0 / iters;
+    c->cmd_inflight = 0;
+    HIPCHK(c, hipGetLastError());
+    return LASR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,809 @@
+// lasr_kernels.hip.h -- gfx950 (MI355X / CDNA4) device code of the streaming RNN-T path.
+//
+// Data layout ("fragment-major", the layout every hot matmul operand lives in)
+// ---------------------------------------------------------------------------
+// All dense contractions here are skinny:  out[rows, N] = A[rows, K] * W[N, K]^T  with
+// rows = stream slots (<= a few hundred) and the weights dominating the bytes.  They run on the
+// exact-f32 matrix instruction v_mfma_f32_16x16x4_f32 (64 lanes; lane l feeds A[i=l&15][k=l>>4]
+// and B[k=l>>4][j=l&15]; C/D: row = 4*(l>>4)+reg, col = l&15).
+//
+// A 16x16 (rows x k) block of an operand is stored as one contiguous 1 KiB "fragment":
+//     frag[lane = g*16 + i][e]  =  X[16*tile + i][16*c + 4*g + e],   g,e in 0..3, i in 0..15
+// so that one 16-byte load per lane (a perfectly coalesced 1 KiB wave load) delivers the A (or B)
+// operands of FOUR consecutive MFMAs (MFMA e consumes element e; the k index it contracts is
+// 16c + 4g + e for both operands, so the products line up; only the summation order differs
+// from a k-sequential dot product).
+//   activations [rows, K]:  off(r,k) = ((c*mt_total + r/16)*64 + g*16 + r%16)*4 + e
+//   weights: tile-major, [n_tile][c][lane][e]  (a tile's K-panel is one contiguous stream)
+//
+// The GEMM kernel (k_gemm) gives each workgroup one 16-row m-tile x NT n-tiles, splits K over its
+// NW waves (wave w takes chunks w, w+NW, ...; 3-deep register prefetch ring, no LDS staging:
+// every weight byte is used by exactly one workgroup per m-tile), reduces the NW partial tiles
+// through LDS and runs a fused epilogue (LSTM / NBRC cell math + BatchNorm(eval) fold, joint
+// projections, tanh) on the 16 rows x 16 hidden units it owns.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lasr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ size_t frag_off(int r, int k, int mt_total) {
+    const int c = k >> 4, g = (k >> 2) & 3, e = k & 3, mt = r >> 4, i = r & 15;
+    return ((size_t)(c * mt_total + mt) * 64 + (g * 16 + i)) * 4 + e;
+}
+
+// precise activations (no fast-math: token-for-token parity after hundreds of recurrent steps)
+__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// GEMM core
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* A[2];     // phase operand: fragment-major (or row-major when AROW)
+    int a_mt_total[2];     // m-tiles in A's fragment layout (or lda when AROW)
+    int a_mt_off[2];       // m-tile offset of this launch's rows inside A
+    int KC[2];             // K chunks (of 16) per phase; 0 = phase absent
+    const float* W[2];     // packed weights of the phase: [n_group][slot][KC][64][4]
+    int a_rows;            // AROW only: rows of A (loads of rows >= a_rows are clamped); 0 = no clamp
+};
+
+template <int MASK>
+struct PopCount {
+    static constexpr int value = (MASK & 1) + PopCount<(MASK >> 1)>::value;
+};
+template <>
+struct PopCount<0> {
+    static constexpr int value = 0;
+};
+
+template <int NS>
+struct Frag {
+    f32x4 a;
+    f32x4 b[NS > 0 ? NS : 1];
+};
+
+template <int MASK, int NT, int NW, bool AROW>
+__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[NT], const float* __restrict__ A, int a_mt_total,
+                                           int a_mt, const float* __restrict__ Wp, int KC, int jb, int w,
+                                           int lane, int a_rows) {
+    constexpr int NS = PopCount<MASK>::value;
+    if constexpr (NS == 0) {
+        return;
+    } else {
+        if (KC <= 0) return;
+        const float* wb = Wp + (size_t)jb * NS * KC * 256 + lane * 4;
+        const float* ab;
+        size_t a_step;
+        if constexpr (AROW) {   // row-major A: lane (i = lane&15, g = lane>>4) reads 16 B of row i
+            int row = a_mt * 16 + (lane & 15);
+            if (a_rows > 0 && row >= a_rows) row = a_rows - 1;
+            ab = A + (size_t)row * a_mt_total + (lane >> 4) * 4;
+            a_step = 16;
+        } else {
+            ab = A + (size_t)a_mt * 256 + lane * 4;
+            a_step = (size_t)a_mt_total * 256;
+        }
+        auto load = [&](Frag<NS>& f, int c) {
+            f.a = *reinterpret_cast<const f32x4*>(ab + (size_t)c * a_step);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                f.b[s] = *reinterpret_cast<const f32x4*>(wb + ((size_t)s * KC + c) * 256);
+        };
+        auto compute = [&](const Frag<NS>& f) {
+            int s = 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if ((MASK >> nt) & 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[e], f.b[s][e], acc[nt], 0, 0, 0);
+                    ++s;
+                }
+            }
+        };
+        // 3-deep rotation: two chunks in flight while one is consumed
+        Frag<NS> f0, f1, f2;
+        int c = w;
+        if (c < KC) load(f0, c);
+        if (c + NW < KC) load(f1, c + NW);
+        for (; c < KC; c += 3 * NW) {
+            if (c + 2 * NW < KC) load(f2, c + 2 * NW);
+            compute(f0);
+            if (c + NW < KC) {
+                if (c + 3 * NW < KC) load(f0, c + 3 * NW);
+                compute(f1);
+            }
+            if (c + 2 * NW < KC) {
+                if (c + 4 * NW < KC) load(f1, c + 4 * NW);
+                compute(f2);
+            }
+        }
+    }
+}
+
+// One workgroup = (n-group jb = blockIdx.x, m-tile mt = blockIdx.y).  Epi supplies:
+//   NT, PH0_TILES, PH1_TILES, struct Args, tile_active(args, mt, lane) [wave-uniform], apply(...)
+template <class Epi, int NW, bool AROW>
+__global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typename Epi::Args ea) {
+    constexpr int NT = Epi::NT;
+    __shared__ float red[NW][16][NT * 16 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int jb = blockIdx.x, mt = blockIdx.y;
+    const bool on = Epi::tile_active(ea, mt, lane);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (on) {
+        gemm_phase<Epi::PH0_TILES, NT, NW, AROW>(acc, g.A[0], g.a_mt_total[0], g.a_mt_off[0] + mt, g.W[0], g.KC[0], jb, w, lane, g.a_rows);
+        gemm_phase<Epi::PH1_TILES, NT, NW, AROW>(acc, g.A[1], g.a_mt_total[1], g.a_mt_off[1] + mt, g.W[1], g.KC[1], jb, w, lane, g.a_rows);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][4 * (lane >> 4) + r][nt * 16 + (lane & 15)] = acc[nt][r];
+    __syncthreads();
+    if (tid < 256) {
+        const int i = tid & 15, ui = tid >> 4;   // row in the m-tile, unit / column in the n-group
+        float v[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) s += red[ww][i][nt * 16 + ui];
+            v[nt] = s;
+        }
+        Epi::apply(ea, mt, jb, i, ui, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool any16(bool flag, int lane) {
+    // wave-uniform OR over lanes 0..15
+    return (__ballot(flag && lane < 16) != 0ull);
+}
+
+// ---- LSTM cell (torch gate order i,f,g,o; custom_rnn.py:172, haste/lstm.py:34-68) + BN(eval) fold.
+// ENC: row r is active at step t iff t < T_row[r].  PRED: active iff emit[r]; phase X is replaced
+// by the per-token table tab[token][4H] when TABLE.
+template <bool PRED, bool TABLE>
+struct EpiLSTM {
+    static constexpr int NT = 4;
+    static constexpr int PH0_TILES = TABLE ? 0 : 0xF;
+    static constexpr int PH1_TILES = 0xF;
+    struct Args {
+        const float* bias;     // [4H] = b_ih + b_hh (zeros when TABLE: folded into tab)
+        const float* tab;      // [V][4H] (TABLE)
+        const int* token;      // [M]     (TABLE)
+        const int* flag;       // ENC: T_row[M];  PRED: emit[M]
+        int t;                 // ENC: time step
+        float* c;              // [H][M] cell state, in place
+        const float* h_in;     // fragment-major [H/16][MT][64][4]
+        float* h_out;          // same layout, other parity
+        float* y;              // BN(h') fragment-major; may be nullptr
+        int y_mt_total, y_mt_off;
+        const float* bn_s;     // [H]
+        const float* bn_t;     // [H]
+        int H, M, MT;
+    };
+    __device__ static bool row_active(const Args& a, int r) { return PRED ? (a.flag[r] != 0) : (a.t < a.flag[r]); }
+    __device__ static bool tile_active(const Args& a, int mt, int lane) {
+        return any16(lane < 16 && row_active(a, mt * 16 + (lane & 15)), lane);
+    }
+    __device__ static void apply(const Args& a, int mt, int jb, int i, int ui, const float (&v)[4]) {
+        const int r = mt * 16 + i, u = jb * 16 + ui;
+        const size_t ho = ((size_t)(jb * a.MT + mt) * 64 + ((ui >> 2) * 16 + i)) * 4 + (ui & 3);
+        if (!row_active(a, r)) {
+            a.h_out[ho] = a.h_in[ho];
+            return;
+        }
+        float gi = v[0], gf = v[1], gg = v[2], go = v[3];
+        const int H = a.H;
+        if (TABLE) {
+            const float* tb = a.tab + (size_t)a.token[r] * 4 * H + u;
+            gi += tb[0]; gf += tb[H]; gg += tb[2 * H]; go += tb[3 * H];
+        } else {
+            gi += a.bias[u]; gf += a.bias[H + u]; gg += a.bias[2 * H + u]; go += a.bias[3 * H + u];
+        }
+        const size_t co = (size_t)u * a.M + r;
+        const float c2 = sigmoid_(gf) * a.c[co] + sigmoid_(gi) * tanhf(gg);
+        const float h2 = sigmoid_(go) * tanhf(c2);
+        a.c[co] = c2;
+        a.h_out[ho] = h2;
+        if (a.y) {
+            const size_t yo = ((size_t)(jb * a.y_mt_total + a.y_mt_off + mt) * 64 + ((ui >> 2) * 16 + i)) * 4 + (ui & 3);
+            a.y[yo] = h2 * a.bn_s[u] + a.bn_t[u];
+        }
+    }
+};
+
+// ---- NBRC / GRU-v1 cell (haste/nbrc.py:30-64; layout z,r,g): tiles {z, r, gx, gh}.
+//   z = s(Wx_z + Rh_z), r = s(Wx_r + Rh_r), g = tanh(Wx_g + r * Rh_g), h' = z h + (1 - z) g.
+// Predictor only (active iff emit[r]).  TABLE: Wx (+ input bias) comes from tab[token][3H].
+template <bool TABLE>
+struct EpiNBRC {
+    static constexpr int NT = 4;
+    static constexpr int PH0_TILES = TABLE ? 0 : 0x7;   // x-phase: z, r, gx
+    static constexpr int PH1_TILES = 0xB;               // h-phase: z, r, gh
+    struct Args {
+        const float* bias;     // [3H] input bias (unused when TABLE)
+        const float* rbias;    // [3H] recurrent bias
+        const float* tab;      // [V][3H]
+        const int* token;
+        const int* emit;
+        const float* h_in;
+        float* h_out;
+        float* y;              // BN(h') fragment-major [H/16][MT][64][4]
+        const float* bn_s;
+        const float* bn_t;
+        int H, MT;
+    };
+    __device__ static bool tile_active(const Args& a, int mt, int lane) {
+        return any16(lane < 16 && a.emit[mt * 16 + (lane & 15)] != 0, lane);
+    }
+    __device__ static void apply(const Args& a, int mt, int jb, int i, int ui, const float (&v)[4]) {
+        const int r = mt * 16 + i, u = jb * 16 + ui, H = a.H;
+        const size_t ho = ((size_t)(jb * a.MT + mt) * 64 + ((ui >> 2) * 16 + i)) * 4 + (ui & 3);
+        const float h = a.h_in[ho];
+        if (!a.emit[r]) {
+            a.h_out[ho] = h;
+            return;
+        }
+        float xz, xr, xg;
+        if (TABLE) {
+            const float* tb = a.tab + (size_t)a.token[r] * 3 * H + u;
+            xz = tb[0]; xr = tb[H]; xg = tb[2 * H];
+        } else {
+            xz = a.bias[u]; xr = a.bias[H + u]; xg = v[2] + a.bias[2 * H + u];
+        }
+        const float z = sigmoid_(v[0] + xz + a.rbias[u]);
+        const float rr = sigmoid_(v[1] + xr + a.rbias[H + u]);
+        const float gc = tanhf(xg + rr * (v[3] + a.rbias[2 * H + u]));
+        const float h2 = z * h + (1.0f - z) * gc;
+        a.h_out[ho] = h2;
+        a.y[ho] = h2 * a.bn_s[u] + a.bn_t[u];
+    }
+};
+
+// ---- plain linear: out[row][col] = acc + bias[col], row-major.
+struct EpiLinear {
+    static constexpr int NT = 1;
+    static constexpr int PH0_TILES = 1;
+    static constexpr int PH1_TILES = 0;
+    struct Args {
+        const float* bias;    // may be nullptr
+        float* out;
+        int ldo;
+        int n_rows;           // rows >= n_rows are not written
+        const int* t_idx;     // optional row gate: row active iff t_idx[r % M] < T_row[r % M]
+        const int* T_row;
+        int M;
+    };
+    __device__ static bool row_on(const Args& a, int r) {
+        if (r >= a.n_rows) return false;
+        if (!a.t_idx) return true;
+        const int q = r % a.M;
+        return a.t_idx[q] < a.T_row[q];
+    }
+    __device__ static bool tile_active(const Args& a, int mt, int lane) {
+        return any16(lane < 16 && row_on(a, mt * 16 + (lane & 15)), lane);
+    }
+    __device__ static void apply(const Args& a, int mt, int jb, int i, int ui, const float (&v)[1]) {
+        const int r = mt * 16 + i, col = jb * 16 + ui;
+        if (!row_on(a, r)) return;
+        a.out[(size_t)r * a.ldo + col] = v[0] + (a.bias ? a.bias[col] : 0.f);
+    }
+};
+
+// ---- predictor half of the joint + fused joint activation:
+//   pp[r] = emit[r] ? h_pred[r] W1p^T + b1 : pp[r]
+//   ja[r] = tanh(pe[t_idx[r]][r] + pp[r])   (fragment-major: it is the A operand of the logits GEMM)
+// Joint.forward 'concat' (models.py:132-140): Linear(cat(pred, enc)) == W1p pred + W1e enc + b1.
+struct EpiPPJ {
+    static constexpr int NT = 1;
+    static constexpr int PH0_TILES = 1;
+    static constexpr int PH1_TILES = 0;
+    struct Args {
+        const float* b1;
+        float* pp;            // [M][J]
+        const float* pe;      // [T][M][J]
+        const int* t_idx;
+        const int* T_row;
+        const int* emit;
+        float* ja;            // fragment-major [J/16][MT][64][4]
+        int J, M, MT;
+    };
+    __device__ static bool tile_active(const Args& a, int mt, int lane) {
+        return any16(lane < 16 && a.emit[mt * 16 + (lane & 15)] != 0, lane);
+    }
+    __device__ static void apply(const Args& a, int mt, int jb, int i, int ui, const float (&v)[1]) {
+        const int r = mt * 16 + i, j = jb * 16 + ui;
+        float p;
+        if (a.emit[r]) {
+            p = v[0] + a.b1[j];
+            a.pp[(size_t)r * a.J + j] = p;
+        } else {
+            p = a.pp[(size_t)r * a.J + j];
+        }
+        const int t = a.t_idx[r];
+        if (t < a.T_row[r]) {
+            const size_t o = ((size_t)(jb * a.MT + mt) * 64 + ((ui >> 2) * 16 + i)) * 4 + (ui & 3);
+            a.ja[o] = tanhf(a.pe[((size_t)t * a.M + r) * a.J + j] + p);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+// joint activation for all rows (start of a step): ja = tanh(pe[t_idx] + pp)
+__global__ void k_ja(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
+                     const int* __restrict__ T_row, float* __restrict__ ja, int J, int M, int MT) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * J) return;
+    const int r = idx / J, j = idx - r * J;
+    const int t = t_idx ? t_idx[r] : 0;
+    if (T_row && t >= T_row[r]) return;
+    ja[frag_off(r, j, MT)] = tanhf(pe[((size_t)t * M + r) * J + j] + pp[(size_t)r * J + j]);
+}
+
+// row-major [rows][K] <-> fragment-major
+__global__ void k_to_frag(const float* __restrict__ src, int lds, float* __restrict__ dst, int rows, int K,
+                          int mt_total, int mt_off) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * K) return;
+    const int r = idx / K, k = idx - r * K;
+    dst[frag_off(r + 16 * mt_off, k, mt_total)] = src[(size_t)r * lds + k];
+}
+__global__ void k_from_frag(const float* __restrict__ src, int mt_total, int mt_off, float* __restrict__ dst, int ldd,
+                            int rows, int K) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * K) return;
+    const int r = idx / K, k = idx - r * K;
+    dst[(size_t)r * ldd + k] = src[frag_off(r + 16 * mt_off, k, mt_total)];
+}
+// [H][M] -> [rows][H]
+__global__ void k_c_to_rows(const float* __restrict__ c, int M, float* __restrict__ dst, int rows, int H) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * H) return;
+    const int r = idx / H, u = idx - r * H;
+    dst[idx] = c[(size_t)u * M + r];
+}
+
+// encoder output of the last layer: fragment-major rows (t*M + b) -> out[b][t][H]
+__global__ void k_enc_out(const float* __restrict__ y, int mt_total, int M, float* __restrict__ out, int B, int T, int H) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * T * H) return;
+    const int u = (int)(idx % H);
+    const int t = (int)((idx / H) % T);
+    const int b = (int)(idx / ((size_t)H * T));
+    out[idx] = y[frag_off(t * M + b, u, mt_total)];
+}
+
+// deterministic pseudo-random fill in [-1, 1) (micro-benchmark operands)
+__global__ void k_fill_rand(float* __restrict__ p, size_t n, unsigned seed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)i * 2654435761u ^ (seed * 40503u + 0x9e3779b9u);
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f;
+}
+
+// (re)initialise recurrent state of flagged rows from the learned initial states
+// (custom_rnn.py:152-158; Transducer.transcribe_stream reset(), models.py:480-500).
+struct ResetArgs {
+    const int* what;          // [M] bit 1: encoder, bit 2: predictor
+    int M, MT, H, Le, Lp, pred_lstm, bos;
+    float* enc_h[16];         // current-parity fragment buffers
+    float* enc_c[16];
+    const float* enc_h0[16];  // [H]
+    const float* enc_c0[16];
+    float* pred_h[8];
+    float* pred_c[8];
+    const float* pred_h0[8];
+    const float* pred_c0[8];
+    int* token;
+    int* emit;
+};
+__global__ void k_reset_rows(const ResetArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.M * a.H) return;
+    const int r = idx / a.H, u = idx - r * a.H;
+    const int wh = a.what[r];
+    if (u == 0) {
+        a.emit[r] = (wh & 2) ? 1 : 0;
+        if (wh & 2) a.token[r] = a.bos;
+    }
+    const size_t ho = frag_off(r, u, a.MT);
+    if (wh & 1)
+        for (int l = 0; l < a.Le; ++l) {
+            a.enc_h[l][ho] = a.enc_h0[l][u];
+            a.enc_c[l][(size_t)u * a.M + r] = a.enc_c0[l][u];
+        }
+    if (wh & 2)
+        for (int l = 0; l < a.Lp; ++l) {
+            a.pred_h[l][ho] = a.pred_h0[l][u];
+            if (a.pred_lstm) a.pred_c[l][(size_t)u * a.M + r] = a.pred_c0[l][u];
+        }
+}
+
+// per-step decode state
+struct DecState {
+    int* t_idx;        // [M] current encoder frame of the row inside this step
+    int* iters;        // [M] joint evaluations done on the current frame
+    int* token;        // [M] last emitted token (predictor input)
+    int* emit;         // [M] 1 iff the row emitted a token in the last select
+    int* step_ntok;    // [M] tokens emitted in this step
+    int* step_tok;     // [M][tok_cap]
+    int tok_cap;
+    double* logp_sum;  // [M] sum of log p of every decision (models.py:420-422)
+    int* sum_iters;    // [M] evaluations in this step
+    int* n_ones;       // [M] frames finished after exactly one evaluation (alignment_score)
+    int* unfinished;   // [n_iter_slots] rows still decoding after iteration i
+};
+
+__global__ void k_step_begin(DecState s, int M, int n_iter_slots, int reset_metrics) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) {
+        s.t_idx[i] = 0;
+        s.iters[i] = 0;
+        s.emit[i] = 0;
+        s.step_ntok[i] = 0;
+        if (reset_metrics) {
+            s.logp_sum[i] = 0.0;
+            s.sum_iters[i] = 0;
+            s.n_ones[i] = 0;
+        }
+    }
+    if (i < n_iter_slots) s.unfinished[i] = 0;
+}
+
+// log-softmax + argmax over the vocabulary and the greedy state machine of
+// Transducer.decode_greedy / transcribe_stream (models.py:405-443, 530-571), one workgroup per row.
+// PLAIN: only (argmax, log p) are produced (op-level joint entry point).
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits, int V, int blank, int max_iters,
+                                                const int* __restrict__ T_row, DecState s, int iter_slot,
+                                                float* __restrict__ out_logp, int* __restrict__ out_arg) {
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (!PLAIN) {
+        const bool act = s.t_idx[r] < T_row[r];
+        if (!act) {
+            if (tid == 0) s.emit[r] = 0;
+            return;
+        }
+    }
+    const float* z = logits + (size_t)r * V;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int j = tid; j < V; j += 256) {
+        const float x = z[j];
+        if (x > best) { best = x; arg = j; }   // ascending j per thread: first max wins
+    }
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ float ss[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oa = __shfl_xor(arg, o);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0) { sv[w] = best; si[w] = arg; }
+    __syncthreads();
+    best = sv[0]; arg = si[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (sv[q] > best || (sv[q] == best && si[q] < arg)) { best = sv[q]; arg = si[q]; }
+    float sum = 0.f;
+    for (int j = tid; j < V; j += 256) sum += expf(z[j] - best);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) ss[w] = sum;
+    __syncthreads();
+    if (tid != 0) return;
+    sum = ss[0] + ss[1] + ss[2] + ss[3];
+    const float logp = -logf(sum);       // log_softmax at the argmax = z_max - logsumexp
+    if (PLAIN) {
+        out_logp[r] = logp;
+        out_arg[r] = arg;
+        return;
+    }
+    s.logp_sum[r] += (double)logp;
+    int it = s.iters[r] + 1;
+    s.sum_iters[r] += 1;
+    bool frame_done;
+    if (arg == blank) {
+        s.emit[r] = 0;
+        frame_done = true;
+    } else {
+        const int n = s.step_ntok[r];
+        if (n < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n] = arg;
+        s.step_ntok[r] = n + 1;
+        s.token[r] = arg;
+        s.emit[r] = 1;
+        frame_done = (it >= max_iters);
+    }
+    int t = s.t_idx[r];
+    if (frame_done) {
+        if (it == 1) s.n_ones[r] += 1;
+        it = 0;
+        t += 1;
+        s.t_idx[r] = t;
+    }
+    s.iters[r] = it;
+    if (t < T_row[r]) atomicAdd(&s.unfinished[iter_slot], 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// front-end: log-mel (TransformTime, transforms.py:306-323) -- framing, Hann window, 1024-point
+// real FFT (as a 512-point complex FFT, radix 8x8x8 in registers + LDS transposes), power,
+// sparse HTK mel filterbank, log(x + 1e-6).  One wave per frame, 4 frames per workgroup.
+// ------------------------------------------------------------------------------------------------
+struct cf { float x, y; };
+__device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }   // * (-i)
+
+// forward 8-point DFT, natural order in and out: X[k] = sum_n x[n] e^{-2 pi i n k / 8}
+__device__ __forceinline__ void dft8(cf (&v)[8]) {
+    const float h = 0.70710678118654752440f;
+    cf a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]);
+    cf a2 = cadd(v[2], v[6]), a3 = mul_mi(csub(v[2], v[6]));
+    cf a4 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    cf a6 = cadd(v[3], v[7]), a7 = mul_mi(csub(v[3], v[7]));
+    cf b0 = cadd(a0, a2), b2 = csub(a0, a2);       // even part: DFT4 of (x0,x2,x4,x6)
+    cf b1 = cadd(a1, a3), b3 = csub(a1, a3);
+    cf c0 = cadd(a4, a6), c2 = csub(a4, a6);       // odd part: DFT4 of (x1,x3,x5,x7)
+    cf c1 = cadd(a5, a7), c3 = csub(a5, a7);
+    // twiddles W8^k on the odd part: W8^1 = (1-i)/sqrt2, W8^2 = -i, W8^3 = (-1-i)/sqrt2
+    cf t1 = cf{(c1.x + c1.y) * h, (c1.y - c1.x) * h};
+    cf t2 = mul_mi(c2);
+    cf t3 = cf{(-c3.x + c3.y) * h, (-c3.y - c3.x) * h};
+    v[0] = cadd(b0, c0); v[4] = csub(b0, c0);
+    v[1] = cadd(b1, t1); v[5] = csub(b1, t1);
+    v[2] = cadd(b2, t2); v[6] = csub(b2, t2);
+    v[3] = cadd(b3, t3); v[7] = csub(b3, t3);
+}
+
+struct MelArgs {
+    const float* window;     // [n_fft] Hann(win) zero-padded, centred
+    const float2* tw512;     // [512]  e^{-2 pi i m / 512}
+    const float2* tw1024;    // [513]  e^{-2 pi i k / 1024}
+    const int* fb_start;     // [n_mels] first bin of filter m
+    const int* fb_off;       // [n_mels + 1] offsets into fb_w
+    const float* fb_w;       // nonzero filter weights, bin-ascending per filter
+    int n_mels, hop;
+    // source addressing
+    const float* pcm;        // offline: [B][N];  stream: ring windows [M][n_window][chunk]
+    long long N;             // samples per row (offline: signal length; stream: n_window*chunk)
+    int stream;              // 0 offline (reflect padded), 1 stream window
+    const int* ring_head;    // stream: [M] index of the oldest chunk in the ring
+    int chunk, n_window;
+    const int* row_sel;      // stream: [M] destination frame slot base (>=0) or -1 = skip row
+    int frame0;              // stream: first frame index of the window to compute (a = T/3 + 1)
+    int frames_per_row;      // frames computed per row by this launch
+    float* out;              // [rows][out_frames][n_mels]
+    int out_frames;          // row stride in frames
+    // offline, ragged batch (optional): per-row length, source offset into pcm, frame count
+    const long long* row_N;
+    const long long* row_src_off;
+    const int* row_frames;
+};
+
+__global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
+    __shared__ float2 sz[4][512 + 8];
+    __shared__ float sp[4][520];
+    const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
+    int fidx = blockIdx.x * 4 + w;                       // frame within the row
+    const int row = blockIdx.y;
+    // a wave without a frame recomputes the last valid one and skips the store: every wave of
+    // the workgroup must reach every __syncthreads()
+    int n_frames = a.frames_per_row;
+    long long N = a.N;
+    if (a.row_frames) {
+        n_frames = a.row_frames[row];
+        if (n_frames <= 0) return;                       // uniform over the workgroup
+        N = a.row_N[row];
+    }
+    const bool valid = fidx < n_frames;
+    if (!valid) fidx = n_frames - 1;
+    int out_frame = fidx;
+    int t = fidx;
+    const float* src = a.pcm;
+    int head = 0;
+    if (a.stream) {
+        const int sel = a.row_sel[row];
+        if (sel < 0) return;                             // uniform over the workgroup (row = blockIdx.y)
+        out_frame = sel + fidx;
+        t = a.frame0 + fidx;
+        head = a.ring_head[row];
+        src = a.pcm + (size_t)row * a.n_window * a.chunk;
+    } else if (a.row_frames) {
+        src = a.pcm + a.row_src_off[row];
+    } else {
+        src = a.pcm + (size_t)row * a.N;
+    }
+    const long long base = (long long)t * a.hop - 512;
+    auto sample = [&](int n) -> float {                  // windowed sample n of the 1024-frame
+        const float wv = a.window[n];
+        if (wv == 0.f) return 0.f;
+        long long q = base + n;
+        if (q < 0) q = -q;                               // reflect (torch.stft center=True, pad_mode="reflect")
+        if (q >= N) q = 2 * (N - 1) - q;
+        float x;
+        if (a.stream) {
+            const int ck = (int)(q / a.chunk), wi = (int)(q - (long long)ck * a.chunk);
+            x = src[(size_t)((head + ck) % a.n_window) * a.chunk + wi];
+        } else {
+            x = src[q];
+        }
+        return x * wv;
+    };
+    // ---- pass 1: z[n] = x[2n] + i x[2n+1]; thread j takes n = j + 64 m
+    cf v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int n = j + 64 * m;
+        v[m] = cf{sample(2 * n), sample(2 * n + 1)};
+    }
+    dft8(v);
+    float2* z = sz[w];
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+        const float2 tw = a.tw512[j * k0];
+        const cf u = cmul(v[k0], cf{tw.x, tw.y});
+        z[k0 * 64 + j] = float2{u.x, u.y};
+    }
+    __syncthreads();
+    // ---- pass 2: thread (k0 = j>>3, b = j&7): DFT over a of u_k0[8a + b], twiddle W64^{b k1}
+    {
+        const int k0 = j >> 3, b = j & 7;
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) {
+            const float2 q = z[k0 * 64 + 8 * aa + b];
+            v[aa] = cf{q.x, q.y};
+        }
+        dft8(v);
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) {
+            const float2 tw = a.tw512[8 * b * k1];
+            const cf u = cmul(v[k1], cf{tw.x, tw.y});
+            z[k0 * 64 + k1 * 8 + b] = float2{u.x, u.y};
+        }
+    }
+    __syncthreads();
+    // ---- pass 3: thread (k0, k1): DFT over b -> Z[k0 + 8 k1 + 64 k2]
+    {
+        const int k0 = j >> 3, k1 = j & 7;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const float2 q = z[k0 * 64 + k1 * 8 + b];
+            v[b] = cf{q.x, q.y};
+        }
+        dft8(v);
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) z[k0 + 8 * k1 + 64 * k2] = float2{v[k2].x, v[k2].y};
+    }
+    __syncthreads();
+    // ---- real-FFT untangle + power: X[k] = (Z[k] + conj Z[512-k])/2 + W1024^k (Z[k] - conj Z[512-k])/(2i)
+    float* P = sp[w];
+    for (int k = j; k <= 512; k += 64) {
+        const float2 zk = z[k & 511];
+        const float2 zn = z[(512 - k) & 511];
+        const cf e = cf{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
+        const cf d = cf{0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y)};   // (Z[k] - conj Zn)/2
+        const float2 tw = a.tw1024[k];
+        const cf o = cmul(cf{tw.x, tw.y}, mul_mi(d));                  // W^k * d / i
+        const cf X = cadd(e, o);
+        P[k] = X.x * X.x + X.y * X.y;
+    }
+    __syncthreads();
+    // ---- sparse HTK mel + log
+    if (!valid) return;
+    float* out = a.out + ((size_t)row * a.out_frames + out_frame) * a.n_mels;
+    for (int m = j; m < a.n_mels; m += 64) {
+        const int s0 = a.fb_start[m], o0 = a.fb_off[m], cnt = a.fb_off[m + 1] - o0;
+        float acc = 0.f;
+        for (int q = 0; q < cnt; ++q) acc += P[s0 + q] * a.fb_w[o0 + q];
+        out[m] = logf(acc + 1e-6f);
+    }
+}
+
+// StackDownsample (transforms.py:436-441): feats[row][t'][m*n_stack + k] = logmel[row][f0 + stride*t' + k][m]
+__global__ void k_stack(const float* __restrict__ logmel, int T_frames, int n_mels, int n_stack, int stride,
+                        float* __restrict__ feats, int Tp, int F) {
+    const int tp = blockIdx.x, row = blockIdx.y;
+    const float* lm = logmel + (size_t)row * T_frames * n_mels;
+    float* o = feats + ((size_t)row * Tp + tp) * F;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const int m = f / n_stack, k = f - m * n_stack;
+        o[f] = lm[(size_t)(stride * tp + k) * n_mels + m];
+    }
+}
+
+// Stack (optional) + LayerNorm(feature_sz) (models.py:84,107) -> fragment-major x0[t'].
+// One wave per (row, t').  mode 0: src = log-mel [rows][src_frames][n_mels] (stack on the fly with
+// frame base `stride * t'` for offline or `n_stack * t'` for the stream buffer);
+// mode 1: src = stacked features [..][F] row-major, row r frame t' at src[(row_off[r] + t') * F].
+struct StackLnArgs {
+    const float* src;
+    int mode;
+    int src_frames;          // mode 0: frames per row in src
+    int frame_step;          // mode 0: frame advance per t' (stride offline, n_stack in stream buffer)
+    const long long* row_off;// mode 1: [M] first stacked-frame index of row r (in frames)
+    const int* T_row;        // [M] frames of row r in this step
+    const float* ln_w;
+    const float* ln_b;
+    float* x0;               // fragment-major [F/16][Tcap*MT][64][4]
+    int F, n_mels, n_stack, M, MT, mt_total;
+    float* feats_out;        // optional row-major copy of the un-normalised stacked features [M][Tmax][F]
+    int Tmax;
+};
+template <int VPL>   // max values per lane: F <= 64 * VPL
+__global__ __launch_bounds__(256) void k_stack_ln(const StackLnArgs a) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tp = blockIdx.x * 4 + w, row = blockIdx.y;
+    if (tp >= a.T_row[row]) return;
+    float x[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+        const int f = lane + 64 * q;
+        float val = 0.f;
+        if (f >= a.F) {
+        } else if (a.mode == 0) {
+            const int m = f / a.n_stack, k = f - m * a.n_stack;
+            val = a.src[((size_t)row * a.src_frames + (size_t)a.frame_step * tp + k) * a.n_mels + m];
+        } else {
+            val = a.src[(size_t)(a.row_off[row] + tp) * a.F + f];
+        }
+        x[q] = val;
+        sum += val;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mu = sum / (float)a.F;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+        const float d = (lane + 64 * q < a.F) ? x[q] - mu : 0.f;
+        var += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)a.F + 1e-5f);
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+        const int f = lane + 64 * q;
+        if (f >= a.F) continue;
+        if (a.feats_out) a.feats_out[((size_t)row * a.Tmax + tp) * a.F + f] = x[q];
+        const float y = (x[q] - mu) * rstd * a.ln_w[f] + a.ln_b[f];
+        // element (t', row, f): m-tile index tp*MT + row/16 inside a layout of mt_total m-tiles
+        const int c = f >> 4, g = (f >> 2) & 3, e = f & 3;
+        a.x0[((size_t)(c * a.mt_total + tp * a.MT + (row >> 4)) * 64 + g * 16 + (row & 15)) * 4 + e] = y;
+    }
+}
+
+// streaming: append one client chunk per flagged row to its ring window
+__global__ void k_push_pcm(const float* __restrict__ src, const int* __restrict__ src_idx, float* __restrict__ win,
+                           int* __restrict__ ring_pos, int chunk, int n_window) {
+    const int row = blockIdx.x;
+    const int si = src_idx[row];
+    if (si < 0) return;
+    const int pos = ring_pos[row];
+    float* d = win + ((size_t)row * n_window + pos) * chunk;
+    const float* s = src + (size_t)si * chunk;
+    for (int i = threadIdx.x; i < chunk; i += blockDim.x) d[i] = s[i];
+    __syncthreads();
+    if (threadIdx.x == 0) ring_pos[row] = (pos + 1) % n_window;
+}
+
+}  // namespace lasr

@@ -1,0 +1,224 @@
+"""
+Engine: thin Python owner of one lasr_ctx (one per process and GPU).
+
+Everything numeric happens in liblasr_hip.so (hand-written gfx950 kernels); this class only
+marshals arguments.  PyTorch is used for device memory and the HIP stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .weights import flatten_state_dict, infer_cfg
+
+FRONTEND_DEFAULTS = dict(n_fft=1024, win=400, hop=160, n_mels=128, n_stack=10, stride=8, n_buffer=2,
+                         n_window=3, chunk=1280, sample_rate=16000)
+
+
+def _ptr(x):
+    """void* of a torch tensor / numpy array / None."""
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(C.c_void_p)
+    raise TypeError(type(x))
+
+
+class Engine:
+    def __init__(self, state_dict, cfg=None, max_streams=64, device=0, max_iters_offline=3,
+                 max_iters_stream=10, blank=0, bos=2, **frontend):
+        self.lib = N.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("libreasr_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                               "and there is no CPU fallback")
+        cfg = dict(cfg) if cfg is not None else infer_cfg(state_dict)
+        self.cfg = cfg
+        fe = dict(FRONTEND_DEFAULTS)
+        fe.update(frontend)
+        d = N.ModelDesc()
+        self.lib.lasr_default_desc(C.byref(d))
+        d.feat, d.hidden, d.embed, d.joint, d.vocab = cfg["feat"], cfg["hidden"], cfg["embed"], cfg["joint"], cfg["vocab"]
+        d.enc_layers, d.pred_layers = cfg["enc_layers"], cfg["pred_layers"]
+        d.pred_cell = 1 if cfg["pred_cell"] == "LSTM" else 0
+        d.blank, d.bos = blank, bos
+        for k, v in fe.items():
+            setattr(d, k, int(v))
+        d.max_streams = int(max_streams)
+        d.max_iters_offline, d.max_iters_stream = int(max_iters_offline), int(max_iters_stream)
+        self.desc = d
+        self.device = torch.device("cuda", device)
+        blob = flatten_state_dict(state_dict, cfg)
+        want = self.lib.lasr_weight_count(C.byref(d))
+        if want == 0:
+            raise ValueError("model description rejected by liblasr_hip (dims must be multiples of 16)")
+        if blob.size != want:
+            raise ValueError(f"weight blob has {blob.size} floats, liblasr_hip expects {want}")
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        ctx = C.c_void_p()
+        rc = self.lib.lasr_create(device, C.byref(d), blob.ctypes.data_as(C.c_void_p), blob.size,
+                                  C.c_void_p(stream), C.byref(ctx))
+        self.ctx = ctx
+        if rc != 0:
+            msg = self.lib.lasr_last_error(ctx).decode() if ctx else "no ctx"
+            if ctx:
+                self.lib.lasr_destroy(ctx)
+            self.ctx = None
+            raise N.LasrError(rc, msg)
+        self.max_streams = int(max_streams)
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise N.LasrError(rc, self.lib.lasr_last_error(self.ctx).decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.lasr_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _slots(slots):
+        a = np.ascontiguousarray(np.asarray(slots, dtype=np.int32))
+        return a, a.ctypes.data_as(C.c_void_p), int(a.size)
+
+    # ------------------------------------------------------------------ slots
+    def open(self):
+        s = C.c_int(-1)
+        self._chk(self.lib.lasr_stream_open(self.ctx, C.byref(s)))
+        return s.value
+
+    def reset(self, slot, what=7):
+        self._chk(self.lib.lasr_stream_reset(self.ctx, int(slot), int(what)))
+
+    def close_slot(self, slot):
+        self._chk(self.lib.lasr_stream_close(self.ctx, int(slot)))
+
+    # ------------------------------------------------------------------ streaming
+    def push(self, slots, pcm):
+        """pcm: [n, chunk] float32 torch (cuda or cpu) tensor or numpy array."""
+        a, p, n = self._slots(slots)
+        if isinstance(pcm, torch.Tensor):
+            pcm = pcm.contiguous()
+            assert pcm.dtype == torch.float32 and pcm.numel() == n * self.desc.chunk
+        else:
+            pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+            assert pcm.size == n * self.desc.chunk
+        self._chk(self.lib.lasr_push_pcm(self.ctx, p, n, _ptr(pcm)))
+
+    def step(self, slots):
+        a, p, n = self._slots(slots)
+        ran = C.c_int(0)
+        self._chk(self.lib.lasr_step_stream(self.ctx, p, n, C.byref(ran)))
+        return ran.value
+
+    def fetch(self, slot, cap=65536):
+        buf = np.empty(cap, dtype=np.int32)
+        n = C.c_int(0)
+        nl, al = C.c_double(0.0), C.c_double(0.0)
+        self._chk(self.lib.lasr_fetch(self.ctx, int(slot), buf.ctypes.data_as(C.c_void_p), cap, C.byref(n),
+                                      C.byref(nl), C.byref(al)))
+        return [int(v) for v in buf[:n.value]], nl.value, al.value
+
+    # ------------------------------------------------------------------ offline
+    def transcribe_pcm(self, slots, pcm_list):
+        """pcm_list: list of 1-D float32 arrays/tensors (one utterance per slot)."""
+        a, p, n = self._slots(slots)
+        assert len(pcm_list) == n
+        if all(isinstance(x, torch.Tensor) and x.is_cuda for x in pcm_list):
+            cat = torch.cat([x.reshape(-1).float() for x in pcm_list]).contiguous()
+        else:
+            cat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in pcm_list]))
+        ns = np.ascontiguousarray(np.array([int(np.prod(x.shape)) for x in pcm_list], dtype=np.int64))
+        self._chk(self.lib.lasr_transcribe_pcm(self.ctx, p, n, _ptr(cat), ns.ctypes.data_as(C.c_void_p)))
+
+    def transcribe_feats(self, slots, feats_list):
+        """feats_list: list of [T', feat] float32 arrays/tensors."""
+        a, p, n = self._slots(slots)
+        assert len(feats_list) == n
+        F = self.desc.feat
+        if all(isinstance(x, torch.Tensor) and x.is_cuda for x in feats_list):
+            cat = torch.cat([x.reshape(-1, F).float() for x in feats_list]).contiguous()
+            nf = [x.reshape(-1, F).shape[0] for x in feats_list]
+        else:
+            arrs = [np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float32).reshape(-1, F) for x in feats_list]
+            cat = np.ascontiguousarray(np.concatenate(arrs))
+            nf = [a_.shape[0] for a_ in arrs]
+        nf = np.ascontiguousarray(np.array(nf, dtype=np.int32))
+        self._chk(self.lib.lasr_transcribe_feats(self.ctx, p, n, _ptr(cat), nf.ctypes.data_as(C.c_void_p)))
+
+    # ------------------------------------------------------------------ op-level (tests, microbench)
+    def logmel(self, pcm):
+        """pcm [B, N] cuda float32 -> [B, T, n_mels]"""
+        assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.dim() == 2
+        pcm = pcm.contiguous()
+        B, Ns = pcm.shape
+        T = 1 + Ns // self.desc.hop
+        out = torch.empty(B, T, self.desc.n_mels, device=pcm.device, dtype=torch.float32)
+        self._chk(self.lib.lasr_logmel(self.ctx, _ptr(pcm), B, Ns, _ptr(out)))
+        return out
+
+    def stack(self, logmel):
+        logmel = logmel.contiguous()
+        B, T, _ = logmel.shape
+        d = self.desc
+        Tp = 0 if T < d.n_stack else (T - d.n_stack) // d.stride + 1
+        out = torch.empty(B, Tp, d.feat, device=logmel.device, dtype=torch.float32)
+        tp = C.c_int(0)
+        self._chk(self.lib.lasr_stack(self.ctx, _ptr(logmel), B, T, _ptr(out), C.byref(tp)))
+        assert tp.value == Tp
+        return out
+
+    def encoder(self, feats, return_state=False):
+        """feats [B, T', feat] cuda -> [B, T', hidden] (fresh learned initial state; clobbers rows 0..B-1)."""
+        feats = feats.contiguous()
+        B, Tp, _ = feats.shape
+        H, L = self.desc.hidden, self.desc.enc_layers
+        out = torch.empty(B, Tp, H, device=feats.device, dtype=torch.float32)
+        h = torch.empty(L, B, H, device=feats.device, dtype=torch.float32) if return_state else None
+        c = torch.empty(L, B, H, device=feats.device, dtype=torch.float32) if return_state else None
+        self._chk(self.lib.lasr_encoder(self.ctx, _ptr(feats), B, Tp, _ptr(out), _ptr(h), _ptr(c)))
+        return (out, h, c) if return_state else out
+
+    def predictor(self, tokens):
+        """tokens [B, U] int (host) -> h_pred [B, hidden] after the last token, from the learned initial state."""
+        tok = np.ascontiguousarray(np.asarray(tokens, dtype=np.int32))
+        B, U = tok.shape
+        out = torch.empty(B, self.desc.hidden, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.lasr_predictor(self.ctx, tok.ctypes.data_as(C.c_void_p), B, U, _ptr(out)))
+        return out
+
+    def joint(self, h_pred, h_enc):
+        h_pred, h_enc = h_pred.contiguous(), h_enc.contiguous()
+        B = h_pred.shape[0]
+        logits = torch.empty(B, self.desc.vocab, device=h_pred.device, dtype=torch.float32)
+        lp = torch.empty(B, device=h_pred.device, dtype=torch.float32)
+        am = torch.empty(B, device=h_pred.device, dtype=torch.int32)
+        self._chk(self.lib.lasr_joint(self.ctx, _ptr(h_pred), _ptr(h_enc), B, _ptr(logits), _ptr(lp), _ptr(am)))
+        return logits, lp, am
+
+    # ------------------------------------------------------------------ stats
+    def set_profiling(self, on=True):
+        self._chk(self.lib.lasr_set_profiling(self.ctx, 1 if on else 0))
+
+    def stats(self):
+        s = N.StepStats()
+        self._chk(self.lib.lasr_get_stats(self.ctx, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in N.StepStats._fields_}
+
+    def sync(self):
+        self._chk(self.lib.lasr_sync(self.ctx))
+
+    def bench_cell(self, layer=1, iters=200):
+        us = C.c_double(0.0)
+        self._chk(self.lib.lasr_bench_cell(self.ctx, int(layer), int(iters), C.byref(us)))
+        return us.value
