@@ -1064,11 +1064,12 @@ int lasr_logmel(lasr_ctx* c, const float* pcm, int B, int64_t N, float* logmel) 
 }
 
 int lasr_stack(lasr_ctx* c, const float* logmel, int B, int T, float* feats, int* Tp) {
-    if (!c || !logmel || !feats || B < 1) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    if (!c) return LASR_EINVAL;
     const lasr_model_desc& d = c->d;
     const int tp = T < d.n_stack ? 0 : (T - d.n_stack) / d.stride + 1;
     if (Tp) *Tp = tp;
-    if (tp == 0) return LASR_OK;
+    if (tp == 0) return LASR_OK;                       // fewer than n_stack frames: no stacked frame
+    if (!logmel || !feats || B < 1) return fail(c, LASR_EINVAL, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_stack, dim3(tp, B), dim3(256), 0, c->stream, logmel, T, d.n_mels, d.n_stack, d.stride, feats, tp, d.feat);
     HIPCHK(c, hipGetLastError());
