@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,10 +20,12 @@ namespace {
 
 constexpr int NW = 8;          // waves per GEMM workgroup (K split)
 constexpr int NCMD = 64;       // ring of host->device command blocks
+constexpr int MTA = 4;         // m-tiles per workgroup in the "A" tiling (64 rows)
 
 struct Cell {                  // one recurrent layer (+ its BatchNorm fold and learned initial state)
     int I = 0;                 // input width
-    float *Wx = nullptr, *Wh = nullptr;   // packed
+    float *Wx = nullptr, *Wh = nullptr;   // packed, tiling "B" (16 units x gates per tile group)
+    float *WxA = nullptr, *WhA = nullptr; // packed, tiling "A" (4 units x gates per tile)
     float *bias = nullptr, *rbias = nullptr;
     float *bn_s = nullptr, *bn_t = nullptr;
     float *h0 = nullptr, *c0 = nullptr;
@@ -52,7 +55,9 @@ struct lasr_ctx {
 
     // recurrent state (row == slot)
     std::vector<float*> enc_h[2], enc_c, pred_h[2], pred_c, pred_y;
-    int enc_par = 0, pred_par = 0;
+    int enc_par = 0;
+    int* hsel = nullptr;            // [M] predictor h buffer holding row r's current state
+    bool enc_tiling_a = false;      // encoder cell tiling ("A": 4 units x 64 rows per workgroup)
     float *pp = nullptr, *ja = nullptr, *logits = nullptr;
     DecState ds{};
     int n_iter_slots = 0;
@@ -155,6 +160,20 @@ void pack_tiles(std::vector<float>& dst, int n_tiles, int KC, F get) {
         }
 }
 
+// "A" tiling of a pseudo-gated (NBRC) phase: tile = 4 units x {3 live gates}; fragment = [g][12 live cols][e]
+// dst[((tile*KC + c)*4 + g)*48 + a*4 + e] = get(tile, a, k), a = live column (gate = a/4, unit = a%4)
+template <class F>
+void pack_tiles12(std::vector<float>& dst, int n_tiles, int KC, F get) {
+    dst.assign((size_t)n_tiles * KC * 192, 0.f);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int c = 0; c < KC; ++c) {
+            float* o = dst.data() + ((size_t)t * KC + c) * 192;
+            for (int g = 0; g < 4; ++g)
+                for (int a = 0; a < 12; ++a)
+                    for (int e = 0; e < 4; ++e) o[(g * 12 + a) * 4 + e] = get(t, a, 16 * c + 4 * g + e);
+        }
+}
+
 bool valid_desc(const lasr_model_desc* d) {
     if (!d) return false;
     auto m16 = [](int v) { return v > 0 && v % 16 == 0; };
@@ -175,9 +194,9 @@ bool valid_desc(const lasr_model_desc* d) {
 // ---------------------------------------------------------------------------- launch helpers
 struct Ctx2 {};  // (placeholder to keep helper signatures short)
 
-template <class Epi, bool AROW>
-void launch_gemm(lasr_ctx* c, int n_groups, int m_tiles, const GemmArgs& g, const typename Epi::Args& ea) {
-    hipLaunchKernelGGL((k_gemm<Epi, NW, AROW>), dim3(n_groups, m_tiles), dim3(NW * 64), 0, c->stream, g, ea);
+template <class Epi, int MT, bool AROW>
+void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g, const typename Epi::Args& ea) {
+    hipLaunchKernelGGL((k_gemm<Epi, MT, NW, AROW>), dim3(n_groups, m_groups), dim3(NW * 64), 0, c->stream, g, ea);
 }
 
 int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
@@ -187,76 +206,88 @@ void launch_enc_cell(lasr_ctx* c, int l, int t, const float* xsrc, int x_mt_tota
     const Cell& L = c->enc[l];
     const int H = c->d.hidden;
     GemmArgs g{};
-    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / 16; g.W[0] = L.Wx;
-    g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16; g.W[1] = L.Wh;
-    EpiLSTM<false, false>::Args ea{};
-    ea.bias = L.bias; ea.tab = nullptr; ea.token = nullptr; ea.flag = c->T_row_dev; ea.t = t;
+    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / 16;
+    g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16;
+    g.M = c->M;
+    EpiLSTM<false, false, 16>::Args ea{};
+    ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t;
     ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
     ea.y = ydst; ea.y_mt_total = y_mt_total; ea.y_mt_off = t * c->MT;
     ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
-    launch_gemm<EpiLSTM<false, false>, false>(c, H / 16, c->MT, g, ea);
+    if (c->enc_tiling_a) {
+        g.W[0] = L.WxA; g.W[1] = L.WhA;
+        EpiLSTM<false, false, 4>::Args eb{};
+        memcpy(&eb, &ea, sizeof(eb));
+        launch_gemm<EpiLSTM<false, false, 4>, MTA, false>(c, H / 4, c->M / (16 * MTA), g, eb);
+    } else {
+        g.W[0] = L.Wx; g.W[1] = L.Wh;
+        launch_gemm<EpiLSTM<false, false, 16>, 1, false>(c, H / 16, c->MT, g, ea);
+    }
 }
 
-// one predictor pass (all layers) for rows with emit != 0; toggles pred_par
+// one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels)
 void launch_predictor(lasr_ctx* c) {
     const int H = c->d.hidden;
-    const int p = c->pred_par;
+    const int mgroups = c->M / (16 * MTA);
     for (int l = 0; l < c->d.pred_layers; ++l) {
         const Cell& L = c->pred[l];
         GemmArgs g{};
         if (l > 0) {
-            g.A[0] = c->pred_y[l - 1]; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = L.Wx;
+            g.A[0] = c->pred_y[l - 1]; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = L.WxA;
         }
-        g.A[1] = c->pred_h[p][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16; g.W[1] = L.Wh;
+        g.A[1] = c->pred_h[0][l]; g.A_alt[1] = c->pred_h[1][l]; g.a_sel[1] = c->hsel;
+        g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16; g.W[1] = L.WhA;
+        g.compact = c->ds.emit; g.M = c->M;
         if (c->d.pred_cell == 1) {
-            EpiLSTM<true, true>::Args ea{};   // same Args type for all EpiLSTM instantiations
-            ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
-            ea.c = c->pred_c[l]; ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l];
+            EpiLSTM<true, true, 4>::Args ea{};
+            ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = nullptr; ea.t = 0;
+            ea.c = c->pred_c[l]; ea.hbuf[0] = c->pred_h[0][l]; ea.hbuf[1] = c->pred_h[1][l]; ea.hsel = c->hsel;
             ea.y = c->pred_y[l]; ea.y_mt_total = c->MT; ea.y_mt_off = 0;
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
             if (l == 0) {
-                launch_gemm<EpiLSTM<true, true>, false>(c, H / 16, c->MT, g, ea);
+                launch_gemm<EpiLSTM<true, true, 4>, MTA, false>(c, H / 4, mgroups, g, ea);
             } else {
-                EpiLSTM<true, false>::Args eb{};
+                EpiLSTM<true, false, 4>::Args eb{};
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<EpiLSTM<true, false>, false>(c, H / 16, c->MT, g, eb);
+                launch_gemm<EpiLSTM<true, false, 4>, MTA, false>(c, H / 4, mgroups, g, eb);
             }
         } else {
-            EpiNBRC<true>::Args ea{};
-            ea.bias = L.bias; ea.rbias = L.rbias; ea.tab = L.tab; ea.token = c->ds.token; ea.emit = c->ds.emit;
-            ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = c->pred_y[l];
+            EpiNBRC<true, 4>::Args ea{};
+            ea.bias = L.bias; ea.rbias = L.rbias; ea.tab = L.tab; ea.token = c->ds.token;
+            ea.hbuf[0] = c->pred_h[0][l]; ea.hbuf[1] = c->pred_h[1][l]; ea.hsel = c->hsel; ea.y = c->pred_y[l];
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.MT = c->MT;
             if (l == 0) {
-                launch_gemm<EpiNBRC<true>, false>(c, H / 16, c->MT, g, ea);
+                launch_gemm<EpiNBRC<true, 4>, MTA, false>(c, H / 4, mgroups, g, ea);
             } else {
-                EpiNBRC<false>::Args eb{};
+                EpiNBRC<false, 4>::Args eb{};
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<EpiNBRC<false>, false>(c, H / 16, c->MT, g, eb);
+                launch_gemm<EpiNBRC<false, 4>, MTA, false>(c, H / 4, mgroups, g, eb);
             }
         }
     }
-    c->pred_par ^= 1;
 }
 
-// pp (for emitting rows) and the joint activation ja = tanh(pe[t_idx] + pp) for all rows
+// pp (for emitting rows), the joint activation ja = tanh(pe[t_idx] + pp) for all rows still decoding,
+// and the flip of the predictor ping-pong selector of the rows that just advanced
 void launch_ppj(lasr_ctx* c) {
     const int H = c->d.hidden, J = c->d.joint;
     GemmArgs g{};
     g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p;
+    g.compact = c->ds.emit; g.M = c->M;
     EpiPPJ::Args ea{};
     ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->ds.t_idx; ea.T_row = c->T_row_dev; ea.emit = c->ds.emit;
-    ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT;
-    launch_gemm<EpiPPJ, false>(c, J / 16, c->MT, g, ea);
+    ea.hsel = c->hsel; ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT;
+    launch_gemm<EpiPPJ, MTA, false>(c, J / 16, c->M / (16 * MTA), g, ea);
 }
 
 void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     const int J = c->d.joint, V = c->d.vocab;
     GemmArgs g{};
-    g.A[0] = c->ja; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = J / 16; g.W[0] = c->W2;
+    g.A[0] = c->ja; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = J / 16; g.W[0] = c->W2; g.M = c->M;
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
     ea.t_idx = gated ? c->ds.t_idx : nullptr; ea.T_row = c->T_row_dev; ea.M = c->M;
-    launch_gemm<EpiLinear, false>(c, V / 16, (n_rows + 15) / 16, g, ea);
+    launch_gemm<EpiLinear, 1, false>(c, V / 16, (n_rows + 15) / 16, g, ea);
 }
 
 // ---------------------------------------------------------------------------- command blocks
@@ -343,9 +374,11 @@ int apply_reset(lasr_ctx* c, bool any_pred) {
         a.enc_h0[l] = c->enc[l].h0; a.enc_c0[l] = c->enc[l].c0;
     }
     for (int l = 0; l < a.Lp; ++l) {
-        a.pred_h[l] = c->pred_h[c->pred_par][l]; a.pred_c[l] = c->d.pred_cell ? c->pred_c[l] : nullptr;
+        a.pred_h[l] = c->pred_h[0][l]; a.pred_h_alt[l] = c->pred_h[1][l];
+        a.pred_c[l] = c->d.pred_cell ? c->pred_c[l] : nullptr;
         a.pred_h0[l] = c->pred[l].h0; a.pred_c0[l] = c->pred[l].c0;
     }
+    a.hsel = c->hsel;
     a.token = c->ds.token; a.emit = c->ds.emit;
     hipLaunchKernelGGL(k_reset_rows, dim3(grid1((size_t)c->M * c->d.hidden)), dim3(256), 0, c->stream, a);
     if (any_pred) {
@@ -380,7 +413,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
     g.A[0] = c->ybuf[(L - 1) & 1]; g.a_mt_total[0] = mt_total; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1e;
     EpiLinear::Args ea{};
     ea.bias = nullptr; ea.out = c->pe; ea.ldo = J; ea.n_rows = T_max * c->M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
-    launch_gemm<EpiLinear, false>(c, J / 16, T_max * c->MT, g, ea);
+    launch_gemm<EpiLinear, 1, false>(c, J / 16, T_max * c->MT, g, ea);
 }
 
 // fix: every layer must start from the same parity and end on the same parity; with layer-major
@@ -535,17 +568,27 @@ int fold_bn(lasr_ctx* c, Reader& rd, int H, float** s_dev, float** t_dev) {
     return LASR_OK;
 }
 
-// LSTM layer in torch layout: W_ih [4H,I], W_hh [4H,H]; packs tiles (jb, gate)
-int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, std::vector<float>* keep_wih, std::vector<float>* keep_bias) {
+// LSTM layer in torch layout: W_ih [4H,I], W_hh [4H,H].
+//   tiling B: tile (jb, gate) = 16 units of one gate;  tiling A: tile jb = 4 units x 4 gates (col = gate*4 + unit)
+int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, bool pack_a, bool pack_b, std::vector<float>* keep_wih,
+              std::vector<float>* keep_bias) {
     L.I = I;
     const float* wih = rd.take((size_t)4 * H * I); const float* whh = rd.take((size_t)4 * H * H);
     const float* bih = rd.take(4 * H); const float* bhh = rd.take(4 * H);
     if (!bhh) return fail(c, LASR_EINVAL, "weight blob too short (lstm)");
     std::vector<float> pk;
-    pack_tiles(pk, (H / 16) * 4, I / 16, [&](int t, int ui, int k) { return wih[((size_t)(t & 3) * H + 16 * (t >> 2) + ui) * I + k]; });
-    RC(upload(c, &L.Wx, pk.data(), pk.size()));
-    pack_tiles(pk, (H / 16) * 4, H / 16, [&](int t, int ui, int k) { return whh[((size_t)(t & 3) * H + 16 * (t >> 2) + ui) * H + k]; });
-    RC(upload(c, &L.Wh, pk.data(), pk.size()));
+    if (pack_b) {
+        pack_tiles(pk, (H / 16) * 4, I / 16, [&](int t, int ui, int k) { return wih[((size_t)(t & 3) * H + 16 * (t >> 2) + ui) * I + k]; });
+        RC(upload(c, &L.Wx, pk.data(), pk.size()));
+        pack_tiles(pk, (H / 16) * 4, H / 16, [&](int t, int ui, int k) { return whh[((size_t)(t & 3) * H + 16 * (t >> 2) + ui) * H + k]; });
+        RC(upload(c, &L.Wh, pk.data(), pk.size()));
+    }
+    if (pack_a) {
+        pack_tiles(pk, H / 4, I / 16, [&](int t, int col, int k) { return wih[((size_t)(col >> 2) * H + 4 * t + (col & 3)) * I + k]; });
+        RC(upload(c, &L.WxA, pk.data(), pk.size()));
+        pack_tiles(pk, H / 4, H / 16, [&](int t, int col, int k) { return whh[((size_t)(col >> 2) * H + 4 * t + (col & 3)) * H + k]; });
+        RC(upload(c, &L.WhA, pk.data(), pk.size()));
+    }
     std::vector<float> bias(4 * H);
     for (int i = 0; i < 4 * H; ++i) bias[i] = bih[i] + bhh[i];
     RC(upload(c, &L.bias, bias.data(), bias.size()));
@@ -607,11 +650,15 @@ const char* lasr_last_error(const lasr_ctx* c) { return c ? c->err.c_str() : "nu
 static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     const lasr_model_desc& d = c->d;
     const int F = d.feat, H = d.hidden, E = d.embed, V = d.vocab, J = d.joint;
-    c->M = (d.max_streams + 15) / 16 * 16;
+    c->M = (d.max_streams + 16 * MTA - 1) / (16 * MTA) * (16 * MTA);   // whole "A"-tiling row groups
     c->MT = c->M / 16;
     const int M = c->M;
     c->G_pred = d.pred_cell ? 4 : 3;
     Reader rd{weights, n_weights};
+    {
+        const char* e = getenv("LASR_ENC_TILING");      // A/B experiment knob; default chosen by measurement
+        c->enc_tiling_a = e ? (e[0] == 'A' || e[0] == 'a') : false;
+    }
 
     // ---- front-end constants
     {
@@ -643,7 +690,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         if (!hs) return fail(c, LASR_EINVAL, "weight blob too short");
         RC(upload(c, &L.h0, hs, H)); RC(upload(c, &L.c0, hs + H, H));
         RC(fold_bn(c, rd, H, &L.bn_s, &L.bn_t));
-        RC(load_lstm(c, rd, L, l == 0 ? F : H, H, nullptr, nullptr));
+        RC(load_lstm(c, rd, L, l == 0 ? F : H, H, c->enc_tiling_a, !c->enc_tiling_a, nullptr, nullptr));
     }
     // ---- predictor
     const float* embed = rd.take((size_t)V * E);
@@ -666,17 +713,17 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         if (S == 2) RC(upload(c, &L.c0, hs + H, H));
         RC(fold_bn(c, rd, H, &L.bn_s, &L.bn_t));
         if (d.pred_cell == 1) {
-            RC(load_lstm(c, rd, L, H, H, l == 0 ? &in0_w : nullptr, l == 0 ? &in0_b : nullptr));
+            RC(load_lstm(c, rd, L, H, H, true, false, l == 0 ? &in0_w : nullptr, l == 0 ? &in0_b : nullptr));
         } else {
             const float* kx = rd.take((size_t)H * 3 * H); const float* kh = rd.take((size_t)H * 3 * H);
             const float* b = rd.take(3 * H); const float* rb = rd.take(3 * H);
             if (!rb) return fail(c, LASR_EINVAL, "weight blob too short (nbrc)");
             std::vector<float> pk;
-            // haste layout [K][3H], gates z,r,g; tiles (jb, slot)
-            pack_tiles(pk, (H / 16) * 3, H / 16, [&](int t, int ui, int k) { return kx[(size_t)k * 3 * H + (size_t)(t % 3) * H + 16 * (t / 3) + ui]; });
-            RC(upload(c, &L.Wx, pk.data(), pk.size()));
-            pack_tiles(pk, (H / 16) * 3, H / 16, [&](int t, int ui, int k) { return kh[(size_t)k * 3 * H + (size_t)(t % 3) * H + 16 * (t / 3) + ui]; });
-            RC(upload(c, &L.Wh, pk.data(), pk.size()));
+            // haste layout [K][3H], gates z,r,g; tiling A: tile = 4 units, live column a -> (gate a/4, unit a%4)
+            pack_tiles12(pk, H / 4, H / 16, [&](int t, int a, int k) { return kx[(size_t)k * 3 * H + (size_t)(a >> 2) * H + 4 * t + (a & 3)]; });
+            RC(upload(c, &L.WxA, pk.data(), pk.size()));
+            pack_tiles12(pk, H / 4, H / 16, [&](int t, int a, int k) { return kh[(size_t)k * 3 * H + (size_t)(a >> 2) * H + 4 * t + (a & 3)]; });
+            RC(upload(c, &L.WhA, pk.data(), pk.size()));
             RC(upload(c, &L.bias, b, 3 * H)); RC(upload(c, &L.rbias, rb, 3 * H));
             if (l == 0) {
                 in0_w.resize((size_t)3 * H * H);
@@ -720,7 +767,8 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, M));
     RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.step_ntok, M)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->T_row_dev, M));
-    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.step_ntok, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev})
+    RC(dalloc(c, &c->hsel, M));
+    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.step_ntok, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev, c->hsel})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
     RC(dalloc(c, &c->win, (size_t)M * d.n_window * d.chunk)); HIPCHK(c, hipMemset(c->win, 0, (size_t)M * d.n_window * d.chunk * 4));
@@ -745,7 +793,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
             RC(dalloc(c, &EF, (size_t)V * H));
             GemmArgs g{}; g.A[0] = emb_dev; g.a_mt_total[0] = E; g.a_mt_off[0] = 0; g.KC[0] = E / 16; g.W[0] = wf; g.a_rows = V;
             EpiLinear::Args ea{}; ea.bias = bf; ea.out = EF; ea.ldo = H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
-            launch_gemm<EpiLinear, true>(c, H / 16, V / 16, g, ea);
+            launch_gemm<EpiLinear, 1, true>(c, H / 16, V / 16, g, ea);
             HIPCHK(c, hipStreamSynchronize(c->stream));
             dfree(c, wf); dfree(c, bf);
         } else {
@@ -758,7 +806,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         RC(dalloc(c, &c->pred[0].tab, (size_t)V * G * H));
         GemmArgs g{}; g.A[0] = EF; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = wt; g.a_rows = V;
         EpiLinear::Args ea{}; ea.bias = bt; ea.out = c->pred[0].tab; ea.ldo = G * H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
-        launch_gemm<EpiLinear, true>(c, G * H / 16, V / 16, g, ea);
+        launch_gemm<EpiLinear, 1, true>(c, G * H / 16, V / 16, g, ea);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
         dfree(c, wt); dfree(c, bt); dfree(c, EF); dfree(c, emb_dev);
@@ -1125,6 +1173,7 @@ int lasr_predictor(lasr_ctx* c, const int32_t* tok, int B, int U, float* out) {
         HIPCHK(c, hipMemcpyAsync(c->ds.token, c->dc.token, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->ds.emit, c->dc.emit, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
         launch_predictor(c);
+        launch_ppj(c);      // flips the ping-pong selector of the rows that advanced (ja is rebuilt at the next step)
     }
     hipLaunchKernelGGL(k_from_frag, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream,
                        (const float*)c->pred_y[c->d.pred_layers - 1], c->MT, 0, out, H, B, H);
@@ -1140,9 +1189,9 @@ int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, floa
     {   // pp = h_pred W1p^T + b1 ; pe[0] = h_enc W1e^T   (row-major A)
         GemmArgs g{}; g.A[0] = h_pred; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p; g.a_rows = B;
         EpiLinear::Args ea{}; ea.bias = c->b1; ea.out = c->pp; ea.ldo = J; ea.n_rows = B; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
-        launch_gemm<EpiLinear, true>(c, J / 16, (B + 15) / 16, g, ea);
+        launch_gemm<EpiLinear, 1, true>(c, J / 16, (B + 15) / 16, g, ea);
         g.A[0] = h_enc; g.W[0] = c->W1e; ea.bias = nullptr; ea.out = c->pe;
-        launch_gemm<EpiLinear, true>(c, J / 16, (B + 15) / 16, g, ea);
+        launch_gemm<EpiLinear, 1, true>(c, J / 16, (B + 15) / 16, g, ea);
     }
     hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)c->M * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)c->pp,
                        (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MT);

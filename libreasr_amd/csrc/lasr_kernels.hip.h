@@ -37,305 +37,7 @@ __device__ __forceinline__ size_t frag_off(int r, int k, int mt_total) {
 // precise activations (no fast-math: token-for-token parity after hundreds of recurrent steps)
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// ------------------------------------------------------------------------------------------------
-// GEMM core
-// ------------------------------------------------------------------------------------------------
-struct GemmArgs {
-    const float* A[2];     // phase operand: fragment-major (or row-major when AROW)
-    int a_mt_total[2];     // m-tiles in A's fragment layout (or lda when AROW)
-    int a_mt_off[2];       // m-tile offset of this launch's rows inside A
-    int KC[2];             // K chunks (of 16) per phase; 0 = phase absent
-    const float* W[2];     // packed weights of the phase: [n_group][slot][KC][64][4]
-    int a_rows;            // AROW only: rows of A (loads of rows >= a_rows are clamped); 0 = no clamp
-};
-
-template <int MASK>
-struct PopCount {
-    static constexpr int value = (MASK & 1) + PopCount<(MASK >> 1)>::value;
-};
-template <>
-struct PopCount<0> {
-    static constexpr int value = 0;
-};
-
-template <int NS>
-struct Frag {
-    f32x4 a;
-    f32x4 b[NS > 0 ? NS : 1];
-};
-
-template <int MASK, int NT, int NW, bool AROW>
-__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[NT], const float* __restrict__ A, int a_mt_total,
-                                           int a_mt, const float* __restrict__ Wp, int KC, int jb, int w,
-                                           int lane, int a_rows) {
-    constexpr int NS = PopCount<MASK>::value;
-    if constexpr (NS == 0) {
-        return;
-    } else {
-        if (KC <= 0) return;
-        const float* wb = Wp + (size_t)jb * NS * KC * 256 + lane * 4;
-        const float* ab;
-        size_t a_step;
-        if constexpr (AROW) {   // row-major A: lane (i = lane&15, g = lane>>4) reads 16 B of row i
-            int row = a_mt * 16 + (lane & 15);
-            if (a_rows > 0 && row >= a_rows) row = a_rows - 1;
-            ab = A + (size_t)row * a_mt_total + (lane >> 4) * 4;
-            a_step = 16;
-        } else {
-            ab = A + (size_t)a_mt * 256 + lane * 4;
-            a_step = (size_t)a_mt_total * 256;
-        }
-        auto load = [&](Frag<NS>& f, int c) {
-            f.a = *reinterpret_cast<const f32x4*>(ab + (size_t)c * a_step);
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                f.b[s] = *reinterpret_cast<const f32x4*>(wb + ((size_t)s * KC + c) * 256);
-        };
-        auto compute = [&](const Frag<NS>& f) {
-            int s = 0;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if ((MASK >> nt) & 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[e], f.b[s][e], acc[nt], 0, 0, 0);
-                    ++s;
-                }
-            }
-        };
-        // 3-deep rotation: two chunks in flight while one is consumed
-        Frag<NS> f0, f1, f2;
-        int c = w;
-        if (c < KC) load(f0, c);
-        if (c + NW < KC) load(f1, c + NW);
-        for (; c < KC; c += 3 * NW) {
-            if (c + 2 * NW < KC) load(f2, c + 2 * NW);
-            compute(f0);
-            if (c + NW < KC) {
-                if (c + 3 * NW < KC) load(f0, c + 3 * NW);
-                compute(f1);
-            }
-            if (c + 2 * NW < KC) {
-                if (c + 4 * NW < KC) load(f1, c + 4 * NW);
-                compute(f2);
-            }
-        }
-    }
-}
-
-// One workgroup = (n-group jb = blockIdx.x, m-tile mt = blockIdx.y).  Epi supplies:
-//   NT, PH0_TILES, PH1_TILES, struct Args, tile_active(args, mt, lane) [wave-uniform], apply(...)
-template <class Epi, int NW, bool AROW>
-__global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typename Epi::Args ea) {
-    constexpr int NT = Epi::NT;
-    __shared__ float red[NW][16][NT * 16 + 1];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int jb = blockIdx.x, mt = blockIdx.y;
-    const bool on = Epi::tile_active(ea, mt, lane);
-
-    f32x4 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (on) {
-        gemm_phase<Epi::PH0_TILES, NT, NW, AROW>(acc, g.A[0], g.a_mt_total[0], g.a_mt_off[0] + mt, g.W[0], g.KC[0], jb, w, lane, g.a_rows);
-        gemm_phase<Epi::PH1_TILES, NT, NW, AROW>(acc, g.A[1], g.a_mt_total[1], g.a_mt_off[1] + mt, g.W[1], g.KC[1], jb, w, lane, g.a_rows);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[w][4 * (lane >> 4) + r][nt * 16 + (lane & 15)] = acc[nt][r];
-    __syncthreads();
-    if (tid < 256) {
-        const int i = tid & 15, ui = tid >> 4;   // row in the m-tile, unit / column in the n-group
-        float v[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float s = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) s += red[ww][i][nt * 16 + ui];
-            v[nt] = s;
-        }
-        Epi::apply(ea, mt, jb, i, ui, v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Epilogues
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool any16(bool flag, int lane) {
-    // wave-uniform OR over lanes 0..15
-    return (__ballot(flag && lane < 16) != 0ull);
-}
-
-// ---- LSTM cell (torch gate order i,f,g,o; custom_rnn.py:172, haste/lstm.py:34-68) + BN(eval) fold.
-// ENC: row r is active at step t iff t < T_row[r].  PRED: active iff emit[r]; phase X is replaced
-// by the per-token table tab[token][4H] when TABLE.
-template <bool PRED, bool TABLE>
-struct EpiLSTM {
-    static constexpr int NT = 4;
-    static constexpr int PH0_TILES = TABLE ? 0 : 0xF;
-    static constexpr int PH1_TILES = 0xF;
-    struct Args {
-        const float* bias;     // [4H] = b_ih + b_hh (zeros when TABLE: folded into tab)
-        const float* tab;      // [V][4H] (TABLE)
-        const int* token;      // [M]     (TABLE)
-        const int* flag;       // ENC: T_row[M];  PRED: emit[M]
-        int t;                 // ENC: time step
-        float* c;              // [H][M] cell state, in place
-        const float* h_in;     // fragment-major [H/16][MT][64][4]
-        float* h_out;          // same layout, other parity
-        float* y;              // BN(h') fragment-major; may be nullptr
-        int y_mt_total, y_mt_off;
-        const float* bn_s;     // [H]
-        const float* bn_t;     // [H]
-        int H, M, MT;
-    };
-    __device__ static bool row_active(const Args& a, int r) { return PRED ? (a.flag[r] != 0) : (a.t < a.flag[r]); }
-    __device__ static bool tile_active(const Args& a, int mt, int lane) {
-        return any16(lane < 16 && row_active(a, mt * 16 + (lane & 15)), lane);
-    }
-    __device__ static void apply(const Args& a, int mt, int jb, int i, int ui, const float (&v)[4]) {
-        const int r = mt * 16 + i, u = jb * 16 + ui;
-        const size_t ho = ((size_t)(jb * a.MT + mt) * 64 + ((ui >> 2) * 16 + i)) * 4 + (ui & 3);
-        if (!row_active(a, r)) {
-            a.h_out[ho] = a.h_in[ho];
-            return;
-        }
-        float gi = v[0], gf = v[1], gg = v[2], go = v[3];
-        const int H = a.H;
-        if (TABLE) {
-            const float* tb = a.tab + (size_t)a.token[r] * 4 * H + u;
-            gi += tb[0]; gf += tb[H]; gg += tb[2 * H]; go += tb[3 * H];
-        } else {
-            gi += a.bias[u]; gf += a.bias[H + u]; gg += a.bias[2 * H + u]; go += a.bias[3 * H + u];
-        }
-        const size_t co = (size_t)u * a.M + r;
-        const float c2 = sigmoid_(gf) * a.c[co] + sigmoid_(gi) * tanhf(gg);
-        const float h2 = sigmoid_(go) * tanhf(c2);
-        a.c[co] = c2;
-        a.h_out[ho] = h2;
-        if (a.y) {
-            const size_t yo = ((size_t)(jb * a.y_mt_total + a.y_mt_off + mt) * 64 + ((ui >> 2) * 16 + i)) * 4 + (ui & 3);
-            a.y[yo] = h2 * a.bn_s[u] + a.bn_t[u];
-        }
-    }
-};
-
-// ---- NBRC / GRU-v1 cell (haste/nbrc.py:30-64; layout z,r,g): tiles {z, r, gx, gh}.
-//   z = s(Wx_z + Rh_z), r = s(Wx_r + Rh_r), g = tanh(Wx_g + r * Rh_g), h' = z h + (1 - z) g.
-// Predictor only (active iff emit[r]).  TABLE: Wx (+ input bias) comes from tab[token][3H].
-template <bool TABLE>
-struct EpiNBRC {
-    static constexpr int NT = 4;
-    static constexpr int PH0_TILES = TABLE ? 0 : 0x7;   // x-phase: z, r, gx
-    static constexpr int PH1_TILES = 0xB;               // h-phase: z, r, gh
-    struct Args {
-        const float* bias;     // [3H] input bias (unused when TABLE)
-        const float* rbias;    // [3H] recurrent bias
-        const float* tab;      // [V][3H]
-        const int* token;
-        const int* emit;
-        const float* h_in;
-        float* h_out;
-        float* y;              // BN(h') fragment-major [H/16][MT][64][4]
-        const float* bn_s;
-        const float* bn_t;
-        int H, MT;
-    };
-    __device__ static bool tile_active(const Args& a, int mt, int lane) {
-        return any16(lane < 16 && a.emit[mt * 16 + (lane & 15)] != 0, lane);
-    }
-    __device__ static void apply(const Args& a, int mt, int jb, int i, int ui, const float (&v)[4]) {
-        const int r = mt * 16 + i, u = jb * 16 + ui, H = a.H;
-        const size_t ho = ((size_t)(jb * a.MT + mt) * 64 + ((ui >> 2) * 16 + i)) * 4 + (ui & 3);
-        const float h = a.h_in[ho];
-        if (!a.emit[r]) {
-            a.h_out[ho] = h;
-            return;
-        }
-        float xz, xr, xg;
-        if (TABLE) {
-            const float* tb = a.tab + (size_t)a.token[r] * 3 * H + u;
-            xz = tb[0]; xr = tb[H]; xg = tb[2 * H];
-        } else {
-            xz = a.bias[u]; xr = a.bias[H + u]; xg = v[2] + a.bias[2 * H + u];
-        }
-        const float z = sigmoid_(v[0] + xz + a.rbias[u]);
-        const float rr = sigmoid_(v[1] + xr + a.rbias[H + u]);
-        const float gc = tanhf(xg + rr * (v[3] + a.rbias[2 * H + u]));
-        const float h2 = z * h + (1.0f - z) * gc;
-        a.h_out[ho] = h2;
-        a.y[ho] = h2 * a.bn_s[u] + a.bn_t[u];
-    }
-};
-
-// ---- plain linear: out[row][col] = acc + bias[col], row-major.
-struct EpiLinear {
-    static constexpr int NT = 1;
-    static constexpr int PH0_TILES = 1;
-    static constexpr int PH1_TILES = 0;
-    struct Args {
-        const float* bias;    // may be nullptr
-        float* out;
-        int ldo;
-        int n_rows;           // rows >= n_rows are not written
-        const int* t_idx;     // optional row gate: row active iff t_idx[r % M] < T_row[r % M]
-        const int* T_row;
-        int M;
-    };
-    __device__ static bool row_on(const Args& a, int r) {
-        if (r >= a.n_rows) return false;
-        if (!a.t_idx) return true;
-        const int q = r % a.M;
-        return a.t_idx[q] < a.T_row[q];
-    }
-    __device__ static bool tile_active(const Args& a, int mt, int lane) {
-        return any16(lane < 16 && row_on(a, mt * 16 + (lane & 15)), lane);
-    }
-    __device__ static void apply(const Args& a, int mt, int jb, int i, int ui, const float (&v)[1]) {
-        const int r = mt * 16 + i, col = jb * 16 + ui;
-        if (!row_on(a, r)) return;
-        a.out[(size_t)r * a.ldo + col] = v[0] + (a.bias ? a.bias[col] : 0.f);
-    }
-};
-
-// ---- predictor half of the joint + fused joint activation:
-//   pp[r] = emit[r] ? h_pred[r] W1p^T + b1 : pp[r]
-//   ja[r] = tanh(pe[t_idx[r]][r] + pp[r])   (fragment-major: it is the A operand of the logits GEMM)
-// Joint.forward 'concat' (models.py:132-140): Linear(cat(pred, enc)) == W1p pred + W1e enc + b1.
-struct EpiPPJ {
-    static constexpr int NT = 1;
-    static constexpr int PH0_TILES = 1;
-    static constexpr int PH1_TILES = 0;
-    struct Args {
-        const float* b1;
-        float* pp;            // [M][J]
-        const float* pe;      // [T][M][J]
-        const int* t_idx;
-        const int* T_row;
-        const int* emit;
-        float* ja;            // fragment-major [J/16][MT][64][4]
-        int J, M, MT;
-    };
-    __device__ static bool tile_active(const Args& a, int mt, int lane) {
-        return any16(lane < 16 && a.emit[mt * 16 + (lane & 15)] != 0, lane);
-    }
-    __device__ static void apply(const Args& a, int mt, int jb, int i, int ui, const float (&v)[1]) {
-        const int r = mt * 16 + i, j = jb * 16 + ui;
-        float p;
-        if (a.emit[r]) {
-            p = v[0] + a.b1[j];
-            a.pp[(size_t)r * a.J + j] = p;
-        } else {
-            p = a.pp[(size_t)r * a.J + j];
-        }
-        const int t = a.t_idx[r];
-        if (t < a.T_row[r]) {
-            const size_t o = ((size_t)(jb * a.MT + mt) * 64 + ((ui >> 2) * 16 + i)) * 4 + (ui & 3);
-            a.ja[o] = tanhf(a.pe[((size_t)t * a.M + r) * a.J + j] + p);
-        }
-    }
-};
+#include "lasr_gemm.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // small kernels
@@ -402,7 +104,9 @@ struct ResetArgs {
     float* enc_c[16];
     const float* enc_h0[16];  // [H]
     const float* enc_c0[16];
-    float* pred_h[8];
+    float* pred_h[8];         // buffer 0
+    float* pred_h_alt[8];     // buffer 1; row r's current state lives in buffer hsel[r]
+    const int* hsel;
     float* pred_c[8];
     const float* pred_h0[8];
     const float* pred_c0[8];
@@ -426,7 +130,7 @@ __global__ void k_reset_rows(const ResetArgs a) {
         }
     if (wh & 2)
         for (int l = 0; l < a.Lp; ++l) {
-            a.pred_h[l][ho] = a.pred_h0[l][u];
+            (a.hsel[r] ? a.pred_h_alt[l] : a.pred_h[l])[ho] = a.pred_h0[l][u];
             if (a.pred_lstm) a.pred_c[l][(size_t)u * a.M + r] = a.pred_c0[l][u];
         }
 }
@@ -470,19 +174,33 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
                                                 const int* __restrict__ T_row, DecState s, int iter_slot,
                                                 float* __restrict__ out_logp, int* __restrict__ out_arg) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // state of the row: loaded up front so the latency overlaps the logits reads
+    int t = 0, Tr = 1, it0 = 0, n0 = 0, si0 = 0, no0 = 0;
+    double lp0 = 0.0;
     if (!PLAIN) {
-        const bool act = s.t_idx[r] < T_row[r];
-        if (!act) {
+        t = s.t_idx[r]; Tr = T_row[r];
+        if (t >= Tr) {
             if (tid == 0) s.emit[r] = 0;
             return;
         }
+        if (tid == 0) {
+            it0 = s.iters[r]; n0 = s.step_ntok[r]; si0 = s.sum_iters[r]; no0 = s.n_ones[r]; lp0 = s.logp_sum[r];
+        }
     }
+    constexpr int KEEP = 16;                        // logits kept in registers per thread (V <= 4096)
     const float* z = logits + (size_t)r * V;
+    float zv[KEEP];
     float best = -INFINITY;
     int arg = 0x7fffffff;
-    for (int j = tid; j < V; j += 256) {
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) {
+        const int j = tid + 256 * q;
+        zv[q] = j < V ? z[j] : -INFINITY;
+        if (zv[q] > best) { best = zv[q]; arg = j; }   // ascending j per thread: first max wins
+    }
+    for (int j = tid + 256 * KEEP; j < V; j += 256) {
         const float x = z[j];
-        if (x > best) { best = x; arg = j; }   // ascending j per thread: first max wins
+        if (x > best) { best = x; arg = j; }
     }
     __shared__ float sv[4];
     __shared__ int si[4];
@@ -500,7 +218,9 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     for (int q = 1; q < 4; ++q)
         if (sv[q] > best || (sv[q] == best && si[q] < arg)) { best = sv[q]; arg = si[q]; }
     float sum = 0.f;
-    for (int j = tid; j < V; j += 256) sum += expf(z[j] - best);
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) sum += expf(zv[q] - best);      // exp(-inf) = 0 for the padding
+    for (int j = tid + 256 * KEEP; j < V; j += 256) sum += expf(z[j] - best);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if (lane == 0) ss[w] = sum;
@@ -513,30 +233,28 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         out_arg[r] = arg;
         return;
     }
-    s.logp_sum[r] += (double)logp;
-    int it = s.iters[r] + 1;
-    s.sum_iters[r] += 1;
+    s.logp_sum[r] = lp0 + (double)logp;
+    int it = it0 + 1;
+    s.sum_iters[r] = si0 + 1;
     bool frame_done;
     if (arg == blank) {
         s.emit[r] = 0;
         frame_done = true;
     } else {
-        const int n = s.step_ntok[r];
-        if (n < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n] = arg;
-        s.step_ntok[r] = n + 1;
+        if (n0 < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n0] = arg;
+        s.step_ntok[r] = n0 + 1;
         s.token[r] = arg;
         s.emit[r] = 1;
         frame_done = (it >= max_iters);
     }
-    int t = s.t_idx[r];
     if (frame_done) {
-        if (it == 1) s.n_ones[r] += 1;
+        if (it == 1) s.n_ones[r] = no0 + 1;
         it = 0;
         t += 1;
         s.t_idx[r] = t;
     }
     s.iters[r] = it;
-    if (t < T_row[r]) atomicAdd(&s.unfinished[iter_slot], 1);
+    if (t < Tr) atomicAdd(&s.unfinished[iter_slot], 1);
 }
 
 // ------------------------------------------------------------------------------------------------
