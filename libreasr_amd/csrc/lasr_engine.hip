@@ -56,8 +56,11 @@ struct lasr_ctx {
     // recurrent state (row == slot)
     std::vector<float*> enc_h[2], enc_c, pred_h[2], pred_c, pred_y;
     int enc_par = 0;
-    int* hsel = nullptr;            // [M] predictor h buffer holding row r's current state
+    int pred_par = 0;               // predictor h ping-pong parity (row-major [M][H] buffers)
     bool enc_tiling_a = false;      // encoder cell tiling ("A": 4 units x 64 rows per workgroup)
+    int rot_mul = 0;                // K-walk rotation multiplier of the encoder cell (GemmArgs::rot_mul)
+    int cell_variant = 0;           // encoder cell (waves, prefetch depth) variant
+    std::vector<unsigned long long> tile_masks;   // per step t: m-tiles with an active row (from the host's T_row)
     float *pp = nullptr, *ja = nullptr, *logits = nullptr;
     DecState ds{};
     int n_iter_slots = 0;
@@ -194,9 +197,9 @@ bool valid_desc(const lasr_model_desc* d) {
 // ---------------------------------------------------------------------------- launch helpers
 struct Ctx2 {};  // (placeholder to keep helper signatures short)
 
-template <class Epi, int MT, bool AROW>
+template <class Epi, int MT, bool AROW, int NWV = NW, int D = 3, int ABL = 0>
 void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g, const typename Epi::Args& ea) {
-    hipLaunchKernelGGL((k_gemm<Epi, MT, NW, AROW>), dim3(n_groups, m_groups), dim3(NW * 64), 0, c->stream, g, ea);
+    hipLaunchKernelGGL((k_gemm<Epi, MT, NWV, AROW, D, ABL>), dim3(n_groups, m_groups), dim3(NWV * 64), 0, c->stream, g, ea);
 }
 
 int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
@@ -208,9 +211,9 @@ void launch_enc_cell(lasr_ctx* c, int l, int t, const float* xsrc, int x_mt_tota
     GemmArgs g{};
     g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / 16;
     g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16;
-    g.M = c->M;
+    g.M = c->M; g.rot_mul = c->rot_mul;
     EpiLSTM<false, false, 16>::Args ea{};
-    ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t;
+    ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t; ea.tile_mask = c->tile_masks.empty() ? ~0ull : c->tile_masks[t];
     ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
     ea.y = ydst; ea.y_mt_total = y_mt_total; ea.y_mt_off = t * c->MT;
     ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
@@ -221,63 +224,76 @@ void launch_enc_cell(lasr_ctx* c, int l, int t, const float* xsrc, int x_mt_tota
         launch_gemm<EpiLSTM<false, false, 4>, MTA, false>(c, H / 4, c->M / (16 * MTA), g, eb);
     } else {
         g.W[0] = L.Wx; g.W[1] = L.Wh;
-        launch_gemm<EpiLSTM<false, false, 16>, 1, false>(c, H / 16, c->MT, g, ea);
+        using E = EpiLSTM<false, false, 16>;
+        switch (c->cell_variant) {      // (waves, ring depth) experiment knob LASR_CELL_VARIANT
+            case 1: launch_gemm<E, 1, false, 8, 5>(c, H / 16, c->MT, g, ea); break;
+            case 2: launch_gemm<E, 1, false, 8, 7>(c, H / 16, c->MT, g, ea); break;
+            case 3: launch_gemm<E, 1, false, 4, 5>(c, H / 16, c->MT, g, ea); break;
+            case 4: launch_gemm<E, 1, false, 4, 8>(c, H / 16, c->MT, g, ea); break;
+            case 5: launch_gemm<E, 1, false, 16, 3>(c, H / 16, c->MT, g, ea); break;
+            case 6: launch_gemm<E, 1, false, 4, 12>(c, H / 16, c->MT, g, ea); break;
+            case 7: launch_gemm<E, 1, false, 8, 3, 1>(c, H / 16, c->MT, g, ea); break;   // ablation: loads only
+            case 8: launch_gemm<E, 1, false, 8, 3, 2>(c, H / 16, c->MT, g, ea); break;   // ablation: MFMA only
+            case 9: launch_gemm<E, 1, false, 8, 2>(c, H / 16, c->MT, g, ea); break;
+            default: launch_gemm<E, 1, false, 8, 3>(c, H / 16, c->MT, g, ea); break;
+        }
     }
 }
 
-// one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels)
+// one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels); predictor
+// state is row-major [M][H]; toggles pred_par
 void launch_predictor(lasr_ctx* c) {
     const int H = c->d.hidden;
     const int mgroups = c->M / (16 * MTA);
+    const int p = c->pred_par;
     for (int l = 0; l < c->d.pred_layers; ++l) {
         const Cell& L = c->pred[l];
         GemmArgs g{};
         if (l > 0) {
-            g.A[0] = c->pred_y[l - 1]; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = L.WxA;
+            g.A[0] = c->pred_y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = L.WxA;
         }
-        g.A[1] = c->pred_h[0][l]; g.A_alt[1] = c->pred_h[1][l]; g.a_sel[1] = c->hsel;
-        g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16; g.W[1] = L.WhA;
+        g.A[1] = c->pred_h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / 16; g.W[1] = L.WhA;
         g.compact = c->ds.emit; g.M = c->M;
         if (c->d.pred_cell == 1) {
             EpiLSTM<true, true, 4>::Args ea{};
-            ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = nullptr; ea.t = 0;
-            ea.c = c->pred_c[l]; ea.hbuf[0] = c->pred_h[0][l]; ea.hbuf[1] = c->pred_h[1][l]; ea.hsel = c->hsel;
-            ea.y = c->pred_y[l]; ea.y_mt_total = c->MT; ea.y_mt_off = 0;
+            ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
+            ea.c = c->pred_c[l]; ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l];
+            ea.y = c->pred_y[l]; ea.y_mt_total = 0; ea.y_mt_off = 0;
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
             if (l == 0) {
-                launch_gemm<EpiLSTM<true, true, 4>, MTA, false>(c, H / 4, mgroups, g, ea);
+                launch_gemm<EpiLSTM<true, true, 4>, MTA, true>(c, H / 4, mgroups, g, ea);
             } else {
                 EpiLSTM<true, false, 4>::Args eb{};
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<EpiLSTM<true, false, 4>, MTA, false>(c, H / 4, mgroups, g, eb);
+                launch_gemm<EpiLSTM<true, false, 4>, MTA, true>(c, H / 4, mgroups, g, eb);
             }
         } else {
             EpiNBRC<true, 4>::Args ea{};
-            ea.bias = L.bias; ea.rbias = L.rbias; ea.tab = L.tab; ea.token = c->ds.token;
-            ea.hbuf[0] = c->pred_h[0][l]; ea.hbuf[1] = c->pred_h[1][l]; ea.hsel = c->hsel; ea.y = c->pred_y[l];
-            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.MT = c->MT;
+            ea.bias = L.bias; ea.rbias = L.rbias; ea.tab = L.tab; ea.token = c->ds.token; ea.emit = c->ds.emit;
+            ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = c->pred_y[l];
+            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M;
             if (l == 0) {
-                launch_gemm<EpiNBRC<true, 4>, MTA, false>(c, H / 4, mgroups, g, ea);
+                launch_gemm<EpiNBRC<true, 4>, MTA, true>(c, H / 4, mgroups, g, ea);
             } else {
                 EpiNBRC<false, 4>::Args eb{};
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<EpiNBRC<false, 4>, MTA, false>(c, H / 4, mgroups, g, eb);
+                launch_gemm<EpiNBRC<false, 4>, MTA, true>(c, H / 4, mgroups, g, eb);
             }
         }
     }
+    c->pred_par ^= 1;
 }
 
-// pp (for emitting rows), the joint activation ja = tanh(pe[t_idx] + pp) for all rows still decoding,
-// and the flip of the predictor ping-pong selector of the rows that just advanced
+// pp (for emitting rows) and the joint activation ja = tanh(pe[t_idx] + pp) for all rows still decoding
 void launch_ppj(lasr_ctx* c) {
     const int H = c->d.hidden, J = c->d.joint;
     GemmArgs g{};
-    g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p;
+    g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p;
     g.compact = c->ds.emit; g.M = c->M;
     EpiPPJ::Args ea{};
     ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->ds.t_idx; ea.T_row = c->T_row_dev; ea.emit = c->ds.emit;
-    ea.hsel = c->hsel; ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT;
-    launch_gemm<EpiPPJ, MTA, false>(c, J / 16, c->M / (16 * MTA), g, ea);
+    ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT;
+    launch_gemm<EpiPPJ, MTA, true>(c, J / 16, c->M / (16 * MTA), g, ea);
 }
 
 void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
@@ -319,6 +335,20 @@ int cmd_begin(lasr_ctx* c) {
 }
 int cmd_commit(lasr_ctx* c) {
     HIPCHK(c, hipMemcpyAsync((char*)c->dc.T_row, (char*)c->hc.T_row, c->cmd_bytes, hipMemcpyHostToDevice, c->stream));
+    return LASR_OK;
+}
+
+// device copy of the step's T_row (from the committed command block) + host-side per-step masks of
+// the m-tiles that contain an active row (passed by value to the encoder cell kernels)
+int commit_T_rows(lasr_ctx* c, int T_max) {
+    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    c->tile_masks.assign(std::max(T_max, 1), 0ull);
+    for (int t = 0; t < T_max; ++t) {
+        unsigned long long m = 0;
+        for (int r = 0; r < c->M; ++r)
+            if (t < c->hc.T_row[r]) m |= 1ull << (r >> 4);
+        c->tile_masks[t] = m;
+    }
     return LASR_OK;
 }
 
@@ -374,11 +404,10 @@ int apply_reset(lasr_ctx* c, bool any_pred) {
         a.enc_h0[l] = c->enc[l].h0; a.enc_c0[l] = c->enc[l].c0;
     }
     for (int l = 0; l < a.Lp; ++l) {
-        a.pred_h[l] = c->pred_h[0][l]; a.pred_h_alt[l] = c->pred_h[1][l];
+        a.pred_h[l] = c->pred_h[c->pred_par][l];
         a.pred_c[l] = c->d.pred_cell ? c->pred_c[l] : nullptr;
         a.pred_h0[l] = c->pred[l].h0; a.pred_c0[l] = c->pred[l].c0;
     }
-    a.hsel = c->hsel;
     a.token = c->ds.token; a.emit = c->ds.emit;
     hipLaunchKernelGGL(k_reset_rows, dim3(grid1((size_t)c->M * c->d.hidden)), dim3(256), 0, c->stream, a);
     if (any_pred) {
@@ -658,6 +687,10 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     {
         const char* e = getenv("LASR_ENC_TILING");      // A/B experiment knob; default chosen by measurement
         c->enc_tiling_a = e ? (e[0] == 'A' || e[0] == 'a') : false;
+        const char* r = getenv("LASR_CELL_ROT");
+        c->rot_mul = r ? atoi(r) : 0;
+        const char* v = getenv("LASR_CELL_VARIANT");
+        c->cell_variant = v ? atoi(v) : 0;
     }
 
     // ---- front-end constants
@@ -767,8 +800,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, M));
     RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.step_ntok, M)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->T_row_dev, M));
-    RC(dalloc(c, &c->hsel, M));
-    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.step_ntok, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev, c->hsel})
+    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.step_ntok, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
     RC(dalloc(c, &c->win, (size_t)M * d.n_window * d.chunk)); HIPCHK(c, hipMemset(c->win, 0, (size_t)M * d.n_window * d.chunk * 4));
@@ -950,7 +982,7 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
     }
     const int Tm = d.n_buffer;
     RC(ensure_T(c, Tm));
-    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    RC(commit_T_rows(c, Tm));
     {
         StackLnArgs a{};
         a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
@@ -975,7 +1007,7 @@ static int transcribe_common(lasr_ctx* c, const int* slots, int n, int T_max) {
     // cmd block (T_row, what) already filled + committed by the caller; x0 holds the features
     const lasr_model_desc& d = c->d;
     std::vector<int> rows(slots, slots + n);
-    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    RC(commit_T_rows(c, T_max));
     rec(c, 1);
     run_encoder(c, T_max);
     rec(c, 2);
@@ -1134,7 +1166,7 @@ int lasr_encoder(lasr_ctx* c, const float* feats, int B, int Tp, float* out, flo
     for (int r = 0; r < B; ++r) { c->hc.T_row[r] = Tp; c->hc.what[r] = 1; c->hc.row_feat_off[r] = (long long)r * Tp; }
     RC(cmd_commit(c));
     RC(apply_reset(c, false));
-    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    RC(commit_T_rows(c, Tp));
     StackLnArgs a{};
     a.src = feats; a.mode = 1; a.row_off = c->dc.row_feat_off; a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b;
     a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels; a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT;
@@ -1173,10 +1205,8 @@ int lasr_predictor(lasr_ctx* c, const int32_t* tok, int B, int U, float* out) {
         HIPCHK(c, hipMemcpyAsync(c->ds.token, c->dc.token, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->ds.emit, c->dc.emit, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
         launch_predictor(c);
-        launch_ppj(c);      // flips the ping-pong selector of the rows that advanced (ja is rebuilt at the next step)
     }
-    hipLaunchKernelGGL(k_from_frag, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream,
-                       (const float*)c->pred_y[c->d.pred_layers - 1], c->MT, 0, out, H, B, H);
+    HIPCHK(c, hipMemcpyAsync(out, c->pred_y[c->d.pred_layers - 1], sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
 }
@@ -1236,7 +1266,7 @@ int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us) {
     RC(cmd_begin(c));
     for (int r = 0; r < c->d.max_streams; ++r) c->hc.T_row[r] = 1;
     RC(cmd_commit(c));
-    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * M, hipMemcpyDeviceToDevice, c->stream));
+    RC(commit_T_rows(c, 1));
     const float* xsrc = layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1];
     const int mt_total = c->Tcap * c->MT;
     for (int i = 0; i < 3; ++i) { launch_enc_cell(c, layer, 0, xsrc, mt_total, c->ybuf[layer & 1], mt_total); c->enc_par ^= 1; }

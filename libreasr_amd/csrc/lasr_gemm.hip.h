@@ -23,8 +23,6 @@
 
 struct GemmArgs {
     const float* A[2];      // phase operand: fragment-major (row-major when AROW)
-    const float* A_alt[2];  // optional second buffer: row r reads A_alt when a_sel[r] != 0
-    const int* a_sel[2];    // per-row buffer selector (predictor h ping-pong), may be nullptr
     int a_mt_total[2];      // m-tiles in A's fragment layout (lda when AROW)
     int a_mt_off[2];        // m-tile index of row 0 inside A
     int KC[2];              // K chunks (of 16) per phase; 0 = phase absent
@@ -32,6 +30,8 @@ struct GemmArgs {
     int a_rows;             // AROW only: loads of rows >= a_rows are clamped (0 = no clamp)
     const int* compact;     // COMPACT epilogues: per-row flag
     int M;                  // rows scanned for compaction
+    int rot_mul;            // workgroup jb walks K starting at chunk (jb*rot_mul) % KC: co-resident
+                            // workgroups then read different lines of the shared operand at any moment
 };
 
 template <int MASK>
@@ -51,10 +51,12 @@ struct Frag {
 
 // DEAD >= 0: columns [DEAD, DEAD+4) of the 16-column tile carry no weights in this phase; the
 // fragment stores only the 12 live columns (768 B) and the dead lanes feed zeros to the MFMA.
-template <int TILES, int DEAD, int MT, int NT, int NW>
+// MTP = number of leading m-tiles processed (no per-tile branches in the K loop); D = ring depth.
+// ABL (ablation, micro-benchmarks only): 0 = normal, 1 = loads without MFMA, 2 = MFMA without loads
+template <int TILES, int DEAD, int MT, int MTP, int NT, int NW, int D, int ABL = 0>
 __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const float* const (&aptr)[MT], size_t a_step,
-                                           const bool (&tile_on)[MT], const float* __restrict__ Wp, int KC, int jb,
-                                           int w, int lane) {
+                                           const float* __restrict__ Wp, int KC, int jb, int w, int lane,
+                                           int rot_mul) {
     constexpr int NS = PopCount<TILES>::value;
     if constexpr (NS == 0) {
         return;
@@ -71,12 +73,21 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const float* co
         }
         const float* wb = Wp + (size_t)jb * NS * KC * FR + loff;
         const int n = (KC - w + NW - 1) / NW;          // chunks of this wave (<= 0: none)
-        auto load = [&](Frag<MT, NS>& f, int i) {
+        const int rot = (int)(((unsigned)jb * (unsigned)rot_mul) % (unsigned)KC);
+        auto load = [&](Frag<MTP, NS>& f, int i) {
+            if constexpr (ABL == 2) {
+#pragma unroll
+                for (int mt = 0; mt < MTP; ++mt) f.a[mt] = f32x4{1.f, 2.f, 3.f, (float)i};
+#pragma unroll
+                for (int s = 0; s < NS; ++s) f.b[s] = f32x4{1.f, 2.f, 3.f, (float)s};
+                return;
+            }
             int c = w + i * NW;
             c = c < KC ? c : KC - 1;                   // clamp: the load stays valid and countable
+            c += rot;
+            c = c >= KC ? c - KC : c;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                if (MT == 1 || tile_on[mt]) f.a[mt] = *reinterpret_cast<const f32x4*>(aptr[mt] + (size_t)c * a_step);
+            for (int mt = 0; mt < MTP; ++mt) f.a[mt] = *reinterpret_cast<const f32x4*>(aptr[mt] + (size_t)c * a_step);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 if (DEAD < 0 || live)
@@ -85,12 +96,18 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const float* co
                     f.b[s] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
-        auto compute = [&](const Frag<MT, NS>& f) {
+        auto compute = [&](const Frag<MTP, NS>& f) {
+            if constexpr (ABL == 1) {
+#pragma unroll
+                for (int mt = 0; mt < MTP; ++mt) asm volatile("" ::"v"(f.a[mt]));
+#pragma unroll
+                for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(f.b[s]));
+                return;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    if (MT > 1 && !tile_on[mt]) continue;
+                for (int mt = 0; mt < MTP; ++mt) {
                     int s = 0;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
@@ -102,17 +119,107 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const float* co
                 }
             }
         };
-        Frag<MT, NS> f0, f1, f2;
-        load(f0, 0);
-        load(f1, 1);
-        for (int i = 0; i < n; i += 3) {
-            load(f2, i + 2);
-            compute(f0);
-            load(f0, i + 3);
-            if (i + 1 < n) compute(f1);
-            load(f1, i + 4);
-            if (i + 2 < n) compute(f2);
+        // D-deep register ring: slot d holds chunk i+d; D-1 chunks are in flight while one is consumed
+        Frag<MTP, NS> f[D];
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) load(f[d], d);
+        for (int i = 0; i < n; i += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                load(f[(d + D - 1) % D], i + d + D - 1);
+                if (d == 0 || i + d < n) compute(f[d]);
+            }
         }
+    }
+}
+
+// Static K schedule: both phases as ONE fully unrolled chunk stream (NCH0 + NCH1 chunks per wave,
+// KC == NCH * NW exactly).  Straight-line code lets the compiler count every load, so the D-deep ring
+// really keeps D-1 chunks in flight (the dynamic loop above is drained to vmcnt(0) at each loop head
+// by hipcc's waitcnt pass) and phase 1's first loads overlap phase 0's last MFMAs.
+template <class Epi, int MT, int MTP, int NT, int NW, int D, int NCH0, int NCH1, int ABL, bool AROW>
+__device__ __forceinline__ void gemm_static(f32x4 (&acc)[MT][NT], const float* const (&ap0)[MT], size_t a_step0,
+                                            const float* const (&ap1)[MT], size_t a_step1, const GemmArgs& g, int jb,
+                                            int w, int lane) {
+    constexpr int NS0 = PopCount<Epi::PH0_TILES>::value, NS1 = PopCount<Epi::PH1_TILES>::value;
+    constexpr int NSM = NS0 > NS1 ? NS0 : NS1;
+    constexpr int N0 = NS0 > 0 ? NCH0 : 0, N1 = NS1 > 0 ? NCH1 : 0, NTOT = N0 + N1;
+    auto lane_off = [&](int dead, bool& live) {
+        if (dead < 0) { live = true; return lane * 4; }
+        const int col = lane & 15, gq = lane >> 4;
+        live = !(col >= dead && col < dead + 4);
+        return (gq * 12 + (col < dead ? col : col - 4)) * 4;
+    };
+    bool live0, live1;
+    const int lo0 = lane_off(Epi::PH0_DEAD, live0), lo1 = lane_off(Epi::PH1_DEAD, live1);
+    constexpr int FR0 = Epi::PH0_DEAD >= 0 ? 192 : 256, FR1 = Epi::PH1_DEAD >= 0 ? 192 : 256;
+    const int KC0 = NCH0 * NW, KC1 = NCH1 * NW;
+    const float* wb0 = NS0 > 0 ? g.W[0] + (size_t)jb * NS0 * KC0 * FR0 + lo0 : nullptr;
+    const float* wb1 = NS1 > 0 ? g.W[1] + (size_t)jb * NS1 * KC1 * FR1 + lo1 : nullptr;
+    Frag<MTP, NSM> f[D];
+    auto load = [&](Frag<MTP, NSM>& fr, int i) {       // i is a compile-time constant after unrolling
+        if constexpr (ABL == 2) {
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = f32x4{1.f, 2.f, 3.f, (float)i};
+#pragma unroll
+            for (int s = 0; s < NSM; ++s) fr.b[s] = f32x4{1.f, 2.f, 3.f, (float)s};
+            return;
+        }
+        // row-major A: a wave takes chunk PAIRS (two 64-B halves of the same 128-B lines, second hits L1)
+        auto chunk = [&](int q) { return AROW ? ((q >> 1) * NW + w) * 2 + (q & 1) : w + q * NW; };
+        if (i < N0) {
+            const int c = chunk(i);
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = *reinterpret_cast<const f32x4*>(ap0[mt] + (size_t)c * a_step0);
+#pragma unroll
+            for (int s = 0; s < NS0; ++s)
+                fr.b[s] = (Epi::PH0_DEAD < 0 || live0) ? *reinterpret_cast<const f32x4*>(wb0 + ((size_t)s * KC0 + c) * FR0)
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const int c = chunk(i - N0);
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = *reinterpret_cast<const f32x4*>(ap1[mt] + (size_t)c * a_step1);
+#pragma unroll
+            for (int s = 0; s < NS1; ++s)
+                fr.b[s] = (Epi::PH1_DEAD < 0 || live1) ? *reinterpret_cast<const f32x4*>(wb1 + ((size_t)s * KC1 + c) * FR1)
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto compute = [&](const Frag<MTP, NSM>& fr, int i) {
+        if constexpr (ABL == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt) asm volatile("" ::"v"(fr.a[mt]));
+#pragma unroll
+            for (int s = 0; s < NSM; ++s) asm volatile("" ::"v"(fr.b[s]));
+            return;
+        }
+        const int tiles = i < N0 ? Epi::PH0_TILES : Epi::PH1_TILES;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt) {
+                int s = 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if ((tiles >> nt) & 1) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.a[mt][e], fr.b[s][e], acc[mt][nt], 0, 0, 0);
+                        ++s;
+                    }
+                }
+            }
+        }
+    };
+    // sched_barrier(0): hipcc's scheduler otherwise sinks the loads next to their first use
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (d < NTOT) load(f[d], d);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NTOT; ++i) {
+        if (i + D - 1 < NTOT) load(f[(i + D - 1) % D], i + D - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f[i % D], i);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -128,7 +235,7 @@ struct RedView {
 };
 
 // One workgroup = (n-group jb = blockIdx.x, m-group mg = blockIdx.y of MT m-tiles).
-template <class Epi, int MT, int NW, bool AROW>
+template <class Epi, int MT, int NW, bool AROW, int D, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typename Epi::Args ea) {
     constexpr int NT = Epi::NT, ROWS = MT * 16, LD = NT * 16 + 1;
     __shared__ float red[NW * ROWS * LD];
@@ -152,7 +259,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
         }
         __syncthreads();
         n_act = n_act_s;
-        if (mg * ROWS >= n_act && !Epi::RUN_ALWAYS) return;
     }
 
     bool tile_on[MT];
@@ -177,10 +283,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
             ap1[mt] = g.A[1] ? g.A[1] + (size_t)rr * g.a_mt_total[1] + (lane >> 4) * 4 : nullptr;
         } else {
             const size_t in_tile = ((size_t)(lane >> 4) * 16 + (orow & 15)) * 4;
-            const float* b0 = (g.a_sel[0] && g.a_sel[0][orow]) ? g.A_alt[0] : g.A[0];
-            const float* b1 = (g.a_sel[1] && g.a_sel[1][orow]) ? g.A_alt[1] : g.A[1];
-            ap0[mt] = b0 + (size_t)(g.a_mt_off[0] + (orow >> 4)) * 256 + in_tile;
-            ap1[mt] = b1 + (size_t)(g.a_mt_off[1] + (orow >> 4)) * 256 + in_tile;
+            ap0[mt] = g.A[0] + (size_t)(g.a_mt_off[0] + (orow >> 4)) * 256 + in_tile;
+            ap1[mt] = g.A[1] + (size_t)(g.a_mt_off[1] + (orow >> 4)) * 256 + in_tile;
         }
     }
     if constexpr (AROW) {
@@ -195,12 +299,39 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    bool any_on = false;
+    // number of leading m-tiles to process: 1 + index of the highest active tile (rows of inactive
+    // tiles inside the prefix are computed and then masked by the epilogue)
+    int P = 0;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) any_on = any_on || tile_on[mt];
-    if (any_on) {   // wave-uniform: no weight is streamed for a workgroup without active rows
-        gemm_phase<Epi::PH0_TILES, Epi::PH0_DEAD, MT, NT, NW>(acc, ap0, a_step0, tile_on, g.W[0], g.KC[0], jb, w, lane);
-        gemm_phase<Epi::PH1_TILES, Epi::PH1_DEAD, MT, NT, NW>(acc, ap1, a_step1, tile_on, g.W[1], g.KC[1], jb, w, lane);
+    for (int mt = 0; mt < MT; ++mt)
+        if (tile_on[mt]) P = mt + 1;
+    // static K schedules for the shapes of the shipped / benchmarked models (chunks per wave and phase)
+    auto run_phases = [&](auto mtp_tag) {
+        constexpr int MTP = decltype(mtp_tag)::value;
+        constexpr bool P0 = PopCount<Epi::PH0_TILES>::value > 0, P1 = PopCount<Epi::PH1_TILES>::value > 0;
+        const int k0 = P0 ? g.KC[0] : 0, k1 = P1 ? g.KC[1] : 0;
+        if (g.rot_mul == 0) {
+#define LASR_TRY(N0, N1)                                                                                        \
+    if ((!P0 || k0 == (N0) * NW) && (!P1 || k1 == (N1) * NW)) {                                                 \
+        gemm_static<Epi, MT, MTP, NT, NW, D, N0, N1, ABL, AROW>(acc, ap0, a_step0, ap1, a_step1, g, jb, w, lane); \
+        return;                                                                                                  \
+    }
+            LASR_TRY(8, 8)       // K = 1024 / 1024  (8 waves)   | K = 512 (4 waves)
+            LASR_TRY(10, 8)      // K = 1280 / 1024  (encoder layer 0)
+            LASR_TRY(12, 12)     // K = 1536 / 1536
+            LASR_TRY(10, 12)     // K = 1280 / 1536
+#undef LASR_TRY
+        }
+        gemm_phase<Epi::PH0_TILES, Epi::PH0_DEAD, MT, MTP, NT, NW, D, ABL>(acc, ap0, a_step0, g.W[0], g.KC[0], jb, w, lane, g.rot_mul);
+        gemm_phase<Epi::PH1_TILES, Epi::PH1_DEAD, MT, MTP, NT, NW, D, ABL>(acc, ap1, a_step1, g.W[1], g.KC[1], jb, w, lane, g.rot_mul);
+    };
+    if constexpr (MT == 1) {
+        if (P == 1) run_phases(std::integral_constant<int, 1>{});   // wave-uniform: an idle workgroup streams nothing
+    } else {
+        if (P == MT) run_phases(std::integral_constant<int, MT>{});
+        else if (P == 1) run_phases(std::integral_constant<int, 1>{});
+        else if (P == 2) run_phases(std::integral_constant<int, 2>{});
+        else if (P == 3) run_phases(std::integral_constant<int, (MT > 3 ? 3 : MT)>{});
     }
 
 #pragma unroll
@@ -226,9 +357,11 @@ __device__ __forceinline__ size_t hfrag(int r, int u, int MT_all) {
 }
 
 // ---- LSTM cell (torch gate order i,f,g,o; custom_rnn.py:172, haste/lstm.py:34-68) + BN(eval) fold.
-// ENC: row r is active at step t iff t < T_row[r]; inactive rows carry h to the other parity buffer.
-// PRED (COMPACT): only emitting rows are touched; h ping-pong is per row (hsel); phase X is the
-// per-token table tab[token][4H] when TABLE.
+// h ping-pongs between two buffers (every workgroup reads all of h while others write their units);
+// rows that do not advance are carried to the other buffer by the workgroup that owns the units.
+// ENC: fragment-major state; row r advances at step t iff t < T_row[r].
+// PRED (COMPACT): row-major state [M][H]; the rows that emitted advance; phase X is the per-token
+// table tab[token][4H] when TABLE.
 template <bool PRED, bool TABLE, int U>
 struct EpiLSTM {
     static constexpr int NT = U == 16 ? 4 : 1;
@@ -236,27 +369,25 @@ struct EpiLSTM {
     static constexpr int PH1_TILES = U == 16 ? 0xF : 1;
     static constexpr int PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = PRED;
-    static constexpr bool RUN_ALWAYS = false;
     struct Args {
         const float* bias;     // [4H] = b_ih + b_hh (folded into tab when TABLE)
         const float* tab;      // [V][4H]
         const int* token;      // [M]
-        const int* flag;       // ENC: T_row[M]
+        const int* flag;       // ENC: T_row[M];  PRED: emit[M]
         int t;                 // ENC: time step
+        unsigned long long tile_mask;   // ENC: bit mt set iff m-tile mt has a row with t < T_row (host-computed:
+                               //      no global load sits in front of the first weight load)
         float* c;              // [H][M] cell state, in place
-        const float* h_in;     // ENC: fragment-major current parity
-        float* h_out;          // ENC: other parity
-        float* hbuf[2];        // PRED: both buffers; row r reads hbuf[hsel[r]], writes hbuf[hsel[r]^1]
-        const int* hsel;       // PRED
-        float* y;              // BN(h') fragment-major; may be nullptr
+        const float* h_in;     // current parity
+        float* h_out;          // other parity
+        float* y;              // BN(h'); ENC fragment-major (may be nullptr), PRED row-major
         int y_mt_total, y_mt_off;
         const float* bn_s;
         const float* bn_t;
         int H, M, MT;
     };
-    __device__ static bool tile_active(const Args& a, int mt, int lane) {
-        return any16(lane < 16 && a.t < a.flag[mt * 16 + (lane & 15)], lane);
-    }
+    __device__ static bool tile_active(const Args& a, int mt, int lane) { return (a.tile_mask >> mt) & 1ull; }
+    __device__ static size_t hidx(const Args& a, int r, int u) { return PRED ? (size_t)r * a.H + u : hfrag(r, u, a.MT); }
     template <int MTB, class Red>
     __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map) {
         constexpr int ROWS = MTB * 16;
@@ -265,16 +396,14 @@ struct EpiLSTM {
             const int row = it % ROWS, uu = it / ROWS;
             const int vr = mg * ROWS + row;
             const int u = jb * U + uu;
-            int r = vr;
-            float* hout = a.h_out;
-            if (PRED) {
+            if (PRED) {     // carry the non-emitting rows of this workgroup's original row range
+                if (vr < a.M && !a.flag[vr]) a.h_out[hidx(a, vr, u)] = a.h_in[hidx(a, vr, u)];
                 if (vr >= n_act) continue;
-                r = row_map[vr];
-                hout = a.hbuf[a.hsel[r] ^ 1];
             }
-            const size_t ho = hfrag(r, u, a.MT);
+            const int r = PRED ? row_map[vr] : vr;
+            const size_t ho = hidx(a, r, u);
             if (!PRED && !(a.t < a.flag[r])) {
-                hout[ho] = a.h_in[ho];
+                a.h_out[ho] = a.h_in[ho];
                 continue;
             }
             float gi = red.sum(row, 0 * U + uu), gf = red.sum(row, 1 * U + uu);
@@ -289,13 +418,14 @@ struct EpiLSTM {
             const float c2 = sigmoid_(gf) * a.c[co] + sigmoid_(gi) * tanhf(gg);
             const float h2 = sigmoid_(go) * tanhf(c2);
             a.c[co] = c2;
-            hout[ho] = h2;
-            if (a.y) a.y[hfrag(r + 16 * a.y_mt_off, u, a.y_mt_total)] = h2 * a.bn_s[u] + a.bn_t[u];
+            a.h_out[ho] = h2;
+            if (PRED) a.y[ho] = h2 * a.bn_s[u] + a.bn_t[u];
+            else if (a.y) a.y[hfrag(r + 16 * a.y_mt_off, u, a.y_mt_total)] = h2 * a.bn_s[u] + a.bn_t[u];
         }
     }
 };
 
-// ---- NBRC / GRU-v1 cell (haste/nbrc.py:30-64; layout z,r,g), predictor only (COMPACT):
+// ---- NBRC / GRU-v1 cell (haste/nbrc.py:30-64; layout z,r,g), predictor only (COMPACT, row-major):
 //   z = s(Wx_z + Rh_z), r = s(Wx_r + Rh_r), g = tanh(Wx_g + r * Rh_g), h' = z h + (1 - z) g.
 // Pseudo-gates {z, r, gx, gh}: the x phase feeds z,r,gx, the h phase z,r,gh.  TABLE: Wx (+ input
 // bias) comes from tab[token][3H] and the x phase is absent.
@@ -307,18 +437,18 @@ struct EpiNBRC {
     static constexpr int PH0_DEAD = U == 16 ? -1 : 12;   // U=4: gh columns carry no x weights
     static constexpr int PH1_DEAD = U == 16 ? -1 : 8;    //      gx columns carry no h weights
     static constexpr bool COMPACT = true;
-    static constexpr bool RUN_ALWAYS = false;
     struct Args {
         const float* bias;     // [3H] input bias (folded into tab when TABLE)
         const float* rbias;    // [3H] recurrent bias
         const float* tab;      // [V][3H]
         const int* token;
-        float* hbuf[2];
-        const int* hsel;
-        float* y;              // BN(h') fragment-major [H/16][MT][64][4]
+        const int* emit;
+        const float* h_in;     // [M][H] current parity
+        float* h_out;          // other parity
+        float* y;              // BN(h') [M][H]
         const float* bn_s;
         const float* bn_t;
-        int H, MT;
+        int H, M;
     };
     template <int MTB, class Red>
     __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map) {
@@ -326,12 +456,12 @@ struct EpiNBRC {
         const int H = a.H;
         for (int it = tid; it < ROWS * U; it += 256) {
             const int row = it % ROWS, uu = it / ROWS;
-            const int vr = mg * ROWS + row;
+            const int vr = mg * ROWS + row, u = jb * U + uu;
+            if (vr < a.M && !a.emit[vr]) a.h_out[(size_t)vr * H + u] = a.h_in[(size_t)vr * H + u];   // carry
             if (vr >= n_act) continue;
-            const int r = row_map[vr], u = jb * U + uu;
-            const int sel = a.hsel[r];
-            const size_t ho = hfrag(r, u, a.MT);
-            const float h = a.hbuf[sel][ho];
+            const int r = row_map[vr];
+            const size_t ho = (size_t)r * H + u;
+            const float h = a.h_in[ho];
             const float vz = red.sum(row, 0 * U + uu), vr_ = red.sum(row, 1 * U + uu);
             const float vgh = red.sum(row, 3 * U + uu);
             float xz, xr, xg;
@@ -345,7 +475,7 @@ struct EpiNBRC {
             const float rr = sigmoid_(vr_ + xr + a.rbias[H + u]);
             const float gc = tanhf(xg + rr * (vgh + a.rbias[2 * H + u]));
             const float h2 = z * h + (1.0f - z) * gc;
-            a.hbuf[sel ^ 1][ho] = h2;
+            a.h_out[ho] = h2;
             a.y[ho] = h2 * a.bn_s[u] + a.bn_t[u];
         }
     }
@@ -356,7 +486,6 @@ struct EpiLinear {
     static constexpr int NT = 1;
     static constexpr int PH0_TILES = 1, PH1_TILES = 0, PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = false;
-    static constexpr bool RUN_ALWAYS = false;
     struct Args {
         const float* bias;    // may be nullptr
         float* out;
@@ -394,13 +523,11 @@ struct EpiLinear {
 //                                                it is the A operand of the logits GEMM)
 // Joint.forward 'concat' (models.py:132-140): Linear(cat(pred, enc)) == W1p pred + W1e enc + b1.
 // Workgroup (jb, mg) refreshes ja for its compacted (emitting) rows and for the NON-emitting rows
-// of the original row range [mg*ROWS, (mg+1)*ROWS); workgroup (0,0) also flips the predictor
-// ping-pong selector of the rows that just advanced.
+// of the original row range [mg*ROWS, (mg+1)*ROWS).
 struct EpiPPJ {
     static constexpr int NT = 1;
     static constexpr int PH0_TILES = 1, PH1_TILES = 0, PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = true;
-    static constexpr bool RUN_ALWAYS = true;
     struct Args {
         const float* b1;
         float* pp;            // [M][J]
@@ -408,7 +535,6 @@ struct EpiPPJ {
         const int* t_idx;
         const int* T_row;
         const int* emit;
-        int* hsel;
         float* ja;            // fragment-major [J/16][MT][64][4]
         int J, M, MT;
     };
@@ -433,7 +559,5 @@ struct EpiPPJ {
                     a.ja[hfrag(r, j, a.MT)] = tanhf(a.pe[((size_t)t * a.M + r) * a.J + j] + a.pp[(size_t)r * a.J + j]);
             }
         }
-        if (jb == 0 && mg == 0)
-            for (int q = tid; q < n_act; q += 256) a.hsel[row_map[q]] ^= 1;
     }
 };

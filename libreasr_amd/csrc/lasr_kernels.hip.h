@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace lasr {
 
@@ -104,9 +105,7 @@ struct ResetArgs {
     float* enc_c[16];
     const float* enc_h0[16];  // [H]
     const float* enc_c0[16];
-    float* pred_h[8];         // buffer 0
-    float* pred_h_alt[8];     // buffer 1; row r's current state lives in buffer hsel[r]
-    const int* hsel;
+    float* pred_h[8];         // current-parity buffers, row-major [M][H]
     float* pred_c[8];
     const float* pred_h0[8];
     const float* pred_c0[8];
@@ -130,7 +129,7 @@ __global__ void k_reset_rows(const ResetArgs a) {
         }
     if (wh & 2)
         for (int l = 0; l < a.Lp; ++l) {
-            (a.hsel[r] ? a.pred_h_alt[l] : a.pred_h[l])[ho] = a.pred_h0[l][u];
+            a.pred_h[l][(size_t)r * a.H + u] = a.pred_h0[l][u];
             if (a.pred_lstm) a.pred_c[l][(size_t)u * a.M + r] = a.pred_c0[l][u];
         }
 }
