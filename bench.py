@@ -159,8 +159,7 @@ def main():
         ran = eng.step(slots)
         ntok = 0
         if ran:
-            for s in slots:
-                ntok += len(eng.fetch(s, cap=256)[0])
+            ntok = sum(len(t) for t in eng.fetch_many(slots, cap=64))
         return ran, ntok
 
     for k in range(W):

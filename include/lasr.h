@@ -125,6 +125,10 @@ int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* fea
 int lasr_fetch(lasr_ctx* c, int slot, int32_t* tokens, int cap, int* n_new, double* neg_logp,
                double* align);
 
+/* Batched form: tokens [n, cap] (row i = new tokens of slots[i]), n_new [n].  One call per step
+ * instead of one per stream. */
+int lasr_fetch_many(lasr_ctx* c, const int* slots, int n, int32_t* tokens, int cap, int* n_new);
+
 /* ---- op-level entry points (parity tests and roofline micro-benchmarks).  Device pointers
  * unless noted; all enqueue on the ctx stream and return without synchronising. -------------- */
 /* log-mel of whole signals: pcm [B, N] -> logmel [B, T, n_mels], T = 1 + N / hop. */

@@ -48,6 +48,7 @@ SYMBOLS = [
     ("lasr_transcribe_feats", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("lasr_fetch", C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                              C.POINTER(C.c_double)]),
+    ("lasr_fetch_many", C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P]),
     ("lasr_logmel", C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     ("lasr_stack", C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int)]),
     ("lasr_encoder", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),

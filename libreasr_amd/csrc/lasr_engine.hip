@@ -359,15 +359,18 @@ int ensure_T(lasr_ctx* c, int T) {
     const int M = c->M, H = c->d.hidden, F = c->d.feat, J = c->d.joint;
     int cap = std::max(T, std::max(2 * c->Tcap, c->d.n_buffer));
     dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe);
-    dfree(c, c->ds.step_tok); dfree(c, c->ds.unfinished);
-    c->x0 = c->ybuf[0] = c->ybuf[1] = c->pe = nullptr; c->ds.step_tok = nullptr; c->ds.unfinished = nullptr;
+    dfree(c, c->ds.step_ntok); dfree(c, c->ds.unfinished);
+    c->x0 = c->ybuf[0] = c->ybuf[1] = c->pe = nullptr; c->ds.step_ntok = nullptr; c->ds.step_tok = nullptr; c->ds.unfinished = nullptr;
     RC(dalloc(c, &c->x0, (size_t)cap * M * F));
     RC(dalloc(c, &c->ybuf[0], (size_t)cap * M * H));
     RC(dalloc(c, &c->ybuf[1], (size_t)cap * M * H));
     RC(dalloc(c, &c->pe, (size_t)cap * M * J));
     const int mi = std::max(c->d.max_iters_offline, c->d.max_iters_stream);
     c->tok_cap_alloc = cap * mi;
-    RC(dalloc(c, &c->ds.step_tok, (size_t)M * c->tok_cap_alloc));
+    // [ntok M][tokens M x tok_cap]: one contiguous block so a group's results reach the host in one copy
+    RC(dalloc(c, &c->ds.step_ntok, (size_t)M + (size_t)M * c->tok_cap_alloc));
+    HIPCHK(c, hipMemset(c->ds.step_ntok, 0, sizeof(int) * M));
+    c->ds.step_tok = c->ds.step_ntok + M;
     c->n_iter_slots = cap * mi + 8;
     RC(dalloc(c, &c->ds.unfinished, (size_t)c->n_iter_slots));
     HIPCHK(c, hipMemset(c->ybuf[0], 0, (size_t)cap * M * H * 4));
@@ -375,7 +378,7 @@ int ensure_T(lasr_ctx* c, int T) {
     HIPCHK(c, hipMemset(c->x0, 0, (size_t)cap * M * F * 4));
     // pinned result block: [0] unfinished, then ntok[M], sum_iters[M], n_ones[M], logp[M] (double), tokens
     if (c->res_host) (void)hipHostFree(c->res_host);
-    c->res_bytes = sizeof(int) * (4 + 3 * (size_t)M) + sizeof(double) * M + sizeof(int) * (size_t)M * c->tok_cap_alloc + 64;
+    c->res_bytes = sizeof(int) * (8 + 3 * (size_t)M) + sizeof(double) * M + sizeof(int) * (size_t)M * c->tok_cap_alloc + 64;
     HIPCHK(c, hipHostMalloc((void**)&c->res_host, c->res_bytes));
     c->Tcap = cap;
     return LASR_OK;
@@ -460,9 +463,17 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
     hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->ds.t_idx,
                        c->T_row_dev, c->ja, J, M, c->MT);
     int iter = 0;
-    int group = offline ? std::min(total_cap, T_max + 16) : std::min(total_cap, T_max + 2);
-    const int next_group = offline ? 32 : 2;
+    // iterations are launched in even-sized groups (the predictor ping-pong parity then returns to
+    // its start); after each group the "rows still decoding" counter and the step's tokens so far
+    // come back in the same round trip
+    int group = offline ? std::min(total_cap, (T_max + 16) & ~1) : std::min(total_cap, (T_max + 4) & ~1);
+    const int next_group = offline ? 32 : 4;
     int* res = c->res_host;
+    int* ntok = res + 4;
+    int* toks = ntok + M;                      // contiguous with ntok, as on the device
+    int* sum_iters = toks + (size_t)M * s.tok_cap;
+    int* n_ones = sum_iters + M;
+    double* logp = (double*)(((uintptr_t)(n_ones + M) + 15) & ~uintptr_t(15));
     while (iter < total_cap) {
         const int n = std::min(group, total_cap - iter);
         for (int q = 0; q < n; ++q, ++iter) {
@@ -473,26 +484,18 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
             launch_ppj(c);
         }
         HIPCHK(c, hipMemcpyAsync(res, c->ds.unfinished + (iter - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * ((size_t)M + (size_t)M * s.tok_cap), hipMemcpyDeviceToHost, c->stream));
+        if (offline) {
+            HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(n_ones, c->ds.n_ones, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(logp, c->ds.logp_sum, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->cmd_inflight = 0;
         if (res[0] == 0) break;
         group = next_group;
     }
     c->stats.decode_iters = iter;
-    // results
-    int* ntok = res + 4;
-    int* sum_iters = ntok + M;
-    int* n_ones = sum_iters + M;
-    double* logp = (double*)(((uintptr_t)(n_ones + M) + 15) & ~uintptr_t(15));
-    int* toks = (int*)(logp + M);
-    HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(toks, c->ds.step_tok, sizeof(int) * (size_t)M * s.tok_cap, hipMemcpyDeviceToHost, c->stream));
-    if (offline) {
-        HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(n_ones, c->ds.n_ones, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(logp, c->ds.logp_sum, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int r : rows) {
         const int n = std::min(ntok[r], s.tok_cap);
         for (int q = 0; q < n; ++q) c->queue[r].push_back(toks[(size_t)r * s.tok_cap + q]);
@@ -798,9 +801,9 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->ja, (size_t)M * J)); HIPCHK(c, hipMemset(c->ja, 0, (size_t)M * J * 4));
     RC(dalloc(c, &c->logits, (size_t)M * V));
     RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, M));
-    RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.step_ntok, M)); RC(dalloc(c, &c->ds.logp_sum, M));
+    RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->T_row_dev, M));
-    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.step_ntok, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev})
+    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
     RC(dalloc(c, &c->win, (size_t)M * d.n_window * d.chunk)); HIPCHK(c, hipMemset(c->win, 0, (size_t)M * d.n_window * d.chunk * 4));
@@ -1122,6 +1125,22 @@ int lasr_fetch(lasr_ctx* c, int slot, int32_t* tokens, int cap, int* n_new, doub
     q.clear();
     if (neg_logp) *neg_logp = c->neg_logp[slot];
     if (align) *align = c->align[slot];
+    return LASR_OK;
+}
+
+int lasr_fetch_many(lasr_ctx* c, const int* slots, int n, int32_t* tokens, int cap, int* n_new) {
+    if (!c || !n_new || (n > 0 && !slots)) return LASR_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        const int slot = slots[i];
+        if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
+        if ((int)c->queue[slot].size() > cap) return fail(c, LASR_EFULL, "token buffer too small: slot %d needs %d", slot, (int)c->queue[slot].size());
+    }
+    for (int i = 0; i < n; ++i) {
+        auto& q = c->queue[slots[i]];
+        if (!q.empty()) memcpy(tokens + (size_t)i * cap, q.data(), sizeof(int32_t) * q.size());
+        n_new[i] = (int)q.size();
+        q.clear();
+    }
     return LASR_OK;
 }
 

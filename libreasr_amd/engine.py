@@ -129,6 +129,15 @@ class Engine:
                                       C.byref(nl), C.byref(al)))
         return [int(v) for v in buf[:n.value]], nl.value, al.value
 
+    def fetch_many(self, slots, cap=256):
+        """New tokens of every listed slot in one call -> list of lists."""
+        a, p, n = self._slots(slots)
+        buf = np.empty((n, cap), dtype=np.int32)
+        cnt = np.zeros(n, dtype=np.int32)
+        self._chk(self.lib.lasr_fetch_many(self.ctx, p, n, buf.ctypes.data_as(C.c_void_p), cap,
+                                           cnt.ctypes.data_as(C.c_void_p)))
+        return [buf[i, :cnt[i]].tolist() for i in range(n)]
+
     # ------------------------------------------------------------------ offline
     def transcribe_pcm(self, slots, pcm_list):
         """pcm_list: list of 1-D float32 arrays/tensors (one utterance per slot)."""
