@@ -119,6 +119,11 @@ int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm,
 int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* feats,
                           const int32_t* n_frames);
 
+/* Streaming on feature chunks instead of PCM (the reference's own split: x_tfm_stream output ->
+ * Transducer.transcribe_stream, models.py:506-575): feats [n, T, feat] host or device, carried
+ * state, max_iters_stream.  Blocks until the tokens are on the host. */
+int lasr_step_feats(lasr_ctx* c, const int* slots, int n, const float* feats, int T);
+
 /* New tokens of `slot` since the last fetch (int32 ids incl. nothing for blanks).
  * neg_logp / align (optional): offline metrics of the last lasr_transcribe_* call
  * (-sum log p of every decision, models.py:420-422,455; alignment_score, models.py:445-453). */

@@ -46,6 +46,7 @@ SYMBOLS = [
     ("lasr_step_stream", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     ("lasr_transcribe_pcm", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("lasr_transcribe_feats", C.c_int, [_P, _P, C.c_int, _P, _P]),
+    ("lasr_step_feats", C.c_int, [_P, _P, C.c_int, _P, C.c_int]),
     ("lasr_fetch", C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                              C.POINTER(C.c_double)]),
     ("lasr_fetch_many", C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P]),

@@ -1112,6 +1112,44 @@ int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* fea
     return transcribe_common(c, slots, n, T_max);
 }
 
+// Transducer.transcribe_stream on feature chunks (models.py:506-575): carried encoder / predictor
+// state, max_iters_stream.  feats [n, T, feat] (host or device), the same T for every listed slot.
+int lasr_step_feats(lasr_ctx* c, const int* slots, int n, const float* feats, int T) {
+    if (!c) return LASR_EINVAL;
+    RC(check_slots(c, slots, n, true));
+    if (n == 0) return LASR_OK;
+    if (!feats || T < 1) return fail(c, LASR_EINVAL, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const lasr_model_desc& d = c->d;
+    RC(ensure_T(c, T));
+    const float* src = feats;
+    if (!is_device_ptr(feats)) {
+        RC(ensure_buf(c, &c->feat_stage, &c->feat_stage_floats, (size_t)n * T * d.feat));
+        HIPCHK(c, hipMemcpyAsync(c->feat_stage, feats, sizeof(float) * (size_t)n * T * d.feat, hipMemcpyHostToDevice, c->stream));
+        src = c->feat_stage;
+    }
+    RC(cmd_begin(c));
+    std::vector<int> rows(slots, slots + n);
+    for (int i = 0; i < n; ++i) { c->hc.T_row[slots[i]] = T; c->hc.row_feat_off[slots[i]] = (long long)i * T; }
+    RC(cmd_commit(c));
+    RC(commit_T_rows(c, T));
+    rec(c, 0);
+    StackLnArgs a{};
+    a.src = src; a.mode = 1; a.row_off = c->dc.row_feat_off; a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b;
+    a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels; a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT;
+    a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = T;
+    hipLaunchKernelGGL((k_stack_ln<32>), dim3((T + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    rec(c, 1);
+    run_encoder(c, T);
+    rec(c, 2);
+    RC(run_decode(c, T, d.max_iters_stream, false, rows));
+    rec(c, 3);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    collect_stats(c, T);
+    return LASR_OK;
+}
+
 int lasr_fetch(lasr_ctx* c, int slot, int32_t* tokens, int cap, int* n_new, double* neg_logp, double* align) {
     if (!c || !n_new) return LASR_EINVAL;
     if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);

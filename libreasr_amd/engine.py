@@ -121,6 +121,18 @@ class Engine:
         self._chk(self.lib.lasr_step_stream(self.ctx, p, n, C.byref(ran)))
         return ran.value
 
+    def step_feats(self, slots, feats):
+        """feats [n, T, feat] (torch cuda/cpu or numpy): one streaming model call with carried state."""
+        a, p, n = self._slots(slots)
+        if isinstance(feats, torch.Tensor):
+            feats = feats.contiguous().float()
+            T = feats.shape[1]
+        else:
+            feats = np.ascontiguousarray(feats, dtype=np.float32)
+            T = feats.shape[1]
+        assert feats.shape[0] == n and feats.shape[2] == self.desc.feat
+        self._chk(self.lib.lasr_step_feats(self.ctx, p, n, _ptr(feats), int(T)))
+
     def fetch(self, slot, cap=65536):
         buf = np.empty(cap, dtype=np.int32)
         n = C.c_int(0)
@@ -145,8 +157,10 @@ class Engine:
         assert len(pcm_list) == n
         if all(isinstance(x, torch.Tensor) and x.is_cuda for x in pcm_list):
             cat = torch.cat([x.reshape(-1).float() for x in pcm_list]).contiguous()
-        else:
-            cat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in pcm_list]))
+        else:   # mixed / host inputs: gather on the host, one H2D copy inside the library
+            cat = np.ascontiguousarray(np.concatenate([
+                np.asarray(x.detach().cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float32).reshape(-1)
+                for x in pcm_list]))
         ns = np.ascontiguousarray(np.array([int(np.prod(x.shape)) for x in pcm_list], dtype=np.int64))
         self._chk(self.lib.lasr_transcribe_pcm(self.ctx, p, n, _ptr(cat), ns.ctypes.data_as(C.c_void_p)))
 

@@ -1,0 +1,50 @@
+"""Mirror of libreasr/lib/inference.py: load_stuff(lang) -> (conf, lang, model, x_tfm, x_tfm_stream)
+(inference.py:18-51; used by ASRServicer.__init__, api-server.py:54-62).
+
+Weights: a plain `state_dict` with the reference's key names from `conf["model"]["path"]`
+(torch.load; a fastai {"model": ...} wrapper is unwrapped) or, when `synthetic=` names a shape in
+libreasr_amd.synth.CONFIGS, seeded synthetic weights (no pretrained model ships with the reference)."""
+import os
+
+import torch
+
+from .. import synth
+from ..engine import Engine
+from ..weights import infer_cfg
+from .config import apply_overrides, model_cfg_from_conf, open_config, stream_settings
+from .language import get_language
+from .models import Transducer
+from .transforms import AudioTensor, OfflinePipeline, StreamPipeline  # noqa: F401
+
+
+def load_state_dict(path):
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "model" in sd and not any(k.startswith("encoder.") for k in sd):
+        sd = sd["model"]                    # fastai learn.save format (model_utils.py:79-85)
+    return {k: v for k, v in sd.items() if torch.is_tensor(v)}
+
+
+def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_streams=16, device=0):
+    torch.set_num_threads(2)                # inference.py:21
+    conf, cfg, sd = {}, None, None
+    if os.path.exists(config_path):
+        conf = apply_overrides(open_config(config_path), inference=True, lang=lang)
+    if synthetic is not None:
+        cfg = synth.model_cfg(synthetic)
+        sd = synth.synth_state_dict(cfg, seed=0)
+    else:
+        path = ((conf.get("model", {}) or {}).get("path")) or f"./tmp/{lang}/model.pth"
+        sd = load_state_dict(path)
+        cfg = model_cfg_from_conf(conf) if "model" in conf else infer_cfg(sd)
+    n_stack, downsample, n_buffer = stream_settings(conf) if conf else (10, 8, 2)
+    eng = Engine(sd, cfg, max_streams=max_streams, device=device, n_stack=n_stack, stride=downsample,
+                 n_buffer=n_buffer)
+    tok = ((conf.get("tokenizer", {}) or {}).get("model_file")) if conf else None
+    language = get_language(tok if tok and os.path.exists(tok) else None)
+    model = Transducer(eng, language)
+    sr = conf.get("sr", 16000) if conf else 16000
+    ch = conf.get("channels", 1) if conf else 1
+    x_tfm = OfflinePipeline(eng, channels=ch, target_sr=sr)
+    x_tfm_stream = StreamPipeline(eng, n_stack=n_stack, n_buffer=n_buffer, channels=ch, target_sr=sr)
+    print("[Inference] Model and Pipeline set up.")
+    return conf, language, model, x_tfm, x_tfm_stream
