@@ -166,6 +166,11 @@ int lasr_set_profiling(lasr_ctx* c, int on);
 /* hipStreamSynchronize on the ctx stream */
 int lasr_sync(lasr_ctx* c);
 
+/* Debug (LASR_DBG_TIMING=1 at create): per-workgroup phase timestamps (s_memtime at entry / setup /
+ * K-loop end / reduce / exit, wall clock at entry / exit) of the last launch of each GEMM kind
+ * (0 encoder cell, 1-2 predictor layers, 3 PPJ, 4 logits): out[5][4096][8]. */
+int lasr_debug_timing(lasr_ctx* c, unsigned long long* out);
+
 /* Roofline micro-benchmark of the dominant kernel (one encoder LSTM-cell launch: all rows active,
  * layer `layer`), `iters` back-to-back launches timed with HIP events on the ctx stream.
  * Returns average microseconds per launch in *us. */

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("lasr_get_stats", C.c_int, [_P, C.POINTER(StepStats)]),
     ("lasr_set_profiling", C.c_int, [_P, C.c_int]),
     ("lasr_sync", C.c_int, [_P]),
+    ("lasr_debug_timing", C.c_int, [_P, _P]),
     ("lasr_bench_cell", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 ]
 

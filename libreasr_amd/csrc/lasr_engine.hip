@@ -26,6 +26,7 @@ struct Cell {                  // one recurrent layer (+ its BatchNorm fold and 
     int I = 0;                 // input width
     float *Wx = nullptr, *Wh = nullptr;   // packed, tiling "B" (16 units x gates per tile group)
     float *WxA = nullptr, *WhA = nullptr; // packed, tiling "A" (4 units x gates per tile)
+    float *WxC = nullptr, *WhC = nullptr; // packed, tiling "C" (8 units x 2 gates per tile, 2 tiles per group)
     float *bias = nullptr, *rbias = nullptr;
     float *bn_s = nullptr, *bn_t = nullptr;
     float *h0 = nullptr, *c0 = nullptr;
@@ -58,8 +59,11 @@ struct lasr_ctx {
     int enc_par = 0;
     int pred_par = 0;               // predictor h ping-pong parity (row-major [M][H] buffers)
     bool enc_tiling_a = false;      // encoder cell tiling ("A": 4 units x 64 rows per workgroup)
+    bool enc_tiling_c = false;      // encoder cell tiling ("C": 8 units x 32 rows per workgroup)
     int rot_mul = 0;                // K-walk rotation multiplier of the encoder cell (GemmArgs::rot_mul)
     int cell_variant = 0;           // encoder cell (waves, prefetch depth) variant
+    bool dbg_gate = true;           // decode kernels record timestamps only in the first iteration of a step
+    unsigned long long* dbg = nullptr;   // LASR_DBG_TIMING: [5 kinds][4096 blocks][8] phase timestamps
     std::vector<unsigned long long> tile_masks;   // per step t: m-tiles with an active row (from the host's T_row)
     float *pp = nullptr, *ja = nullptr, *logits = nullptr;
     DecState ds{};
@@ -211,13 +215,18 @@ void launch_enc_cell(lasr_ctx* c, int l, int t, const float* xsrc, int x_mt_tota
     GemmArgs g{};
     g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / 16;
     g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16;
-    g.M = c->M; g.rot_mul = c->rot_mul;
+    g.M = c->M; g.rot_mul = c->rot_mul; g.dbg = c->dbg;
     EpiLSTM<false, false, 16>::Args ea{};
     ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t; ea.tile_mask = c->tile_masks.empty() ? ~0ull : c->tile_masks[t];
     ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
     ea.y = ydst; ea.y_mt_total = y_mt_total; ea.y_mt_off = t * c->MT;
     ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
-    if (c->enc_tiling_a) {
+    if (c->enc_tiling_c) {
+        g.W[0] = L.WxC; g.W[1] = L.WhC;
+        EpiLSTM<false, false, 8>::Args eb{};
+        memcpy(&eb, &ea, sizeof(eb));
+        launch_gemm<EpiLSTM<false, false, 8>, 2, false>(c, H / 8, c->M / 32, g, eb);
+    } else if (c->enc_tiling_a) {
         g.W[0] = L.WxA; g.W[1] = L.WhA;
         EpiLSTM<false, false, 4>::Args eb{};
         memcpy(&eb, &ea, sizeof(eb));
@@ -253,7 +262,7 @@ void launch_predictor(lasr_ctx* c) {
             g.A[0] = c->pred_y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = L.WxA;
         }
         g.A[1] = c->pred_h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / 16; g.W[1] = L.WhA;
-        g.compact = c->ds.emit; g.M = c->M;
+        g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)(1 + std::min(l, 1)) * 4096 * 8 : nullptr;
         if (c->d.pred_cell == 1) {
             EpiLSTM<true, true, 4>::Args ea{};
             ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
@@ -261,11 +270,11 @@ void launch_predictor(lasr_ctx* c) {
             ea.y = c->pred_y[l]; ea.y_mt_total = 0; ea.y_mt_off = 0;
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
             if (l == 0) {
-                launch_gemm<EpiLSTM<true, true, 4>, MTA, true>(c, H / 4, mgroups, g, ea);
+                launch_gemm<EpiLSTM<true, true, 4>, MTA, true, NW, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 EpiLSTM<true, false, 4>::Args eb{};
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<EpiLSTM<true, false, 4>, MTA, true>(c, H / 4, mgroups, g, eb);
+                launch_gemm<EpiLSTM<true, false, 4>, MTA, true, NW, -1>(c, H / 4, mgroups, g, eb);
             }
         } else {
             EpiNBRC<true, 4>::Args ea{};
@@ -273,11 +282,11 @@ void launch_predictor(lasr_ctx* c) {
             ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = c->pred_y[l];
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M;
             if (l == 0) {
-                launch_gemm<EpiNBRC<true, 4>, MTA, true>(c, H / 4, mgroups, g, ea);
+                launch_gemm<EpiNBRC<true, 4>, MTA, true, NW, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 EpiNBRC<false, 4>::Args eb{};
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<EpiNBRC<false, 4>, MTA, true>(c, H / 4, mgroups, g, eb);
+                launch_gemm<EpiNBRC<false, 4>, MTA, true, NW, -1>(c, H / 4, mgroups, g, eb);
             }
         }
     }
@@ -289,21 +298,22 @@ void launch_ppj(lasr_ctx* c) {
     const int H = c->d.hidden, J = c->d.joint;
     GemmArgs g{};
     g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p;
-    g.compact = c->ds.emit; g.M = c->M;
+    g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 8 : nullptr;
     EpiPPJ::Args ea{};
     ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->ds.t_idx; ea.T_row = c->T_row_dev; ea.emit = c->ds.emit;
     ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT;
-    launch_gemm<EpiPPJ, MTA, true>(c, J / 16, c->M / (16 * MTA), g, ea);
+    launch_gemm<EpiPPJ, 1, true, NW, -1>(c, J / 16, c->MT, g, ea);
 }
 
 void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     const int J = c->d.joint, V = c->d.vocab;
     GemmArgs g{};
     g.A[0] = c->ja; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = J / 16; g.W[0] = c->W2; g.M = c->M;
+    g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)4 * 4096 * 8 : nullptr;
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
     ea.t_idx = gated ? c->ds.t_idx : nullptr; ea.T_row = c->T_row_dev; ea.M = c->M;
-    launch_gemm<EpiLinear, 1, false>(c, V / 16, (n_rows + 15) / 16, g, ea);
+    launch_gemm<EpiLinear, 1, false, NW, -1>(c, V / 16, (n_rows + 15) / 16, g, ea);
 }
 
 // ---------------------------------------------------------------------------- command blocks
@@ -477,6 +487,7 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
     while (iter < total_cap) {
         const int n = std::min(group, total_cap - iter);
         for (int q = 0; q < n; ++q, ++iter) {
+            c->dbg_gate = (iter == 0);
             launch_logits(c, c->logits, M, true);
             hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, max_iters,
                                c->T_row_dev, s, iter, (float*)nullptr, (int*)nullptr);
@@ -603,7 +614,7 @@ int fold_bn(lasr_ctx* c, Reader& rd, int H, float** s_dev, float** t_dev) {
 // LSTM layer in torch layout: W_ih [4H,I], W_hh [4H,H].
 //   tiling B: tile (jb, gate) = 16 units of one gate;  tiling A: tile jb = 4 units x 4 gates (col = gate*4 + unit)
 int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, bool pack_a, bool pack_b, std::vector<float>* keep_wih,
-              std::vector<float>* keep_bias) {
+              std::vector<float>* keep_bias, bool pack_c = false) {
     L.I = I;
     const float* wih = rd.take((size_t)4 * H * I); const float* whh = rd.take((size_t)4 * H * H);
     const float* bih = rd.take(4 * H); const float* bhh = rd.take(4 * H);
@@ -614,6 +625,12 @@ int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, bool pack_a, bool 
         RC(upload(c, &L.Wx, pk.data(), pk.size()));
         pack_tiles(pk, (H / 16) * 4, H / 16, [&](int t, int ui, int k) { return whh[((size_t)(t & 3) * H + 16 * (t >> 2) + ui) * H + k]; });
         RC(upload(c, &L.Wh, pk.data(), pk.size()));
+    }
+    if (pack_c) {   // tile t = (jb = t/2, nt = t%2): column col -> gate 2*nt + col/8, unit 8*jb + col%8
+        pack_tiles(pk, (H / 8) * 2, I / 16, [&](int t, int col, int k) { return wih[((size_t)(2 * (t & 1) + (col >> 3)) * H + 8 * (t >> 1) + (col & 7)) * I + k]; });
+        RC(upload(c, &L.WxC, pk.data(), pk.size()));
+        pack_tiles(pk, (H / 8) * 2, H / 16, [&](int t, int col, int k) { return whh[((size_t)(2 * (t & 1) + (col >> 3)) * H + 8 * (t >> 1) + (col & 7)) * H + k]; });
+        RC(upload(c, &L.WhC, pk.data(), pk.size()));
     }
     if (pack_a) {
         pack_tiles(pk, H / 4, I / 16, [&](int t, int col, int k) { return wih[((size_t)(col >> 2) * H + 4 * t + (col & 3)) * I + k]; });
@@ -690,10 +707,15 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     {
         const char* e = getenv("LASR_ENC_TILING");      // A/B experiment knob; default chosen by measurement
         c->enc_tiling_a = e ? (e[0] == 'A' || e[0] == 'a') : false;
+        c->enc_tiling_c = e ? (e[0] == 'C' || e[0] == 'c') : true;    // default "C": least L2->CU traffic (measured best)
         const char* r = getenv("LASR_CELL_ROT");
         c->rot_mul = r ? atoi(r) : 0;
         const char* v = getenv("LASR_CELL_VARIANT");
         c->cell_variant = v ? atoi(v) : 0;
+        if (getenv("LASR_DBG_TIMING")) {
+            RC(dalloc(c, &c->dbg, (size_t)5 * 4096 * 8));
+            HIPCHK(c, hipMemset(c->dbg, 0, sizeof(unsigned long long) * 5 * 4096 * 8));
+        }
     }
 
     // ---- front-end constants
@@ -726,7 +748,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         if (!hs) return fail(c, LASR_EINVAL, "weight blob too short");
         RC(upload(c, &L.h0, hs, H)); RC(upload(c, &L.c0, hs + H, H));
         RC(fold_bn(c, rd, H, &L.bn_s, &L.bn_t));
-        RC(load_lstm(c, rd, L, l == 0 ? F : H, H, c->enc_tiling_a, !c->enc_tiling_a, nullptr, nullptr));
+        RC(load_lstm(c, rd, L, l == 0 ? F : H, H, c->enc_tiling_a, !c->enc_tiling_a && !c->enc_tiling_c, nullptr, nullptr, c->enc_tiling_c));
     }
     // ---- predictor
     const float* embed = rd.take((size_t)V * E);
@@ -1303,6 +1325,15 @@ int lasr_set_profiling(lasr_ctx* c, int on) {
     c->profiling = on != 0;
     return LASR_OK;
 }
+// debug: copy the phase timestamps of the last launch of each GEMM kind (cell, pred0, pred1, ppj, logits)
+int lasr_debug_timing(lasr_ctx* c, unsigned long long* out /*[5*4096*8]*/) {
+    if (!c || !out) return LASR_EINVAL;
+    if (!c->dbg) return fail(c, LASR_ESTATE, "set LASR_DBG_TIMING=1 before lasr_create");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->dbg, sizeof(unsigned long long) * 5 * 4096 * 8, hipMemcpyDeviceToHost));
+    return LASR_OK;
+}
+
 int lasr_sync(lasr_ctx* c) {
     if (!c) return LASR_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));

@@ -14,6 +14,9 @@
 // Two tilings of the same math are used:
 //   U = 16 ("B"): MT = 1, NT = gates : 16 hidden units x all gates x 16 rows per workgroup;
 //                 grid (H/16, M/16).  Weights are re-read by the M/16 row groups (via L2).
+//   U = 8  ("C"): MT = 2, NT = 2     : 8 hidden units x all gates x 32 rows per workgroup;
+//                 grid (H/8, M/32).  2 A + 2 W fragment loads per 16 MFMAs instead of 1 + 4:
+//                 20 % less L2->CU traffic at the same 256-workgroup parallelism.
 //   U = 4  ("A"): MT = 4, NT = 1     : 4 hidden units x all gates x 64 rows per workgroup;
 //                 grid (H/4, M/64).  Every weight byte is fetched exactly once chip-wide and all
 //                 256 CUs pull on the weight stream even when a single m-tile is active (decode).
@@ -30,6 +33,7 @@ struct GemmArgs {
     int a_rows;             // AROW only: loads of rows >= a_rows are clamped (0 = no clamp)
     const int* compact;     // COMPACT epilogues: per-row flag
     int M;                  // rows scanned for compaction
+    unsigned long long* dbg; // optional per-workgroup phase timestamps [blocks][8] (LASR_DBG_TIMING)
     int rot_mul;            // workgroup jb walks K starting at chunk (jb*rot_mul) % KC: co-resident
                             // workgroups then read different lines of the shared operand at any moment
 };
@@ -140,7 +144,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const float* co
 template <class Epi, int MT, int MTP, int NT, int NW, int D, int NCH0, int NCH1, int ABL, bool AROW>
 __device__ __forceinline__ void gemm_static(f32x4 (&acc)[MT][NT], const float* const (&ap0)[MT], size_t a_step0,
                                             const float* const (&ap1)[MT], size_t a_step1, const GemmArgs& g, int jb,
-                                            int w, int lane) {
+                                            int w, int lane, const f32x4* wpre) {
     constexpr int NS0 = PopCount<Epi::PH0_TILES>::value, NS1 = PopCount<Epi::PH1_TILES>::value;
     constexpr int NSM = NS0 > NS1 ? NS0 : NS1;
     constexpr int N0 = NS0 > 0 ? NCH0 : 0, N1 = NS1 > 0 ? NCH1 : 0, NTOT = N0 + N1;
@@ -173,16 +177,18 @@ __device__ __forceinline__ void gemm_static(f32x4 (&acc)[MT][NT], const float* c
             for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = *reinterpret_cast<const f32x4*>(ap0[mt] + (size_t)c * a_step0);
 #pragma unroll
             for (int s = 0; s < NS0; ++s)
-                fr.b[s] = (Epi::PH0_DEAD < 0 || live0) ? *reinterpret_cast<const f32x4*>(wb0 + ((size_t)s * KC0 + c) * FR0)
-                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+                fr.b[s] = (i == 0 && wpre) ? wpre[s]          // chunk 0 was issued at kernel entry
+                          : (Epi::PH0_DEAD < 0 || live0) ? *reinterpret_cast<const f32x4*>(wb0 + ((size_t)s * KC0 + c) * FR0)
+                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
             const int c = chunk(i - N0);
 #pragma unroll
             for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = *reinterpret_cast<const f32x4*>(ap1[mt] + (size_t)c * a_step1);
 #pragma unroll
             for (int s = 0; s < NS1; ++s)
-                fr.b[s] = (Epi::PH1_DEAD < 0 || live1) ? *reinterpret_cast<const f32x4*>(wb1 + ((size_t)s * KC1 + c) * FR1)
-                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+                fr.b[s] = (i == 0 && wpre) ? wpre[s]
+                          : (Epi::PH1_DEAD < 0 || live1) ? *reinterpret_cast<const f32x4*>(wb1 + ((size_t)s * KC1 + c) * FR1)
+                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto compute = [&](const Frag<MTP, NSM>& fr, int i) {
@@ -243,6 +249,35 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
     __shared__ int n_act_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jb = blockIdx.x, mg = blockIdx.y;
+    unsigned long long* dbg = g.dbg ? g.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    if (dbg && tid == 0) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[5] = wall_clock64(); }
+
+    // (0) this wave's first weight fragment does not depend on flags / compaction: put it in flight
+    //     before anything else (first-touch latency of the weight stream is the long pole)
+    constexpr int NS0k = PopCount<Epi::PH0_TILES>::value, NS1k = PopCount<Epi::PH1_TILES>::value;
+    constexpr int NSMk = NS0k > NS1k ? NS0k : NS1k;
+    f32x4 wpre[NSMk];
+    {
+        constexpr int PHF = NS0k > 0 ? 0 : 1;                                  // first phase with tiles
+        constexpr int NSF = NS0k > 0 ? NS0k : NS1k;
+        constexpr int DEADF = NS0k > 0 ? Epi::PH0_DEAD : Epi::PH1_DEAD;
+        constexpr int FRF = DEADF >= 0 ? 192 : 256;
+        const int KCF = g.KC[PHF];
+        int c0 = AROW ? 2 * w : w;
+        c0 = c0 < KCF ? c0 : KCF - 1;
+        int loff = lane * 4;
+        bool live = true;
+        if constexpr (DEADF >= 0) {
+            const int col = lane & 15, gq = lane >> 4;
+            live = !(col >= DEADF && col < DEADF + 4);
+            loff = (gq * 12 + (col < DEADF ? col : col - 4)) * 4;
+        }
+        const float* wb = g.W[PHF] + (size_t)jb * NSF * KCF * FRF + loff;
+#pragma unroll
+        for (int s = 0; s < NSMk; ++s)
+            wpre[s] = (s < NSF && live) ? *reinterpret_cast<const f32x4*>(wb + ((size_t)s * KCF + c0) * FRF)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     int n_act = g.M;
     if constexpr (Epi::COMPACT) {
@@ -299,6 +334,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if (dbg && tid == 0) dbg[1] = __builtin_amdgcn_s_memtime();
+    // (1) operands of this thread's epilogue item (biases, old state, table rows): issued now so
+    //     their latency overlaps the K loop instead of trailing it
+    const typename Epi::Pre pre = Epi::template prefetch<MT>(ea, tid, jb, mg, n_act, row_map);
+
     // number of leading m-tiles to process: 1 + index of the highest active tile (rows of inactive
     // tiles inside the prefix are computed and then masked by the epilogue)
     int P = 0;
@@ -308,12 +348,18 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
     // static K schedules for the shapes of the shipped / benchmarked models (chunks per wave and phase)
     auto run_phases = [&](auto mtp_tag) {
         constexpr int MTP = decltype(mtp_tag)::value;
+        // D < 0: latency-bound kernel (predictor / joint): ring depth from the register budget --
+        // one m-tile x one weight slot is 2 fragments per chunk, so the whole K range can be in flight
+        constexpr int NSMx = (PopCount<Epi::PH0_TILES>::value > PopCount<Epi::PH1_TILES>::value)
+                                 ? PopCount<Epi::PH0_TILES>::value : PopCount<Epi::PH1_TILES>::value;
+        constexpr int FPC = MTP + NSMx;                                   // fragments per chunk
+        constexpr int DD = D > 0 ? D : (FPC <= 2 ? 9 : FPC <= 3 ? 7 : FPC <= 5 ? 4 : 3);
         constexpr bool P0 = PopCount<Epi::PH0_TILES>::value > 0, P1 = PopCount<Epi::PH1_TILES>::value > 0;
         const int k0 = P0 ? g.KC[0] : 0, k1 = P1 ? g.KC[1] : 0;
         if (g.rot_mul == 0) {
 #define LASR_TRY(N0, N1)                                                                                        \
     if ((!P0 || k0 == (N0) * NW) && (!P1 || k1 == (N1) * NW)) {                                                 \
-        gemm_static<Epi, MT, MTP, NT, NW, D, N0, N1, ABL, AROW>(acc, ap0, a_step0, ap1, a_step1, g, jb, w, lane); \
+        gemm_static<Epi, MT, MTP, NT, NW, DD, N0, N1, ABL, AROW>(acc, ap0, a_step0, ap1, a_step1, g, jb, w, lane, wpre); \
         return;                                                                                                  \
     }
             LASR_TRY(8, 8)       // K = 1024 / 1024  (8 waves)   | K = 512 (4 waves)
@@ -322,8 +368,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
             LASR_TRY(10, 12)     // K = 1280 / 1536
 #undef LASR_TRY
         }
-        gemm_phase<Epi::PH0_TILES, Epi::PH0_DEAD, MT, MTP, NT, NW, D, ABL>(acc, ap0, a_step0, g.W[0], g.KC[0], jb, w, lane, g.rot_mul);
-        gemm_phase<Epi::PH1_TILES, Epi::PH1_DEAD, MT, MTP, NT, NW, D, ABL>(acc, ap1, a_step1, g.W[1], g.KC[1], jb, w, lane, g.rot_mul);
+        gemm_phase<Epi::PH0_TILES, Epi::PH0_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD), ABL>(acc, ap0, a_step0, g.W[0], g.KC[0], jb, w, lane, g.rot_mul);
+        gemm_phase<Epi::PH1_TILES, Epi::PH1_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD), ABL>(acc, ap1, a_step1, g.W[1], g.KC[1], jb, w, lane, g.rot_mul);
     };
     if constexpr (MT == 1) {
         if (P == 1) run_phases(std::integral_constant<int, 1>{});   // wave-uniform: an idle workgroup streams nothing
@@ -334,6 +380,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
         else if (P == 3) run_phases(std::integral_constant<int, (MT > 3 ? 3 : MT)>{});
     }
 
+    if (dbg && tid == 0) dbg[2] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -342,7 +389,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
             for (int r = 0; r < 4; ++r)
                 red[(w * ROWS + mt * 16 + 4 * (lane >> 4) + r) * LD + nt * 16 + (lane & 15)] = acc[mt][nt][r];
     __syncthreads();
-    Epi::template run<MT>(ea, RedView<NW, ROWS, LD>{red}, tid, jb, mg, n_act, row_map);
+    if (dbg && tid == 0) dbg[3] = __builtin_amdgcn_s_memtime();
+    Epi::template run<MT>(ea, RedView<NW, ROWS, LD>{red}, tid, jb, mg, n_act, row_map, pre, NW * 64);
+    if (dbg && tid == 0) { dbg[4] = __builtin_amdgcn_s_memtime(); dbg[6] = wall_clock64(); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,11 +411,12 @@ __device__ __forceinline__ size_t hfrag(int r, int u, int MT_all) {
 // ENC: fragment-major state; row r advances at step t iff t < T_row[r].
 // PRED (COMPACT): row-major state [M][H]; the rows that emitted advance; phase X is the per-token
 // table tab[token][4H] when TABLE.
+// Each workgroup tile has exactly ROWS*U = 256 (row, unit) items: one per thread.
 template <bool PRED, bool TABLE, int U>
 struct EpiLSTM {
-    static constexpr int NT = U == 16 ? 4 : 1;
-    static constexpr int PH0_TILES = TABLE ? 0 : (U == 16 ? 0xF : 1);
-    static constexpr int PH1_TILES = U == 16 ? 0xF : 1;
+    static constexpr int NT = U / 4;                       // 4 gates x U units = NT 16-column tiles
+    static constexpr int PH0_TILES = TABLE ? 0 : ((1 << NT) - 1);
+    static constexpr int PH1_TILES = (1 << NT) - 1;
     static constexpr int PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = PRED;
     struct Args {
@@ -386,42 +436,65 @@ struct EpiLSTM {
         const float* bn_t;
         int H, M, MT;
     };
+    struct Pre {
+        int r;                 // row this thread finishes (-1: none)
+        bool carry;            // PRED: this thread carries h of original row vr (did not emit)
+        float carry_h;
+        bool act;
+        float x[4];            // bias or table values per gate
+        float c_old, h_old, s, t;
+    };
     __device__ static bool tile_active(const Args& a, int mt, int lane) { return (a.tile_mask >> mt) & 1ull; }
     __device__ static size_t hidx(const Args& a, int r, int u) { return PRED ? (size_t)r * a.H + u : hfrag(r, u, a.MT); }
-    template <int MTB, class Red>
-    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map) {
+    template <int MTB>
+    __device__ static Pre prefetch(const Args& a, int tid, int jb, int mg, int n_act, const int* row_map) {
         constexpr int ROWS = MTB * 16;
-        const int H = a.H;
-        for (int it = tid; it < ROWS * U; it += 256) {
-            const int row = it % ROWS, uu = it / ROWS;
-            const int vr = mg * ROWS + row;
-            const int u = jb * U + uu;
-            if (PRED) {     // carry the non-emitting rows of this workgroup's original row range
-                if (vr < a.M && !a.flag[vr]) a.h_out[hidx(a, vr, u)] = a.h_in[hidx(a, vr, u)];
-                if (vr >= n_act) continue;
-            }
-            const int r = PRED ? row_map[vr] : vr;
-            const size_t ho = hidx(a, r, u);
-            if (!PRED && !(a.t < a.flag[r])) {
-                a.h_out[ho] = a.h_in[ho];
-                continue;
-            }
-            float gi = red.sum(row, 0 * U + uu), gf = red.sum(row, 1 * U + uu);
-            float gg = red.sum(row, 2 * U + uu), go = red.sum(row, 3 * U + uu);
-            if (TABLE) {
-                const float* tb = a.tab + (size_t)a.token[r] * 4 * H + u;
-                gi += tb[0]; gf += tb[H]; gg += tb[2 * H]; go += tb[3 * H];
-            } else {
-                gi += a.bias[u]; gf += a.bias[H + u]; gg += a.bias[2 * H + u]; go += a.bias[3 * H + u];
-            }
-            const size_t co = (size_t)u * a.M + r;
-            const float c2 = sigmoid_(gf) * a.c[co] + sigmoid_(gi) * tanhf(gg);
-            const float h2 = sigmoid_(go) * tanhf(c2);
-            a.c[co] = c2;
-            a.h_out[ho] = h2;
-            if (PRED) a.y[ho] = h2 * a.bn_s[u] + a.bn_t[u];
-            else if (a.y) a.y[hfrag(r + 16 * a.y_mt_off, u, a.y_mt_total)] = h2 * a.bn_s[u] + a.bn_t[u];
+        static_assert(ROWS * U == 256, "one (row, unit) item per thread");
+        Pre p;
+        p.r = -1; p.carry = false; p.act = false;
+        if (tid >= 256) return p;
+        const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
+        if (PRED) {
+            if (vr < a.M && !a.flag[vr]) { p.carry = true; p.carry_h = a.h_in[hidx(a, vr, u)]; }
+            if (vr >= n_act) return p;
+            p.r = row_map[vr];
+            p.act = true;
+        } else {
+            p.r = vr;
+            p.act = a.t < a.flag[vr];
+            if (!p.act) { p.h_old = a.h_in[hidx(a, vr, u)]; return p; }
         }
+        if (TABLE) {
+            const float* tb = a.tab + (size_t)a.token[p.r] * 4 * H + u;
+            p.x[0] = tb[0]; p.x[1] = tb[H]; p.x[2] = tb[2 * H]; p.x[3] = tb[3 * H];
+        } else {
+            p.x[0] = a.bias[u]; p.x[1] = a.bias[H + u]; p.x[2] = a.bias[2 * H + u]; p.x[3] = a.bias[3 * H + u];
+        }
+        p.c_old = a.c[(size_t)u * a.M + p.r];
+        p.s = a.bn_s[u]; p.t = a.bn_t[u];
+        return p;
+    }
+    template <int MTB, class Red>
+    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
+                               const Pre& p, int) {
+        constexpr int ROWS = MTB * 16;
+        if (tid >= 256) return;
+        const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu;
+        if (PRED && p.carry) a.h_out[hidx(a, vr, u)] = p.carry_h;
+        if (p.r < 0) return;
+        const size_t ho = hidx(a, p.r, u);
+        if (!p.act) {
+            a.h_out[ho] = p.h_old;
+            return;
+        }
+        const float gi = red.sum(row, 0 * U + uu) + p.x[0], gf = red.sum(row, 1 * U + uu) + p.x[1];
+        const float gg = red.sum(row, 2 * U + uu) + p.x[2], go = red.sum(row, 3 * U + uu) + p.x[3];
+        const float c2 = sigmoid_(gf) * p.c_old + sigmoid_(gi) * tanhf(gg);
+        const float h2 = sigmoid_(go) * tanhf(c2);
+        a.c[(size_t)u * a.M + p.r] = c2;
+        a.h_out[ho] = h2;
+        if (PRED) a.y[ho] = h2 * p.s + p.t;
+        else if (a.y) a.y[hfrag(p.r + 16 * a.y_mt_off, u, a.y_mt_total)] = h2 * p.s + p.t;
     }
 };
 
@@ -450,34 +523,50 @@ struct EpiNBRC {
         const float* bn_t;
         int H, M;
     };
-    template <int MTB, class Red>
-    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map) {
+    struct Pre {
+        int r;
+        bool carry;
+        float carry_h, h, xz, xr, xg, rz, rr, rg, s, t;
+    };
+    template <int MTB>
+    __device__ static Pre prefetch(const Args& a, int tid, int jb, int mg, int n_act, const int* row_map) {
         constexpr int ROWS = MTB * 16;
-        const int H = a.H;
-        for (int it = tid; it < ROWS * U; it += 256) {
-            const int row = it % ROWS, uu = it / ROWS;
-            const int vr = mg * ROWS + row, u = jb * U + uu;
-            if (vr < a.M && !a.emit[vr]) a.h_out[(size_t)vr * H + u] = a.h_in[(size_t)vr * H + u];   // carry
-            if (vr >= n_act) continue;
-            const int r = row_map[vr];
-            const size_t ho = (size_t)r * H + u;
-            const float h = a.h_in[ho];
-            const float vz = red.sum(row, 0 * U + uu), vr_ = red.sum(row, 1 * U + uu);
-            const float vgh = red.sum(row, 3 * U + uu);
-            float xz, xr, xg;
-            if (TABLE) {
-                const float* tb = a.tab + (size_t)a.token[r] * 3 * H + u;
-                xz = tb[0]; xr = tb[H]; xg = tb[2 * H];
-            } else {
-                xz = a.bias[u]; xr = a.bias[H + u]; xg = red.sum(row, 2 * U + uu) + a.bias[2 * H + u];
-            }
-            const float z = sigmoid_(vz + xz + a.rbias[u]);
-            const float rr = sigmoid_(vr_ + xr + a.rbias[H + u]);
-            const float gc = tanhf(xg + rr * (vgh + a.rbias[2 * H + u]));
-            const float h2 = z * h + (1.0f - z) * gc;
-            a.h_out[ho] = h2;
-            a.y[ho] = h2 * a.bn_s[u] + a.bn_t[u];
+        static_assert(ROWS * U == 256, "one (row, unit) item per thread");
+        Pre p;
+        p.r = -1; p.carry = false;
+        if (tid >= 256) return p;
+        const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
+        if (vr < a.M && !a.emit[vr]) { p.carry = true; p.carry_h = a.h_in[(size_t)vr * H + u]; }
+        if (vr >= n_act) return p;
+        p.r = row_map[vr];
+        p.h = a.h_in[(size_t)p.r * H + u];
+        if (TABLE) {
+            const float* tb = a.tab + (size_t)a.token[p.r] * 3 * H + u;
+            p.xz = tb[0]; p.xr = tb[H]; p.xg = tb[2 * H];
+        } else {
+            p.xz = a.bias[u]; p.xr = a.bias[H + u]; p.xg = a.bias[2 * H + u];
         }
+        p.rz = a.rbias[u]; p.rr = a.rbias[H + u]; p.rg = a.rbias[2 * H + u];
+        p.s = a.bn_s[u]; p.t = a.bn_t[u];
+        return p;
+    }
+    template <int MTB, class Red>
+    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
+                               const Pre& p, int) {
+        constexpr int ROWS = MTB * 16;
+        if (tid >= 256) return;
+        const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
+        if (p.carry) a.h_out[(size_t)vr * H + u] = p.carry_h;
+        if (p.r < 0) return;
+        const size_t ho = (size_t)p.r * H + u;
+        const float vz = red.sum(row, 0 * U + uu), vr_ = red.sum(row, 1 * U + uu), vgh = red.sum(row, 3 * U + uu);
+        const float xg = TABLE ? p.xg : red.sum(row, 2 * U + uu) + p.xg;
+        const float z = sigmoid_(vz + p.xz + p.rz);
+        const float rr = sigmoid_(vr_ + p.xr + p.rr);
+        const float gc = tanhf(xg + rr * (vgh + p.rg));
+        const float h2 = z * p.h + (1.0f - z) * gc;
+        a.h_out[ho] = h2;
+        a.y[ho] = h2 * p.s + p.t;
     }
 };
 
@@ -504,10 +593,14 @@ struct EpiLinear {
     __device__ static bool tile_active(const Args& a, int mt, int lane) {
         return any16(lane < 16 && row_on(a, mt * 16 + (lane & 15)), lane);
     }
+    struct Pre {};
+    template <int MTB>
+    __device__ static Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
     template <int MTB, class Red>
-    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int, const int*) {
+    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int, const int*, const Pre&,
+                               int nthr) {
         constexpr int ROWS = MTB * 16;
-        for (int it = tid; it < ROWS * 16; it += 256) {
+        for (int it = tid; it < ROWS * 16; it += nthr) {
             const int col = it & 15, row = it >> 4;        // consecutive threads -> consecutive columns
             const int r = mg * ROWS + row;
             if (!row_on(a, r)) continue;
@@ -538,10 +631,14 @@ struct EpiPPJ {
         float* ja;            // fragment-major [J/16][MT][64][4]
         int J, M, MT;
     };
+    struct Pre {};
+    template <int MTB>
+    __device__ static Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
     template <int MTB, class Red>
-    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map) {
+    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
+                               const Pre&, int nthr) {
         constexpr int ROWS = MTB * 16;
-        for (int it = tid; it < ROWS * 16; it += 256) {
+        for (int it = tid; it < ROWS * 16; it += nthr) {
             const int col = it & 15, row = it >> 4;
             const int j = jb * 16 + col;
             const int vr = mg * ROWS + row;
