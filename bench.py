@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=8)
     ap.add_argument("--cpu-chunks", type=int, default=100)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU-only: exercise sharding + aggregation over gloo (no GPU work)")
     args = ap.parse_args()
@@ -154,38 +156,70 @@ def main():
     slots = [eng.open() for _ in range(B)]
     assert slots == list(range(B))
 
-    def one_step(k):
+    pipelined = not args.no_pipeline
+    push_t = {}                                   # chunk index -> host time of its push (latency bookkeeping)
+    order = []                                    # model chunks submitted and not yet collected
+
+    def one_step(k, lat_out=None):
+        """One 80 ms chunk for every stream.  Synchronous mode: push + step + fetch.  Pipelined mode:
+        push + submit (front-end and encoder of chunk k go to the GPU), then collect the tokens of
+        the previous model step, whose decode loop runs on a second HIP stream under encoder(k)."""
+        t_push = time.perf_counter()
         eng.push(slots, pcm_dev[k])
-        ran = eng.step(slots)
-        ntok = 0
-        if ran:
-            ntok = sum(len(t) for t in eng.fetch_many(slots, cap=64))
-        return ran, ntok
+        ntok, done = 0, 0
+        if not pipelined:
+            if eng.step(slots):
+                ntok = sum(len(t) for t in eng.fetch_many(slots, cap=64))
+                done = 1
+                if lat_out is not None:
+                    lat_out.append(time.perf_counter() - t_push)
+            return done, ntok
+        before = eng.pending()
+        eng.submit(slots)
+        if eng.pending() > before:
+            order.append(k)
+            push_t[k] = t_push
+        if eng.pending() >= 2:
+            done, ntok = collect(lat_out)
+        return done, ntok
+
+    def collect(lat_out):
+        if not eng.wait():
+            return 0, 0
+        ntok = sum(len(t) for t in eng.fetch_many(slots, cap=64))
+        kk = order.pop(0)
+        if lat_out is not None:
+            lat_out.append(time.perf_counter() - push_t.pop(kk))
+        return 1, ntok
 
     for k in range(W):
         one_step(k)
+    while pipelined and eng.pending():
+        collect(None)
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
-    eng.set_profiling(True)
-    lat, lat_model, enc_ms, dec_ms, fe_ms, iters, tokens = [], [], [], [], [], [], 0
+    if not pipelined:
+        eng.set_profiling(True)
+    lat_model, enc_ms, dec_ms, fe_ms, iters, tokens = [], [], [], [], [], 0
     t0 = time.perf_counter()
     for k in range(W, W + K):
-        t1 = time.perf_counter()
-        ran, ntok = one_step(k)
-        dt = time.perf_counter() - t1
-        lat.append(dt)
+        ran, ntok = one_step(k, lat_model)
         tokens += ntok
         if ran:
-            lat_model.append(dt)
             st = eng.stats()
-            enc_ms.append(st["encoder_ms"]); dec_ms.append(st["decode_ms"]); fe_ms.append(st["frontend_ms"])
             iters.append(st["decode_iters"])
+            if not pipelined:
+                enc_ms.append(st["encoder_ms"]); dec_ms.append(st["decode_ms"]); fe_ms.append(st["frontend_ms"])
+    while pipelined and eng.pending():            # the timed region ends when every token is on the host
+        ran, ntok = collect(lat_model)
+        tokens += ntok
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     eng.set_profiling(False)
+    lat = lat_model
 
     audio_local = K * B * CHUNK / SR
     elapsed_max, audio_total = aggregate(dist, elapsed, audio_local, device)
@@ -213,9 +247,11 @@ def main():
             "config": {"workload": f"configs[1]: {B} concurrent 16 kHz streams/GPU, 4x1024 uni-LSTM encoder, "
                                    "2xNBRC predictor, J=1024, V=2048, greedy, fp32, 80 ms chunks, "
                                    "3-chunk window, 2-frame buffer (model every 160 ms)",
-                       "streams_per_gpu": B, "chunk_ms": 80, "parallelism": f"dp{world} (independent streams, no collective)"},
+                       "streams_per_gpu": B, "chunk_ms": 80, "parallelism": f"dp{world} (independent streams, no collective)",
+                       "pipeline": "submit/wait, 2 steps in flight (encoder k+1 overlaps decode k)" if pipelined else "synchronous"},
             "per_gpu_value": round(audio_total / elapsed_max / world, 1),
-            "latency_ms": {"p50_chunk": round(1e3 * float(np.median(lat)), 4),
+            "latency_ms": {"definition": "host time from lasr_push_pcm of a model chunk to its tokens on the host"
+                                         + (" (pipelined: includes the overlap with the next chunk's encoder)" if pipelined else ""),
                            "p50_model_chunk": round(1e3 * float(np.median(lat_model)), 4) if lat_model else None,
                            "p95_model_chunk": round(1e3 * float(np.percentile(lat_model, 95)), 4) if lat_model else None,
                            "p50_per_40ms_equiv": round(0.5e3 * float(np.median(lat_model)), 4) if lat_model else None},

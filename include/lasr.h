@@ -109,6 +109,17 @@ int lasr_stream_close(lasr_ctx* c, int slot);
 int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm);
 int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran);
 
+/* Pipelined form (throughput mode): lasr_step_submit enqueues this chunk's front-end + encoder on the
+ * ctx stream and returns; lasr_step_wait runs the greedy decode loop of the OLDEST submitted model
+ * step on a second HIP stream and blocks until its tokens are on the host (n_ran = its slot count,
+ * 0 if no model step was pending).  Issue submit(k+1) before wait(k): the encoder of the next chunk
+ * then overlaps the latency-bound decode loop of the current one.  At most two steps in flight;
+ * every other state-changing call returns LASR_ESTATE while a submitted step is uncollected.
+ * Results are identical to lasr_step_stream (same kernels, same order per stream). */
+int lasr_step_submit(lasr_ctx* c, const int* slots, int n);
+int lasr_step_wait(lasr_ctx* c, int* n_ran);
+int lasr_step_pending(lasr_ctx* c);   /* submitted model steps not yet collected (0..2) */
+
 /* ---- offline path (Transcribe RPC, api-server.py:64-80 -> Transducer.transcribe,
  * models.py:365-455): whole utterances, fresh state, max_iters_offline.
  * pcm: concatenated samples of the n utterances (host or device), n_samples[i] each (>= 2400).

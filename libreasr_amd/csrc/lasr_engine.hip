@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -69,6 +71,20 @@ struct lasr_ctx {
     DecState ds{};
     int n_iter_slots = 0;
     int* T_row_dev = nullptr;       // [M] current step's frames per row (copied from the cmd block)
+    int* T_row_dec = nullptr;       // what the decode kernels read (== T_row_dev unless pipelined)
+    // software pipeline (lasr_step_submit / lasr_step_wait): front-end + encoder of step k+1 run on
+    // the main stream while the decode loop of step k runs on stream_dec
+    hipStream_t stream_dec = nullptr;
+    hipEvent_t ev_enc[2] = {nullptr, nullptr};
+    float* pe_buf[2] = {nullptr, nullptr};
+    int* T_row_decbuf[2] = {nullptr, nullptr};
+    struct PendingStep { std::vector<int> rows; int Tm; int idx; };
+    std::vector<PendingStep> pending;
+    long long model_steps = 0;
+    // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
+    // predictor parity at group start, frames)
+    std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+    bool use_graphs = true;
 
     // time-series buffers (capacity Tcap frames)
     int Tcap = 0;
@@ -300,7 +316,7 @@ void launch_ppj(lasr_ctx* c) {
     g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p;
     g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 8 : nullptr;
     EpiPPJ::Args ea{};
-    ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->ds.t_idx; ea.T_row = c->T_row_dev; ea.emit = c->ds.emit;
+    ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->ds.t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
     ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT;
     launch_gemm<EpiPPJ, 1, true, NW, -1>(c, J / 16, c->MT, g, ea);
 }
@@ -312,7 +328,7 @@ void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)4 * 4096 * 8 : nullptr;
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
-    ea.t_idx = gated ? c->ds.t_idx : nullptr; ea.T_row = c->T_row_dev; ea.M = c->M;
+    ea.t_idx = gated ? c->ds.t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M;
     launch_gemm<EpiLinear, 1, false, NW, -1>(c, V / 16, (n_rows + 15) / 16, g, ea);
 }
 
@@ -366,15 +382,20 @@ int commit_T_rows(lasr_ctx* c, int T_max) {
 int ensure_T(lasr_ctx* c, int T) {
     if (T <= c->Tcap) return LASR_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);   // captured pointers become stale
+    c->graphs.clear();
     const int M = c->M, H = c->d.hidden, F = c->d.feat, J = c->d.joint;
     int cap = std::max(T, std::max(2 * c->Tcap, c->d.n_buffer));
-    dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe);
+    dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe_buf[0]); dfree(c, c->pe_buf[1]);
+    c->pe_buf[0] = c->pe_buf[1] = nullptr;
     dfree(c, c->ds.step_ntok); dfree(c, c->ds.unfinished);
     c->x0 = c->ybuf[0] = c->ybuf[1] = c->pe = nullptr; c->ds.step_ntok = nullptr; c->ds.step_tok = nullptr; c->ds.unfinished = nullptr;
     RC(dalloc(c, &c->x0, (size_t)cap * M * F));
     RC(dalloc(c, &c->ybuf[0], (size_t)cap * M * H));
     RC(dalloc(c, &c->ybuf[1], (size_t)cap * M * H));
-    RC(dalloc(c, &c->pe, (size_t)cap * M * J));
+    RC(dalloc(c, &c->pe_buf[0], (size_t)cap * M * J));
+    RC(dalloc(c, &c->pe_buf[1], (size_t)cap * M * J));
+    c->pe = c->pe_buf[0];
     const int mi = std::max(c->d.max_iters_offline, c->d.max_iters_stream);
     c->tok_cap_alloc = cap * mi;
     // [ntok M][tokens M x tok_cap]: one contiguous block so a group's results reach the host in one copy
@@ -468,14 +489,11 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
     DecState s = c->ds;
     s.tok_cap = T_max * max_iters;
     const int total_cap = T_max * max_iters;
-    hipLaunchKernelGGL(k_step_begin, dim3(grid1(std::max(M, c->n_iter_slots))), dim3(256), 0, c->stream, s, M,
-                       c->n_iter_slots, offline ? 1 : 0);
-    hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->ds.t_idx,
-                       c->T_row_dev, c->ja, J, M, c->MT);
     int iter = 0;
     // iterations are launched in even-sized groups (the predictor ping-pong parity then returns to
     // its start); after each group the "rows still decoding" counter and the step's tokens so far
-    // come back in the same round trip
+    // come back in the same round trip.  In streaming mode every group is a cached hipGraph: one
+    // launch instead of 4 kernels per iteration, so the GPU is not fed at host launch speed.
     int group = offline ? std::min(total_cap, (T_max + 16) & ~1) : std::min(total_cap, (T_max + 4) & ~1);
     const int next_group = offline ? 32 : 4;
     int* res = c->res_host;
@@ -484,25 +502,70 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
     int* sum_iters = toks + (size_t)M * s.tok_cap;
     int* n_ones = sum_iters + M;
     double* logp = (double*)(((uintptr_t)(n_ones + M) + 15) & ~uintptr_t(15));
-    while (iter < total_cap) {
-        const int n = std::min(group, total_cap - iter);
-        for (int q = 0; q < n; ++q, ++iter) {
-            c->dbg_gate = (iter == 0);
+    // (the legacy NULL stream cannot be captured: graphs then only serve the pipelined path, whose
+    //  decode loop runs on the ctx-owned stream_dec)
+    const bool graphs = c->use_graphs && !offline && !c->profiling && !c->dbg && c->stream != nullptr;
+    const int buf_idx = (c->pe == c->pe_buf[1]) ? 1 : 0;
+    auto enqueue_group = [&](int first, int n) -> int {
+        if (first == 0) {
+            hipLaunchKernelGGL(k_step_begin, dim3(grid1(std::max(M, c->n_iter_slots))), dim3(256), 0, c->stream, s, M,
+                               c->n_iter_slots, offline ? 1 : 0);
+            hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->ds.t_idx,
+                               c->T_row_dec, c->ja, J, M, c->MT);
+        }
+        for (int q = 0; q < n; ++q) {
+            const int it = first + q;
+            c->dbg_gate = (it == 0);
             launch_logits(c, c->logits, M, true);
             hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, max_iters,
-                               c->T_row_dev, s, iter, (float*)nullptr, (int*)nullptr);
+                               c->T_row_dec, s, it, (float*)nullptr, (int*)nullptr);
             launch_predictor(c);
             launch_ppj(c);
         }
-        HIPCHK(c, hipMemcpyAsync(res, c->ds.unfinished + (iter - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        // payload first, the "rows still decoding" word last: the host spins on that word
         HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * ((size_t)M + (size_t)M * s.tok_cap), hipMemcpyDeviceToHost, c->stream));
         if (offline) {
             HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(n_ones, c->ds.n_ones, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(logp, c->ds.logp_sum, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->cmd_inflight = 0;
+        HIPCHK(c, hipMemcpyAsync(res, c->ds.unfinished + (first + n - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        return LASR_OK;
+    };
+    while (iter < total_cap) {
+        const int n = std::min(group, total_cap - iter);
+        bool launched = false;
+        if (graphs && (n % 2) == 0) {
+            const auto key = std::make_tuple(iter, n, buf_idx, c->pred_par, T_max * 1024 + max_iters);
+            auto it = c->graphs.find(key);
+            if (it == c->graphs.end()) {
+                hipGraph_t gr = nullptr;
+                hipGraphExec_t ex = nullptr;
+                HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                int rc = enqueue_group(iter, n);
+                hipError_t e = hipStreamEndCapture(c->stream, &gr);
+                if (rc) return rc;
+                if (e != hipSuccess || !gr) return fail(c, LASR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+                e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(gr);
+                if (e != hipSuccess) return fail(c, LASR_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+                it = c->graphs.emplace(key, ex).first;
+            }
+            HIPCHK(c, hipGraphLaunch(it->second, c->stream));
+            launched = true;
+        }
+        __atomic_store_n(&res[0], -1, __ATOMIC_RELEASE);      // sentinel, overwritten by the last copy of the group
+        if (!launched) RC(enqueue_group(iter, n));
+        iter += n;
+        // spin on the pinned word instead of hipStreamSynchronize (interrupt wake-up costs ~10-20 us per
+        // round trip, and there are 2-4 per step); fall back to a real sync if nothing arrives
+        {
+            unsigned long long spins = 0;
+            while (__atomic_load_n((volatile int*)&res[0], __ATOMIC_ACQUIRE) == -1) {
+                __builtin_ia32_pause();
+                if (++spins > (1ull << 27)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
+            }
+        }
         if (res[0] == 0) break;
         group = next_group;
     }
@@ -543,6 +606,11 @@ int check_slots(lasr_ctx* c, const int* slots, int n, bool need_open) {
         seen[s] = 1;
         if (need_open && !c->open_[s]) return fail(c, LASR_ESTATE, "slot %d is not open", s);
     }
+    return LASR_OK;
+}
+
+int require_idle(lasr_ctx* c) {
+    if (!c->pending.empty()) return fail(c, LASR_ESTATE, "%d submitted step(s) not collected: call lasr_step_wait first", (int)c->pending.size());
     return LASR_OK;
 }
 
@@ -691,6 +759,10 @@ void lasr_destroy(lasr_ctx* c) {
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     if (c->ev_ok)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_enc)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
     delete c;
 }
 
@@ -712,6 +784,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         c->rot_mul = r ? atoi(r) : 0;
         const char* v = getenv("LASR_CELL_VARIANT");
         c->cell_variant = v ? atoi(v) : 0;
+        if (getenv("LASR_NO_GRAPH")) c->use_graphs = false;
         if (getenv("LASR_DBG_TIMING")) {
             RC(dalloc(c, &c->dbg, (size_t)5 * 4096 * 8));
             HIPCHK(c, hipMemset(c->dbg, 0, sizeof(unsigned long long) * 5 * 4096 * 8));
@@ -825,6 +898,13 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, M));
     RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->T_row_dev, M));
+    for (int q = 0; q < 2; ++q) {
+        RC(dalloc(c, &c->T_row_decbuf[q], M));
+        HIPCHK(c, hipMemset(c->T_row_decbuf[q], 0, sizeof(int) * M));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_enc[q], hipEventDisableTiming));
+    }
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
+    c->T_row_dec = c->T_row_dev;
     for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
@@ -914,6 +994,7 @@ int lasr_stream_open(lasr_ctx* c, int* slot) {
 int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
     if (!c) return LASR_EINVAL;
     if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
+    RC(require_idle(c));
     HIPCHK(c, hipSetDevice(c->device));
     if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); }
     if (what & 3) {
@@ -962,11 +1043,9 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
     return LASR_OK;
 }
 
-int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
-    if (!c) return LASR_EINVAL;
-    if (n_ran) *n_ran = 0;
-    RC(check_slots(c, slots, n, true));
-    HIPCHK(c, hipSetDevice(c->device));
+// front-end of one client chunk for the listed slots and, for the slots whose frame buffer filled up,
+// LayerNorm + encoder + encoder half of the joint -- all enqueued on c->stream, nothing synchronises
+static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::vector<int>& model_rows, int& Tm) {
     const lasr_model_desc& d = c->d;
     // window geometry (api-server.py:95-102 + TransformTime + StreamPostprocess)
     const long long N = (long long)d.n_window * d.chunk;
@@ -976,7 +1055,7 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
     if (nf < d.n_stack) return fail(c, LASR_EINVAL, "chunk of %d samples is too short: window yields %d < n_stack frames", d.chunk, nf);
     if (N <= d.n_fft / 2) return fail(c, LASR_EINVAL, "window shorter than the reflect padding");
     RC(cmd_begin(c));
-    std::vector<int> model_rows;
+    model_rows.clear();
     bool any_feat = false;
     for (int r = 0; r < c->M; ++r) c->hc.feat_sel[r] = -1;
     for (int i = 0; i < n; ++i) {
@@ -1001,11 +1080,8 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
         m.row_N = nullptr; m.row_src_off = nullptr; m.row_frames = nullptr;
         hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), 0, c->stream, m);
     }
-    if (model_rows.empty()) {
-        HIPCHK(c, hipGetLastError());
-        return LASR_OK;
-    }
-    const int Tm = d.n_buffer;
+    Tm = d.n_buffer;
+    if (model_rows.empty()) return LASR_OK;
     RC(ensure_T(c, Tm));
     RC(commit_T_rows(c, Tm));
     {
@@ -1018,12 +1094,86 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
     rec(c, 1);
     run_encoder(c, Tm);
     rec(c, 2);
-    RC(run_decode(c, Tm, d.max_iters_stream, false, model_rows));
+    return LASR_OK;
+}
+
+int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
+    if (!c) return LASR_EINVAL;
+    if (n_ran) *n_ran = 0;
+    RC(check_slots(c, slots, n, true));
+    RC(require_idle(c));
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int> model_rows;
+    int Tm = 0;
+    RC(enqueue_frontend_encoder(c, slots, n, model_rows, Tm));
+    if (model_rows.empty()) {
+        HIPCHK(c, hipGetLastError());
+        return LASR_OK;
+    }
+    RC(run_decode(c, Tm, c->d.max_iters_stream, false, model_rows));
     rec(c, 3);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     collect_stats(c, Tm);
     if (n_ran) *n_ran = (int)model_rows.size();
+    return LASR_OK;
+}
+
+// Pipelined form of lasr_step_stream: submit enqueues front-end + encoder of this chunk on the main
+// stream and returns; wait runs the decode loop of the OLDEST submitted model step on a second HIP
+// stream and blocks until its tokens are on the host.  With submit(k+1) issued before wait(k) the
+// encoder of the next chunk overlaps the (latency-bound) decode loop of the current one.
+int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
+    if (!c) return LASR_EINVAL;
+    RC(check_slots(c, slots, n, true));
+    if (c->pending.size() >= 2) return fail(c, LASR_ESTATE, "two steps already in flight: call lasr_step_wait");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int idx = (int)(c->model_steps & 1);
+    c->pe = c->pe_buf[idx];                 // the encoder half of the joint of this step lands here
+    std::vector<int> model_rows;
+    int Tm = 0;
+    const bool prof = c->profiling;
+    c->profiling = false;
+    int rc = enqueue_frontend_encoder(c, slots, n, model_rows, Tm);
+    c->profiling = prof;
+    if (rc) return rc;
+    if (model_rows.empty()) {
+        HIPCHK(c, hipGetLastError());
+        return LASR_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->T_row_decbuf[idx], c->T_row_dev, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_enc[idx], c->stream));
+    c->pending.push_back(lasr_ctx::PendingStep{model_rows, Tm, idx});
+    c->model_steps++;
+    HIPCHK(c, hipGetLastError());
+    return LASR_OK;
+}
+
+int lasr_step_pending(lasr_ctx* c) { return c ? (int)c->pending.size() : 0; }
+
+int lasr_step_wait(lasr_ctx* c, int* n_ran) {
+    if (!c) return LASR_EINVAL;
+    if (n_ran) *n_ran = 0;
+    if (c->pending.empty()) return LASR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    lasr_ctx::PendingStep p = c->pending.front();
+    c->pending.erase(c->pending.begin());
+    hipStream_t main_stream = c->stream;
+    float* pe_keep = c->pe;
+    HIPCHK(c, hipStreamWaitEvent(c->stream_dec, c->ev_enc[p.idx], 0));
+    c->stream = c->stream_dec;              // decode kernels, copies and syncs go to the decode stream
+    c->pe = c->pe_buf[p.idx];
+    c->T_row_dec = c->T_row_decbuf[p.idx];
+    const bool prof = c->profiling;
+    c->profiling = false;
+    int rc = run_decode(c, p.Tm, c->d.max_iters_stream, false, p.rows);
+    c->profiling = prof;
+    c->stream = main_stream;
+    c->pe = pe_keep;
+    c->T_row_dec = c->T_row_dev;
+    if (rc) return rc;
+    c->stats.frames = p.Tm;
+    if (n_ran) *n_ran = (int)p.rows.size();
     return LASR_OK;
 }
 
@@ -1046,6 +1196,7 @@ static int transcribe_common(lasr_ctx* c, const int* slots, int n, int T_max) {
 
 int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, const int64_t* n_samples) {
     if (!c) return LASR_EINVAL;
+    RC(require_idle(c));
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
     if (!pcm || !n_samples) return fail(c, LASR_EINVAL, "null argument");
@@ -1098,6 +1249,7 @@ int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, 
 
 int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* feats, const int32_t* n_frames) {
     if (!c) return LASR_EINVAL;
+    RC(require_idle(c));
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
     if (!feats || !n_frames) return fail(c, LASR_EINVAL, "null argument");
@@ -1138,6 +1290,7 @@ int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* fea
 // state, max_iters_stream.  feats [n, T, feat] (host or device), the same T for every listed slot.
 int lasr_step_feats(lasr_ctx* c, const int* slots, int n, const float* feats, int T) {
     if (!c) return LASR_EINVAL;
+    RC(require_idle(c));
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
     if (!feats || T < 1) return fail(c, LASR_EINVAL, "bad argument");

@@ -121,6 +121,20 @@ class Engine:
         self._chk(self.lib.lasr_step_stream(self.ctx, p, n, C.byref(ran)))
         return ran.value
 
+    def submit(self, slots):
+        """Pipelined step: enqueue front-end + encoder of the chunk just pushed; returns immediately."""
+        a, p, n = self._slots(slots)
+        self._chk(self.lib.lasr_step_submit(self.ctx, p, n))
+
+    def pending(self):
+        return int(self.lib.lasr_step_pending(self.ctx))
+
+    def wait(self):
+        """Decode the oldest submitted model step; returns the number of slots it ran for (0 = none pending)."""
+        ran = C.c_int(0)
+        self._chk(self.lib.lasr_step_wait(self.ctx, C.byref(ran)))
+        return ran.value
+
     def step_feats(self, slots, feats):
         """feats [n, T, feat] (torch cuda/cpu or numpy): one streaming model call with carried state."""
         a, p, n = self._slots(slots)
