@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=8)
     ap.add_argument("--cpu-chunks", type=int, default=100)
+    ap.add_argument("--depth", type=int, default=6,
+                    help="pipelined mode: model steps in flight before the oldest is collected (1..7)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
     ap.add_argument("--selftest-dist", action="store_true",
@@ -179,7 +181,7 @@ def main():
         if eng.pending() > before:
             order.append(k)
             push_t[k] = t_push
-        if eng.pending() >= 2:
+        if eng.pending() >= args.depth:
             done, ntok = collect(lat_out)
         return done, ntok
 
@@ -248,7 +250,8 @@ def main():
                                    "2xNBRC predictor, J=1024, V=2048, greedy, fp32, 80 ms chunks, "
                                    "3-chunk window, 2-frame buffer (model every 160 ms)",
                        "streams_per_gpu": B, "chunk_ms": 80, "parallelism": f"dp{world} (independent streams, no collective)",
-                       "pipeline": "submit/wait, 2 steps in flight (encoder k+1 overlaps decode k)" if pipelined else "synchronous"},
+                       "pipeline": (f"submit/wait, {args.depth} model steps in flight: encoder of later chunks on the main stream, "
+                                    "one continuous greedy loop on a second stream") if pipelined else "synchronous"},
             "per_gpu_value": round(audio_total / elapsed_max / world, 1),
             "latency_ms": {"definition": "host time from lasr_push_pcm of a model chunk to its tokens on the host"
                                          + (" (pipelined: includes the overlap with the next chunk's encoder)" if pipelined else ""),

@@ -72,15 +72,25 @@ struct lasr_ctx {
     int n_iter_slots = 0;
     int* T_row_dev = nullptr;       // [M] current step's frames per row (copied from the cmd block)
     int* T_row_dec = nullptr;       // what the decode kernels read (== T_row_dev unless pipelined)
-    // software pipeline (lasr_step_submit / lasr_step_wait): front-end + encoder of step k+1 run on
-    // the main stream while the decode loop of step k runs on stream_dec
+    int* dec_t_idx = nullptr;       // frame cursor array the decode kernels use (ds.t_idx, or c_cur when continuous)
+    int pe_ring_R = 1 << 30;        // pe frame t lives at slot t % pe_ring_R
+    // continuous decode (lasr_step_submit / lasr_step_wait): front-end + encoder of later chunks run on
+    // the main stream while ONE greedy loop keeps running on stream_dec across chunk boundaries: a row
+    // that finished chunk k moves on to chunk k+1's frames while a bursty row is still on chunk k.
     hipStream_t stream_dec = nullptr;
-    hipEvent_t ev_enc[2] = {nullptr, nullptr};
-    float* pe_buf[2] = {nullptr, nullptr};
-    int* T_row_decbuf[2] = {nullptr, nullptr};
-    struct PendingStep { std::vector<int> rows; int Tm; int idx; };
+    static constexpr int NFLY = 8;  // steps in flight (ring of events / T_row snapshots)
+    static constexpr int RING = 32; // pe ring, frames per row
+    static constexpr int TOKRING = 256, ENDSLOTS = 16;
+    hipEvent_t ev_enc[NFLY] = {};
+    int* T_row_ring[NFLY] = {};
+    float* pe_ring = nullptr;
+    int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
+    int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr;
+    int* cont_host = nullptr;       // pinned: [0] flag, [4..] target staging (NFLY blocks), then ntok_end + token ring
+    struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; };
     std::vector<PendingStep> pending;
-    long long model_steps = 0;
+    std::vector<long long> h_frames_sub, h_fetched;
+    long long model_steps = 0, cont_iters = 0;
     // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
     // predictor parity at group start, frames)
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
@@ -88,7 +98,7 @@ struct lasr_ctx {
 
     // time-series buffers (capacity Tcap frames)
     int Tcap = 0;
-    float *x0 = nullptr, *ybuf[2] = {nullptr, nullptr}, *pe = nullptr;
+    float *x0 = nullptr, *ybuf[2] = {nullptr, nullptr}, *pe = nullptr, *pe_sync = nullptr;
     int tok_cap_alloc = 0;
 
     // front-end buffers
@@ -316,8 +326,8 @@ void launch_ppj(lasr_ctx* c) {
     g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p;
     g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 8 : nullptr;
     EpiPPJ::Args ea{};
-    ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->ds.t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
-    ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT;
+    ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
+    ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT; ea.ring = c->pe_ring_R;
     launch_gemm<EpiPPJ, 1, true, NW, -1>(c, J / 16, c->MT, g, ea);
 }
 
@@ -328,7 +338,7 @@ void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)4 * 4096 * 8 : nullptr;
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
-    ea.t_idx = gated ? c->ds.t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M;
+    ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M;
     launch_gemm<EpiLinear, 1, false, NW, -1>(c, V / 16, (n_rows + 15) / 16, g, ea);
 }
 
@@ -386,16 +396,15 @@ int ensure_T(lasr_ctx* c, int T) {
     c->graphs.clear();
     const int M = c->M, H = c->d.hidden, F = c->d.feat, J = c->d.joint;
     int cap = std::max(T, std::max(2 * c->Tcap, c->d.n_buffer));
-    dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe_buf[0]); dfree(c, c->pe_buf[1]);
-    c->pe_buf[0] = c->pe_buf[1] = nullptr;
+    dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe_sync);
+    c->pe_sync = nullptr;
     dfree(c, c->ds.step_ntok); dfree(c, c->ds.unfinished);
     c->x0 = c->ybuf[0] = c->ybuf[1] = c->pe = nullptr; c->ds.step_ntok = nullptr; c->ds.step_tok = nullptr; c->ds.unfinished = nullptr;
     RC(dalloc(c, &c->x0, (size_t)cap * M * F));
     RC(dalloc(c, &c->ybuf[0], (size_t)cap * M * H));
     RC(dalloc(c, &c->ybuf[1], (size_t)cap * M * H));
-    RC(dalloc(c, &c->pe_buf[0], (size_t)cap * M * J));
-    RC(dalloc(c, &c->pe_buf[1], (size_t)cap * M * J));
-    c->pe = c->pe_buf[0];
+    RC(dalloc(c, &c->pe_sync, (size_t)cap * M * J));
+    c->pe = c->pe_sync;
     const int mi = std::max(c->d.max_iters_offline, c->d.max_iters_stream);
     c->tok_cap_alloc = cap * mi;
     // [ntok M][tokens M x tok_cap]: one contiguous block so a group's results reach the host in one copy
@@ -476,6 +485,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
     g.A[0] = c->ybuf[(L - 1) & 1]; g.a_mt_total[0] = mt_total; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1e;
     EpiLinear::Args ea{};
     ea.bias = nullptr; ea.out = c->pe; ea.ldo = J; ea.n_rows = T_max * c->M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
+    if (c->pe == c->pe_ring) { ea.ring_base = c->c_enc_frames; ea.ring = lasr_ctx::RING; }   // continuous mode: per-row frame ring
     launch_gemm<EpiLinear, 1, false>(c, J / 16, T_max * c->MT, g, ea);
 }
 
@@ -505,13 +515,13 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
     // (the legacy NULL stream cannot be captured: graphs then only serve the pipelined path, whose
     //  decode loop runs on the ctx-owned stream_dec)
     const bool graphs = c->use_graphs && !offline && !c->profiling && !c->dbg && c->stream != nullptr;
-    const int buf_idx = (c->pe == c->pe_buf[1]) ? 1 : 0;
+    const int buf_idx = 0;
     auto enqueue_group = [&](int first, int n) -> int {
         if (first == 0) {
             hipLaunchKernelGGL(k_step_begin, dim3(grid1(std::max(M, c->n_iter_slots))), dim3(256), 0, c->stream, s, M,
                                c->n_iter_slots, offline ? 1 : 0);
-            hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->ds.t_idx,
-                               c->T_row_dec, c->ja, J, M, c->MT);
+            hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->dec_t_idx,
+                               c->T_row_dec, c->ja, J, M, c->MT, c->pe_ring_R);
         }
         for (int q = 0; q < n; ++q) {
             const int it = first + q;
@@ -756,6 +766,7 @@ void lasr_destroy(lasr_ctx* c) {
     for (void* p : c->dev_allocs) (void)hipFree(p);
     if (c->cmd_host) (void)hipHostFree(c->cmd_host);
     if (c->res_host) (void)hipHostFree(c->res_host);
+    if (c->cont_host) (void)hipHostFree(c->cont_host);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     if (c->ev_ok)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -898,12 +909,25 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, M));
     RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->T_row_dev, M));
-    for (int q = 0; q < 2; ++q) {
-        RC(dalloc(c, &c->T_row_decbuf[q], M));
-        HIPCHK(c, hipMemset(c->T_row_decbuf[q], 0, sizeof(int) * M));
+    for (int q = 0; q < lasr_ctx::NFLY; ++q) {
+        RC(dalloc(c, &c->T_row_ring[q], M));
+        HIPCHK(c, hipMemset(c->T_row_ring[q], 0, sizeof(int) * M));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_enc[q], hipEventDisableTiming));
     }
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
+    RC(dalloc(c, &c->pe_ring, (size_t)lasr_ctx::RING * M * J));
+    HIPCHK(c, hipMemset(c->pe_ring, 0, sizeof(float) * (size_t)lasr_ctx::RING * M * J));
+    RC(dalloc(c, &c->c_cur, M)); RC(dalloc(c, &c->c_avail, M)); RC(dalloc(c, &c->c_iters, M)); RC(dalloc(c, &c->c_target, M));
+    RC(dalloc(c, &c->c_ntotal, M)); RC(dalloc(c, &c->c_enc_frames, M)); RC(dalloc(c, &c->c_behind, 64));
+    RC(dalloc(c, &c->c_ntok_end, (size_t)M * lasr_ctx::ENDSLOTS)); RC(dalloc(c, &c->c_tok_ring, (size_t)M * lasr_ctx::TOKRING));
+    for (int* p : {c->c_cur, c->c_avail, c->c_iters, c->c_target, c->c_ntotal, c->c_enc_frames})
+        HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
+    HIPCHK(c, hipMemset(c->c_behind, 0, sizeof(int) * 64));
+    HIPCHK(c, hipMemset(c->c_ntok_end, 0, sizeof(int) * (size_t)M * lasr_ctx::ENDSLOTS));
+    HIPCHK(c, hipMemset(c->c_tok_ring, 0, sizeof(int) * (size_t)M * lasr_ctx::TOKRING));
+    HIPCHK(c, hipHostMalloc((void**)&c->cont_host, sizeof(int) * (16 + (size_t)M * (lasr_ctx::NFLY + lasr_ctx::ENDSLOTS + lasr_ctx::TOKRING))));
+    c->h_frames_sub.assign(M, 0); c->h_fetched.assign(M, 0);
+    c->dec_t_idx = c->ds.t_idx;
     c->T_row_dec = c->T_row_dev;
     for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
@@ -1119,31 +1143,41 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
     return LASR_OK;
 }
 
-// Pipelined form of lasr_step_stream: submit enqueues front-end + encoder of this chunk on the main
-// stream and returns; wait runs the decode loop of the OLDEST submitted model step on a second HIP
-// stream and blocks until its tokens are on the host.  With submit(k+1) issued before wait(k) the
-// encoder of the next chunk overlaps the (latency-bound) decode loop of the current one.
+// Pipelined + continuous form of lasr_step_stream.  submit: front-end + encoder of this chunk on the
+// main stream (the encoder half of the joint goes to a per-row frame ring).  wait: keeps ONE greedy
+// loop running on stream_dec until every row of the OLDEST submitted step has consumed that step's
+// frames; rows that are done early continue with the frames of the later, already encoded steps, so
+// the latency-bound tail of a bursty stream overlaps useful work instead of idling 63 rows.
+// Tokens are attributed to the step whose frames produced them: per-step results are identical to
+// lasr_step_stream.
 int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     if (!c) return LASR_EINVAL;
     RC(check_slots(c, slots, n, true));
-    if (c->pending.size() >= 2) return fail(c, LASR_ESTATE, "two steps already in flight: call lasr_step_wait");
+    if ((int)c->pending.size() >= lasr_ctx::NFLY - 1) return fail(c, LASR_ESTATE, "%d steps already in flight: call lasr_step_wait", (int)c->pending.size());
     HIPCHK(c, hipSetDevice(c->device));
-    const int idx = (int)(c->model_steps & 1);
-    c->pe = c->pe_buf[idx];                 // the encoder half of the joint of this step lands here
+    const int idx = (int)(c->model_steps % lasr_ctx::NFLY);
+    float* pe_keep = c->pe;
+    c->pe = c->pe_ring;                     // run_encoder writes the joint's encoder half into the ring
     std::vector<int> model_rows;
     int Tm = 0;
     const bool prof = c->profiling;
     c->profiling = false;
     int rc = enqueue_frontend_encoder(c, slots, n, model_rows, Tm);
     c->profiling = prof;
+    c->pe = pe_keep;
     if (rc) return rc;
     if (model_rows.empty()) {
         HIPCHK(c, hipGetLastError());
         return LASR_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(c->T_row_decbuf[idx], c->T_row_dev, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->T_row_ring[idx], c->T_row_dev, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_advance, dim3(grid1(c->M)), dim3(256), 0, c->stream, c->c_enc_frames, (const int*)c->T_row_dev, c->M);
     HIPCHK(c, hipEventRecord(c->ev_enc[idx], c->stream));
-    c->pending.push_back(lasr_ctx::PendingStep{model_rows, Tm, idx});
+    lasr_ctx::PendingStep p;
+    p.rows = model_rows; p.Tm = Tm; p.idx = idx; p.admitted = false; p.target_set = false;
+    p.target.assign(c->M, 0);
+    for (int r : model_rows) { c->h_frames_sub[r] += Tm; p.target[r] = (int)c->h_frames_sub[r]; }
+    c->pending.push_back(std::move(p));
     c->model_steps++;
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
@@ -1151,30 +1185,104 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
 
 int lasr_step_pending(lasr_ctx* c) { return c ? (int)c->pending.size() : 0; }
 
+static int spin_flag(lasr_ctx* c, volatile int* flag) {
+    unsigned long long spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == -1) {
+        __builtin_ia32_pause();
+        if (++spins > (1ull << 27)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
+    }
+    return LASR_OK;
+}
+
 int lasr_step_wait(lasr_ctx* c, int* n_ran) {
     if (!c) return LASR_EINVAL;
     if (n_ran) *n_ran = 0;
     if (c->pending.empty()) return LASR_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    lasr_ctx::PendingStep p = c->pending.front();
-    c->pending.erase(c->pending.begin());
+    const int M = c->M, V = c->d.vocab, J = c->d.joint;
     hipStream_t main_stream = c->stream;
     float* pe_keep = c->pe;
-    HIPCHK(c, hipStreamWaitEvent(c->stream_dec, c->ev_enc[p.idx], 0));
-    c->stream = c->stream_dec;              // decode kernels, copies and syncs go to the decode stream
-    c->pe = c->pe_buf[p.idx];
-    c->T_row_dec = c->T_row_decbuf[p.idx];
-    const bool prof = c->profiling;
-    c->profiling = false;
-    int rc = run_decode(c, p.Tm, c->d.max_iters_stream, false, p.rows);
-    c->profiling = prof;
+    // decode-side view: global frame cursors, frames available, pe ring
+    c->stream = c->stream_dec;
+    c->pe = c->pe_ring; c->pe_ring_R = lasr_ctx::RING;
+    c->dec_t_idx = c->c_cur; c->T_row_dec = c->c_avail;
+    DecState s = c->ds;
+    s.t_idx = c->c_cur; s.iters = c->c_iters; s.step_ntok = c->c_ntotal; s.step_tok = c->c_tok_ring;
+    s.tok_cap = lasr_ctx::TOKRING; s.unfinished = c->c_behind; s.cont = 1; s.target = c->c_target;
+    s.ntok_end = c->c_ntok_end; s.step_T = c->pending.front().Tm; s.end_slots = lasr_ctx::ENDSLOTS;
+    int* flag = c->cont_host;                       // pinned
+    int* tgt_stage = c->cont_host + 16;             // NFLY blocks of M ints
+    int* h_end = tgt_stage + (size_t)lasr_ctx::NFLY * M;
+    int* h_ring = h_end + (size_t)M * lasr_ctx::ENDSLOTS;
+    int rc = LASR_OK;
+    auto body = [&]() -> int {
+        lasr_ctx::PendingStep& P = c->pending.front();
+        const int max_iters = c->d.max_iters_stream;
+        int guard = 0;
+        const long long it0 = c->cont_iters;
+        while (true) {
+            // admit encoded steps in order: the oldest unconditionally, later ones only if their encoder is done
+            bool admitted_any = false;
+            for (auto& q : c->pending) {
+                if (q.admitted) continue;
+                if (&q != &P && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_enc[q.idx], 0));
+                hipLaunchKernelGGL(k_advance, dim3(grid1(M)), dim3(256), 0, c->stream, c->c_avail, (const int*)c->T_row_ring[q.idx], M);
+                q.admitted = true;
+                admitted_any = true;
+            }
+            if (admitted_any)   // rows that were idle need their joint activation for the new frames
+                hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
+                                   c->c_avail, c->ja, J, M, c->MT, c->pe_ring_R);
+            if (!P.target_set) {
+                int* st = tgt_stage + (size_t)P.idx * M;
+                memcpy(st, P.target.data(), sizeof(int) * M);
+                HIPCHK(c, hipMemcpyAsync(c->c_target, st, sizeof(int) * M, hipMemcpyHostToDevice, c->stream));
+                P.target_set = true;
+            }
+            const int G = 2;
+            int slot = 0;
+            for (int q = 0; q < G; ++q) {
+                slot = (int)(c->cont_iters & 63);
+                c->cont_iters++;
+                c->dbg_gate = false;
+                launch_logits(c, c->logits, M, true);
+                hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, max_iters,
+                                   c->c_avail, s, slot, (float*)nullptr, (int*)nullptr);
+                launch_predictor(c);
+                launch_ppj(c);
+            }
+            __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
+            HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            RC(spin_flag(c, flag));
+            if (*flag == 0) break;
+            if (++guard > 4096) return fail(c, LASR_EHIP, "decode loop did not converge");
+        }
+        // results of step P: tokens between the previous and this step boundary of every row
+        HIPCHK(c, hipMemcpyAsync(h_end, c->c_ntok_end, sizeof(int) * (size_t)M * lasr_ctx::ENDSLOTS, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_ring, c->c_tok_ring, sizeof(int) * (size_t)M * lasr_ctx::TOKRING, hipMemcpyDeviceToHost, c->stream));
+        __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
+        HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + 63, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // any non-negative word
+        RC(spin_flag(c, flag));
+        for (int r : P.rows) {
+            const int j = P.target[r] / P.Tm - 1;
+            const long long end = h_end[(size_t)r * lasr_ctx::ENDSLOTS + (j % lasr_ctx::ENDSLOTS)];
+            for (long long q = c->h_fetched[r]; q < end; ++q)
+                c->queue[r].push_back(h_ring[(size_t)r * lasr_ctx::TOKRING + (q % lasr_ctx::TOKRING)]);
+            c->h_fetched[r] = end;
+        }
+        c->stats.frames = P.Tm;
+        c->stats.decode_iters = (int)(c->cont_iters - it0);
+        if (n_ran) *n_ran = (int)P.rows.size();
+        c->pending.erase(c->pending.begin());
+        return LASR_OK;
+    };
+    rc = body();
     c->stream = main_stream;
-    c->pe = pe_keep;
-    c->T_row_dec = c->T_row_dev;
-    if (rc) return rc;
-    c->stats.frames = p.Tm;
-    if (n_ran) *n_ran = (int)p.rows.size();
-    return LASR_OK;
+    c->pe = pe_keep; c->pe_ring_R = 1 << 30;
+    c->dec_t_idx = c->ds.t_idx; c->T_row_dec = c->T_row_dev;
+    c->cmd_inflight = 0;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------- offline
@@ -1456,7 +1564,7 @@ int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, floa
         launch_gemm<EpiLinear, 1, true>(c, J / 16, (B + 15) / 16, g, ea);
     }
     hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)c->M * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)c->pp,
-                       (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MT);
+                       (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MT, 1 << 30);
     launch_logits(c, logits, B, false);
     if (logp_max && argmax) {
         DecState s = c->ds;

@@ -583,6 +583,8 @@ struct EpiLinear {
         const int* t_idx;     // optional row gate: row active iff t_idx[r % M] < T_row[r % M]
         const int* T_row;
         int M;
+        const int* ring_base; // optional: GEMM row (t*M + r) is written to row ((ring_base[r] + t) % ring)*M + r
+        int ring;
     };
     __device__ static bool row_on(const Args& a, int r) {
         if (r >= a.n_rows) return false;
@@ -605,7 +607,12 @@ struct EpiLinear {
             const int r = mg * ROWS + row;
             if (!row_on(a, r)) continue;
             const int n = jb * 16 + col;
-            a.out[(size_t)r * a.ldo + n] = red.sum(row, col) + (a.bias ? a.bias[n] : 0.f);
+            size_t orow = (size_t)r;
+            if (a.ring_base) {
+                const int t = r / a.M, q = r - t * a.M;
+                orow = (size_t)((a.ring_base[q] + t) % a.ring) * a.M + q;
+            }
+            a.out[orow * a.ldo + n] = red.sum(row, col) + (a.bias ? a.bias[n] : 0.f);
         }
     }
 };
@@ -630,6 +637,7 @@ struct EpiPPJ {
         const int* emit;
         float* ja;            // fragment-major [J/16][MT][64][4]
         int J, M, MT;
+        int ring;             // pe holds frame t of row r at slot t % ring (ring >= frames of a step)
     };
     struct Pre {};
     template <int MTB>
@@ -647,13 +655,13 @@ struct EpiPPJ {
                 const float p = red.sum(row, col) + a.b1[j];
                 a.pp[(size_t)r * a.J + j] = p;
                 const int t = a.t_idx[r];
-                if (t < a.T_row[r]) a.ja[hfrag(r, j, a.MT)] = tanhf(a.pe[((size_t)t * a.M + r) * a.J + j] + p);
+                if (t < a.T_row[r]) a.ja[hfrag(r, j, a.MT)] = tanhf(a.pe[((size_t)(t % a.ring) * a.M + r) * a.J + j] + p);
             }
             const int r = vr;                           // original row of this range, if it did not emit
             if (r < a.M && !a.emit[r]) {
                 const int t = a.t_idx[r];
                 if (t < a.T_row[r])
-                    a.ja[hfrag(r, j, a.MT)] = tanhf(a.pe[((size_t)t * a.M + r) * a.J + j] + a.pp[(size_t)r * a.J + j]);
+                    a.ja[hfrag(r, j, a.MT)] = tanhf(a.pe[((size_t)(t % a.ring) * a.M + r) * a.J + j] + a.pp[(size_t)r * a.J + j]);
             }
         }
     }

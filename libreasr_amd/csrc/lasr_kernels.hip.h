@@ -45,13 +45,13 @@ __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(
 // ------------------------------------------------------------------------------------------------
 // joint activation for all rows (start of a step): ja = tanh(pe[t_idx] + pp)
 __global__ void k_ja(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
-                     const int* __restrict__ T_row, float* __restrict__ ja, int J, int M, int MT) {
+                     const int* __restrict__ T_row, float* __restrict__ ja, int J, int M, int MT, int ring) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * J) return;
     const int r = idx / J, j = idx - r * J;
     const int t = t_idx ? t_idx[r] : 0;
     if (T_row && t >= T_row[r]) return;
-    ja[frag_off(r, j, MT)] = tanhf(pe[((size_t)t * M + r) * J + j] + pp[(size_t)r * J + j]);
+    ja[frag_off(r, j, MT)] = tanhf(pe[((size_t)(t % ring) * M + r) * J + j] + pp[(size_t)r * J + j]);
 }
 
 // row-major [rows][K] <-> fragment-major
@@ -147,7 +147,21 @@ struct DecState {
     int* sum_iters;    // [M] evaluations in this step
     int* n_ones;       // [M] frames finished after exactly one evaluation (alignment_score)
     int* unfinished;   // [n_iter_slots] rows still decoding after iteration i
+    // continuous mode (decode loop running across chunk boundaries, lasr_step_submit/_wait):
+    //   t_idx = global frame cursor, T_row = frames available, step_ntok = tokens emitted so far,
+    //   step_tok = token ring of tok_cap entries per row
+    int cont;
+    const int* target; // [M] frame count the oldest pending step needs from row r (0: not part of it)
+    int* ntok_end;     // [M][end_slots] tokens emitted when row r finished its step j (slot j % end_slots)
+    int step_T;        // frames per model step (n_buffer)
+    int end_slots;
 };
+
+// frames of newly encoded steps become visible to the decode loop (continuous mode)
+__global__ void k_advance(int* __restrict__ counter, const int* __restrict__ add, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) counter[i] += add[i];
+}
 
 __global__ void k_step_begin(DecState s, int M, int n_iter_slots, int reset_metrics) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,6 +187,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
                                                 const int* __restrict__ T_row, DecState s, int iter_slot,
                                                 float* __restrict__ out_logp, int* __restrict__ out_arg) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (!PLAIN && s.cont && r == 0 && tid == 0) s.unfinished[(iter_slot + 32) & 63] = 0;   // recycle the flag ring
     // state of the row: loaded up front so the latency overlaps the logits reads
     int t = 0, Tr = 1, it0 = 0, n0 = 0, si0 = 0, no0 = 0;
     double lp0 = 0.0;
@@ -240,8 +255,10 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         s.emit[r] = 0;
         frame_done = true;
     } else {
-        if (n0 < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n0] = arg;
+        if (s.cont) s.step_tok[(size_t)r * s.tok_cap + (n0 % s.tok_cap)] = arg;
+        else if (n0 < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n0] = arg;
         s.step_ntok[r] = n0 + 1;
+        n0 += 1;
         s.token[r] = arg;
         s.emit[r] = 1;
         frame_done = (it >= max_iters);
@@ -251,9 +268,11 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         it = 0;
         t += 1;
         s.t_idx[r] = t;
+        if (s.cont && t % s.step_T == 0)      // the row just finished one of its model steps
+            s.ntok_end[(size_t)r * s.end_slots + ((t / s.step_T - 1) % s.end_slots)] = n0;
     }
     s.iters[r] = it;
-    if (t < Tr) atomicAdd(&s.unfinished[iter_slot], 1);
+    if (s.cont ? (t < s.target[r]) : (t < Tr)) atomicAdd(&s.unfinished[iter_slot], 1);
 }
 
 // ------------------------------------------------------------------------------------------------
