@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=8)
     ap.add_argument("--cpu-chunks", type=int, default=100)
-    ap.add_argument("--depth", type=int, default=6,
+    ap.add_argument("--depth", type=int, default=4,
                     help="pipelined mode: model steps in flight before the oldest is collected (1..7)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")

@@ -50,7 +50,7 @@ struct lasr_ctx {
 
     // front-end constants
     float* window = nullptr; float2* tw512 = nullptr; float2* tw1024 = nullptr;
-    int* fb_start = nullptr; int* fb_off = nullptr; float* fb_w = nullptr;
+    int* fb_start = nullptr; int* fb_off = nullptr; float* fb_w = nullptr; int fb_nnz = 0;
     float *ln_w = nullptr, *ln_b = nullptr;
 
     std::vector<Cell> enc, pred;
@@ -70,8 +70,9 @@ struct lasr_ctx {
     float *pp = nullptr, *ja = nullptr, *logits = nullptr;
     DecState ds{};
     int n_iter_slots = 0;
-    int* T_row_dev = nullptr;       // [M] current step's frames per row (copied from the cmd block)
-    int* T_row_dec = nullptr;       // what the decode kernels read (== T_row_dev unless pipelined)
+    int* T_row_dev = nullptr;       // [M] current step's frames per row: points INTO the step's device command block
+    int* zero_rows = nullptr;       // [M] zeros (reset passes: "no row is decoding")
+    int* T_row_dec = nullptr;       // what the decode kernels read (T_row_dev; frames-available counters when continuous)
     int* dec_t_idx = nullptr;       // frame cursor array the decode kernels use (ds.t_idx, or c_cur when continuous)
     int pe_ring_R = 1 << 30;        // pe frame t lives at slot t % pe_ring_R
     // continuous decode (lasr_step_submit / lasr_step_wait): front-end + encoder of later chunks run on
@@ -87,10 +88,12 @@ struct lasr_ctx {
     int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
     int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr;
     int* cont_host = nullptr;       // pinned: [0] flag, [4..] target staging (NFLY blocks), then ntok_end + token ring
-    struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; };
+    struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; const int* T_row_ptr; };
     std::vector<PendingStep> pending;
     std::vector<long long> h_frames_sub, h_fetched;
     long long model_steps = 0, cont_iters = 0;
+    bool group_inflight = false;
+    int kick_iters = 0;
     // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
     // predictor parity at group start, frames)
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
@@ -223,6 +226,15 @@ bool valid_desc(const lasr_model_desc* d) {
     if (d->dtype != 0 || d->beam != 1) return false;
     return true;
 }
+
+// k_stack_ln: the reference shape (1280 = 128 mels x 10 frames) has a fully static instantiation
+#define LAUNCH_STACK_LN(grid, block, shmem, stream, args)                                              \
+    do {                                                                                               \
+        if ((args).F == 1280 && (args).n_stack == 10)                                                  \
+            hipLaunchKernelGGL((k_stack_ln<20, 10>), grid, block, shmem, stream, args);                \
+        else                                                                                           \
+            hipLaunchKernelGGL((k_stack_ln<32, 0>), grid, block, shmem, stream, args);                 \
+    } while (0)
 
 // ---------------------------------------------------------------------------- launch helpers
 struct Ctx2 {};  // (placeholder to keep helper signatures short)
@@ -377,7 +389,8 @@ int cmd_commit(lasr_ctx* c) {
 // device copy of the step's T_row (from the committed command block) + host-side per-step masks of
 // the m-tiles that contain an active row (passed by value to the encoder cell kernels)
 int commit_T_rows(lasr_ctx* c, int T_max) {
-    HIPCHK(c, hipMemcpyAsync(c->T_row_dev, c->dc.T_row, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    c->T_row_dev = c->dc.T_row;             // the command ring (NCMD blocks) outlives every step in flight
+    c->T_row_dec = c->T_row_dev;
     c->tile_masks.assign(std::max(T_max, 1), 0ull);
     for (int t = 0; t < T_max; ++t) {
         unsigned long long m = 0;
@@ -455,10 +468,12 @@ int apply_reset(lasr_ctx* c, bool any_pred) {
     hipLaunchKernelGGL(k_reset_rows, dim3(grid1((size_t)c->M * c->d.hidden)), dim3(256), 0, c->stream, a);
     if (any_pred) {
         // T_row = 0 for every row: EpiPPJ then only refreshes pp (models.py:489: predictor(BOS))
-        HIPCHK(c, hipMemsetAsync(c->T_row_dev, 0, sizeof(int) * c->M, c->stream));
+        int* keep_dec = c->T_row_dec;
+        c->T_row_dec = c->zero_rows;
         HIPCHK(c, hipMemsetAsync(c->ds.t_idx, 0, sizeof(int) * c->M, c->stream));
         launch_predictor(c);
         launch_ppj(c);
+        c->T_row_dec = keep_dec;
     }
     return LASR_OK;
 }
@@ -818,6 +833,8 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         RC(upload(c, &c->fb_start, st.data(), st.size()));
         RC(upload(c, &c->fb_off, of.data(), of.size()));
         RC(upload(c, &c->fb_w, w.data(), w.size()));
+        c->fb_nnz = (int)w.size();
+        if (c->fb_nnz > 1536 || d.n_mels > 128) return fail(c, LASR_EINVAL, "mel filterbank too large for the LDS staging (%d weights)", c->fb_nnz);
     }
     // ---- encoder
     {
@@ -908,7 +925,9 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->logits, (size_t)M * V));
     RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, M));
     RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.logp_sum, M));
-    RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->T_row_dev, M));
+    RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->zero_rows, M));
+    HIPCHK(c, hipMemset(c->zero_rows, 0, sizeof(int) * M));
+    c->T_row_dev = c->zero_rows;
     for (int q = 0; q < lasr_ctx::NFLY; ++q) {
         RC(dalloc(c, &c->T_row_ring[q], M));
         HIPCHK(c, hipMemset(c->T_row_ring[q], 0, sizeof(int) * M));
@@ -929,7 +948,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     c->h_frames_sub.assign(M, 0); c->h_fetched.assign(M, 0);
     c->dec_t_idx = c->ds.t_idx;
     c->T_row_dec = c->T_row_dev;
-    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.sum_iters, c->ds.n_ones, c->T_row_dev})
+    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.sum_iters, c->ds.n_ones})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
     RC(dalloc(c, &c->win, (size_t)M * d.n_window * d.chunk)); HIPCHK(c, hipMemset(c->win, 0, (size_t)M * d.n_window * d.chunk * 4));
@@ -1102,6 +1121,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
         m.ring_head = c->ring_pos; m.chunk = d.chunk; m.n_window = d.n_window; m.row_sel = c->dc.feat_sel; m.frame0 = a0;
         m.frames_per_row = d.n_stack; m.out = c->pend; m.out_frames = d.n_buffer * d.n_stack;
         m.row_N = nullptr; m.row_src_off = nullptr; m.row_frames = nullptr;
+        m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win; m.fb_nnz = c->fb_nnz;
         hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), 0, c->stream, m);
     }
     Tm = d.n_buffer;
@@ -1113,7 +1133,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
         a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
         a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
         a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = Tm;
-        hipLaunchKernelGGL((k_stack_ln<32>), dim3((Tm + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+        LAUNCH_STACK_LN( dim3((Tm + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     }
     rec(c, 1);
     run_encoder(c, Tm);
@@ -1143,6 +1163,8 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
     return LASR_OK;
 }
 
+static int cont_launch_group(lasr_ctx* c, int G);
+
 // Pipelined + continuous form of lasr_step_stream.  submit: front-end + encoder of this chunk on the
 // main stream (the encoder half of the joint goes to a per-row frame ring).  wait: keeps ONE greedy
 // loop running on stream_dec until every row of the OLDEST submitted step has consumed that step's
@@ -1155,6 +1177,11 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     RC(check_slots(c, slots, n, true));
     if ((int)c->pending.size() >= lasr_ctx::NFLY - 1) return fail(c, LASR_ESTATE, "%d steps already in flight: call lasr_step_wait", (int)c->pending.size());
     HIPCHK(c, hipSetDevice(c->device));
+    // keep the decode stream busy while the host enqueues (and the GPU runs) this chunk's encoder
+    if (!c->pending.empty() && !c->group_inflight) {
+        c->kick_iters = 4;
+        RC(cont_launch_group(c, c->kick_iters));
+    }
     const int idx = (int)(c->model_steps % lasr_ctx::NFLY);
     float* pe_keep = c->pe;
     c->pe = c->pe_ring;                     // run_encoder writes the joint's encoder half into the ring
@@ -1170,11 +1197,11 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
         HIPCHK(c, hipGetLastError());
         return LASR_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(c->T_row_ring[idx], c->T_row_dev, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_advance, dim3(grid1(c->M)), dim3(256), 0, c->stream, c->c_enc_frames, (const int*)c->T_row_dev, c->M);
     HIPCHK(c, hipEventRecord(c->ev_enc[idx], c->stream));
     lasr_ctx::PendingStep p;
     p.rows = model_rows; p.Tm = Tm; p.idx = idx; p.admitted = false; p.target_set = false;
+    p.T_row_ptr = c->T_row_dev;             // lives in the command ring until long after this step is collected
     p.target.assign(c->M, 0);
     for (int r : model_rows) { c->h_frames_sub[r] += Tm; p.target[r] = (int)c->h_frames_sub[r]; }
     c->pending.push_back(std::move(p));
@@ -1185,12 +1212,71 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
 
 int lasr_step_pending(lasr_ctx* c) { return c ? (int)c->pending.size() : 0; }
 
-static int spin_flag(lasr_ctx* c, volatile int* flag) {
+static int spin_flag(lasr_ctx* c, volatile int* flag, hipStream_t st) {
     unsigned long long spins = 0;
     while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == -1) {
         __builtin_ia32_pause();
-        if (++spins > (1ull << 27)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
+        if (++spins > (1ull << 27)) { HIPCHK(c, hipStreamSynchronize(st)); break; }
     }
+    return LASR_OK;
+}
+
+// decode-side view of the ctx while the continuous loop is being fed (restored by the guard)
+struct ContScope {
+    lasr_ctx* c; hipStream_t st; float* pe; int ring; int* tidx; int* trow;
+    explicit ContScope(lasr_ctx* c_) : c(c_), st(c_->stream), pe(c_->pe), ring(c_->pe_ring_R), tidx(c_->dec_t_idx), trow(c_->T_row_dec) {
+        c->stream = c->stream_dec; c->pe = c->pe_ring; c->pe_ring_R = lasr_ctx::RING;
+        c->dec_t_idx = c->c_cur; c->T_row_dec = c->c_avail;
+    }
+    ~ContScope() { c->stream = st; c->pe = pe; c->pe_ring_R = ring; c->dec_t_idx = tidx; c->T_row_dec = trow; }
+};
+
+// One group of G greedy iterations on stream_dec for whatever rows have frames to decode, followed by
+// the copy of "rows of the oldest pending step still behind" into the pinned flag.  Does not wait.
+static int cont_launch_group(lasr_ctx* c, int G) {
+    const int M = c->M, V = c->d.vocab, J = c->d.joint;
+    ContScope scope(c);
+    lasr_ctx::PendingStep& P = c->pending.front();
+    DecState s = c->ds;
+    s.t_idx = c->c_cur; s.iters = c->c_iters; s.step_ntok = c->c_ntotal; s.step_tok = c->c_tok_ring;
+    s.tok_cap = lasr_ctx::TOKRING; s.unfinished = c->c_behind; s.cont = 1; s.target = c->c_target;
+    s.ntok_end = c->c_ntok_end; s.step_T = P.Tm; s.end_slots = lasr_ctx::ENDSLOTS;
+    int* flag = c->cont_host;
+    int* tgt_stage = c->cont_host + 16;
+    // admit encoded steps in order: the oldest unconditionally, later ones only if their encoder is done
+    bool admitted_any = false;
+    for (auto& q : c->pending) {
+        if (q.admitted) continue;
+        if (&q != &P && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_enc[q.idx], 0));
+        hipLaunchKernelGGL(k_advance, dim3(grid1(M)), dim3(256), 0, c->stream, c->c_avail, q.T_row_ptr, M);
+        q.admitted = true;
+        admitted_any = true;
+    }
+    if (admitted_any)   // rows that were idle need their joint activation for the new frames
+        hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
+                           c->c_avail, c->ja, J, M, c->MT, c->pe_ring_R);
+    if (!P.target_set) {
+        int* st = tgt_stage + (size_t)P.idx * M;
+        memcpy(st, P.target.data(), sizeof(int) * M);
+        HIPCHK(c, hipMemcpyAsync(c->c_target, st, sizeof(int) * M, hipMemcpyHostToDevice, c->stream));
+        P.target_set = true;
+    }
+    int slot = 0;
+    for (int q = 0; q < G; ++q) {
+        slot = (int)(c->cont_iters & 63);
+        c->cont_iters++;
+        c->dbg_gate = false;
+        launch_logits(c, c->logits, M, true);
+        hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, c->d.max_iters_stream,
+                           c->c_avail, s, slot, (float*)nullptr, (int*)nullptr);
+        launch_predictor(c);
+        launch_ppj(c);
+    }
+    __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
+    HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->group_inflight = true;
+    HIPCHK(c, hipGetLastError());
     return LASR_OK;
 }
 
@@ -1199,90 +1285,38 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran) {
     if (n_ran) *n_ran = 0;
     if (c->pending.empty()) return LASR_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    const int M = c->M, V = c->d.vocab, J = c->d.joint;
-    hipStream_t main_stream = c->stream;
-    float* pe_keep = c->pe;
-    // decode-side view: global frame cursors, frames available, pe ring
-    c->stream = c->stream_dec;
-    c->pe = c->pe_ring; c->pe_ring_R = lasr_ctx::RING;
-    c->dec_t_idx = c->c_cur; c->T_row_dec = c->c_avail;
-    DecState s = c->ds;
-    s.t_idx = c->c_cur; s.iters = c->c_iters; s.step_ntok = c->c_ntotal; s.step_tok = c->c_tok_ring;
-    s.tok_cap = lasr_ctx::TOKRING; s.unfinished = c->c_behind; s.cont = 1; s.target = c->c_target;
-    s.ntok_end = c->c_ntok_end; s.step_T = c->pending.front().Tm; s.end_slots = lasr_ctx::ENDSLOTS;
-    int* flag = c->cont_host;                       // pinned
-    int* tgt_stage = c->cont_host + 16;             // NFLY blocks of M ints
-    int* h_end = tgt_stage + (size_t)lasr_ctx::NFLY * M;
+    const int M = c->M;
+    int* flag = c->cont_host;
+    int* h_end = c->cont_host + 16 + (size_t)lasr_ctx::NFLY * M;
     int* h_ring = h_end + (size_t)M * lasr_ctx::ENDSLOTS;
-    int rc = LASR_OK;
-    auto body = [&]() -> int {
-        lasr_ctx::PendingStep& P = c->pending.front();
-        const int max_iters = c->d.max_iters_stream;
-        int guard = 0;
-        const long long it0 = c->cont_iters;
-        while (true) {
-            // admit encoded steps in order: the oldest unconditionally, later ones only if their encoder is done
-            bool admitted_any = false;
-            for (auto& q : c->pending) {
-                if (q.admitted) continue;
-                if (&q != &P && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_enc[q.idx], 0));
-                hipLaunchKernelGGL(k_advance, dim3(grid1(M)), dim3(256), 0, c->stream, c->c_avail, (const int*)c->T_row_ring[q.idx], M);
-                q.admitted = true;
-                admitted_any = true;
-            }
-            if (admitted_any)   // rows that were idle need their joint activation for the new frames
-                hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
-                                   c->c_avail, c->ja, J, M, c->MT, c->pe_ring_R);
-            if (!P.target_set) {
-                int* st = tgt_stage + (size_t)P.idx * M;
-                memcpy(st, P.target.data(), sizeof(int) * M);
-                HIPCHK(c, hipMemcpyAsync(c->c_target, st, sizeof(int) * M, hipMemcpyHostToDevice, c->stream));
-                P.target_set = true;
-            }
-            const int G = 2;
-            int slot = 0;
-            for (int q = 0; q < G; ++q) {
-                slot = (int)(c->cont_iters & 63);
-                c->cont_iters++;
-                c->dbg_gate = false;
-                launch_logits(c, c->logits, M, true);
-                hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, max_iters,
-                                   c->c_avail, s, slot, (float*)nullptr, (int*)nullptr);
-                launch_predictor(c);
-                launch_ppj(c);
-            }
-            __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
-            HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            RC(spin_flag(c, flag));
-            if (*flag == 0) break;
-            if (++guard > 4096) return fail(c, LASR_EHIP, "decode loop did not converge");
-        }
-        // results of step P: tokens between the previous and this step boundary of every row
-        HIPCHK(c, hipMemcpyAsync(h_end, c->c_ntok_end, sizeof(int) * (size_t)M * lasr_ctx::ENDSLOTS, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(h_ring, c->c_tok_ring, sizeof(int) * (size_t)M * lasr_ctx::TOKRING, hipMemcpyDeviceToHost, c->stream));
-        __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
-        HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + 63, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // any non-negative word
-        RC(spin_flag(c, flag));
-        for (int r : P.rows) {
-            const int j = P.target[r] / P.Tm - 1;
-            const long long end = h_end[(size_t)r * lasr_ctx::ENDSLOTS + (j % lasr_ctx::ENDSLOTS)];
-            for (long long q = c->h_fetched[r]; q < end; ++q)
-                c->queue[r].push_back(h_ring[(size_t)r * lasr_ctx::TOKRING + (q % lasr_ctx::TOKRING)]);
-            c->h_fetched[r] = end;
-        }
-        c->stats.frames = P.Tm;
-        c->stats.decode_iters = (int)(c->cont_iters - it0);
-        if (n_ran) *n_ran = (int)P.rows.size();
-        c->pending.erase(c->pending.begin());
-        return LASR_OK;
-    };
-    rc = body();
-    c->stream = main_stream;
-    c->pe = pe_keep; c->pe_ring_R = 1 << 30;
-    c->dec_t_idx = c->ds.t_idx; c->T_row_dec = c->T_row_dev;
+    const long long it0 = c->cont_iters - (c->group_inflight ? c->kick_iters : 0);
+    for (int guard = 0;; ++guard) {
+        if (!c->group_inflight) RC(cont_launch_group(c, 2));
+        RC(spin_flag(c, flag, c->stream_dec));
+        c->group_inflight = false;
+        if (*flag == 0) break;
+        if (guard > 4096) return fail(c, LASR_EHIP, "decode loop did not converge");
+    }
+    // results of the oldest step: tokens between the previous and this step boundary of every row
+    lasr_ctx::PendingStep& P = c->pending.front();
+    HIPCHK(c, hipMemcpyAsync(h_end, c->c_ntok_end, sizeof(int) * (size_t)M * lasr_ctx::ENDSLOTS, hipMemcpyDeviceToHost, c->stream_dec));
+    HIPCHK(c, hipMemcpyAsync(h_ring, c->c_tok_ring, sizeof(int) * (size_t)M * lasr_ctx::TOKRING, hipMemcpyDeviceToHost, c->stream_dec));
+    __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
+    HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + 63, sizeof(int), hipMemcpyDeviceToHost, c->stream_dec));   // any word >= 0: completion marker
+    RC(spin_flag(c, flag, c->stream_dec));
+    for (int r : P.rows) {
+        const int j = P.target[r] / P.Tm - 1;
+        const long long end = h_end[(size_t)r * lasr_ctx::ENDSLOTS + (j % lasr_ctx::ENDSLOTS)];
+        for (long long q = c->h_fetched[r]; q < end; ++q)
+            c->queue[r].push_back(h_ring[(size_t)r * lasr_ctx::TOKRING + (q % lasr_ctx::TOKRING)]);
+        c->h_fetched[r] = end;
+    }
+    c->stats.frames = P.Tm;
+    c->stats.decode_iters = (int)(c->cont_iters - it0);
+    if (n_ran) *n_ran = (int)P.rows.size();
+    c->pending.erase(c->pending.begin());
     c->cmd_inflight = 0;
-    return rc;
+    return LASR_OK;
 }
 
 // ---------------------------------------------------------------------------- offline
@@ -1346,12 +1380,13 @@ int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, 
     m.ring_head = nullptr; m.chunk = d.chunk; m.n_window = d.n_window; m.row_sel = nullptr; m.frame0 = 0;
     m.frames_per_row = Tmel_max; m.out = c->lm_buf; m.out_frames = Tmel_max;
     m.row_N = c->dc.row_N; m.row_src_off = c->dc.row_src_off; m.row_frames = c->dc.row_frames;
+    m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win; m.fb_nnz = c->fb_nnz;
     hipLaunchKernelGGL(k_logmel, dim3((Tmel_max + 3) / 4, c->M), dim3(256), 0, c->stream, m);
     StackLnArgs a{};
     a.src = c->lm_buf; a.mode = 0; a.src_frames = Tmel_max; a.frame_step = d.stride; a.row_off = nullptr;
     a.T_row = c->dc.T_row; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
     a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = T_max;
-    hipLaunchKernelGGL((k_stack_ln<32>), dim3((T_max + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    LAUNCH_STACK_LN( dim3((T_max + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     return transcribe_common(c, slots, n, T_max);
 }
 
@@ -1390,7 +1425,7 @@ int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* fea
     a.src = src; a.mode = 1; a.src_frames = 0; a.frame_step = 0; a.row_off = c->dc.row_feat_off;
     a.T_row = c->dc.T_row; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
     a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = T_max;
-    hipLaunchKernelGGL((k_stack_ln<32>), dim3((T_max + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    LAUNCH_STACK_LN( dim3((T_max + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     return transcribe_common(c, slots, n, T_max);
 }
 
@@ -1421,7 +1456,7 @@ int lasr_step_feats(lasr_ctx* c, const int* slots, int n, const float* feats, in
     a.src = src; a.mode = 1; a.row_off = c->dc.row_feat_off; a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b;
     a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels; a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT;
     a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = T;
-    hipLaunchKernelGGL((k_stack_ln<32>), dim3((T + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    LAUNCH_STACK_LN( dim3((T + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     rec(c, 1);
     run_encoder(c, T);
     rec(c, 2);
@@ -1478,6 +1513,7 @@ int lasr_logmel(lasr_ctx* c, const float* pcm, int B, int64_t N, float* logmel) 
     m.ring_head = nullptr; m.chunk = d.chunk; m.n_window = d.n_window; m.row_sel = nullptr; m.frame0 = 0;
     m.frames_per_row = T; m.out = logmel; m.out_frames = T;
     m.row_N = nullptr; m.row_src_off = nullptr; m.row_frames = nullptr;
+    m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win; m.fb_nnz = c->fb_nnz;
     hipLaunchKernelGGL(k_logmel, dim3((T + 3) / 4, B), dim3(256), 0, c->stream, m);
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
@@ -1511,7 +1547,7 @@ int lasr_encoder(lasr_ctx* c, const float* feats, int B, int Tp, float* out, flo
     a.src = feats; a.mode = 1; a.row_off = c->dc.row_feat_off; a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b;
     a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels; a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT;
     a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = Tp;
-    hipLaunchKernelGGL((k_stack_ln<32>), dim3((Tp + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    LAUNCH_STACK_LN( dim3((Tp + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     run_encoder(c, Tp);
     hipLaunchKernelGGL(k_enc_out, dim3(grid1((size_t)B * Tp * H)), dim3(256), 0, c->stream,
                        (const float*)c->ybuf[(d.enc_layers - 1) & 1], c->Tcap * c->MT, c->M, out, B, Tp, H);

@@ -330,12 +330,20 @@ struct MelArgs {
     const long long* row_N;
     const long long* row_src_off;
     const int* row_frames;
+    int win_off, win_len;    // non-zero span of the window inside the n_fft frame
+    int fb_nnz;              // total non-zero filter weights (<= 1536: staged in LDS)
 };
 
 __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     __shared__ float2 sz[4][512 + 8];
     __shared__ float sp[4][520];
+    __shared__ float s_fbw[1536];
+    __shared__ int s_fbs[128], s_fbo[129];
     const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
+    // filterbank -> LDS once per workgroup (coalesced); the mel loop then has no global loads
+    for (int q = threadIdx.x; q < a.fb_nnz; q += 256) s_fbw[q] = a.fb_w[q];
+    for (int q = threadIdx.x; q < a.n_mels; q += 256) s_fbs[q] = a.fb_start[q];
+    for (int q = threadIdx.x; q <= a.n_mels; q += 256) s_fbo[q] = a.fb_off[q];
     int fidx = blockIdx.x * 4 + w;                       // frame within the row
     const int row = blockIdx.y;
     // a wave without a frame recomputes the last valid one and skips the store: every wave of
@@ -367,15 +375,20 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     }
     const long long base = (long long)t * a.hop - 512;
     auto sample = [&](int n) -> float {                  // windowed sample n of the 1024-frame
+        // the window is zero outside [win_off, win_off + win_len): decided from the index, so the
+        // window and the PCM loads are independent (no load -> branch -> load chain)
+        if (n < a.win_off || n >= a.win_off + a.win_len) return 0.f;
         const float wv = a.window[n];
-        if (wv == 0.f) return 0.f;
         long long q = base + n;
         if (q < 0) q = -q;                               // reflect (torch.stft center=True, pad_mode="reflect")
         if (q >= N) q = 2 * (N - 1) - q;
         float x;
         if (a.stream) {
-            const int ck = (int)(q / a.chunk), wi = (int)(q - (long long)ck * a.chunk);
-            x = src[(size_t)((head + ck) % a.n_window) * a.chunk + wi];
+            const int qi = (int)q;                       // < n_window * chunk
+            const int ck = qi / a.chunk, wi = qi - ck * a.chunk;
+            int slot = head + ck;
+            if (slot >= a.n_window) slot -= a.n_window;
+            x = src[(size_t)slot * a.chunk + wi];
         } else {
             x = src[q];
         }
@@ -446,9 +459,9 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     if (!valid) return;
     float* out = a.out + ((size_t)row * a.out_frames + out_frame) * a.n_mels;
     for (int m = j; m < a.n_mels; m += 64) {
-        const int s0 = a.fb_start[m], o0 = a.fb_off[m], cnt = a.fb_off[m + 1] - o0;
+        const int s0 = s_fbs[m], o0 = s_fbo[m], cnt = s_fbo[m + 1] - o0;
         float acc = 0.f;
-        for (int q = 0; q < cnt; ++q) acc += P[s0 + q] * a.fb_w[o0 + q];
+        for (int q = 0; q < cnt; ++q) acc += P[s0 + q] * s_fbw[o0 + q];
         out[m] = logf(acc + 1e-6f);
     }
 }
@@ -483,20 +496,23 @@ struct StackLnArgs {
     float* feats_out;        // optional row-major copy of the un-normalised stacked features [M][Tmax][F]
     int Tmax;
 };
-template <int VPL>   // max values per lane: F <= 64 * VPL
+// VPL: max values per lane (F <= 64 * VPL); NSTACK > 0: compile-time n_stack (F == 64 * VPL exactly,
+// constant divisors, fully unrolled independent loads), 0: runtime shape
+template <int VPL, int NSTACK = 0>
 __global__ __launch_bounds__(256) void k_stack_ln(const StackLnArgs a) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tp = blockIdx.x * 4 + w, row = blockIdx.y;
     if (tp >= a.T_row[row]) return;
     float x[VPL];
     float sum = 0.f;
+    const int n_stack = NSTACK > 0 ? NSTACK : a.n_stack;
 #pragma unroll
     for (int q = 0; q < VPL; ++q) {
         const int f = lane + 64 * q;
         float val = 0.f;
-        if (f >= a.F) {
+        if (NSTACK == 0 && f >= a.F) {
         } else if (a.mode == 0) {
-            const int m = f / a.n_stack, k = f - m * a.n_stack;
+            const int m = f / n_stack, k = f - m * n_stack;
             val = a.src[((size_t)row * a.src_frames + (size_t)a.frame_step * tp + k) * a.n_mels + m];
         } else {
             val = a.src[(size_t)(a.row_off[row] + tp) * a.F + f];
