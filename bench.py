@@ -233,6 +233,12 @@ def main():
         flops = cell_flops(cfg, 1, B)
         achieved = flops / (cell_us * 1e-6) / 1e12
         n_cells = cfg["enc_layers"] * 2
+        traffic = None                      # HBM bytes per launch from the committed PMC passes (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_cell_pmc.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch"] if args.model == "cfg2" and B == 64 else None
+        except Exception:
+            traffic = None
         out = {
             "metric": "audio-sec/sec/GPU (16 kHz streaming RNN-T) + p50 per-chunk latency",
             "value": round(audio_total / elapsed_max, 1),
@@ -265,7 +271,7 @@ def main():
             "tokens_per_frame": round(tokens / max(1, K * B), 4),
             "roofline": {"bound": "mfma", "kernel": "k_gemm<EpiLSTM> (encoder LSTM cell, layer 1, 64 rows)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(cell_us, 3), "flops_per_launch": flops,
                          "weight_bytes_per_launch": 4.0 * 4 * cfg["hidden"] * 2 * cfg["hidden"],
                          "in_situ_encoder_us_per_cell": round(1e3 * float(np.mean(enc_ms)) / n_cells, 3) if enc_ms else None},

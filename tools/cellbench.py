@@ -9,7 +9,8 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 cfg = synth.model_cfg(name); sd = synth.synth_state_dict(cfg)
 eng = Engine(sd, cfg, max_streams=B)
 H = cfg["hidden"]
-for layer in (0, 1):
+layers = [int(x) for x in os.environ.get("LASR_BENCH_LAYERS", "0,1").split(",")]
+for layer in layers:
     I = cfg["feat"] if layer == 0 else H
     us = eng.bench_cell(layer, iters)
     fl = 2.0 * B * 4 * H * (I + H)
