@@ -88,11 +88,13 @@ struct lasr_ctx {
     int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
     int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr;
     int* cont_host = nullptr;       // pinned: [0] flag, [4..] target staging (NFLY blocks), then ntok_end + token ring
-    struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; const int* T_row_ptr; };
+    struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; const int* T_row_ptr; long long serial; };
     std::vector<PendingStep> pending;
     std::vector<long long> h_frames_sub, h_fetched;
     long long model_steps = 0, cont_iters = 0;
-    bool group_inflight = false;
+    bool group_inflight = false;    // a decode group has been launched and its flag not yet consumed
+    long long inflight_for = -1;    // serial of the pending step the in-flight group's flag refers to
+    long long done_serial = -1;     // serial of a pending step already known to be fully decoded
     int kick_iters = 0;
     // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
     // predictor parity at group start, frames)
@@ -1164,6 +1166,7 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
 }
 
 static int cont_launch_group(lasr_ctx* c, int G);
+static void cont_poll(lasr_ctx* c);
 
 // Pipelined + continuous form of lasr_step_stream.  submit: front-end + encoder of this chunk on the
 // main stream (the encoder half of the joint goes to a per-row frame ring).  wait: keeps ONE greedy
@@ -1178,6 +1181,7 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     if ((int)c->pending.size() >= lasr_ctx::NFLY - 1) return fail(c, LASR_ESTATE, "%d steps already in flight: call lasr_step_wait", (int)c->pending.size());
     HIPCHK(c, hipSetDevice(c->device));
     // keep the decode stream busy while the host enqueues (and the GPU runs) this chunk's encoder
+    cont_poll(c);
     if (!c->pending.empty() && !c->group_inflight) {
         c->kick_iters = 4;
         RC(cont_launch_group(c, c->kick_iters));
@@ -1202,6 +1206,7 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     lasr_ctx::PendingStep p;
     p.rows = model_rows; p.Tm = Tm; p.idx = idx; p.admitted = false; p.target_set = false;
     p.T_row_ptr = c->T_row_dev;             // lives in the command ring until long after this step is collected
+    p.serial = c->model_steps;
     p.target.assign(c->M, 0);
     for (int r : model_rows) { c->h_frames_sub[r] += Tm; p.target[r] = (int)c->h_frames_sub[r]; }
     c->pending.push_back(std::move(p));
@@ -1276,8 +1281,18 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
     HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->group_inflight = true;
+    c->inflight_for = P.serial;
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
+}
+
+// non-blocking: if the in-flight group has finished, consume its flag
+static void cont_poll(lasr_ctx* c) {
+    if (!c->group_inflight) return;
+    const int v = __atomic_load_n((volatile int*)c->cont_host, __ATOMIC_ACQUIRE);
+    if (v == -1) return;
+    c->group_inflight = false;
+    if (v == 0) c->done_serial = c->inflight_for;
 }
 
 int lasr_step_wait(lasr_ctx* c, int* n_ran) {
@@ -1290,12 +1305,18 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran) {
     int* h_end = c->cont_host + 16 + (size_t)lasr_ctx::NFLY * M;
     int* h_ring = h_end + (size_t)M * lasr_ctx::ENDSLOTS;
     const long long it0 = c->cont_iters - (c->group_inflight ? c->kick_iters : 0);
-    for (int guard = 0;; ++guard) {
+    const long long serial = c->pending.front().serial;
+    for (int guard = 0; c->done_serial != serial; ++guard) {
         if (!c->group_inflight) RC(cont_launch_group(c, 2));
         RC(spin_flag(c, flag, c->stream_dec));
         c->group_inflight = false;
-        if (*flag == 0) break;
+        // a group launched while an older step was the target says nothing about this one
+        if (c->inflight_for == serial && *flag == 0) c->done_serial = serial;
         if (guard > 4096) return fail(c, LASR_EHIP, "decode loop did not converge");
+    }
+    if (c->group_inflight) {            // drain a group kicked after this step was already known done:
+        RC(spin_flag(c, flag, c->stream_dec));   // the result copies below reuse the pinned flag word
+        c->group_inflight = false;
     }
     // results of the oldest step: tokens between the previous and this step boundary of every row
     lasr_ctx::PendingStep& P = c->pending.front();
