@@ -83,6 +83,7 @@ struct lasr_ctx {
     static constexpr int RING = 32; // pe ring, frames per row
     static constexpr int TOKRING = 256, ENDSLOTS = 16;
     hipEvent_t ev_enc[NFLY] = {};
+    hipEvent_t ev_misc = nullptr;
     int* T_row_ring[NFLY] = {};
     float* pe_ring = nullptr;
     int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
@@ -453,9 +454,9 @@ int ensure_buf(lasr_ctx* c, T** p, size_t* have, size_t need) {
 
 // ---------------------------------------------------------------------------- reset
 // applies c->dc.what (already committed) to the state; runs the predictor on BOS for rows with bit 2
-int apply_reset(lasr_ctx* c, bool any_pred) {
+int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3) {
     ResetArgs a{};
-    a.what = c->dc.what; a.M = c->M; a.MT = c->MT; a.H = c->d.hidden; a.Le = c->d.enc_layers; a.Lp = c->d.pred_layers;
+    a.what = c->dc.what; a.mask = mask; a.M = c->M; a.MT = c->MT; a.H = c->d.hidden; a.Le = c->d.enc_layers; a.Lp = c->d.pred_layers;
     a.pred_lstm = c->d.pred_cell; a.bos = c->d.bos;
     for (int l = 0; l < a.Le; ++l) {
         a.enc_h[l] = c->enc_h[c->enc_par][l]; a.enc_c[l] = c->enc_c[l];
@@ -789,6 +790,7 @@ void lasr_destroy(lasr_ctx* c) {
         for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->ev_enc)
         if (e) (void)hipEventDestroy(e);
+    if (c->ev_misc) (void)hipEventDestroy(c->ev_misc);
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
     delete c;
@@ -936,6 +938,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_enc[q], hipEventDisableTiming));
     }
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_misc, hipEventDisableTiming));
     RC(dalloc(c, &c->pe_ring, (size_t)lasr_ctx::RING * M * J));
     HIPCHK(c, hipMemset(c->pe_ring, 0, sizeof(float) * (size_t)lasr_ctx::RING * M * J));
     RC(dalloc(c, &c->c_cur, M)); RC(dalloc(c, &c->c_avail, M)); RC(dalloc(c, &c->c_iters, M)); RC(dalloc(c, &c->c_target, M));
@@ -1039,14 +1042,31 @@ int lasr_stream_open(lasr_ctx* c, int* slot) {
 int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
     if (!c) return LASR_EINVAL;
     if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
-    RC(require_idle(c));
+    for (const auto& p : c->pending)
+        if (std::find(p.rows.begin(), p.rows.end(), slot) != p.rows.end())
+            return fail(c, LASR_ESTATE, "slot %d has a submitted step in flight: call lasr_step_wait first", slot);
     HIPCHK(c, hipSetDevice(c->device));
     if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); }
     if (what & 3) {
         RC(cmd_begin(c));
         c->hc.what[slot] = what & 3;
         RC(cmd_commit(c));
-        RC(apply_reset(c, (what & 2) != 0));
+        if (c->pending.empty() && !c->group_inflight) {
+            RC(apply_reset(c, (what & 2) != 0));
+        } else {
+            // other streams have steps in flight: the encoder side of the reset is ordered on the main
+            // stream, the predictor side (BOS pass) on the decode stream, between two iteration groups
+            if (what & 1) RC(apply_reset(c, false, 1));
+            if (what & 2) {
+                HIPCHK(c, hipEventRecord(c->ev_misc, c->stream));
+                hipStream_t keep = c->stream;
+                HIPCHK(c, hipStreamWaitEvent(c->stream_dec, c->ev_misc, 0));
+                c->stream = c->stream_dec;
+                int rc = apply_reset(c, true, 2);
+                c->stream = keep;
+                if (rc) return rc;
+            }
+        }
     }
     return LASR_OK;
 }
@@ -1054,6 +1074,9 @@ int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
 int lasr_stream_close(lasr_ctx* c, int slot) {
     if (!c) return LASR_EINVAL;
     if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
+    for (const auto& p : c->pending)
+        if (std::find(p.rows.begin(), p.rows.end(), slot) != p.rows.end())
+            return fail(c, LASR_ESTATE, "slot %d has a submitted step in flight: call lasr_step_wait first", slot);
     c->open_[slot] = 0;
     c->queue[slot].clear();
     return LASR_OK;

@@ -100,6 +100,7 @@ __global__ void k_fill_rand(float* __restrict__ p, size_t n, unsigned seed) {
 // (custom_rnn.py:152-158; Transducer.transcribe_stream reset(), models.py:480-500).
 struct ResetArgs {
     const int* what;          // [M] bit 1: encoder, bit 2: predictor
+    int mask;                 // bits of `what` this launch honours
     int M, MT, H, Le, Lp, pred_lstm, bos;
     float* enc_h[16];         // current-parity fragment buffers
     float* enc_c[16];
@@ -116,8 +117,8 @@ __global__ void k_reset_rows(const ResetArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.M * a.H) return;
     const int r = idx / a.H, u = idx - r * a.H;
-    const int wh = a.what[r];
-    if (u == 0) {
+    const int wh = a.what[r] & a.mask;
+    if (u == 0 && (a.mask & 2)) {
         a.emit[r] = (wh & 2) ? 1 : 0;
         if (wh & 2) a.token[r] = a.bos;
     }

@@ -277,3 +277,70 @@ def test_pipelined_submit_wait_matches_reference(name, n_sec, n_streams, golden_
     finally:
         for slot in slots:
             eng.close_slot(slot)
+
+
+def test_wide_batch_128_rows_and_staggered_streams():
+    """128 slots (two 64-row groups in the predictor / joint kernels; config 4/5 batch shape) with
+    streams that start at different chunks and drop out early, through the continuous submit/wait
+    path and the synchronous path: every stream's tokens equal the oracle's for that stream alone."""
+    import __graft_entry__ as graft
+    from libreasr_amd.engine import Engine
+    graft.build()
+    cfg = synth.model_cfg("tiny")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    m = O.OracleTransducer(sd, cfg)
+    eng = Engine(sd, cfg, max_streams=128)
+    try:
+        rng = np.random.default_rng(3)
+        n_streams = 100
+        lens = rng.integers(6, 22, n_streams)                  # chunks per stream
+        starts = rng.integers(0, 9, n_streams)                 # first global chunk index
+        pcm = [synth.synth_pcm(1, int(l) * 1280, seed=200 + i)[0] for i, l in enumerate(lens)]
+        ref = []
+        for i in range(n_streams):
+            fe, dec = O.StreamFrontend(), m.stream_decoder()
+            for k in range(int(lens[i])):
+                o = fe.push(pcm[i][k * 1280:(k + 1) * 1280])
+                if o is not None:
+                    dec.step(o)
+            ref.append(dec.y)
+        for mode in ("continuous", "sync"):
+            slots = {}
+            got = [[] for _ in range(n_streams)]
+            total = int((starts + lens).max())
+
+            def collect():
+                if eng.wait():
+                    live = sorted(slots)
+                    for i, t in zip(live, eng.fetch_many([slots[i] for i in live], 64)):
+                        got[i] += t
+
+            for g in range(total + 1):
+                for i in range(n_streams):                     # streams join ...
+                    if starts[i] == g:
+                        slots[i] = eng.open()
+                active = [i for i in sorted(slots) if g - starts[i] < lens[i]]
+                if active:
+                    sl = [slots[i] for i in active]
+                    chunk = np.stack([pcm[i][(g - starts[i]) * 1280:(g - starts[i] + 1) * 1280] for i in active])
+                    eng.push(sl, dev(chunk))
+                    if mode == "sync":
+                        if eng.step(sl):
+                            for i, t in zip(active, eng.fetch_many(sl, 64)):
+                                got[i] += t
+                    else:
+                        eng.submit(sl)
+                        if eng.pending() >= 3:
+                            collect()
+                done = [i for i in sorted(slots) if g - starts[i] >= lens[i] - 1]
+                if done and mode == "continuous":              # ... and leave: a slot with a step in flight
+                    while eng.pending():                       #     cannot be closed, so drain first
+                        collect()
+                for i in done:
+                    eng.close_slot(slots.pop(i))
+            while eng.pending():
+                collect()
+            for i in range(n_streams):
+                assert got[i] == ref[i], f"{mode}: stream {i} (start {starts[i]}, {lens[i]} chunks)"
+    finally:
+        eng.close()
