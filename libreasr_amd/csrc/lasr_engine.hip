@@ -62,6 +62,7 @@ struct lasr_ctx {
     int pred_par = 0;               // predictor h ping-pong parity (row-major [M][H] buffers)
     bool enc_tiling_a = false;      // encoder cell tiling ("A": 4 units x 64 rows per workgroup)
     bool enc_tiling_c = false;      // encoder cell tiling ("C": 8 units x 32 rows per workgroup)
+    int nt_w = 0;                   // experiment knob LASR_NT_W: non-temporal weight loads in the encoder cell
     int rot_mul = 0;                // K-walk rotation multiplier of the encoder cell (GemmArgs::rot_mul)
     int cell_variant = 0;           // encoder cell (waves, prefetch depth) variant
     bool dbg_gate = true;           // decode kernels record timestamps only in the first iteration of a step
@@ -256,7 +257,7 @@ void launch_enc_cell(lasr_ctx* c, int l, int t, const float* xsrc, int x_mt_tota
     GemmArgs g{};
     g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / 16;
     g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16;
-    g.M = c->M; g.rot_mul = c->rot_mul; g.dbg = c->dbg;
+    g.M = c->M; g.rot_mul = c->rot_mul; g.dbg = c->dbg; g.nt_w = c->nt_w;
     EpiLSTM<false, false, 16>::Args ea{};
     ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t; ea.tile_mask = c->tile_masks.empty() ? ~0ull : c->tile_masks[t];
     ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
@@ -812,6 +813,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         c->enc_tiling_c = e ? (e[0] == 'C' || e[0] == 'c') : true;    // default "C": least L2->CU traffic (measured best)
         const char* r = getenv("LASR_CELL_ROT");
         c->rot_mul = r ? atoi(r) : 0;
+        if (getenv("LASR_NT_W")) c->nt_w = atoi(getenv("LASR_NT_W"));
         const char* v = getenv("LASR_CELL_VARIANT");
         c->cell_variant = v ? atoi(v) : 0;
         if (getenv("LASR_NO_GRAPH")) c->use_graphs = false;

@@ -33,6 +33,7 @@ struct GemmArgs {
     int a_rows;             // AROW only: loads of rows >= a_rows are clamped (0 = no clamp)
     const int* compact;     // COMPACT epilogues: per-row flag
     int M;                  // rows scanned for compaction
+    int nt_w;               // experiment: stream weights with non-temporal loads
     unsigned long long* dbg; // optional per-workgroup phase timestamps [blocks][8] (LASR_DBG_TIMING)
     int rot_mul;            // workgroup jb walks K starting at chunk (jb*rot_mul) % KC: co-resident
                             // workgroups then read different lines of the shared operand at any moment
@@ -178,7 +179,8 @@ __device__ __forceinline__ void gemm_static(f32x4 (&acc)[MT][NT], const float* c
 #pragma unroll
             for (int s = 0; s < NS0; ++s)
                 fr.b[s] = (i == 0 && wpre) ? wpre[s]          // chunk 0 was issued at kernel entry
-                          : (Epi::PH0_DEAD < 0 || live0) ? *reinterpret_cast<const f32x4*>(wb0 + ((size_t)s * KC0 + c) * FR0)
+                          : (Epi::PH0_DEAD < 0 || live0) ? (g.nt_w ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wb0 + ((size_t)s * KC0 + c) * FR0))
+                                                                  : *reinterpret_cast<const f32x4*>(wb0 + ((size_t)s * KC0 + c) * FR0))
                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
             const int c = chunk(i - N0);
@@ -187,7 +189,8 @@ __device__ __forceinline__ void gemm_static(f32x4 (&acc)[MT][NT], const float* c
 #pragma unroll
             for (int s = 0; s < NS1; ++s)
                 fr.b[s] = (i == 0 && wpre) ? wpre[s]
-                          : (Epi::PH1_DEAD < 0 || live1) ? *reinterpret_cast<const f32x4*>(wb1 + ((size_t)s * KC1 + c) * FR1)
+                          : (Epi::PH1_DEAD < 0 || live1) ? (g.nt_w ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wb1 + ((size_t)s * KC1 + c) * FR1))
+                                                                  : *reinterpret_cast<const f32x4*>(wb1 + ((size_t)s * KC1 + c) * FR1))
                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
