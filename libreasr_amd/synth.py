@@ -34,10 +34,10 @@ CONFIGS = {
                       pred_layers=2, pred_cell="LSTM", blank_bias=14.2, out_scale=8.0),
     # reference default 6-2-1024 (config/testing.yaml:202-229)
     "ref6": dict(feat=1280, embed=512, vocab=2048, hidden=1024, joint=1024, enc_layers=6,
-                 pred_layers=2, pred_cell="NBRC", blank_bias=14.2, out_scale=8.0),
+                 pred_layers=2, pred_cell="NBRC", blank_bias=15.0, out_scale=8.0),
     # config 5: 8x1536 encoder, 2-layer LSTM predictor
     "cfg5": dict(feat=1280, embed=512, vocab=2048, hidden=1536, joint=1536, enc_layers=8,
-                 pred_layers=2, pred_cell="LSTM", blank_bias=14.2, out_scale=8.0),
+                 pred_layers=2, pred_cell="LSTM", blank_bias=17.4, out_scale=8.0),
 }
 
 

@@ -138,7 +138,7 @@ if __name__ == "__main__":
     assert rf.available(), "/root/reference is required to generate goldens"
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["frontend", "tiny", "tiny_lstm", "cfg2", "cfg2_lstm", "flac"]
+    which = sys.argv[1:] or ["frontend", "tiny", "tiny_lstm", "cfg2", "cfg2_lstm", "ref6", "cfg5", "flac"]
     if "frontend" in which:
         golden_frontend()
     if "tiny" in which:
@@ -149,6 +149,10 @@ if __name__ == "__main__":
         golden_model("cfg2", 4.0, 2, True)
     if "cfg2_lstm" in which:
         golden_model("cfg2_lstm", 2.0, 1, True)
+    if "ref6" in which:
+        golden_model("ref6", 2.0, 1, False)       # the reference's shipped shape (config/testing.yaml:202-229)
+    if "cfg5" in which:
+        golden_model("cfg5", 2.0, 1, False)       # BASELINE configs[4] model shape, fp32
     if "flac" in which:
         try:
             golden_flac()

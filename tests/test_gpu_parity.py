@@ -123,7 +123,8 @@ def test_predictor_and_joint(name, golden_dir):
 
 # ------------------------------------------------------------------------------- end to end
 @pytest.mark.parametrize("name,n_sec,n_streams", [("tiny", 3.0, 3), ("tiny_lstm", 3.0, 2),
-                                                   ("cfg2", 4.0, 2), ("cfg2_lstm", 2.0, 1)])
+                                                   ("cfg2", 4.0, 2), ("cfg2_lstm", 2.0, 1),
+                                                   ("ref6", 2.0, 1), ("cfg5", 2.0, 1)])
 def test_offline_transcribe_matches_reference(name, n_sec, n_streams, golden_dir):
     eng, m, cfg = engine(name)
     g = np.load(os.path.join(golden_dir, f"model_{name}.npz"))
@@ -146,7 +147,8 @@ def test_offline_transcribe_matches_reference(name, n_sec, n_streams, golden_dir
 
 
 @pytest.mark.parametrize("name,n_sec,n_streams", [("tiny", 3.0, 3), ("tiny_lstm", 3.0, 2),
-                                                   ("cfg2", 4.0, 2), ("cfg2_lstm", 2.0, 1)])
+                                                   ("cfg2", 4.0, 2), ("cfg2_lstm", 2.0, 1),
+                                                   ("ref6", 2.0, 1), ("cfg5", 2.0, 1)])
 def test_streaming_matches_reference(name, n_sec, n_streams, golden_dir):
     eng, m, cfg = engine(name)
     g = np.load(os.path.join(golden_dir, f"model_{name}.npz"))
@@ -344,3 +346,47 @@ def test_wide_batch_128_rows_and_staggered_streams():
                 assert got[i] == ref[i], f"{mode}: stream {i} (start {starts[i]}, {lens[i]} chunks)"
     finally:
         eng.close()
+
+
+def test_config5_shape_against_oracle():
+    """BASELINE configs[4] model shape (8 x LSTM(1536) encoder, 2-layer LSTM predictor, J = 1536) in fp32:
+    offline and continuous-streaming tokens of streams the goldens do not cover, against the oracle."""
+    eng, m, cfg = engine("cfg5")
+    pcm = synth.synth_pcm(3, 16000 * 2, seed=77)
+    slots = [eng.open() for _ in range(3)]
+    try:
+        eng.transcribe_pcm(slots, [dev(p) for p in pcm])
+        for s, slot in enumerate(slots):
+            ref = m.decode_greedy(O.features_offline(pcm[s]))
+            toks, neg_logp, align = eng.fetch(slot)
+            assert toks == ref[0]
+            assert abs(neg_logp - ref[1]) < 2e-2 * max(1.0, abs(ref[1]))
+        for slot in slots:
+            eng.reset(slot, 15)
+        chunks = [synth.stream_chunks(p, 1280, lead=1, tail=6) for p in pcm]
+        got = [[] for _ in slots]
+        refs = []
+        for s in range(3):
+            fe, dec = O.StreamFrontend(), m.stream_decoder()
+            for c in chunks[s]:
+                o = fe.push(c)
+                if o is not None:
+                    dec.step(o)
+            refs.append(dec.y)
+
+        def collect():
+            if eng.wait():
+                for s, t in enumerate(eng.fetch_many(slots, 64)):
+                    got[s] += t
+
+        for k in range(len(chunks[0])):
+            eng.push(slots, dev(np.stack([c[k] for c in chunks])))
+            eng.submit(slots)
+            if eng.pending() >= 3:
+                collect()
+        while eng.pending():
+            collect()
+        assert got == refs
+    finally:
+        for slot in slots:
+            eng.close_slot(slot)
