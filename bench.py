@@ -276,6 +276,21 @@ def main():
                          "weight_bytes_per_launch": 4.0 * 4 * cfg["hidden"] * 2 * cfg["hidden"],
                          "in_situ_encoder_us_per_cell": round(1e3 * float(np.mean(enc_ms)) / n_cells, 3) if enc_ms else None},
         }
+        # secondary figure: the offline path (Transcribe RPC) on whole 20.65 s utterances (the demo's length)
+        try:
+            n_off = 330400
+            off_pcm = [torch.as_tensor(synth.synth_pcm(1, n_off, seed=5000 + s)[0]).to(device) for s in range(min(B, 64))]
+            eng.transcribe_pcm(slots[:len(off_pcm)], off_pcm)              # warm-up (buffer growth)
+            torch.cuda.synchronize(device)
+            t_off = time.perf_counter()
+            eng.transcribe_pcm(slots[:len(off_pcm)], off_pcm)
+            n_off_tok = sum(len(t) for t in eng.fetch_many(slots[:len(off_pcm)], cap=2048))
+            dt_off = time.perf_counter() - t_off
+            out["offline"] = {"audio_sec_per_sec": round(len(off_pcm) * n_off / SR / dt_off, 1), "utterances": len(off_pcm),
+                              "seconds_each": round(n_off / SR, 2), "wall_ms": round(1e3 * dt_off, 2), "tokens": n_off_tok,
+                              "note": "lasr_transcribe_pcm: fresh state, max_iters 3, synchronous decode loop"}
+        except Exception as e:                                            # never let the extra figure break the contract line
+            out["offline"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline:
             rows = [pcm_host[i] for i in range(min(args.cpu_streams, B))]
             out["cpu_baseline"] = cpu_baseline(cfg, sd, rows, args.cpu_chunks)
