@@ -1,0 +1,210 @@
+"""gRPC front of the engine: the reference's `api-server.py` (ASRServicer, ports, reset policy,
+transcript diffing) with a batching scheduler in place of its 4-thread / batch-1 model calls.
+
+Reference behaviour kept (api-server.py:16-26, 44-50, 64-135):
+  * `ASR.Transcribe(Audio) -> Transcript`, `ASR.TranscribeStream(stream Audio) -> stream Transcript`,
+    ports en 50051 / de 50052 / fr 50053, `Audio.data` = raw little-endian float32 PCM.
+  * streaming: the model runs once the 3-chunk window is full and the 2-frame Buffer is complete;
+    after every model call: if the chunk produced text, re-denumericalize the whole hypothesis and
+    send only the characters that changed (zip_longest diff), skipping a repeat of the previous
+    diff; otherwise, after >= 4000 ms of empty output (10 ms * downsample * n_buffer * steps), reset().
+What differs: the reference shares one model + one stateful `Buffer` transform between 4 worker
+threads at batch 1 (a race).  Here RPC threads only queue PCM; ONE scheduler thread
+owns the engine (a lasr_ctx is single-caller) and steps every stream that has a chunk ready in a
+single batched `lasr_push_pcm` + `lasr_step_stream`."""
+import collections
+import itertools as it
+import queue
+import threading
+from concurrent import futures
+
+import grpc
+import numpy as np
+
+from .interfaces import libreasr_pb2 as ap
+from .interfaces import libreasr_pb2_grpc as apg
+from .lib.utils import tensorize
+
+WORKERS = 64
+PORTS = {"en": "[::]:50051", "de": "[::]:50052", "fr": "[::]:50053"}
+THRESH = 4000           # ms without output before reset (api-server.py:25)
+
+
+def should_reset(steps, downsample, n_buffer):
+    return int(10.0 * downsample * n_buffer * steps) >= THRESH          # api-server.py:44-50
+
+
+class _Stream:
+    def __init__(self, slot):
+        self.slot, self.inq, self.outq = slot, collections.deque(), queue.Queue()
+        self.n_chunks, self.n_pend = 0, 0
+
+
+class Scheduler(threading.Thread):
+    """Single owner of the engine.  Every tick: run queued offline jobs, then push + step ALL streams
+    that have a chunk waiting as one batch."""
+
+    def __init__(self, engine):
+        super().__init__(daemon=True, name="lasr-scheduler")
+        self.eng, self.cv = engine, threading.Condition()
+        self.streams, self.jobs, self.ctl, self.stop_flag = {}, collections.deque(), collections.deque(), False
+        self.batches = []                   # sizes of the streaming batches (observability / tests)
+
+    # ---- called from RPC threads -----------------------------------------------------------
+    def _call(self, fn):
+        done = queue.Queue()
+        with self.cv:
+            self.ctl.append((fn, done))
+            self.cv.notify()
+        res = done.get()
+        if isinstance(res, Exception):
+            raise res
+        return res
+
+    def open(self):
+        return self._call(lambda: self._open())
+
+    def close(self, st):
+        self._call(lambda: self._close(st))
+
+    def reset(self, st):
+        self._call(lambda: self.eng.reset(st.slot, 1 | 2 | 4))             # models.py:494-497
+
+    def transcribe(self, pcm):
+        return self._call(lambda: self._offline(pcm))
+
+    def push(self, st, chunk):
+        with self.cv:
+            st.inq.append(chunk)
+            self.cv.notify()
+        return st.outq.get()                # None = model did not run for this chunk, else list of new token ids
+
+    def shutdown(self):
+        with self.cv:
+            self.stop_flag = True
+            self.cv.notify()
+
+    # ---- scheduler thread ------------------------------------------------------------------
+    def _open(self):
+        st = _Stream(self.eng.open())
+        self.streams[st.slot] = st
+        return st
+
+    def _close(self, st):
+        self.streams.pop(st.slot, None)
+        self.eng.close_slot(st.slot)
+
+    def _offline(self, pcm):
+        slot = self.eng.open()
+        try:
+            self.eng.transcribe_pcm([slot], [pcm])
+            return self.eng.fetch(slot)
+        finally:
+            self.eng.close_slot(slot)
+
+    def run(self):
+        d = self.eng.desc
+        while True:
+            with self.cv:
+                while not self.stop_flag and not self.ctl and not any(s.inq for s in self.streams.values()):
+                    self.cv.wait()
+                if self.stop_flag:
+                    return
+                ctl = list(self.ctl)
+                self.ctl.clear()
+                ready = [s for s in self.streams.values() if s.inq]
+                chunks = [s.inq.popleft() for s in ready]
+            for fn, done in ctl:
+                try:
+                    done.put(fn())
+                except Exception as e:       # surfaced in the calling RPC thread
+                    done.put(e)
+            if not ready:
+                continue
+            try:
+                slots = [s.slot for s in ready]
+                self.eng.push(slots, np.stack(chunks))
+                self.eng.step(slots)
+                toks = self.eng.fetch_many(slots, cap=256)
+                self.batches.append(len(ready))
+                for s, t in zip(ready, toks):
+                    s.n_chunks += 1
+                    ran = False
+                    if s.n_chunks >= d.n_window:            # window full -> one more frame in the Buffer
+                        s.n_pend += 1
+                        if s.n_pend == d.n_buffer:
+                            s.n_pend, ran = 0, True
+                    s.outq.put(t if ran else None)
+            except Exception as e:
+                for s in ready:
+                    s.outq.put(e)
+
+
+class ASRServicer(apg.ASRServicer):
+    def __init__(self, lang, scheduler, language, conf=None):
+        self.lang_name, self.sched, self.lang = lang, scheduler, language
+        eng = scheduler.eng
+        self.downsample, self.n_buffer, self.chunk = eng.desc.stride, eng.desc.n_buffer, eng.desc.chunk
+
+    def Transcribe(self, request, context):                                # api-server.py:64-80
+        aud = tensorize(request.data)[0].numpy()
+        if request.sr not in (0, 16000):
+            context.abort(grpc.StatusCode.INVALID_ARGUMENT, "only 16 kHz input is in scope")
+        tokens, _, _ = self.sched.transcribe(aud)
+        return ap.Transcript(data=self.lang.denumericalize(tokens))
+
+    def TranscribeStream(self, request_iterator, context):                 # api-server.py:82-134
+        st = self.sched.open()
+        try:
+            y, last, last_diff, steps = [], "", "", 0
+            for frame in request_iterator:
+                pcm = tensorize(frame.data)[0].numpy()
+                if pcm.shape[0] != self.chunk:
+                    context.abort(grpc.StatusCode.INVALID_ARGUMENT,
+                                  f"chunks must be {self.chunk} samples (80 ms at 16 kHz), got {pcm.shape[0]}")
+                res = self.sched.push(st, pcm)
+                if isinstance(res, Exception):
+                    raise res
+                if res is None:
+                    continue                                               # no model call for this chunk
+                steps += 1
+                y = y + res
+                y_one = self.lang.denumericalize(res)
+                if y_one != "":
+                    now = self.lang.denumericalize(y)
+                    diff = "".join(b for a, b in it.zip_longest(last, now) if a != b)
+                    last = now
+                    if diff == last_diff:
+                        continue
+                    last_diff = diff
+                    yield ap.Transcript(data=diff)
+                elif should_reset(steps, self.downsample, self.n_buffer):
+                    self.sched.reset(st)
+                    steps = 0
+        finally:
+            self.sched.close(st)
+
+
+def serve(lang="en", port=None, block=True, **load_kw):
+    """Start the gRPC server (api-server.py:138-145).  Returns (server, scheduler, port)."""
+    from .lib.inference import load_stuff
+    conf, language, model, _, _ = load_stuff(lang, **load_kw)
+    sched = Scheduler(model.engine)
+    sched.start()
+    server = grpc.server(futures.ThreadPoolExecutor(max_workers=WORKERS))
+    apg.add_ASRServicer_to_server(ASRServicer(lang, sched, language, conf), server)
+    bound = server.add_insecure_port(port or PORTS[lang])
+    server.start()
+    print("[api-server] gRPC server running on", port or PORTS[lang], "language", lang)
+    if block:
+        server.wait_for_termination()
+    return server, sched, bound
+
+
+if __name__ == "__main__":
+    import argparse
+    p = argparse.ArgumentParser()
+    p.add_argument("lang", help="language to serve")
+    p.add_argument("--synthetic", default=None, help="seeded synthetic weights of this shape (libreasr_amd.synth.CONFIGS)")
+    a = p.parse_args()
+    serve(a.lang, synthetic=a.synthetic, max_streams=64)
