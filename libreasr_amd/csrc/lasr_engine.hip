@@ -85,6 +85,9 @@ struct lasr_ctx {
     static constexpr int TOKRING = 256, ENDSLOTS = 16;
     hipEvent_t ev_enc[NFLY] = {};
     hipEvent_t ev_misc = nullptr;
+    hipStream_t stream_enc2 = nullptr;   // second encoder stream (layer-diagonal wavefront, T = 2)
+    hipEvent_t ev_wave[17] = {};
+    bool enc_wavefront = false;
     int* T_row_ring[NFLY] = {};
     float* pe_ring = nullptr;
     int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
@@ -488,6 +491,25 @@ void run_encoder(lasr_ctx* c, int T_max) {
     const int L = c->d.enc_layers;
     const int mt_total = c->Tcap * c->MT;
     const int par0 = c->enc_par;
+    if (T_max == 2 && c->enc_wavefront && c->stream_enc2) {
+        // layer-diagonal wavefront on two HIP streams: cell (l, 1) depends on (l, 0) and (l-1, 1),
+        // cell (l+1, 0) only on (l, 0): the t = 1 chain runs one layer behind the t = 0 chain, so the
+        // prologue / LDS reduction / epilogue of one cell overlaps the K loop of an independent one
+        hipStream_t A = c->stream, B = c->stream_enc2;
+        for (int l = 0; l < L; ++l) {
+            const float* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
+            float* ydst = c->ybuf[l & 1];
+            c->stream = A; c->enc_par = par0;
+            launch_enc_cell(c, l, 0, xsrc, mt_total, ydst, mt_total);
+            (void)hipEventRecord(c->ev_wave[l], A);
+            (void)hipStreamWaitEvent(B, c->ev_wave[l], 0);
+            c->stream = B; c->enc_par = par0 ^ 1;
+            launch_enc_cell(c, l, 1, xsrc, mt_total, ydst, mt_total);
+        }
+        (void)hipEventRecord(c->ev_wave[L], B);
+        (void)hipStreamWaitEvent(A, c->ev_wave[L], 0);
+        c->stream = A; c->enc_par = par0;
+    } else
     for (int l = 0; l < L; ++l) {
         c->enc_par = par0;
         const float* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
@@ -792,6 +814,9 @@ void lasr_destroy(lasr_ctx* c) {
     for (auto& e : c->ev_enc)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_misc) (void)hipEventDestroy(c->ev_misc);
+    for (auto& e : c->ev_wave)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream_enc2) { (void)hipStreamSynchronize(c->stream_enc2); (void)hipStreamDestroy(c->stream_enc2); }
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
     delete c;
@@ -941,6 +966,9 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     }
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_misc, hipEventDisableTiming));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_enc2, hipStreamNonBlocking));
+    for (auto& e : c->ev_wave) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->enc_wavefront = getenv("LASR_ENC_WAVEFRONT") ? atoi(getenv("LASR_ENC_WAVEFRONT")) != 0 : false;
     RC(dalloc(c, &c->pe_ring, (size_t)lasr_ctx::RING * M * J));
     HIPCHK(c, hipMemset(c->pe_ring, 0, sizeof(float) * (size_t)lasr_ctx::RING * M * J));
     RC(dalloc(c, &c->c_cur, M)); RC(dalloc(c, &c->c_avail, M)); RC(dalloc(c, &c->c_iters, M)); RC(dalloc(c, &c->c_target, M));
@@ -1099,11 +1127,19 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
         HIPCHK(c, hipMemcpyAsync(c->stage_pcm, pcm, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream));
         src = c->stage_pcm;
     }
-    RC(cmd_begin(c));
-    for (int r = 0; r < c->M; ++r) c->hc.src_idx[r] = -1;
-    for (int i = 0; i < n; ++i) c->hc.src_idx[slots[i]] = i;
-    RC(cmd_commit(c));
-    hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, c->dc.src_idx, c->win, c->ring_pos, CH, c->d.n_window);
+    if (c->M <= 512) {      // slot -> staging-row map by value: no command-block copy for a push
+        PushIdx pi;
+        for (int r = 0; r < 512; ++r) pi.idx[r] = -1;
+        for (int i = 0; i < n; ++i) pi.idx[slots[i]] = (short)i;
+        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, (const int*)nullptr, pi, c->win, c->ring_pos, CH, c->d.n_window);
+    } else {
+        RC(cmd_begin(c));
+        for (int r = 0; r < c->M; ++r) c->hc.src_idx[r] = -1;
+        for (int i = 0; i < n; ++i) c->hc.src_idx[slots[i]] = i;
+        RC(cmd_commit(c));
+        PushIdx pi;
+        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, (const int*)c->dc.src_idx, pi, c->win, c->ring_pos, CH, c->d.n_window);
+    }
     for (int i = 0; i < n; ++i) c->n_chunks[slots[i]]++;
     if (!is_device_ptr(pcm)) {
         // the staging buffer is reused by the next push: keep ordering simple

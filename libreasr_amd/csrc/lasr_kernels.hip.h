@@ -340,8 +340,12 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     __shared__ float sp[4][520];
     __shared__ float s_fbw[1536];
     __shared__ int s_fbs[128], s_fbo[129];
+    __shared__ float2 s_tw512[512], s_tw1024[513];
     const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
-    // filterbank -> LDS once per workgroup (coalesced); the mel loop then has no global loads
+    // twiddles + filterbank -> LDS once per workgroup (coalesced, all in flight together): the FFT
+    // passes and the mel loop then have no global loads (each was a dependent ~1 us L2 round trip)
+    for (int q = threadIdx.x; q < 512; q += 256) s_tw512[q] = a.tw512[q];
+    for (int q = threadIdx.x; q <= 512; q += 256) s_tw1024[q] = a.tw1024[q];
     for (int q = threadIdx.x; q < a.fb_nnz; q += 256) s_fbw[q] = a.fb_w[q];
     for (int q = threadIdx.x; q < a.n_mels; q += 256) s_fbs[q] = a.fb_start[q];
     for (int q = threadIdx.x; q <= a.n_mels; q += 256) s_fbo[q] = a.fb_off[q];
@@ -403,10 +407,11 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
         v[m] = cf{sample(2 * n), sample(2 * n + 1)};
     }
     dft8(v);
+    __syncthreads();                                     // staged twiddles / filterbank visible
     float2* z = sz[w];
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
-        const float2 tw = a.tw512[j * k0];
+        const float2 tw = s_tw512[j * k0];
         const cf u = cmul(v[k0], cf{tw.x, tw.y});
         z[k0 * 64 + j] = float2{u.x, u.y};
     }
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
         __syncthreads();
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1) {
-            const float2 tw = a.tw512[8 * b * k1];
+            const float2 tw = s_tw512[8 * b * k1];
             const cf u = cmul(v[k1], cf{tw.x, tw.y});
             z[k0 * 64 + k1 * 8 + b] = float2{u.x, u.y};
         }
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
         const float2 zn = z[(512 - k) & 511];
         const cf e = cf{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
         const cf d = cf{0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y)};   // (Z[k] - conj Zn)/2
-        const float2 tw = a.tw1024[k];
+        const float2 tw = s_tw1024[k];
         const cf o = cmul(cf{tw.x, tw.y}, mul_mi(d));                  // W^k * d / i
         const cf X = cadd(e, o);
         P[k] = X.x * X.x + X.y * X.y;
@@ -546,10 +551,11 @@ __global__ __launch_bounds__(256) void k_stack_ln(const StackLnArgs a) {
 }
 
 // streaming: append one client chunk per flagged row to its ring window
-__global__ void k_push_pcm(const float* __restrict__ src, const int* __restrict__ src_idx, float* __restrict__ win,
-                           int* __restrict__ ring_pos, int chunk, int n_window) {
+struct PushIdx { short idx[512]; };   // staging row of slot r (-1: slot not pushed), passed by value
+__global__ void k_push_pcm(const float* __restrict__ src, const int* __restrict__ src_idx, const PushIdx pidx,
+                           float* __restrict__ win, int* __restrict__ ring_pos, int chunk, int n_window) {
     const int row = blockIdx.x;
-    const int si = src_idx[row];
+    const int si = src_idx ? src_idx[row] : (int)pidx.idx[row];
     if (si < 0) return;
     const int pos = ring_pos[row];
     float* d = win + ((size_t)row * n_window + pos) * chunk;
