@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 STREAMS_PER_GPU = 64
 CHUNK = 1280                 # 80 ms at 16 kHz
 SR = 16000
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
@@ -110,6 +111,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="cfg2")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (the headline metric); bf16 = configs[2] arithmetic "
+                         "(bf16 MFMA operands, f32 accumulate/state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=8)
     ap.add_argument("--cpu-chunks", type=int, default=100)
@@ -147,7 +151,7 @@ def main():
     cfg = synth.model_cfg(args.model)
     sd = synth.synth_state_dict(cfg, seed=0)
     B = args.streams
-    eng = Engine(sd, cfg, max_streams=B, device=local)
+    eng = Engine(sd, cfg, max_streams=B, device=local, dtype=args.dtype)
     my_streams = shard_streams(B * world, world, rank)
     K, W = args.steps, args.warmup
     n_chunks = K + W + 4
@@ -233,10 +237,11 @@ def main():
         flops = cell_flops(cfg, 1, B)
         achieved = flops / (cell_us * 1e-6) / 1e12
         n_cells = cfg["enc_layers"] * 2
+        wbytes = (4.0 if args.dtype == "f32" else 2.0) * 4 * cfg["hidden"] * 2 * cfg["hidden"]
         traffic = None                      # HBM bytes per launch from the committed PMC passes (profiles/)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_cell_pmc.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"] if args.model == "cfg2" and B == 64 else None
+                traffic = json.load(f)["hbm_bytes_per_launch"] if args.model == "cfg2" and B == 64 and args.dtype == "f32" else None
         except Exception:
             traffic = None
         out = {
@@ -250,10 +255,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: {B} concurrent 16 kHz streams/GPU, 4x1024 uni-LSTM encoder, "
-                                   "2xNBRC predictor, J=1024, V=2048, greedy, fp32, 80 ms chunks, "
+            "config": {"workload": f"configs[{1 if args.dtype == 'f32' else 2}]: {B} concurrent 16 kHz streams/GPU, 4x1024 uni-LSTM encoder, "
+                                   f"2xNBRC predictor, J=1024, V=2048, greedy, {'fp32' if args.dtype == 'f32' else 'bf16 operands / f32 accumulate'}, 80 ms chunks, "
                                    "3-chunk window, 2-frame buffer (model every 160 ms)",
                        "streams_per_gpu": B, "chunk_ms": 80, "parallelism": f"dp{world} (independent streams, no collective)",
                        "pipeline": (f"submit/wait, {args.depth} model steps in flight: encoder of later chunks on the main stream, "
@@ -273,7 +278,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(cell_us, 3), "flops_per_launch": flops,
-                         "weight_bytes_per_launch": 4.0 * 4 * cfg["hidden"] * 2 * cfg["hidden"],
+                         "weight_bytes_per_launch": wbytes,
                          "in_situ_encoder_us_per_cell": round(1e3 * float(np.mean(enc_ms)) / n_cells, 3) if enc_ms else None},
         }
         # secondary figure: the offline path (Transcribe RPC) on whole 20.65 s utterances (the demo's length)
@@ -291,6 +296,13 @@ def main():
                               "note": "lasr_transcribe_pcm: fresh state, max_iters 3, synchronous decode loop"}
         except Exception as e:                                            # never let the extra figure break the contract line
             out["offline"] = {"error": str(e)[:200]}
+        if args.dtype == "bf16":
+            # 64 rows x 2 flop / 2 B = 64 flop/B is far below the bf16 ridge (2500 TFLOP/s / 8 TB/s = 312):
+            # the bf16 cell is bound by streaming its weights, so it is priced against HBM bandwidth
+            gbs = wbytes / (cell_us * 1e-6) / 1e9
+            out["roofline"].update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                    "note": "algorithmic bytes = packed bf16 weights of one cell (W_ih + W_hh)"})
         if not args.no_cpu_baseline:
             rows = [pcm_host[i] for i in range(min(args.cpu_streams, B))]
             out["cpu_baseline"] = cpu_baseline(cfg, sd, rows, args.cpu_chunks)

@@ -58,7 +58,9 @@ typedef struct {
     int32_t n_window;    /* 3  (BUFFER_N_FRAMES, api-server.py:26)                       */
     int32_t chunk;       /* client chunk length in samples (1280 = 80 ms)                */
     int32_t sample_rate; /* 16000 */
-    int32_t dtype;       /* 0 = f32 (bf16 reserved)                                      */
+    int32_t dtype;       /* 0 = f32; 1 = bf16 MFMA operands (weights + GEMM-input        */
+                         /* activations), f32 accumulate / cell state / logits; needs    */
+                         /* feat, hidden, joint % 32 == 0                                */
     int32_t max_streams; /* number of stream slots (= batch rows)                        */
     int32_t max_iters_offline; /* 3  (decode_greedy default, models.py:369)             */
     int32_t max_iters_stream;  /* 10 (transcribe_stream default, models.py:458)         */
@@ -179,7 +181,7 @@ int lasr_sync(lasr_ctx* c);
 
 /* Debug (LASR_DBG_TIMING=1 at create): per-workgroup phase timestamps (s_memtime at entry / setup /
  * K-loop end / reduce / exit, wall clock at entry / exit) of the last launch of each GEMM kind
- * (0 encoder cell, 1-2 predictor layers, 3 PPJ, 4 logits): out[5][4096][8]. */
+ * (0 encoder cell, 1-2 predictor layers, 3 PPJ, 4 logits): out[5][4096][16] (slots 8..15: per-wave end of the K loop). */
 int lasr_debug_timing(lasr_ctx* c, unsigned long long* out);
 
 /* Roofline micro-benchmark of the dominant kernel (one encoder LSTM-cell launch: all rows active,

@@ -26,9 +26,8 @@ constexpr int MTA = 4;         // m-tiles per workgroup in the "A" tiling (64 ro
 
 struct Cell {                  // one recurrent layer (+ its BatchNorm fold and learned initial state)
     int I = 0;                 // input width
-    float *Wx = nullptr, *Wh = nullptr;   // packed, tiling "B" (16 units x gates per tile group)
-    float *WxA = nullptr, *WhA = nullptr; // packed, tiling "A" (4 units x gates per tile)
-    float *WxC = nullptr, *WhC = nullptr; // packed, tiling "C" (8 units x 2 gates per tile, 2 tiles per group)
+    void *WxA = nullptr, *WhA = nullptr;  // packed (element-typed), tiling "A" (4 units x gates per tile): predictor
+    void *WxC = nullptr, *WhC = nullptr;  // packed, tiling "C" (8 units x 2 gates per tile, 2 tiles per group): encoder
     float *bias = nullptr, *rbias = nullptr;
     float *bn_s = nullptr, *bn_t = nullptr;
     float *h0 = nullptr, *c0 = nullptr;
@@ -46,6 +45,9 @@ struct lasr_ctx {
     std::vector<void*> host_allocs;
 
     int M = 0, MT = 0;         // padded rows, m-tiles
+    int bf = 0;                // 1: bf16 operands (weights + GEMM-input activations), f32 accumulate / state / logits
+    int kch = 16;              // k per MFMA chunk (16 f32, 32 bf16)
+    size_t esz = 4;            // bytes per operand element
     int G_pred = 0;            // gates of the predictor cell (3 NBRC / 4 LSTM)
 
     // front-end constants
@@ -54,21 +56,20 @@ struct lasr_ctx {
     float *ln_w = nullptr, *ln_b = nullptr;
 
     std::vector<Cell> enc, pred;
-    float *W1p = nullptr, *W1e = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
+    void *W1p = nullptr, *W1e = nullptr, *W2 = nullptr;   // packed, element-typed
+    float *b1 = nullptr, *b2 = nullptr;
 
     // recurrent state (row == slot)
-    std::vector<float*> enc_h[2], enc_c, pred_h[2], pred_c, pred_y;
+    std::vector<void*> enc_h[2], pred_h[2], pred_y;      // element-typed (A operands)
+    std::vector<float*> enc_c, pred_c;
     int enc_par = 0;
     int pred_par = 0;               // predictor h ping-pong parity (row-major [M][H] buffers)
-    bool enc_tiling_a = false;      // encoder cell tiling ("A": 4 units x 64 rows per workgroup)
-    bool enc_tiling_c = false;      // encoder cell tiling ("C": 8 units x 32 rows per workgroup)
-    int nt_w = 0;                   // experiment knob LASR_NT_W: non-temporal weight loads in the encoder cell
-    int rot_mul = 0;                // K-walk rotation multiplier of the encoder cell (GemmArgs::rot_mul)
-    int cell_variant = 0;           // encoder cell (waves, prefetch depth) variant
+    void *cvt_a = nullptr, *cvt_b = nullptr;   // [M][H] element-typed staging of f32 op-level inputs
     bool dbg_gate = true;           // decode kernels record timestamps only in the first iteration of a step
-    unsigned long long* dbg = nullptr;   // LASR_DBG_TIMING: [5 kinds][4096 blocks][8] phase timestamps
+    unsigned long long* dbg = nullptr;   // LASR_DBG_TIMING: [5 kinds][4096 blocks][16] phase timestamps
     std::vector<unsigned long long> tile_masks;   // per step t: m-tiles with an active row (from the host's T_row)
-    float *pp = nullptr, *ja = nullptr, *logits = nullptr;
+    float *pp = nullptr, *logits = nullptr;
+    void* ja = nullptr;             // joint activation, fragment-major, element-typed
     DecState ds{};
     int n_iter_slots = 0;
     int* T_row_dev = nullptr;       // [M] current step's frames per row: points INTO the step's device command block
@@ -85,9 +86,6 @@ struct lasr_ctx {
     static constexpr int TOKRING = 256, ENDSLOTS = 16;
     hipEvent_t ev_enc[NFLY] = {};
     hipEvent_t ev_misc = nullptr;
-    hipStream_t stream_enc2 = nullptr;   // second encoder stream (layer-diagonal wavefront, T = 2)
-    hipEvent_t ev_wave[17] = {};
-    bool enc_wavefront = false;
     int* T_row_ring[NFLY] = {};
     float* pe_ring = nullptr;
     int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
@@ -108,7 +106,8 @@ struct lasr_ctx {
 
     // time-series buffers (capacity Tcap frames)
     int Tcap = 0;
-    float *x0 = nullptr, *ybuf[2] = {nullptr, nullptr}, *pe = nullptr, *pe_sync = nullptr;
+    void *x0 = nullptr, *ybuf[2] = {nullptr, nullptr};   // element-typed, fragment-major
+    float *pe = nullptr, *pe_sync = nullptr;
     int tok_cap_alloc = 0;
 
     // front-end buffers
@@ -191,30 +190,55 @@ int upload(lasr_ctx* c, T** p, const T* src, size_t n) {
         if (rc_) return rc_; \
     } while (0)
 
-// dst[(tile*KC + c)*256 + lane*4 + e] = get(tile, ui, k) with ui = lane&15, k = 16c + 4(lane>>4) + e
-template <class F>
-void pack_tiles(std::vector<float>& dst, int n_tiles, int KC, F get) {
-    dst.assign((size_t)n_tiles * KC * 256, 0.f);
-    for (int t = 0; t < n_tiles; ++t)
-        for (int c = 0; c < KC; ++c) {
-            float* o = dst.data() + ((size_t)t * KC + c) * 256;
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 4; ++e) o[lane * 4 + e] = get(t, lane & 15, 16 * c + 4 * (lane >> 4) + e);
-        }
+unsigned short host_bf16(float x) {            // round to nearest even (same as the device f32_to_bf16)
+    unsigned u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
 }
-
-// "A" tiling of a pseudo-gated (NBRC) phase: tile = 4 units x {3 live gates}; fragment = [g][12 live cols][e]
-// dst[((tile*KC + c)*4 + g)*48 + a*4 + e] = get(tile, a, k), a = live column (gate = a/4, unit = a%4)
+struct Packed {                                // host image of a packed operand
+    std::vector<char> bytes;
+    int bf = 0;
+    void resize(size_t n_elems, int bf_) { bf = bf_; bytes.assign(n_elems * (bf_ ? 2 : 4), 0); }
+    void set(size_t i, float v) {
+        if (bf) ((unsigned short*)bytes.data())[i] = host_bf16(v);
+        else ((float*)bytes.data())[i] = v;
+    }
+};
+// Weight tile [16 columns][K] -> fragments: elem((tile*KC + c)*64 + lane, e) = get(tile, col = lane&15, k),
+// k = KCH*c + EPL*(lane>>4) + e   (KCH = 16, EPL = 4 for f32;  32, 8 for bf16)
 template <class F>
-void pack_tiles12(std::vector<float>& dst, int n_tiles, int KC, F get) {
-    dst.assign((size_t)n_tiles * KC * 192, 0.f);
+void pack_tiles(Packed& dst, int bf, int n_tiles, int K, F get) {
+    const int KCH = bf ? 32 : 16, EPL = bf ? 8 : 4, KC = K / KCH;
+    dst.resize((size_t)n_tiles * KC * 64 * EPL, bf);
     for (int t = 0; t < n_tiles; ++t)
-        for (int c = 0; c < KC; ++c) {
-            float* o = dst.data() + ((size_t)t * KC + c) * 192;
+        for (int c = 0; c < KC; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < EPL; ++e)
+                    dst.set((((size_t)t * KC + c) * 64 + lane) * EPL + e, get(t, lane & 15, KCH * c + EPL * (lane >> 4) + e));
+}
+// "A" tiling of a pseudo-gated (NBRC) phase: tile = 4 units x {3 live gates}; fragment = [g][12 live cols][EPL]
+// a = live column (gate = a/4, unit = a%4)
+template <class F>
+void pack_tiles12(Packed& dst, int bf, int n_tiles, int K, F get) {
+    const int KCH = bf ? 32 : 16, EPL = bf ? 8 : 4, KC = K / KCH;
+    dst.resize((size_t)n_tiles * KC * 48 * EPL, bf);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int c = 0; c < KC; ++c)
             for (int g = 0; g < 4; ++g)
                 for (int a = 0; a < 12; ++a)
-                    for (int e = 0; e < 4; ++e) o[(g * 12 + a) * 4 + e] = get(t, a, 16 * c + 4 * g + e);
-        }
+                    for (int e = 0; e < EPL; ++e)
+                        dst.set((((size_t)t * KC + c) * 48 + g * 12 + a) * EPL + e, get(t, a, KCH * c + EPL * g + e));
+}
+int upload_packed(lasr_ctx* c, void** p, const Packed& pk) {
+    char* q = nullptr;
+    int rc = dalloc(c, &q, pk.bytes.size());
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(q, pk.bytes.data(), pk.bytes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(c, LASR_EHIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+    *p = q;
+    return LASR_OK;
 }
 
 bool valid_desc(const lasr_model_desc* d) {
@@ -230,7 +254,11 @@ bool valid_desc(const lasr_model_desc* d) {
     if (d->max_streams < 1 || d->max_streams > 1024) return false;
     if (d->max_iters_offline < 1 || d->max_iters_stream < 1) return false;
     if (d->blank < 0 || d->blank >= d->vocab || d->bos < 0 || d->bos >= d->vocab) return false;
-    if (d->dtype != 0 || d->beam != 1) return false;
+    if ((d->dtype != 0 && d->dtype != 1) || d->beam != 1) return false;
+    if (d->dtype == 1) {   // bf16 operands: 32-wide K chunks
+        auto m32 = [](int v) { return v % 32 == 0; };
+        if (!m32(d->feat) || !m32(d->hidden) || !m32(d->joint)) return false;
+    }
     return true;
 }
 
@@ -244,59 +272,39 @@ bool valid_desc(const lasr_model_desc* d) {
     } while (0)
 
 // ---------------------------------------------------------------------------- launch helpers
-struct Ctx2 {};  // (placeholder to keep helper signatures short)
-
-template <class Epi, int MT, bool AROW, int NWV = NW, int D = 3, int ABL = 0>
+template <class Ops, class Epi, int MT, bool AROW, int D = 3>
 void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g, const typename Epi::Args& ea) {
-    hipLaunchKernelGGL((k_gemm<Epi, MT, NWV, AROW, D, ABL>), dim3(n_groups, m_groups), dim3(NWV * 64), 0, c->stream, g, ea);
+    hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NW, AROW, D>), dim3(n_groups, m_groups), dim3(NW * 64), 0, c->stream, g, ea);
 }
 
 int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
 
-// encoder LSTM cell (layer l, step t): x from `xsrc` (fragment-major, K = I)
-void launch_enc_cell(lasr_ctx* c, int l, int t, const float* xsrc, int x_mt_total, float* ydst, int y_mt_total) {
+// encoder LSTM cell (layer l, step t): x from `xsrc` (fragment-major, K = I); tiling "C"
+template <class Ops>
+void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
     const Cell& L = c->enc[l];
     const int H = c->d.hidden;
     GemmArgs g{};
-    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / 16;
-    g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / 16;
-    g.M = c->M; g.rot_mul = c->rot_mul; g.dbg = c->dbg; g.nt_w = c->nt_w;
-    EpiLSTM<false, false, 16>::Args ea{};
+    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / Ops::KCH; g.W[0] = L.WxC;
+    g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhC;
+    g.M = c->M; g.dbg = c->dbg;
+    using E = EpiLSTM<Ops, false, false, 8>;
+    typename E::Args ea{};
     ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t; ea.tile_mask = c->tile_masks.empty() ? ~0ull : c->tile_masks[t];
     ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
     ea.y = ydst; ea.y_mt_total = y_mt_total; ea.y_mt_off = t * c->MT;
     ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
-    if (c->enc_tiling_c) {
-        g.W[0] = L.WxC; g.W[1] = L.WhC;
-        EpiLSTM<false, false, 8>::Args eb{};
-        memcpy(&eb, &ea, sizeof(eb));
-        launch_gemm<EpiLSTM<false, false, 8>, 2, false>(c, H / 8, c->M / 32, g, eb);
-    } else if (c->enc_tiling_a) {
-        g.W[0] = L.WxA; g.W[1] = L.WhA;
-        EpiLSTM<false, false, 4>::Args eb{};
-        memcpy(&eb, &ea, sizeof(eb));
-        launch_gemm<EpiLSTM<false, false, 4>, MTA, false>(c, H / 4, c->M / (16 * MTA), g, eb);
-    } else {
-        g.W[0] = L.Wx; g.W[1] = L.Wh;
-        using E = EpiLSTM<false, false, 16>;
-        switch (c->cell_variant) {      // (waves, ring depth) experiment knob LASR_CELL_VARIANT
-            case 1: launch_gemm<E, 1, false, 8, 5>(c, H / 16, c->MT, g, ea); break;
-            case 2: launch_gemm<E, 1, false, 8, 7>(c, H / 16, c->MT, g, ea); break;
-            case 3: launch_gemm<E, 1, false, 4, 5>(c, H / 16, c->MT, g, ea); break;
-            case 4: launch_gemm<E, 1, false, 4, 8>(c, H / 16, c->MT, g, ea); break;
-            case 5: launch_gemm<E, 1, false, 16, 3>(c, H / 16, c->MT, g, ea); break;
-            case 6: launch_gemm<E, 1, false, 4, 12>(c, H / 16, c->MT, g, ea); break;
-            case 7: launch_gemm<E, 1, false, 8, 3, 1>(c, H / 16, c->MT, g, ea); break;   // ablation: loads only
-            case 8: launch_gemm<E, 1, false, 8, 3, 2>(c, H / 16, c->MT, g, ea); break;   // ablation: MFMA only
-            case 9: launch_gemm<E, 1, false, 8, 2>(c, H / 16, c->MT, g, ea); break;
-            default: launch_gemm<E, 1, false, 8, 3>(c, H / 16, c->MT, g, ea); break;
-        }
-    }
+    launch_gemm<Ops, E, 2, false>(c, H / 8, c->M / 32, g, ea);
+}
+void launch_enc_cell(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
+    if (c->bf) launch_enc_cell_t<OpsBF16>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
+    else launch_enc_cell_t<OpsF32>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
 }
 
 // one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels); predictor
 // state is row-major [M][H]; toggles pred_par
-void launch_predictor(lasr_ctx* c) {
+template <class Ops>
+void launch_predictor_t(lasr_ctx* c) {
     const int H = c->d.hidden;
     const int mgroups = c->M / (16 * MTA);
     const int p = c->pred_par;
@@ -304,61 +312,80 @@ void launch_predictor(lasr_ctx* c) {
         const Cell& L = c->pred[l];
         GemmArgs g{};
         if (l > 0) {
-            g.A[0] = c->pred_y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = L.WxA;
+            g.A[0] = c->pred_y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA;
         }
-        g.A[1] = c->pred_h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / 16; g.W[1] = L.WhA;
-        g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)(1 + std::min(l, 1)) * 4096 * 8 : nullptr;
+        g.A[1] = c->pred_h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhA;
+        g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)(1 + std::min(l, 1)) * 4096 * 16 : nullptr;
         if (c->d.pred_cell == 1) {
-            EpiLSTM<true, true, 4>::Args ea{};
+            typename EpiLSTM<Ops, true, true, 4>::Args ea{};
             ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
             ea.c = c->pred_c[l]; ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l];
             ea.y = c->pred_y[l]; ea.y_mt_total = 0; ea.y_mt_off = 0;
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
             if (l == 0) {
-                launch_gemm<EpiLSTM<true, true, 4>, MTA, true, NW, -1>(c, H / 4, mgroups, g, ea);
+                launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
-                EpiLSTM<true, false, 4>::Args eb{};
+                typename EpiLSTM<Ops, true, false, 4>::Args eb{};
+                static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<EpiLSTM<true, false, 4>, MTA, true, NW, -1>(c, H / 4, mgroups, g, eb);
+                launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         } else {
-            EpiNBRC<true, 4>::Args ea{};
+            typename EpiNBRC<Ops, true>::Args ea{};
             ea.bias = L.bias; ea.rbias = L.rbias; ea.tab = L.tab; ea.token = c->ds.token; ea.emit = c->ds.emit;
             ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = c->pred_y[l];
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M;
             if (l == 0) {
-                launch_gemm<EpiNBRC<true, 4>, MTA, true, NW, -1>(c, H / 4, mgroups, g, ea);
+                launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
-                EpiNBRC<false, 4>::Args eb{};
+                typename EpiNBRC<Ops, false>::Args eb{};
+                static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<EpiNBRC<false, 4>, MTA, true, NW, -1>(c, H / 4, mgroups, g, eb);
+                launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         }
     }
     c->pred_par ^= 1;
 }
+void launch_predictor(lasr_ctx* c) {
+    if (c->bf) launch_predictor_t<OpsBF16>(c);
+    else launch_predictor_t<OpsF32>(c);
+}
 
 // pp (for emitting rows) and the joint activation ja = tanh(pe[t_idx] + pp) for all rows still decoding
-void launch_ppj(lasr_ctx* c) {
+template <class Ops>
+void launch_ppj_t(lasr_ctx* c) {
     const int H = c->d.hidden, J = c->d.joint;
     GemmArgs g{};
-    g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p;
-    g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 8 : nullptr;
-    EpiPPJ::Args ea{};
+    g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = c->W1p;
+    g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 16 : nullptr;
+    typename EpiPPJ<Ops>::Args ea{};
     ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
     ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT; ea.ring = c->pe_ring_R;
-    launch_gemm<EpiPPJ, 1, true, NW, -1>(c, J / 16, c->MT, g, ea);
+    launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MT, g, ea);
+}
+void launch_ppj(lasr_ctx* c) {
+    if (c->bf) launch_ppj_t<OpsBF16>(c);
+    else launch_ppj_t<OpsF32>(c);
+}
+
+// plain linear over element-typed A (fragment-major, or row-major when AROW); f32 row-major output
+template <bool AROW, int D = 3>
+void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea) {
+    g.KC[0] = K / c->kch;
+    if (c->bf) launch_gemm<OpsBF16, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
+    else launch_gemm<OpsF32, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
 }
 
 void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     const int J = c->d.joint, V = c->d.vocab;
     GemmArgs g{};
-    g.A[0] = c->ja; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.KC[0] = J / 16; g.W[0] = c->W2; g.M = c->M;
-    g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)4 * 4096 * 8 : nullptr;
+    g.A[0] = c->ja; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.W[0] = c->W2; g.M = c->M;
+    g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)4 * 4096 * 16 : nullptr;
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
     ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M;
-    launch_gemm<EpiLinear, 1, false, NW, -1>(c, V / 16, (n_rows + 15) / 16, g, ea);
+    launch_linear<false, -1>(c, V / 16, (n_rows + 15) / 16, g, J, ea);
 }
 
 // ---------------------------------------------------------------------------- command blocks
@@ -420,9 +447,9 @@ int ensure_T(lasr_ctx* c, int T) {
     c->pe_sync = nullptr;
     dfree(c, c->ds.step_ntok); dfree(c, c->ds.unfinished);
     c->x0 = c->ybuf[0] = c->ybuf[1] = c->pe = nullptr; c->ds.step_ntok = nullptr; c->ds.step_tok = nullptr; c->ds.unfinished = nullptr;
-    RC(dalloc(c, &c->x0, (size_t)cap * M * F));
-    RC(dalloc(c, &c->ybuf[0], (size_t)cap * M * H));
-    RC(dalloc(c, &c->ybuf[1], (size_t)cap * M * H));
+    RC(dalloc(c, (char**)&c->x0, (size_t)cap * M * F * c->esz));
+    RC(dalloc(c, (char**)&c->ybuf[0], (size_t)cap * M * H * c->esz));
+    RC(dalloc(c, (char**)&c->ybuf[1], (size_t)cap * M * H * c->esz));
     RC(dalloc(c, &c->pe_sync, (size_t)cap * M * J));
     c->pe = c->pe_sync;
     const int mi = std::max(c->d.max_iters_offline, c->d.max_iters_stream);
@@ -433,9 +460,9 @@ int ensure_T(lasr_ctx* c, int T) {
     c->ds.step_tok = c->ds.step_ntok + M;
     c->n_iter_slots = cap * mi + 8;
     RC(dalloc(c, &c->ds.unfinished, (size_t)c->n_iter_slots));
-    HIPCHK(c, hipMemset(c->ybuf[0], 0, (size_t)cap * M * H * 4));
-    HIPCHK(c, hipMemset(c->ybuf[1], 0, (size_t)cap * M * H * 4));
-    HIPCHK(c, hipMemset(c->x0, 0, (size_t)cap * M * F * 4));
+    HIPCHK(c, hipMemset(c->ybuf[0], 0, (size_t)cap * M * H * c->esz));
+    HIPCHK(c, hipMemset(c->ybuf[1], 0, (size_t)cap * M * H * c->esz));
+    HIPCHK(c, hipMemset(c->x0, 0, (size_t)cap * M * F * c->esz));
     // pinned result block: [0] unfinished, then ntok[M], sum_iters[M], n_ones[M], logp[M] (double), tokens
     if (c->res_host) (void)hipHostFree(c->res_host);
     c->res_bytes = sizeof(int) * (8 + 3 * (size_t)M) + sizeof(double) * M + sizeof(int) * (size_t)M * c->tok_cap_alloc + 64;
@@ -461,7 +488,7 @@ int ensure_buf(lasr_ctx* c, T** p, size_t* have, size_t need) {
 int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3) {
     ResetArgs a{};
     a.what = c->dc.what; a.mask = mask; a.M = c->M; a.MT = c->MT; a.H = c->d.hidden; a.Le = c->d.enc_layers; a.Lp = c->d.pred_layers;
-    a.pred_lstm = c->d.pred_cell; a.bos = c->d.bos;
+    a.pred_lstm = c->d.pred_cell; a.bos = c->d.bos; a.bf = c->bf;
     for (int l = 0; l < a.Le; ++l) {
         a.enc_h[l] = c->enc_h[c->enc_par][l]; a.enc_c[l] = c->enc_c[l];
         a.enc_h0[l] = c->enc[l].h0; a.enc_c0[l] = c->enc[l].c0;
@@ -491,48 +518,26 @@ void run_encoder(lasr_ctx* c, int T_max) {
     const int L = c->d.enc_layers;
     const int mt_total = c->Tcap * c->MT;
     const int par0 = c->enc_par;
-    if (T_max == 2 && c->enc_wavefront && c->stream_enc2) {
-        // layer-diagonal wavefront on two HIP streams: cell (l, 1) depends on (l, 0) and (l-1, 1),
-        // cell (l+1, 0) only on (l, 0): the t = 1 chain runs one layer behind the t = 0 chain, so the
-        // prologue / LDS reduction / epilogue of one cell overlaps the K loop of an independent one
-        hipStream_t A = c->stream, B = c->stream_enc2;
-        for (int l = 0; l < L; ++l) {
-            const float* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
-            float* ydst = c->ybuf[l & 1];
-            c->stream = A; c->enc_par = par0;
-            launch_enc_cell(c, l, 0, xsrc, mt_total, ydst, mt_total);
-            (void)hipEventRecord(c->ev_wave[l], A);
-            (void)hipStreamWaitEvent(B, c->ev_wave[l], 0);
-            c->stream = B; c->enc_par = par0 ^ 1;
-            launch_enc_cell(c, l, 1, xsrc, mt_total, ydst, mt_total);
-        }
-        (void)hipEventRecord(c->ev_wave[L], B);
-        (void)hipStreamWaitEvent(A, c->ev_wave[L], 0);
-        c->stream = A; c->enc_par = par0;
-    } else
+    // layer-major order: every layer starts from parity par0 and toggles T_max times (enc_h[par][l] is
+    // indexed by the parity at launch time, so all layers end on par0 ^ (T_max & 1))
     for (int l = 0; l < L; ++l) {
         c->enc_par = par0;
-        const float* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
-        float* ydst = c->ybuf[l & 1];
+        const void* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
+        void* ydst = c->ybuf[l & 1];
         for (int t = 0; t < T_max; ++t) {
             launch_enc_cell(c, l, t, xsrc, mt_total, ydst, mt_total);
             c->enc_par ^= 1;
         }
     }
-    // every layer toggled T_max times from par0; all end at the same parity
     // encoder half of the joint for all frames: pe[t][r] = W1e * enc[t][r]
     const int H = c->d.hidden, J = c->d.joint;
     GemmArgs g{};
-    g.A[0] = c->ybuf[(L - 1) & 1]; g.a_mt_total[0] = mt_total; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1e;
+    g.A[0] = c->ybuf[(L - 1) & 1]; g.a_mt_total[0] = mt_total; g.a_mt_off[0] = 0; g.W[0] = c->W1e;
     EpiLinear::Args ea{};
     ea.bias = nullptr; ea.out = c->pe; ea.ldo = J; ea.n_rows = T_max * c->M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
     if (c->pe == c->pe_ring) { ea.ring_base = c->c_enc_frames; ea.ring = lasr_ctx::RING; }   // continuous mode: per-row frame ring
-    launch_gemm<EpiLinear, 1, false>(c, J / 16, T_max * c->MT, g, ea);
+    launch_linear<false>(c, J / 16, T_max * c->MT, g, H, ea);
 }
-
-// fix: every layer must start from the same parity and end on the same parity; with layer-major
-// order the h buffers of layer l toggle T_max times.  enc_h[par][l] is indexed by the parity at
-// launch time, so all layers share c->enc_par (restored to par0 per layer, final = par0 ^ (T_max&1)).
 
 // Greedy decode of the current step (T_row_dev, pe ready).  Blocks until done; fills host queues.
 int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows) {
@@ -562,7 +567,7 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
             hipLaunchKernelGGL(k_step_begin, dim3(grid1(std::max(M, c->n_iter_slots))), dim3(256), 0, c->stream, s, M,
                                c->n_iter_slots, offline ? 1 : 0);
             hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->dec_t_idx,
-                               c->T_row_dec, c->ja, J, M, c->MT, c->pe_ring_R);
+                               c->T_row_dec, c->ja, J, M, c->MT, c->pe_ring_R, c->bf);
         }
         for (int q = 0; q < n; ++q) {
             const int it = first + q;
@@ -731,31 +736,25 @@ int fold_bn(lasr_ctx* c, Reader& rd, int H, float** s_dev, float** t_dev) {
 }
 
 // LSTM layer in torch layout: W_ih [4H,I], W_hh [4H,H].
-//   tiling B: tile (jb, gate) = 16 units of one gate;  tiling A: tile jb = 4 units x 4 gates (col = gate*4 + unit)
-int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, bool pack_a, bool pack_b, std::vector<float>* keep_wih,
-              std::vector<float>* keep_bias, bool pack_c = false) {
+//   tiling C (encoder): tile t = (jb = t/2, nt = t%2): column col -> gate 2*nt + col/8, unit 8*jb + col%8
+//   tiling A (predictor): tile jb = 4 units x 4 gates (col = gate*4 + unit)
+int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, bool tiling_a, std::vector<float>* keep_wih,
+              std::vector<float>* keep_bias) {
     L.I = I;
     const float* wih = rd.take((size_t)4 * H * I); const float* whh = rd.take((size_t)4 * H * H);
     const float* bih = rd.take(4 * H); const float* bhh = rd.take(4 * H);
     if (!bhh) return fail(c, LASR_EINVAL, "weight blob too short (lstm)");
-    std::vector<float> pk;
-    if (pack_b) {
-        pack_tiles(pk, (H / 16) * 4, I / 16, [&](int t, int ui, int k) { return wih[((size_t)(t & 3) * H + 16 * (t >> 2) + ui) * I + k]; });
-        RC(upload(c, &L.Wx, pk.data(), pk.size()));
-        pack_tiles(pk, (H / 16) * 4, H / 16, [&](int t, int ui, int k) { return whh[((size_t)(t & 3) * H + 16 * (t >> 2) + ui) * H + k]; });
-        RC(upload(c, &L.Wh, pk.data(), pk.size()));
-    }
-    if (pack_c) {   // tile t = (jb = t/2, nt = t%2): column col -> gate 2*nt + col/8, unit 8*jb + col%8
-        pack_tiles(pk, (H / 8) * 2, I / 16, [&](int t, int col, int k) { return wih[((size_t)(2 * (t & 1) + (col >> 3)) * H + 8 * (t >> 1) + (col & 7)) * I + k]; });
-        RC(upload(c, &L.WxC, pk.data(), pk.size()));
-        pack_tiles(pk, (H / 8) * 2, H / 16, [&](int t, int col, int k) { return whh[((size_t)(2 * (t & 1) + (col >> 3)) * H + 8 * (t >> 1) + (col & 7)) * H + k]; });
-        RC(upload(c, &L.WhC, pk.data(), pk.size()));
-    }
-    if (pack_a) {
-        pack_tiles(pk, H / 4, I / 16, [&](int t, int col, int k) { return wih[((size_t)(col >> 2) * H + 4 * t + (col & 3)) * I + k]; });
-        RC(upload(c, &L.WxA, pk.data(), pk.size()));
-        pack_tiles(pk, H / 4, H / 16, [&](int t, int col, int k) { return whh[((size_t)(col >> 2) * H + 4 * t + (col & 3)) * H + k]; });
-        RC(upload(c, &L.WhA, pk.data(), pk.size()));
+    Packed pk;
+    if (!tiling_a) {
+        pack_tiles(pk, c->bf, (H / 8) * 2, I, [&](int t, int col, int k) { return wih[((size_t)(2 * (t & 1) + (col >> 3)) * H + 8 * (t >> 1) + (col & 7)) * I + k]; });
+        RC(upload_packed(c, &L.WxC, pk));
+        pack_tiles(pk, c->bf, (H / 8) * 2, H, [&](int t, int col, int k) { return whh[((size_t)(2 * (t & 1) + (col >> 3)) * H + 8 * (t >> 1) + (col & 7)) * H + k]; });
+        RC(upload_packed(c, &L.WhC, pk));
+    } else {
+        pack_tiles(pk, c->bf, H / 4, I, [&](int t, int col, int k) { return wih[((size_t)(col >> 2) * H + 4 * t + (col & 3)) * I + k]; });
+        RC(upload_packed(c, &L.WxA, pk));
+        pack_tiles(pk, c->bf, H / 4, H, [&](int t, int col, int k) { return whh[((size_t)(col >> 2) * H + 4 * t + (col & 3)) * H + k]; });
+        RC(upload_packed(c, &L.WhA, pk));
     }
     std::vector<float> bias(4 * H);
     for (int i = 0; i < 4 * H; ++i) bias[i] = bih[i] + bhh[i];
@@ -814,9 +813,6 @@ void lasr_destroy(lasr_ctx* c) {
     for (auto& e : c->ev_enc)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_misc) (void)hipEventDestroy(c->ev_misc);
-    for (auto& e : c->ev_wave)
-        if (e) (void)hipEventDestroy(e);
-    if (c->stream_enc2) { (void)hipStreamSynchronize(c->stream_enc2); (void)hipStreamDestroy(c->stream_enc2); }
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
     delete c;
@@ -831,20 +827,13 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     c->MT = c->M / 16;
     const int M = c->M;
     c->G_pred = d.pred_cell ? 4 : 3;
+    c->bf = d.dtype == 1; c->kch = c->bf ? 32 : 16; c->esz = c->bf ? 2 : 4;
     Reader rd{weights, n_weights};
     {
-        const char* e = getenv("LASR_ENC_TILING");      // A/B experiment knob; default chosen by measurement
-        c->enc_tiling_a = e ? (e[0] == 'A' || e[0] == 'a') : false;
-        c->enc_tiling_c = e ? (e[0] == 'C' || e[0] == 'c') : true;    // default "C": least L2->CU traffic (measured best)
-        const char* r = getenv("LASR_CELL_ROT");
-        c->rot_mul = r ? atoi(r) : 0;
-        if (getenv("LASR_NT_W")) c->nt_w = atoi(getenv("LASR_NT_W"));
-        const char* v = getenv("LASR_CELL_VARIANT");
-        c->cell_variant = v ? atoi(v) : 0;
         if (getenv("LASR_NO_GRAPH")) c->use_graphs = false;
         if (getenv("LASR_DBG_TIMING")) {
-            RC(dalloc(c, &c->dbg, (size_t)5 * 4096 * 8));
-            HIPCHK(c, hipMemset(c->dbg, 0, sizeof(unsigned long long) * 5 * 4096 * 8));
+            RC(dalloc(c, &c->dbg, (size_t)5 * 4096 * 16));
+            HIPCHK(c, hipMemset(c->dbg, 0, sizeof(unsigned long long) * 5 * 4096 * 16));
         }
     }
 
@@ -880,7 +869,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         if (!hs) return fail(c, LASR_EINVAL, "weight blob too short");
         RC(upload(c, &L.h0, hs, H)); RC(upload(c, &L.c0, hs + H, H));
         RC(fold_bn(c, rd, H, &L.bn_s, &L.bn_t));
-        RC(load_lstm(c, rd, L, l == 0 ? F : H, H, c->enc_tiling_a, !c->enc_tiling_a && !c->enc_tiling_c, nullptr, nullptr, c->enc_tiling_c));
+        RC(load_lstm(c, rd, L, l == 0 ? F : H, H, false, nullptr, nullptr));
     }
     // ---- predictor
     const float* embed = rd.take((size_t)V * E);
@@ -903,17 +892,17 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         if (S == 2) RC(upload(c, &L.c0, hs + H, H));
         RC(fold_bn(c, rd, H, &L.bn_s, &L.bn_t));
         if (d.pred_cell == 1) {
-            RC(load_lstm(c, rd, L, H, H, true, false, l == 0 ? &in0_w : nullptr, l == 0 ? &in0_b : nullptr));
+            RC(load_lstm(c, rd, L, H, H, true, l == 0 ? &in0_w : nullptr, l == 0 ? &in0_b : nullptr));
         } else {
             const float* kx = rd.take((size_t)H * 3 * H); const float* kh = rd.take((size_t)H * 3 * H);
             const float* b = rd.take(3 * H); const float* rb = rd.take(3 * H);
             if (!rb) return fail(c, LASR_EINVAL, "weight blob too short (nbrc)");
-            std::vector<float> pk;
+            Packed pk;
             // haste layout [K][3H], gates z,r,g; tiling A: tile = 4 units, live column a -> (gate a/4, unit a%4)
-            pack_tiles12(pk, H / 4, H / 16, [&](int t, int a, int k) { return kx[(size_t)k * 3 * H + (size_t)(a >> 2) * H + 4 * t + (a & 3)]; });
-            RC(upload(c, &L.WxA, pk.data(), pk.size()));
-            pack_tiles12(pk, H / 4, H / 16, [&](int t, int a, int k) { return kh[(size_t)k * 3 * H + (size_t)(a >> 2) * H + 4 * t + (a & 3)]; });
-            RC(upload(c, &L.WhA, pk.data(), pk.size()));
+            pack_tiles12(pk, c->bf, H / 4, H, [&](int t, int a, int k) { return kx[(size_t)k * 3 * H + (size_t)(a >> 2) * H + 4 * t + (a & 3)]; });
+            RC(upload_packed(c, &L.WxA, pk));
+            pack_tiles12(pk, c->bf, H / 4, H, [&](int t, int a, int k) { return kh[(size_t)k * 3 * H + (size_t)(a >> 2) * H + 4 * t + (a & 3)]; });
+            RC(upload_packed(c, &L.WhA, pk));
             RC(upload(c, &L.bias, b, 3 * H)); RC(upload(c, &L.rbias, rb, 3 * H));
             if (l == 0) {
                 in0_w.resize((size_t)3 * H * H);
@@ -929,13 +918,13 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         const float* w2 = rd.take((size_t)V * J); const float* b2 = rd.take(V);
         if (!b2) return fail(c, LASR_EINVAL, "weight blob too short (joint)");
         if (rd.left != 0) return fail(c, LASR_EINVAL, "weight blob has %zu extra floats", rd.left);
-        std::vector<float> pk;
-        pack_tiles(pk, J / 16, H / 16, [&](int t, int ui, int k) { return w0[(size_t)(16 * t + ui) * 2 * H + k]; });          // pred half (cat order pred, enc: models.py:136)
-        RC(upload(c, &c->W1p, pk.data(), pk.size()));
-        pack_tiles(pk, J / 16, H / 16, [&](int t, int ui, int k) { return w0[(size_t)(16 * t + ui) * 2 * H + H + k]; });
-        RC(upload(c, &c->W1e, pk.data(), pk.size()));
-        pack_tiles(pk, V / 16, J / 16, [&](int t, int ui, int k) { return w2[(size_t)(16 * t + ui) * J + k]; });
-        RC(upload(c, &c->W2, pk.data(), pk.size()));
+        Packed pk;
+        pack_tiles(pk, c->bf, J / 16, H, [&](int t, int ui, int k) { return w0[(size_t)(16 * t + ui) * 2 * H + k]; });          // pred half (cat order pred, enc: models.py:136)
+        RC(upload_packed(c, &c->W1p, pk));
+        pack_tiles(pk, c->bf, J / 16, H, [&](int t, int ui, int k) { return w0[(size_t)(16 * t + ui) * 2 * H + H + k]; });
+        RC(upload_packed(c, &c->W1e, pk));
+        pack_tiles(pk, c->bf, V / 16, J, [&](int t, int ui, int k) { return w2[(size_t)(16 * t + ui) * J + k]; });
+        RC(upload_packed(c, &c->W2, pk));
         RC(upload(c, &c->b1, b0, J)); RC(upload(c, &c->b2, b2, V));
     }
 
@@ -943,16 +932,17 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     for (int p = 0; p < 2; ++p) { c->enc_h[p].resize(d.enc_layers); c->pred_h[p].resize(d.pred_layers); }
     c->enc_c.resize(d.enc_layers); c->pred_c.assign(d.pred_layers, nullptr); c->pred_y.resize(d.pred_layers);
     for (int l = 0; l < d.enc_layers; ++l) {
-        for (int p = 0; p < 2; ++p) { RC(dalloc(c, &c->enc_h[p][l], (size_t)M * H)); HIPCHK(c, hipMemset(c->enc_h[p][l], 0, (size_t)M * H * 4)); }
+        for (int p = 0; p < 2; ++p) { RC(dalloc(c, (char**)&c->enc_h[p][l], (size_t)M * H * c->esz)); HIPCHK(c, hipMemset(c->enc_h[p][l], 0, (size_t)M * H * c->esz)); }
         RC(dalloc(c, &c->enc_c[l], (size_t)M * H)); HIPCHK(c, hipMemset(c->enc_c[l], 0, (size_t)M * H * 4));
     }
     for (int l = 0; l < d.pred_layers; ++l) {
-        for (int p = 0; p < 2; ++p) { RC(dalloc(c, &c->pred_h[p][l], (size_t)M * H)); HIPCHK(c, hipMemset(c->pred_h[p][l], 0, (size_t)M * H * 4)); }
+        for (int p = 0; p < 2; ++p) { RC(dalloc(c, (char**)&c->pred_h[p][l], (size_t)M * H * c->esz)); HIPCHK(c, hipMemset(c->pred_h[p][l], 0, (size_t)M * H * c->esz)); }
         if (d.pred_cell) { RC(dalloc(c, &c->pred_c[l], (size_t)M * H)); HIPCHK(c, hipMemset(c->pred_c[l], 0, (size_t)M * H * 4)); }
-        RC(dalloc(c, &c->pred_y[l], (size_t)M * H)); HIPCHK(c, hipMemset(c->pred_y[l], 0, (size_t)M * H * 4));
+        RC(dalloc(c, (char**)&c->pred_y[l], (size_t)M * H * c->esz)); HIPCHK(c, hipMemset(c->pred_y[l], 0, (size_t)M * H * c->esz));
     }
     RC(dalloc(c, &c->pp, (size_t)M * J)); HIPCHK(c, hipMemset(c->pp, 0, (size_t)M * J * 4));
-    RC(dalloc(c, &c->ja, (size_t)M * J)); HIPCHK(c, hipMemset(c->ja, 0, (size_t)M * J * 4));
+    RC(dalloc(c, (char**)&c->ja, (size_t)M * J * c->esz)); HIPCHK(c, hipMemset(c->ja, 0, (size_t)M * J * c->esz));
+    RC(dalloc(c, (char**)&c->cvt_a, (size_t)M * H * c->esz)); RC(dalloc(c, (char**)&c->cvt_b, (size_t)M * H * c->esz));
     RC(dalloc(c, &c->logits, (size_t)M * V));
     RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, M));
     RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.logp_sum, M));
@@ -966,9 +956,6 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     }
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_misc, hipEventDisableTiming));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_enc2, hipStreamNonBlocking));
-    for (auto& e : c->ev_wave) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    c->enc_wavefront = getenv("LASR_ENC_WAVEFRONT") ? atoi(getenv("LASR_ENC_WAVEFRONT")) != 0 : false;
     RC(dalloc(c, &c->pe_ring, (size_t)lasr_ctx::RING * M * J));
     HIPCHK(c, hipMemset(c->pe_ring, 0, sizeof(float) * (size_t)lasr_ctx::RING * M * J));
     RC(dalloc(c, &c->c_cur, M)); RC(dalloc(c, &c->c_avail, M)); RC(dalloc(c, &c->c_iters, M)); RC(dalloc(c, &c->c_target, M));
@@ -997,31 +984,32 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->cmd_dev, c->cmd_bytes * NCMD));
     RC(ensure_T(c, std::max(d.n_buffer, 4)));
 
-    // ---- predictor input tables (one-time, on device):  EF = ffn(embed);  tab = EF * Wx0^T + b
+    // ---- predictor input tables (one-time, on device, always exact f32: the table is f32 in both
+    //      dtypes):  EF = ffn(embed);  tab = EF * Wx0^T + b
     {
         float* emb_dev = nullptr; float* EF = nullptr;
         RC(upload(c, &emb_dev, embed, (size_t)V * E));
         if (E != H) {
-            std::vector<float> pk; float* wf = nullptr; float* bf = nullptr;
-            pack_tiles(pk, H / 16, E / 16, [&](int t, int ui, int k) { return ffn_w[(size_t)(16 * t + ui) * E + k]; });
-            RC(upload(c, &wf, pk.data(), pk.size())); RC(upload(c, &bf, ffn_b, H));
+            Packed pk; void* wf = nullptr; float* bfn = nullptr;
+            pack_tiles(pk, 0, H / 16, E, [&](int t, int ui, int k) { return ffn_w[(size_t)(16 * t + ui) * E + k]; });
+            RC(upload_packed(c, &wf, pk)); RC(upload(c, &bfn, ffn_b, H));
             RC(dalloc(c, &EF, (size_t)V * H));
             GemmArgs g{}; g.A[0] = emb_dev; g.a_mt_total[0] = E; g.a_mt_off[0] = 0; g.KC[0] = E / 16; g.W[0] = wf; g.a_rows = V;
-            EpiLinear::Args ea{}; ea.bias = bf; ea.out = EF; ea.ldo = H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
-            launch_gemm<EpiLinear, 1, true>(c, H / 16, V / 16, g, ea);
+            EpiLinear::Args ea{}; ea.bias = bfn; ea.out = EF; ea.ldo = H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
+            launch_gemm<OpsF32, EpiLinear, 1, true>(c, H / 16, V / 16, g, ea);
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            dfree(c, wf); dfree(c, bf);
+            dfree(c, wf); dfree(c, bfn);
         } else {
             EF = emb_dev; emb_dev = nullptr;
         }
         const int G = c->G_pred;
-        std::vector<float> pk; float* wt = nullptr; float* bt = nullptr;
-        pack_tiles(pk, G * H / 16, H / 16, [&](int t, int ui, int k) { return in0_w[(size_t)(16 * t + ui) * H + k]; });
-        RC(upload(c, &wt, pk.data(), pk.size())); RC(upload(c, &bt, in0_b.data(), in0_b.size()));
+        Packed pk; void* wt = nullptr; float* bt = nullptr;
+        pack_tiles(pk, 0, G * H / 16, H, [&](int t, int ui, int k) { return in0_w[(size_t)(16 * t + ui) * H + k]; });
+        RC(upload_packed(c, &wt, pk)); RC(upload(c, &bt, in0_b.data(), in0_b.size()));
         RC(dalloc(c, &c->pred[0].tab, (size_t)V * G * H));
         GemmArgs g{}; g.A[0] = EF; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = wt; g.a_rows = V;
         EpiLinear::Args ea{}; ea.bias = bt; ea.out = c->pred[0].tab; ea.ldo = G * H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
-        launch_gemm<EpiLinear, 1, true>(c, G * H / 16, V / 16, g, ea);
+        launch_gemm<OpsF32, EpiLinear, 1, true>(c, G * H / 16, V / 16, g, ea);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
         dfree(c, wt); dfree(c, bt); dfree(c, EF); dfree(c, emb_dev);
@@ -1195,7 +1183,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
         StackLnArgs a{};
         a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
         a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
-        a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = Tm;
+        a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.bf = c->bf; a.Tmax = Tm;
         LAUNCH_STACK_LN( dim3((Tm + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     }
     rec(c, 1);
@@ -1321,7 +1309,7 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     }
     if (admitted_any)   // rows that were idle need their joint activation for the new frames
         hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
-                           c->c_avail, c->ja, J, M, c->MT, c->pe_ring_R);
+                           c->c_avail, c->ja, J, M, c->MT, c->pe_ring_R, c->bf);
     if (!P.target_set) {
         int* st = tgt_stage + (size_t)P.idx * M;
         memcpy(st, P.target.data(), sizeof(int) * M);
@@ -1467,7 +1455,7 @@ int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, 
     StackLnArgs a{};
     a.src = c->lm_buf; a.mode = 0; a.src_frames = Tmel_max; a.frame_step = d.stride; a.row_off = nullptr;
     a.T_row = c->dc.T_row; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
-    a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = T_max;
+    a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.bf = c->bf; a.Tmax = T_max;
     LAUNCH_STACK_LN( dim3((T_max + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     return transcribe_common(c, slots, n, T_max);
 }
@@ -1506,7 +1494,7 @@ int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* fea
     StackLnArgs a{};
     a.src = src; a.mode = 1; a.src_frames = 0; a.frame_step = 0; a.row_off = c->dc.row_feat_off;
     a.T_row = c->dc.T_row; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
-    a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = T_max;
+    a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.bf = c->bf; a.Tmax = T_max;
     LAUNCH_STACK_LN( dim3((T_max + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     return transcribe_common(c, slots, n, T_max);
 }
@@ -1537,7 +1525,7 @@ int lasr_step_feats(lasr_ctx* c, const int* slots, int n, const float* feats, in
     StackLnArgs a{};
     a.src = src; a.mode = 1; a.row_off = c->dc.row_feat_off; a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b;
     a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels; a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT;
-    a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = T;
+    a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.bf = c->bf; a.Tmax = T;
     LAUNCH_STACK_LN( dim3((T + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     rec(c, 1);
     run_encoder(c, T);
@@ -1628,15 +1616,15 @@ int lasr_encoder(lasr_ctx* c, const float* feats, int B, int Tp, float* out, flo
     StackLnArgs a{};
     a.src = feats; a.mode = 1; a.row_off = c->dc.row_feat_off; a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b;
     a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels; a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT;
-    a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.Tmax = Tp;
+    a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.bf = c->bf; a.Tmax = Tp;
     LAUNCH_STACK_LN( dim3((Tp + 3) / 4, c->M), dim3(256), 0, c->stream, a);
     run_encoder(c, Tp);
     hipLaunchKernelGGL(k_enc_out, dim3(grid1((size_t)B * Tp * H)), dim3(256), 0, c->stream,
-                       (const float*)c->ybuf[(d.enc_layers - 1) & 1], c->Tcap * c->MT, c->M, out, B, Tp, H);
+                       (const void*)c->ybuf[(d.enc_layers - 1) & 1], c->Tcap * c->MT, c->M, out, B, Tp, H, c->bf);
     for (int l = 0; l < d.enc_layers; ++l) {
         if (h_out)
             hipLaunchKernelGGL(k_from_frag, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream,
-                               (const float*)c->enc_h[c->enc_par][l], c->MT, 0, h_out + (size_t)l * B * H, H, B, H);
+                               (const void*)c->enc_h[c->enc_par][l], c->MT, 0, h_out + (size_t)l * B * H, H, B, H, c->bf);
         if (c_out)
             hipLaunchKernelGGL(k_c_to_rows, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream,
                                (const float*)c->enc_c[l], c->M, c_out + (size_t)l * B * H, B, H);
@@ -1664,7 +1652,8 @@ int lasr_predictor(lasr_ctx* c, const int32_t* tok, int B, int U, float* out) {
         HIPCHK(c, hipMemcpyAsync(c->ds.emit, c->dc.emit, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
         launch_predictor(c);
     }
-    HIPCHK(c, hipMemcpyAsync(out, c->pred_y[c->d.pred_layers - 1], sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_from_elem, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream, (const void*)c->pred_y[c->d.pred_layers - 1],
+                       out, (size_t)B * H, c->bf);
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
 }
@@ -1675,14 +1664,20 @@ int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, floa
     const int H = c->d.hidden, J = c->d.joint, V = c->d.vocab;
     RC(ensure_T(c, 1));
     {   // pp = h_pred W1p^T + b1 ; pe[0] = h_enc W1e^T   (row-major A)
-        GemmArgs g{}; g.A[0] = h_pred; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = c->W1p; g.a_rows = B;
+        const void* ap = h_pred; const void* ae = h_enc;
+        if (c->bf) {   // bf16 operands: round the f32 inputs once
+            hipLaunchKernelGGL(k_to_elem, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream, h_pred, c->cvt_a, (size_t)B * H, 1);
+            hipLaunchKernelGGL(k_to_elem, dim3(grid1((size_t)B * H)), dim3(256), 0, c->stream, h_enc, c->cvt_b, (size_t)B * H, 1);
+            ap = c->cvt_a; ae = c->cvt_b;
+        }
+        GemmArgs g{}; g.A[0] = ap; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.W[0] = c->W1p; g.a_rows = B;
         EpiLinear::Args ea{}; ea.bias = c->b1; ea.out = c->pp; ea.ldo = J; ea.n_rows = B; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
-        launch_gemm<EpiLinear, 1, true>(c, J / 16, (B + 15) / 16, g, ea);
-        g.A[0] = h_enc; g.W[0] = c->W1e; ea.bias = nullptr; ea.out = c->pe;
-        launch_gemm<EpiLinear, 1, true>(c, J / 16, (B + 15) / 16, g, ea);
+        launch_linear<true>(c, J / 16, (B + 15) / 16, g, H, ea);
+        g.A[0] = ae; g.W[0] = c->W1e; ea.bias = nullptr; ea.out = c->pe;
+        launch_linear<true>(c, J / 16, (B + 15) / 16, g, H, ea);
     }
     hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)c->M * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)c->pp,
-                       (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MT, 1 << 30);
+                       (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MT, 1 << 30, c->bf);
     launch_logits(c, logits, B, false);
     if (logp_max && argmax) {
         DecState s = c->ds;
@@ -1709,7 +1704,7 @@ int lasr_debug_timing(lasr_ctx* c, unsigned long long* out /*[5*4096*8]*/) {
     if (!c || !out) return LASR_EINVAL;
     if (!c->dbg) return fail(c, LASR_ESTATE, "set LASR_DBG_TIMING=1 before lasr_create");
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, c->dbg, sizeof(unsigned long long) * 5 * 4096 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->dbg, sizeof(unsigned long long) * 5 * 4096 * 16, hipMemcpyDeviceToHost));
     return LASR_OK;
 }
 
@@ -1727,14 +1722,14 @@ int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us) {
     RC(ensure_T(c, 1));
     const int H = c->d.hidden, I = c->enc[layer].I, M = c->M;
     // random (not zero) operands: zero-filled data inflates the clock (DVFS)
-    hipLaunchKernelGGL(k_fill_rand, dim3(grid1((size_t)M * I)), dim3(256), 0, c->stream, layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1], (size_t)M * I, 17u);
+    hipLaunchKernelGGL(k_fill_rand, dim3(grid1((size_t)M * I)), dim3(256), 0, c->stream, layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1], (size_t)M * I, 17u, c->bf);
     for (int p = 0; p < 2; ++p)
-        hipLaunchKernelGGL(k_fill_rand, dim3(grid1((size_t)M * H)), dim3(256), 0, c->stream, c->enc_h[p][layer], (size_t)M * H, 23u + p);
+        hipLaunchKernelGGL(k_fill_rand, dim3(grid1((size_t)M * H)), dim3(256), 0, c->stream, c->enc_h[p][layer], (size_t)M * H, 23u + p, c->bf);
     RC(cmd_begin(c));
     for (int r = 0; r < c->d.max_streams; ++r) c->hc.T_row[r] = 1;
     RC(cmd_commit(c));
     RC(commit_T_rows(c, 1));
-    const float* xsrc = layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1];
+    const void* xsrc = layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1];
     const int mt_total = c->Tcap * c->MT;
     for (int i = 0; i < 3; ++i) { launch_enc_cell(c, layer, 0, xsrc, mt_total, c->ybuf[layer & 1], mt_total); c->enc_par ^= 1; }
     hipEvent_t e0, e1;

@@ -1,42 +1,96 @@
-// lasr_gemm.hip.h -- the skinny-GEMM core (v_mfma_f32_16x16x4_f32) and its fused epilogues.
-// Included from lasr_kernels.hip.h inside namespace lasr (after frag_off / sigmoid_).
+// lasr_gemm.hip.h -- the skinny-GEMM core (MFMA) and its fused epilogues.
+// Included from lasr_kernels.hip.h inside namespace lasr.
 //
 //   out[rows, N] = A[rows, K] * W[N, K]^T      rows = stream slots, W streamed from HBM
 //
 // A workgroup owns MT 16-row m-tiles x NT 16-column n-tiles and the whole K range, which it splits
 // over its NW waves (wave w takes K chunks w, w+NW, ...).  Operands go global -> VGPR directly in
-// MFMA-fragment order (1 KiB perfectly coalesced wave loads, see lasr_kernels.hip.h) through a
-// 3-deep register ring whose loads are UNCONDITIONAL (chunk indices are clamped, never branched
-// on) so that the compiler can count them and emit partial s_waitcnt vmcnt(N) instead of
-// draining the queue before every MFMA block.  The NW partial tiles are reduced through LDS and a
-// fused epilogue finishes the cell / projection for the rows x units the workgroup owns.
+// MFMA-fragment order (one 16-byte load per lane = a perfectly coalesced 1 KiB wave load) through a
+// register ring; the NW partial tiles are reduced through LDS and a fused epilogue finishes the
+// cell / projection for the rows x units the workgroup owns.
 //
-// Two tilings of the same math are used:
-//   U = 16 ("B"): MT = 1, NT = gates : 16 hidden units x all gates x 16 rows per workgroup;
-//                 grid (H/16, M/16).  Weights are re-read by the M/16 row groups (via L2).
-//   U = 8  ("C"): MT = 2, NT = 2     : 8 hidden units x all gates x 32 rows per workgroup;
-//                 grid (H/8, M/32).  2 A + 2 W fragment loads per 16 MFMAs instead of 1 + 4:
-//                 20 % less L2->CU traffic at the same 256-workgroup parallelism.
-//   U = 4  ("A"): MT = 4, NT = 1     : 4 hidden units x all gates x 64 rows per workgroup;
-//                 grid (H/4, M/64).  Every weight byte is fetched exactly once chip-wide and all
-//                 256 CUs pull on the weight stream even when a single m-tile is active (decode).
+// Operand types (Ops): every fragment is 16 bytes per lane in both.
+//   OpsF32 : v_mfma_f32_16x16x4_f32, chunk = 16 k.  frag[lane = g*16+i][e] = X[16*tile+i][16c + 4g + e]
+//            (four MFMAs per fragment pair; exact f32 fmaf chains, only the k order differs from a
+//            sequential dot product)
+//   OpsBF16: v_mfma_f32_16x16x32_bf16, chunk = 32 k.  frag[lane = g*16+i][e] = X[16*tile+i][32c + 8g + e]
+//            (one MFMA per fragment pair; bf16 operands, f32 accumulate)
+// Activations [rows, K] are stored [K/chunk][rows/16][64 lanes][16 B]; weights tile-major
+// [n_tile][K/chunk][64 lanes][16 B], so every operand address below is in 16-byte units and the K
+// loop is identical for both types.
+//
+// Tilings of the recurrent cells (U = hidden units per workgroup):
+//   U = 8  ("C", encoder): MT = 2, NT = 2: 8 units x 4 gates x 32 rows; grid (H/8, M/32) = 256
+//           workgroups at 64 rows.  2 A + 2 W fragment loads per chunk: the least L2->CU traffic a
+//           1024-output per-CU tile allows (32 x 32).
+//   U = 4  ("A", predictor / joint): MT = 4, NT = 1: 4 units x all gates x up to 64 rows; grid
+//           (H/4, M/64).  Every weight byte is fetched exactly once and all 256 CUs pull on the
+//           weight stream even when a single m-tile is active (decode).
 // COMPACT epilogues (predictor path) gather the rows whose flag is set into dense m-tiles inside
 // the kernel (ballot prefix scan -> LDS row map), so MFMA work follows the number of emitting
 // streams while the weight stream stays full width.
+//
+// The K loop is a static schedule whenever KC == NCH * NW for a known NCH: both phases (x part,
+// h part) form ONE fully unrolled chunk stream, so hipcc can count every load and emit partial
+// s_waitcnt vmcnt(N) (a dynamic loop is drained to vmcnt(0) at each loop head), and
+// sched_barrier(0) keeps the scheduler from sinking the loads next to their first use.
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float x) {   // round to nearest even
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+
+struct OpsF32 {
+    static constexpr int KCH = 16, EPL = 4, BF = 0;
+    typedef float elem;
+    __device__ static __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    }
+    // element index of (row r, column k) in a fragment-major activation buffer
+    __device__ static __forceinline__ size_t aoff(int r, int k, int mt_total) {
+        return ((size_t)((k >> 4) * mt_total + (r >> 4)) * 64 + (((k >> 2) & 3) * 16 + (r & 15))) * 4 + (k & 3);
+    }
+    __device__ static __forceinline__ float ld(const void* p, size_t i) { return ((const float*)p)[i]; }
+    __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+};
+struct OpsBF16 {
+    static constexpr int KCH = 32, EPL = 8, BF = 1;
+    typedef unsigned short elem;
+    __device__ static __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    __device__ static __forceinline__ size_t aoff(int r, int k, int mt_total) {
+        return ((size_t)((k >> 5) * mt_total + (r >> 4)) * 64 + (((k >> 3) & 3) * 16 + (r & 15))) * 8 + (k & 7);
+    }
+    __device__ static __forceinline__ float ld(const void* p, size_t i) { return bf16_to_f32(((const unsigned short*)p)[i]); }
+    __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((unsigned short*)p)[i] = f32_to_bf16(v); }
+};
+// runtime-typed access for the small kernels (is_bf16 flag)
+__device__ __forceinline__ size_t act_off(int bf, int r, int k, int mt_total) {
+    return bf ? OpsBF16::aoff(r, k, mt_total) : OpsF32::aoff(r, k, mt_total);
+}
+__device__ __forceinline__ float act_ld(int bf, const void* p, size_t i) { return bf ? OpsBF16::ld(p, i) : OpsF32::ld(p, i); }
+__device__ __forceinline__ void act_st(int bf, void* p, size_t i, float v) {
+    if (bf) OpsBF16::st(p, i, v); else OpsF32::st(p, i, v);
+}
 
 struct GemmArgs {
-    const float* A[2];      // phase operand: fragment-major (row-major when AROW)
-    int a_mt_total[2];      // m-tiles in A's fragment layout (lda when AROW)
+    const void* A[2];       // phase operand: fragment-major (row-major when AROW), element type of Ops
+    int a_mt_total[2];      // m-tiles in A's fragment layout (lda in elements when AROW)
     int a_mt_off[2];        // m-tile index of row 0 inside A
-    int KC[2];              // K chunks (of 16) per phase; 0 = phase absent
-    const float* W[2];      // packed weights: [n_group][slot][KC][fragment]
+    int KC[2];              // K chunks (of Ops::KCH) per phase; 0 = phase absent
+    const void* W[2];       // packed weights: [n_group][slot][KC][fragment]
     int a_rows;             // AROW only: loads of rows >= a_rows are clamped (0 = no clamp)
     const int* compact;     // COMPACT epilogues: per-row flag
     int M;                  // rows scanned for compaction
-    int nt_w;               // experiment: stream weights with non-temporal loads
-    unsigned long long* dbg; // optional per-workgroup phase timestamps [blocks][8] (LASR_DBG_TIMING)
-    int rot_mul;            // workgroup jb walks K starting at chunk (jb*rot_mul) % KC: co-resident
-                            // workgroups then read different lines of the shared operand at any moment
+    unsigned long long* dbg; // optional per-workgroup phase timestamps [blocks][16] (LASR_DBG_TIMING)
 };
 
 template <int MASK>
@@ -50,81 +104,60 @@ struct PopCount<0> {
 
 template <int MT, int NS>
 struct Frag {
-    f32x4 a[MT];
+    f32x4 a[MT];                       // 16-byte containers (f32x4 or 8 x bf16)
     f32x4 b[NS > 0 ? NS : 1];
 };
 
-// DEAD >= 0: columns [DEAD, DEAD+4) of the 16-column tile carry no weights in this phase; the
-// fragment stores only the 12 live columns (768 B) and the dead lanes feed zeros to the MFMA.
-// MTP = number of leading m-tiles processed (no per-tile branches in the K loop); D = ring depth.
-// ABL (ablation, micro-benchmarks only): 0 = normal, 1 = loads without MFMA, 2 = MFMA without loads
-template <int TILES, int DEAD, int MT, int MTP, int NT, int NW, int D, int ABL = 0>
-__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const float* const (&aptr)[MT], size_t a_step,
-                                           const float* __restrict__ Wp, int KC, int jb, int w, int lane,
-                                           int rot_mul) {
+// weight-fragment addressing of one phase.  DEAD >= 0: columns [DEAD, DEAD+4) of the 16-column tile
+// carry no weights in this phase; the fragment stores only the 12 live columns (768 B) and the dead
+// lanes feed zeros to the MFMA.
+template <int DEAD>
+struct WLane {
+    int off;      // in 16-byte units
+    bool live;
+    static constexpr int FRU = DEAD >= 0 ? 48 : 64;    // 16-byte units per fragment
+    __device__ __forceinline__ explicit WLane(int lane) {
+        if constexpr (DEAD >= 0) {
+            const int col = lane & 15, gq = lane >> 4;
+            live = !(col >= DEAD && col < DEAD + 4);
+            off = gq * 12 + (col < DEAD ? col : col - 4);
+        } else {
+            live = true;
+            off = lane;
+        }
+    }
+};
+
+// Dynamic fallback (any KC): per-phase loop, D-deep ring with clamped (always valid, countable) loads.
+template <class Ops, int TILES, int DEAD, int MT, int MTP, int NT, int NW, int D>
+__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const f32x4* const (&aptr)[MT], size_t a_step,
+                                           const f32x4* __restrict__ Wp, int KC, int jb, int w, int lane) {
     constexpr int NS = PopCount<TILES>::value;
     if constexpr (NS == 0) {
         return;
     } else {
         if (KC <= 0) return;
-        constexpr int FR = DEAD >= 0 ? 192 : 256;
-        int loff = lane * 4;
-        bool live = true;
-        if constexpr (DEAD >= 0) {
-            const int col = lane & 15, gq = lane >> 4;
-            live = !(col >= DEAD && col < DEAD + 4);
-            const int ai = col < DEAD ? col : col - 4;
-            loff = (gq * 12 + ai) * 4;
-        }
-        const float* wb = Wp + (size_t)jb * NS * KC * FR + loff;
+        const WLane<DEAD> wl(lane);
+        const f32x4* wb = Wp + (size_t)jb * NS * KC * WLane<DEAD>::FRU + wl.off;
         const int n = (KC - w + NW - 1) / NW;          // chunks of this wave (<= 0: none)
-        const int rot = (int)(((unsigned)jb * (unsigned)rot_mul) % (unsigned)KC);
         auto load = [&](Frag<MTP, NS>& f, int i) {
-            if constexpr (ABL == 2) {
-#pragma unroll
-                for (int mt = 0; mt < MTP; ++mt) f.a[mt] = f32x4{1.f, 2.f, 3.f, (float)i};
-#pragma unroll
-                for (int s = 0; s < NS; ++s) f.b[s] = f32x4{1.f, 2.f, 3.f, (float)s};
-                return;
-            }
             int c = w + i * NW;
             c = c < KC ? c : KC - 1;                   // clamp: the load stays valid and countable
-            c += rot;
-            c = c >= KC ? c - KC : c;
 #pragma unroll
-            for (int mt = 0; mt < MTP; ++mt) f.a[mt] = *reinterpret_cast<const f32x4*>(aptr[mt] + (size_t)c * a_step);
+            for (int mt = 0; mt < MTP; ++mt) f.a[mt] = aptr[mt][(size_t)c * a_step];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (DEAD < 0 || live)
-                    f.b[s] = *reinterpret_cast<const f32x4*>(wb + ((size_t)s * KC + c) * FR);
-                else
-                    f.b[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int s = 0; s < NS; ++s)
+                f.b[s] = wl.live ? wb[((size_t)s * KC + c) * WLane<DEAD>::FRU] : f32x4{0.f, 0.f, 0.f, 0.f};
         };
         auto compute = [&](const Frag<MTP, NS>& f) {
-            if constexpr (ABL == 1) {
 #pragma unroll
-                for (int mt = 0; mt < MTP; ++mt) asm volatile("" ::"v"(f.a[mt]));
+            for (int mt = 0; mt < MTP; ++mt) {
+                int s = 0;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(f.b[s]));
-                return;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int mt = 0; mt < MTP; ++mt) {
-                    int s = 0;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        if ((TILES >> nt) & 1) {
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[mt][e], f.b[s][e], acc[mt][nt], 0, 0, 0);
-                            ++s;
-                        }
-                    }
-                }
+                for (int nt = 0; nt < NT; ++nt)
+                    if ((TILES >> nt) & 1) { Ops::mma(acc[mt][nt], f.a[mt], f.b[s]); ++s; }
             }
         };
-        // D-deep register ring: slot d holds chunk i+d; D-1 chunks are in flight while one is consumed
         Frag<MTP, NS> f[D];
 #pragma unroll
         for (int d = 0; d < D - 1; ++d) load(f[d], d);
@@ -138,84 +171,50 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const float* co
     }
 }
 
-// Static K schedule: both phases as ONE fully unrolled chunk stream (NCH0 + NCH1 chunks per wave,
-// KC == NCH * NW exactly).  Straight-line code lets the compiler count every load, so the D-deep ring
-// really keeps D-1 chunks in flight (the dynamic loop above is drained to vmcnt(0) at each loop head
-// by hipcc's waitcnt pass) and phase 1's first loads overlap phase 0's last MFMAs.
-template <class Epi, int MT, int MTP, int NT, int NW, int D, int NCH0, int NCH1, int ABL, bool AROW>
-__device__ __forceinline__ void gemm_static(f32x4 (&acc)[MT][NT], const float* const (&ap0)[MT], size_t a_step0,
-                                            const float* const (&ap1)[MT], size_t a_step1, const GemmArgs& g, int jb,
+// Static K schedule: NCH0 + NCH1 chunks per wave (KC == NCH * NW exactly), fully unrolled.
+template <class Ops, class Epi, int MT, int MTP, int NT, int NW, int D, int NCH0, int NCH1, bool AROW>
+__device__ __forceinline__ void gemm_static(f32x4 (&acc)[MT][NT], const f32x4* const (&ap0)[MT], size_t a_step0,
+                                            const f32x4* const (&ap1)[MT], size_t a_step1, const GemmArgs& g, int jb,
                                             int w, int lane, const f32x4* wpre) {
     constexpr int NS0 = PopCount<Epi::PH0_TILES>::value, NS1 = PopCount<Epi::PH1_TILES>::value;
     constexpr int NSM = NS0 > NS1 ? NS0 : NS1;
     constexpr int N0 = NS0 > 0 ? NCH0 : 0, N1 = NS1 > 0 ? NCH1 : 0, NTOT = N0 + N1;
-    auto lane_off = [&](int dead, bool& live) {
-        if (dead < 0) { live = true; return lane * 4; }
-        const int col = lane & 15, gq = lane >> 4;
-        live = !(col >= dead && col < dead + 4);
-        return (gq * 12 + (col < dead ? col : col - 4)) * 4;
-    };
-    bool live0, live1;
-    const int lo0 = lane_off(Epi::PH0_DEAD, live0), lo1 = lane_off(Epi::PH1_DEAD, live1);
-    constexpr int FR0 = Epi::PH0_DEAD >= 0 ? 192 : 256, FR1 = Epi::PH1_DEAD >= 0 ? 192 : 256;
+    const WLane<Epi::PH0_DEAD> wl0(lane);
+    const WLane<Epi::PH1_DEAD> wl1(lane);
+    constexpr int FR0 = WLane<Epi::PH0_DEAD>::FRU, FR1 = WLane<Epi::PH1_DEAD>::FRU;
     const int KC0 = NCH0 * NW, KC1 = NCH1 * NW;
-    const float* wb0 = NS0 > 0 ? g.W[0] + (size_t)jb * NS0 * KC0 * FR0 + lo0 : nullptr;
-    const float* wb1 = NS1 > 0 ? g.W[1] + (size_t)jb * NS1 * KC1 * FR1 + lo1 : nullptr;
+    const f32x4* wb0 = NS0 > 0 ? (const f32x4*)g.W[0] + (size_t)jb * NS0 * KC0 * FR0 + wl0.off : nullptr;
+    const f32x4* wb1 = NS1 > 0 ? (const f32x4*)g.W[1] + (size_t)jb * NS1 * KC1 * FR1 + wl1.off : nullptr;
     Frag<MTP, NSM> f[D];
     auto load = [&](Frag<MTP, NSM>& fr, int i) {       // i is a compile-time constant after unrolling
-        if constexpr (ABL == 2) {
-#pragma unroll
-            for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = f32x4{1.f, 2.f, 3.f, (float)i};
-#pragma unroll
-            for (int s = 0; s < NSM; ++s) fr.b[s] = f32x4{1.f, 2.f, 3.f, (float)s};
-            return;
-        }
         // row-major A: a wave takes chunk PAIRS (two 64-B halves of the same 128-B lines, second hits L1)
         auto chunk = [&](int q) { return AROW ? ((q >> 1) * NW + w) * 2 + (q & 1) : w + q * NW; };
         if (i < N0) {
             const int c = chunk(i);
 #pragma unroll
-            for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = *reinterpret_cast<const f32x4*>(ap0[mt] + (size_t)c * a_step0);
+            for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = ap0[mt][(size_t)c * a_step0];
 #pragma unroll
             for (int s = 0; s < NS0; ++s)
                 fr.b[s] = (i == 0 && wpre) ? wpre[s]          // chunk 0 was issued at kernel entry
-                          : (Epi::PH0_DEAD < 0 || live0) ? (g.nt_w ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wb0 + ((size_t)s * KC0 + c) * FR0))
-                                                                  : *reinterpret_cast<const f32x4*>(wb0 + ((size_t)s * KC0 + c) * FR0))
-                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+                          : wl0.live ? wb0[((size_t)s * KC0 + c) * FR0] : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
             const int c = chunk(i - N0);
 #pragma unroll
-            for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = *reinterpret_cast<const f32x4*>(ap1[mt] + (size_t)c * a_step1);
+            for (int mt = 0; mt < MTP; ++mt) fr.a[mt] = ap1[mt][(size_t)c * a_step1];
 #pragma unroll
             for (int s = 0; s < NS1; ++s)
                 fr.b[s] = (i == 0 && wpre) ? wpre[s]
-                          : (Epi::PH1_DEAD < 0 || live1) ? (g.nt_w ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wb1 + ((size_t)s * KC1 + c) * FR1))
-                                                                  : *reinterpret_cast<const f32x4*>(wb1 + ((size_t)s * KC1 + c) * FR1))
-                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+                          : wl1.live ? wb1[((size_t)s * KC1 + c) * FR1] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto compute = [&](const Frag<MTP, NSM>& fr, int i) {
-        if constexpr (ABL == 1) {
-#pragma unroll
-            for (int mt = 0; mt < MTP; ++mt) asm volatile("" ::"v"(fr.a[mt]));
-#pragma unroll
-            for (int s = 0; s < NSM; ++s) asm volatile("" ::"v"(fr.b[s]));
-            return;
-        }
         const int tiles = i < N0 ? Epi::PH0_TILES : Epi::PH1_TILES;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int mt = 0; mt < MTP; ++mt) {
+            int s = 0;
 #pragma unroll
-            for (int mt = 0; mt < MTP; ++mt) {
-                int s = 0;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if ((tiles >> nt) & 1) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.a[mt][e], fr.b[s][e], acc[mt][nt], 0, 0, 0);
-                        ++s;
-                    }
-                }
-            }
+            for (int nt = 0; nt < NT; ++nt)
+                if ((tiles >> nt) & 1) { Ops::mma(acc[mt][nt], fr.a[mt], fr.b[s]); ++s; }
         }
     };
     // sched_barrier(0): hipcc's scheduler otherwise sinks the loads next to their first use
@@ -244,15 +243,19 @@ struct RedView {
 };
 
 // One workgroup = (n-group jb = blockIdx.x, m-group mg = blockIdx.y of MT m-tiles).
-template <class Epi, int MT, int NW, bool AROW, int D, int ABL = 0>
+// D > 0: ring depth; D < 0: latency-bound kernel, depth from the register budget.
+template <class Ops, class Epi, int MT, int NW, bool AROW, int D>
 __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typename Epi::Args ea) {
     constexpr int NT = Epi::NT, ROWS = MT * 16, LD = NT * 16 + 1;
     __shared__ float red[NW * ROWS * LD];
     __shared__ int row_map[Epi::COMPACT ? 1024 : 1];
     __shared__ int n_act_s;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // w (and everything derived from it: chunk counts, loop bounds) must be wave-uniform FOR THE
+    // COMPILER: a condition it believes divergent is lowered to EXEC masking, and MFMA ignores EXEC
+    // (a masked-off v_mfma still accumulates) -- seen as double-counted K chunks in the bf16 path
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jb = blockIdx.x, mg = blockIdx.y;
-    unsigned long long* dbg = g.dbg ? g.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    unsigned long long* dbg = g.dbg ? g.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
     if (dbg && tid == 0) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[5] = wall_clock64(); }
 
     // (0) this wave's first weight fragment does not depend on flags / compaction: put it in flight
@@ -264,22 +267,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
         constexpr int PHF = NS0k > 0 ? 0 : 1;                                  // first phase with tiles
         constexpr int NSF = NS0k > 0 ? NS0k : NS1k;
         constexpr int DEADF = NS0k > 0 ? Epi::PH0_DEAD : Epi::PH1_DEAD;
-        constexpr int FRF = DEADF >= 0 ? 192 : 256;
+        const WLane<DEADF> wl(lane);
         const int KCF = g.KC[PHF];
         int c0 = AROW ? 2 * w : w;
         c0 = c0 < KCF ? c0 : KCF - 1;
-        int loff = lane * 4;
-        bool live = true;
-        if constexpr (DEADF >= 0) {
-            const int col = lane & 15, gq = lane >> 4;
-            live = !(col >= DEADF && col < DEADF + 4);
-            loff = (gq * 12 + (col < DEADF ? col : col - 4)) * 4;
-        }
-        const float* wb = g.W[PHF] + (size_t)jb * NSF * KCF * FRF + loff;
+        const f32x4* wb = (const f32x4*)g.W[PHF] + (size_t)jb * NSF * KCF * WLane<DEADF>::FRU + wl.off;
 #pragma unroll
         for (int s = 0; s < NSMk; ++s)
-            wpre[s] = (s < NSF && live) ? *reinterpret_cast<const f32x4*>(wb + ((size_t)s * KCF + c0) * FRF)
-                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+            wpre[s] = (s < NSF && wl.live) ? wb[((size_t)s * KCF + c0) * WLane<DEADF>::FRU] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     int n_act = g.M;
@@ -296,12 +291,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
             if (lane == 0) n_act_s = cnt;
         }
         __syncthreads();
-        n_act = n_act_s;
+        n_act = __builtin_amdgcn_readfirstlane(n_act_s);
     }
 
     bool tile_on[MT];
-    const float* ap0[MT];
-    const float* ap1[MT];
+    const f32x4* ap0[MT];
+    const f32x4* ap1[MT];
     size_t a_step0, a_step1;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -314,21 +309,21 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
             tile_on[mt] = Epi::tile_active(ea, mg * MT + mt, lane);
             orow = vr;
         }
-        if constexpr (AROW) {
+        if constexpr (AROW) {   // row-major: lane (i, g) reads 16 B of row i at element KCH*c + EPL*g
             int rr = orow;
             if (g.a_rows > 0 && rr >= g.a_rows) rr = g.a_rows - 1;
-            ap0[mt] = g.A[0] + (size_t)rr * g.a_mt_total[0] + (lane >> 4) * 4;
-            ap1[mt] = g.A[1] ? g.A[1] + (size_t)rr * g.a_mt_total[1] + (lane >> 4) * 4 : nullptr;
+            ap0[mt] = (const f32x4*)g.A[0] + (size_t)rr * (g.a_mt_total[0] / Ops::EPL) + (lane >> 4);
+            ap1[mt] = g.A[1] ? (const f32x4*)g.A[1] + (size_t)rr * (g.a_mt_total[1] / Ops::EPL) + (lane >> 4) : nullptr;
         } else {
-            const size_t in_tile = ((size_t)(lane >> 4) * 16 + (orow & 15)) * 4;
-            ap0[mt] = g.A[0] + (size_t)(g.a_mt_off[0] + (orow >> 4)) * 256 + in_tile;
-            ap1[mt] = g.A[1] + (size_t)(g.a_mt_off[1] + (orow >> 4)) * 256 + in_tile;
+            const size_t in_tile = (size_t)(lane >> 4) * 16 + (orow & 15);
+            ap0[mt] = (const f32x4*)g.A[0] + (size_t)(g.a_mt_off[0] + (orow >> 4)) * 64 + in_tile;
+            ap1[mt] = (const f32x4*)g.A[1] + (size_t)(g.a_mt_off[1] + (orow >> 4)) * 64 + in_tile;
         }
     }
     if constexpr (AROW) {
-        a_step0 = 16; a_step1 = 16;
+        a_step0 = 4; a_step1 = 4;                        // KCH / EPL 16-byte units per chunk
     } else {
-        a_step0 = (size_t)g.a_mt_total[0] * 256; a_step1 = (size_t)g.a_mt_total[1] * 256;
+        a_step0 = (size_t)g.a_mt_total[0] * 64; a_step1 = (size_t)g.a_mt_total[1] * 64;
     }
 
     f32x4 acc[MT][NT];
@@ -348,31 +343,32 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
         if (tile_on[mt]) P = mt + 1;
-    // static K schedules for the shapes of the shipped / benchmarked models (chunks per wave and phase)
     auto run_phases = [&](auto mtp_tag) {
         constexpr int MTP = decltype(mtp_tag)::value;
-        // D < 0: latency-bound kernel (predictor / joint): ring depth from the register budget --
-        // one m-tile x one weight slot is 2 fragments per chunk, so the whole K range can be in flight
-        constexpr int NSMx = (PopCount<Epi::PH0_TILES>::value > PopCount<Epi::PH1_TILES>::value)
-                                 ? PopCount<Epi::PH0_TILES>::value : PopCount<Epi::PH1_TILES>::value;
-        constexpr int FPC = MTP + NSMx;                                   // fragments per chunk
+        constexpr bool P0 = NS0k > 0, P1 = NS1k > 0;
+        constexpr int FPC = MTP + NSMk;                                   // fragments per chunk
         constexpr int DD = D > 0 ? D : (FPC <= 2 ? 9 : FPC <= 3 ? 7 : FPC <= 5 ? 4 : 3);
-        constexpr bool P0 = PopCount<Epi::PH0_TILES>::value > 0, P1 = PopCount<Epi::PH1_TILES>::value > 0;
         const int k0 = P0 ? g.KC[0] : 0, k1 = P1 ? g.KC[1] : 0;
-        if (g.rot_mul == 0) {
-#define LASR_TRY(N0, N1)                                                                                        \
-    if ((!P0 || k0 == (N0) * NW) && (!P1 || k1 == (N1) * NW)) {                                                 \
-        gemm_static<Epi, MT, MTP, NT, NW, DD, N0, N1, ABL, AROW>(acc, ap0, a_step0, ap1, a_step1, g, jb, w, lane, wpre); \
-        return;                                                                                                  \
+#define LASR_TRY(N0, N1)                                                                                              \
+    if ((!P0 || k0 == (N0) * NW) && (!P1 || k1 == (N1) * NW)) {                                                       \
+        gemm_static<Ops, Epi, MT, MTP, NT, NW, DD, N0, N1, AROW>(acc, ap0, a_step0, ap1, a_step1, g, jb, w, lane, wpre); \
+        return;                                                                                                        \
     }
-            LASR_TRY(8, 8)       // K = 1024 / 1024  (8 waves)   | K = 512 (4 waves)
-            LASR_TRY(10, 8)      // K = 1280 / 1024  (encoder layer 0)
-            LASR_TRY(12, 12)     // K = 1536 / 1536
-            LASR_TRY(10, 12)     // K = 1280 / 1536
-#undef LASR_TRY
+        // static schedules for the shapes of the shipped / benchmarked models (chunks per wave and phase)
+        if constexpr (Ops::BF) {
+            LASR_TRY(4, 4)       // K = 1024 / 1024
+            LASR_TRY(5, 4)       // K = 1280 / 1024  (encoder layer 0)
+            LASR_TRY(6, 6)       // K = 1536 / 1536
+            LASR_TRY(5, 6)       // K = 1280 / 1536
+        } else {
+            LASR_TRY(8, 8)
+            LASR_TRY(10, 8)
+            LASR_TRY(12, 12)
+            LASR_TRY(10, 12)
         }
-        gemm_phase<Epi::PH0_TILES, Epi::PH0_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD), ABL>(acc, ap0, a_step0, g.W[0], g.KC[0], jb, w, lane, g.rot_mul);
-        gemm_phase<Epi::PH1_TILES, Epi::PH1_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD), ABL>(acc, ap1, a_step1, g.W[1], g.KC[1], jb, w, lane, g.rot_mul);
+#undef LASR_TRY
+        gemm_phase<Ops, Epi::PH0_TILES, Epi::PH0_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD)>(acc, ap0, a_step0, (const f32x4*)g.W[0], g.KC[0], jb, w, lane);
+        gemm_phase<Ops, Epi::PH1_TILES, Epi::PH1_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD)>(acc, ap1, a_step1, (const f32x4*)g.W[1], g.KC[1], jb, w, lane);
     };
     if constexpr (MT == 1) {
         if (P == 1) run_phases(std::integral_constant<int, 1>{});   // wave-uniform: an idle workgroup streams nothing
@@ -384,6 +380,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
     }
 
     if (dbg && tid == 0) dbg[2] = __builtin_amdgcn_s_memtime();
+    if (dbg && lane == 0 && w < 8) dbg[8 + w] = __builtin_amdgcn_s_memtime();   // per-wave end of the K loop
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -398,14 +395,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
 }
 
 // ------------------------------------------------------------------------------------------------
-// Epilogues.  run<MT>() walks the (row, unit) items of the workgroup tile with a 256-thread stride;
-// a tile column of (gate g, unit uu) is g*U + uu.
+// Epilogues.  A tile column of (gate g, unit uu) is g*U + uu.  Buffers that are A operands of another
+// GEMM (h, BN(h), the joint activation) hold Ops::elem; everything else is f32.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool any16(bool flag, int lane) {
     return (__ballot(flag && lane < 16) != 0ull);   // wave-uniform OR over lanes 0..15
-}
-__device__ __forceinline__ size_t hfrag(int r, int u, int MT_all) {
-    return ((size_t)((u >> 4) * MT_all + (r >> 4)) * 64 + (((u >> 2) & 3) * 16 + (r & 15))) * 4 + (u & 3);
 }
 
 // ---- LSTM cell (torch gate order i,f,g,o; custom_rnn.py:172, haste/lstm.py:34-68) + BN(eval) fold.
@@ -415,7 +409,7 @@ __device__ __forceinline__ size_t hfrag(int r, int u, int MT_all) {
 // PRED (COMPACT): row-major state [M][H]; the rows that emitted advance; phase X is the per-token
 // table tab[token][4H] when TABLE.
 // Each workgroup tile has exactly ROWS*U = 256 (row, unit) items: one per thread.
-template <bool PRED, bool TABLE, int U>
+template <class Ops, bool PRED, bool TABLE, int U>
 struct EpiLSTM {
     static constexpr int NT = U / 4;                       // 4 gates x U units = NT 16-column tiles
     static constexpr int PH0_TILES = TABLE ? 0 : ((1 << NT) - 1);
@@ -430,10 +424,10 @@ struct EpiLSTM {
         int t;                 // ENC: time step
         unsigned long long tile_mask;   // ENC: bit mt set iff m-tile mt has a row with t < T_row (host-computed:
                                //      no global load sits in front of the first weight load)
-        float* c;              // [H][M] cell state, in place
-        const float* h_in;     // current parity
-        float* h_out;          // other parity
-        float* y;              // BN(h'); ENC fragment-major (may be nullptr), PRED row-major
+        float* c;              // [H][M] cell state (f32), in place
+        const void* h_in;      // current parity
+        void* h_out;           // other parity
+        void* y;               // BN(h'); ENC fragment-major (may be nullptr), PRED row-major
         int y_mt_total, y_mt_off;
         const float* bn_s;
         const float* bn_t;
@@ -448,7 +442,7 @@ struct EpiLSTM {
         float c_old, h_old, s, t;
     };
     __device__ static bool tile_active(const Args& a, int mt, int lane) { return (a.tile_mask >> mt) & 1ull; }
-    __device__ static size_t hidx(const Args& a, int r, int u) { return PRED ? (size_t)r * a.H + u : hfrag(r, u, a.MT); }
+    __device__ static size_t hidx(const Args& a, int r, int u) { return PRED ? (size_t)r * a.H + u : Ops::aoff(r, u, a.MT); }
     template <int MTB>
     __device__ static Pre prefetch(const Args& a, int tid, int jb, int mg, int n_act, const int* row_map) {
         constexpr int ROWS = MTB * 16;
@@ -458,14 +452,14 @@ struct EpiLSTM {
         if (tid >= 256) return p;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
         if (PRED) {
-            if (vr < a.M && !a.flag[vr]) { p.carry = true; p.carry_h = a.h_in[hidx(a, vr, u)]; }
+            if (vr < a.M && !a.flag[vr]) { p.carry = true; p.carry_h = Ops::ld(a.h_in, hidx(a, vr, u)); }
             if (vr >= n_act) return p;
             p.r = row_map[vr];
             p.act = true;
         } else {
             p.r = vr;
             p.act = a.t < a.flag[vr];
-            if (!p.act) { p.h_old = a.h_in[hidx(a, vr, u)]; return p; }
+            if (!p.act) { p.h_old = Ops::ld(a.h_in, hidx(a, vr, u)); return p; }
         }
         if (TABLE) {
             const float* tb = a.tab + (size_t)a.token[p.r] * 4 * H + u;
@@ -483,11 +477,11 @@ struct EpiLSTM {
         constexpr int ROWS = MTB * 16;
         if (tid >= 256) return;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu;
-        if (PRED && p.carry) a.h_out[hidx(a, vr, u)] = p.carry_h;
+        if (PRED && p.carry) Ops::st(a.h_out, hidx(a, vr, u), p.carry_h);
         if (p.r < 0) return;
         const size_t ho = hidx(a, p.r, u);
         if (!p.act) {
-            a.h_out[ho] = p.h_old;
+            Ops::st(a.h_out, ho, p.h_old);
             return;
         }
         const float gi = red.sum(row, 0 * U + uu) + p.x[0], gf = red.sum(row, 1 * U + uu) + p.x[1];
@@ -495,23 +489,25 @@ struct EpiLSTM {
         const float c2 = sigmoid_(gf) * p.c_old + sigmoid_(gi) * tanhf(gg);
         const float h2 = sigmoid_(go) * tanhf(c2);
         a.c[(size_t)u * a.M + p.r] = c2;
-        a.h_out[ho] = h2;
-        if (PRED) a.y[ho] = h2 * p.s + p.t;
-        else if (a.y) a.y[hfrag(p.r + 16 * a.y_mt_off, u, a.y_mt_total)] = h2 * p.s + p.t;
+        Ops::st(a.h_out, ho, h2);
+        if (PRED) Ops::st(a.y, ho, h2 * p.s + p.t);
+        else if (a.y) Ops::st(a.y, Ops::aoff(p.r + 16 * a.y_mt_off, u, a.y_mt_total), h2 * p.s + p.t);
     }
 };
 
 // ---- NBRC / GRU-v1 cell (haste/nbrc.py:30-64; layout z,r,g), predictor only (COMPACT, row-major):
 //   z = s(Wx_z + Rh_z), r = s(Wx_r + Rh_r), g = tanh(Wx_g + r * Rh_g), h' = z h + (1 - z) g.
-// Pseudo-gates {z, r, gx, gh}: the x phase feeds z,r,gx, the h phase z,r,gh.  TABLE: Wx (+ input
-// bias) comes from tab[token][3H] and the x phase is absent.
-template <bool TABLE, int U>
+// Pseudo-gates {z, r, gx, gh} in one 16-column tile (4 units): the x phase feeds z,r,gx (gh columns
+// dead), the h phase z,r,gh (gx dead).  TABLE: Wx (+ input bias) comes from tab[token][3H] and the x
+// phase is absent.
+template <class Ops, bool TABLE>
 struct EpiNBRC {
-    static constexpr int NT = U == 16 ? 4 : 1;
-    static constexpr int PH0_TILES = TABLE ? 0 : (U == 16 ? 0x7 : 1);
-    static constexpr int PH1_TILES = U == 16 ? 0xB : 1;
-    static constexpr int PH0_DEAD = U == 16 ? -1 : 12;   // U=4: gh columns carry no x weights
-    static constexpr int PH1_DEAD = U == 16 ? -1 : 8;    //      gx columns carry no h weights
+    static constexpr int U = 4;
+    static constexpr int NT = 1;
+    static constexpr int PH0_TILES = TABLE ? 0 : 1;
+    static constexpr int PH1_TILES = 1;
+    static constexpr int PH0_DEAD = 12;   // gh columns carry no x weights
+    static constexpr int PH1_DEAD = 8;    // gx columns carry no h weights
     static constexpr bool COMPACT = true;
     struct Args {
         const float* bias;     // [3H] input bias (folded into tab when TABLE)
@@ -519,9 +515,9 @@ struct EpiNBRC {
         const float* tab;      // [V][3H]
         const int* token;
         const int* emit;
-        const float* h_in;     // [M][H] current parity
-        float* h_out;          // other parity
-        float* y;              // BN(h') [M][H]
+        const void* h_in;      // [M][H] current parity
+        void* h_out;           // other parity
+        void* y;               // BN(h') [M][H]
         const float* bn_s;
         const float* bn_t;
         int H, M;
@@ -539,10 +535,10 @@ struct EpiNBRC {
         p.r = -1; p.carry = false;
         if (tid >= 256) return p;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
-        if (vr < a.M && !a.emit[vr]) { p.carry = true; p.carry_h = a.h_in[(size_t)vr * H + u]; }
+        if (vr < a.M && !a.emit[vr]) { p.carry = true; p.carry_h = Ops::ld(a.h_in, (size_t)vr * H + u); }
         if (vr >= n_act) return p;
         p.r = row_map[vr];
-        p.h = a.h_in[(size_t)p.r * H + u];
+        p.h = Ops::ld(a.h_in, (size_t)p.r * H + u);
         if (TABLE) {
             const float* tb = a.tab + (size_t)a.token[p.r] * 3 * H + u;
             p.xz = tb[0]; p.xr = tb[H]; p.xg = tb[2 * H];
@@ -559,7 +555,7 @@ struct EpiNBRC {
         constexpr int ROWS = MTB * 16;
         if (tid >= 256) return;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
-        if (p.carry) a.h_out[(size_t)vr * H + u] = p.carry_h;
+        if (p.carry) Ops::st(a.h_out, (size_t)vr * H + u, p.carry_h);
         if (p.r < 0) return;
         const size_t ho = (size_t)p.r * H + u;
         const float vz = red.sum(row, 0 * U + uu), vr_ = red.sum(row, 1 * U + uu), vgh = red.sum(row, 3 * U + uu);
@@ -568,12 +564,12 @@ struct EpiNBRC {
         const float rr = sigmoid_(vr_ + p.xr + p.rr);
         const float gc = tanhf(xg + rr * (vgh + p.rg));
         const float h2 = z * p.h + (1.0f - z) * gc;
-        a.h_out[ho] = h2;
-        a.y[ho] = h2 * p.s + p.t;
+        Ops::st(a.h_out, ho, h2);
+        Ops::st(a.y, ho, h2 * p.s + p.t);
     }
 };
 
-// ---- plain linear: out[row][col] = acc + bias[col], row-major.
+// ---- plain linear: out[row][col] = acc + bias[col], row-major f32.
 struct EpiLinear {
     static constexpr int NT = 1;
     static constexpr int PH0_TILES = 1, PH1_TILES = 0, PH0_DEAD = -1, PH1_DEAD = -1;
@@ -627,18 +623,19 @@ struct EpiLinear {
 // Joint.forward 'concat' (models.py:132-140): Linear(cat(pred, enc)) == W1p pred + W1e enc + b1.
 // Workgroup (jb, mg) refreshes ja for its compacted (emitting) rows and for the NON-emitting rows
 // of the original row range [mg*ROWS, (mg+1)*ROWS).
+template <class Ops>
 struct EpiPPJ {
     static constexpr int NT = 1;
     static constexpr int PH0_TILES = 1, PH1_TILES = 0, PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = true;
     struct Args {
         const float* b1;
-        float* pp;            // [M][J]
-        const float* pe;      // [T][M][J]
+        float* pp;            // [M][J] f32
+        const float* pe;      // [ring][M][J] f32
         const int* t_idx;
         const int* T_row;
         const int* emit;
-        float* ja;            // fragment-major [J/16][MT][64][4]
+        void* ja;             // fragment-major [J/KCH][MT][64][16 B]
         int J, M, MT;
         int ring;             // pe holds frame t of row r at slot t % ring (ring >= frames of a step)
     };
@@ -658,13 +655,15 @@ struct EpiPPJ {
                 const float p = red.sum(row, col) + a.b1[j];
                 a.pp[(size_t)r * a.J + j] = p;
                 const int t = a.t_idx[r];
-                if (t < a.T_row[r]) a.ja[hfrag(r, j, a.MT)] = tanhf(a.pe[((size_t)(t % a.ring) * a.M + r) * a.J + j] + p);
+                if (t < a.T_row[r])
+                    Ops::st(a.ja, Ops::aoff(r, j, a.MT), tanhf(a.pe[((size_t)(t % a.ring) * a.M + r) * a.J + j] + p));
             }
             const int r = vr;                           // original row of this range, if it did not emit
             if (r < a.M && !a.emit[r]) {
                 const int t = a.t_idx[r];
                 if (t < a.T_row[r])
-                    a.ja[hfrag(r, j, a.MT)] = tanhf(a.pe[((size_t)(t % a.ring) * a.M + r) * a.J + j] + a.pp[(size_t)r * a.J + j]);
+                    Ops::st(a.ja, Ops::aoff(r, j, a.MT),
+                            tanhf(a.pe[((size_t)(t % a.ring) * a.M + r) * a.J + j] + a.pp[(size_t)r * a.J + j]));
             }
         }
     }

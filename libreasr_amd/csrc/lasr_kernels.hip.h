@@ -16,11 +16,11 @@
 //   activations [rows, K]:  off(r,k) = ((c*mt_total + r/16)*64 + g*16 + r%16)*4 + e
 //   weights: tile-major, [n_tile][c][lane][e]  (a tile's K-panel is one contiguous stream)
 //
-// The GEMM kernel (k_gemm) gives each workgroup one 16-row m-tile x NT n-tiles, splits K over its
-// NW waves (wave w takes chunks w, w+NW, ...; 3-deep register prefetch ring, no LDS staging:
-// every weight byte is used by exactly one workgroup per m-tile), reduces the NW partial tiles
-// through LDS and runs a fused epilogue (LSTM / NBRC cell math + BatchNorm(eval) fold, joint
-// projections, tanh) on the 16 rows x 16 hidden units it owns.
+// The GEMM kernel (k_gemm, lasr_gemm.hip.h) gives each workgroup MT m-tiles x NT n-tiles, splits K
+// over its NW waves (register prefetch ring, no LDS staging), reduces the NW partial tiles through
+// LDS and runs a fused epilogue (LSTM / NBRC cell math + BatchNorm(eval) fold, joint projections,
+// tanh).  With dtype = bf16 the same layout holds with 32-k chunks of 8 x bf16 per lane
+// (v_mfma_f32_16x16x32_bf16); "bf" flags below select the element type of activation buffers.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,11 +29,6 @@
 namespace lasr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ size_t frag_off(int r, int k, int mt_total) {
-    const int c = k >> 4, g = (k >> 2) & 3, e = k & 3, mt = r >> 4, i = r & 15;
-    return ((size_t)(c * mt_total + mt) * 64 + (g * 16 + i)) * 4 + e;
-}
 
 // precise activations (no fast-math: token-for-token parity after hundreds of recurrent steps)
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -45,29 +40,31 @@ __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(
 // ------------------------------------------------------------------------------------------------
 // joint activation for all rows (start of a step): ja = tanh(pe[t_idx] + pp)
 __global__ void k_ja(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
-                     const int* __restrict__ T_row, float* __restrict__ ja, int J, int M, int MT, int ring) {
+                     const int* __restrict__ T_row, void* __restrict__ ja, int J, int M, int MT, int ring, int bf) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * J) return;
     const int r = idx / J, j = idx - r * J;
     const int t = t_idx ? t_idx[r] : 0;
     if (T_row && t >= T_row[r]) return;
-    ja[frag_off(r, j, MT)] = tanhf(pe[((size_t)(t % ring) * M + r) * J + j] + pp[(size_t)r * J + j]);
+    act_st(bf, ja, act_off(bf, r, j, MT), tanhf(pe[((size_t)(t % ring) * M + r) * J + j] + pp[(size_t)r * J + j]));
 }
 
-// row-major [rows][K] <-> fragment-major
-__global__ void k_to_frag(const float* __restrict__ src, int lds, float* __restrict__ dst, int rows, int K,
-                          int mt_total, int mt_off) {
+// fragment-major -> row-major [rows][K] f32
+__global__ void k_from_frag(const void* __restrict__ src, int mt_total, int mt_off, float* __restrict__ dst, int ldd,
+                            int rows, int K, int bf) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * K) return;
     const int r = idx / K, k = idx - r * K;
-    dst[frag_off(r + 16 * mt_off, k, mt_total)] = src[(size_t)r * lds + k];
+    dst[(size_t)r * ldd + k] = act_ld(bf, src, act_off(bf, r + 16 * mt_off, k, mt_total));
 }
-__global__ void k_from_frag(const float* __restrict__ src, int mt_total, int mt_off, float* __restrict__ dst, int ldd,
-                            int rows, int K) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * K) return;
-    const int r = idx / K, k = idx - r * K;
-    dst[(size_t)r * ldd + k] = src[frag_off(r + 16 * mt_off, k, mt_total)];
+// flat f32 <-> element-typed copies (op-level entry points in bf16 mode)
+__global__ void k_to_elem(const float* __restrict__ src, void* __restrict__ dst, size_t n, int bf) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) act_st(bf, dst, i, src[i]);
+}
+__global__ void k_from_elem(const void* __restrict__ src, float* __restrict__ dst, size_t n, int bf) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = act_ld(bf, src, i);
 }
 // [H][M] -> [rows][H]
 __global__ void k_c_to_rows(const float* __restrict__ c, int M, float* __restrict__ dst, int rows, int H) {
@@ -78,22 +75,22 @@ __global__ void k_c_to_rows(const float* __restrict__ c, int M, float* __restric
 }
 
 // encoder output of the last layer: fragment-major rows (t*M + b) -> out[b][t][H]
-__global__ void k_enc_out(const float* __restrict__ y, int mt_total, int M, float* __restrict__ out, int B, int T, int H) {
+__global__ void k_enc_out(const void* __restrict__ y, int mt_total, int M, float* __restrict__ out, int B, int T, int H, int bf) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * T * H) return;
     const int u = (int)(idx % H);
     const int t = (int)((idx / H) % T);
     const int b = (int)(idx / ((size_t)H * T));
-    out[idx] = y[frag_off(t * M + b, u, mt_total)];
+    out[idx] = act_ld(bf, y, act_off(bf, t * M + b, u, mt_total));
 }
 
 // deterministic pseudo-random fill in [-1, 1) (micro-benchmark operands)
-__global__ void k_fill_rand(float* __restrict__ p, size_t n, unsigned seed) {
+__global__ void k_fill_rand(void* __restrict__ p, size_t n, unsigned seed, int bf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned x = (unsigned)i * 2654435761u ^ (seed * 40503u + 0x9e3779b9u);
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    p[i] = (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f;
+    act_st(bf, p, i, (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f);
 }
 
 // (re)initialise recurrent state of flagged rows from the learned initial states
@@ -101,12 +98,12 @@ __global__ void k_fill_rand(float* __restrict__ p, size_t n, unsigned seed) {
 struct ResetArgs {
     const int* what;          // [M] bit 1: encoder, bit 2: predictor
     int mask;                 // bits of `what` this launch honours
-    int M, MT, H, Le, Lp, pred_lstm, bos;
-    float* enc_h[16];         // current-parity fragment buffers
+    int M, MT, H, Le, Lp, pred_lstm, bos, bf;
+    void* enc_h[16];          // current-parity fragment buffers (element-typed)
     float* enc_c[16];
     const float* enc_h0[16];  // [H]
     const float* enc_c0[16];
-    float* pred_h[8];         // current-parity buffers, row-major [M][H]
+    void* pred_h[8];          // current-parity buffers, row-major [M][H] (element-typed)
     float* pred_c[8];
     const float* pred_h0[8];
     const float* pred_c0[8];
@@ -122,15 +119,15 @@ __global__ void k_reset_rows(const ResetArgs a) {
         a.emit[r] = (wh & 2) ? 1 : 0;
         if (wh & 2) a.token[r] = a.bos;
     }
-    const size_t ho = frag_off(r, u, a.MT);
+    const size_t ho = act_off(a.bf, r, u, a.MT);
     if (wh & 1)
         for (int l = 0; l < a.Le; ++l) {
-            a.enc_h[l][ho] = a.enc_h0[l][u];
+            act_st(a.bf, a.enc_h[l], ho, a.enc_h0[l][u]);
             a.enc_c[l][(size_t)u * a.M + r] = a.enc_c0[l][u];
         }
     if (wh & 2)
         for (int l = 0; l < a.Lp; ++l) {
-            a.pred_h[l][(size_t)r * a.H + u] = a.pred_h0[l][u];
+            act_st(a.bf, a.pred_h[l], (size_t)r * a.H + u, a.pred_h0[l][u]);
             if (a.pred_lstm) a.pred_c[l][(size_t)u * a.M + r] = a.pred_c0[l][u];
         }
 }
@@ -497,8 +494,8 @@ struct StackLnArgs {
     const int* T_row;        // [M] frames of row r in this step
     const float* ln_w;
     const float* ln_b;
-    float* x0;               // fragment-major [F/16][Tcap*MT][64][4]
-    int F, n_mels, n_stack, M, MT, mt_total;
+    void* x0;                // fragment-major [F/chunk][Tcap*MT][64][16 B], element-typed
+    int F, n_mels, n_stack, M, MT, mt_total, bf;
     float* feats_out;        // optional row-major copy of the un-normalised stacked features [M][Tmax][F]
     int Tmax;
 };
@@ -545,8 +542,7 @@ __global__ __launch_bounds__(256) void k_stack_ln(const StackLnArgs a) {
         if (a.feats_out) a.feats_out[((size_t)row * a.Tmax + tp) * a.F + f] = x[q];
         const float y = (x[q] - mu) * rstd * a.ln_w[f] + a.ln_b[f];
         // element (t', row, f): m-tile index tp*MT + row/16 inside a layout of mt_total m-tiles
-        const int c = f >> 4, g = (f >> 2) & 3, e = f & 3;
-        a.x0[((size_t)(c * a.mt_total + tp * a.MT + (row >> 4)) * 64 + g * 16 + (row & 15)) * 4 + e] = y;
+        act_st(a.bf, a.x0, act_off(a.bf, tp * a.MT * 16 + row, f, a.mt_total), y);
     }
 }
 

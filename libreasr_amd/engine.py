@@ -29,7 +29,7 @@ def _ptr(x):
 
 class Engine:
     def __init__(self, state_dict, cfg=None, max_streams=64, device=0, max_iters_offline=3,
-                 max_iters_stream=10, blank=0, bos=2, **frontend):
+                 max_iters_stream=10, blank=0, bos=2, dtype="f32", **frontend):
         self.lib = N.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("libreasr_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
@@ -44,6 +44,10 @@ class Engine:
         d.enc_layers, d.pred_layers = cfg["enc_layers"], cfg["pred_layers"]
         d.pred_cell = 1 if cfg["pred_cell"] == "LSTM" else 0
         d.blank, d.bos = blank, bos
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        d.dtype = 1 if dtype == "bf16" else 0      # bf16: weights + GEMM-input activations, f32 accumulate
+        self.dtype = dtype
         for k, v in fe.items():
             setattr(d, k, int(v))
         d.max_streams = int(max_streams)
@@ -53,7 +57,7 @@ class Engine:
         blob = flatten_state_dict(state_dict, cfg)
         want = self.lib.lasr_weight_count(C.byref(d))
         if want == 0:
-            raise ValueError("model description rejected by liblasr_hip (dims must be multiples of 16)")
+            raise ValueError("model description rejected by liblasr_hip (dims must be multiples of 16; 32 for bf16)")
         if blob.size != want:
             raise ValueError(f"weight blob has {blob.size} floats, liblasr_hip expects {want}")
         with torch.cuda.device(self.device):

@@ -110,6 +110,13 @@ class StreamFrontend:
 
 
 # ----------------------------------------------------------------------------- model pieces
+def bf16_round(x):
+    """f32 -> nearest-even bf16 -> f32 (what the engine stores with dtype=bf16)."""
+    u = np.ascontiguousarray(x, dtype=F32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(F32)
+
+
 def sigmoid(x):
     return (1.0 / (1.0 + np.exp(-x.astype(F32)))).astype(F32)
 
@@ -159,7 +166,13 @@ class OracleTransducer:
     """Restatement of Encoder / Predictor / Joint / Transducer.decode_greedy / transcribe_stream
     (models.py:68-187, 369-455, 457-577) + CustomRNN (custom_rnn.py:140-232)."""
 
-    def __init__(self, sd, cfg, blank=0, bos=2):
+    def __init__(self, sd, cfg, blank=0, bos=2, operand="f32"):
+        """operand="bf16" emulates the engine's dtype=bf16 contract (NOT a reference mode: the
+        reference is fp32 only): GEMM weights and GEMM-input activations (LayerNorm output, h state,
+        BN(h), joint activation) are rounded to bf16; accumulation, cell state, biases, the
+        predictor's embed->ffn->layer-0 input projection, pe/pp and logits stay f32."""
+        assert operand in ("f32", "bf16")
+        self.q = bf16_round if operand == "bf16" else (lambda a: a)
         self.cfg = cfg
         self.blank, self.bos = blank, bos  # models.py:203,225,227
         self.Le, self.Lp, self.H = cfg["enc_layers"], cfg["pred_layers"], cfg["hidden"]
@@ -179,17 +192,27 @@ class OracleTransducer:
         self.j0_b = np.asarray(sd["joint.joint.0.bias"], F32)
         self.j2_w = np.asarray(sd["joint.joint.2.weight"], F32)
         self.j2_b = np.asarray(sd["joint.joint.2.bias"], F32)
+        if operand == "bf16":
+            for i, l in enumerate(self.enc + self.pred):
+                first_pred = i == self.Le            # predictor layer 0: input side stays f32 (table)
+                for k in ("weight_ih_l0", "kernel"):
+                    if k in l["rnn"] and not first_pred:
+                        l["rnn"][k] = bf16_round(l["rnn"][k])
+                for k in ("weight_hh_l0", "recurrent_kernel"):
+                    if k in l["rnn"]:
+                        l["rnn"][k] = bf16_round(l["rnn"][k])
+            self.j0_w, self.j2_w = bf16_round(self.j0_w), bf16_round(self.j2_w)
 
     # -- encoder -------------------------------------------------------------------------
     def enc_init_state(self, B):
         # learned initial state broadcast over the batch (custom_rnn.py:152-158)
-        return [(np.repeat(l["hs"][0, 0], B, 0).copy(), np.repeat(l["hs"][1, 0], B, 0).copy())
+        return [(self.q(np.repeat(l["hs"][0, 0], B, 0).copy()), np.repeat(l["hs"][1, 0], B, 0).copy())
                 for l in self.enc]
 
     def encoder(self, x, state=None):
         """Encoder.forward (models.py:105-113).  x [B,T,F] -> ([B,T,H], state)."""
         B, T, _ = x.shape
-        x = layer_norm(x.reshape(B, T, -1), self.ln_w, self.ln_b)   # models.py:107
+        x = self.q(layer_norm(x.reshape(B, T, -1), self.ln_w, self.ln_b))   # models.py:107
         if state is None:
             state = self.enc_init_state(B)
         new_state = []
@@ -198,16 +221,17 @@ class OracleTransducer:
             for t in range(T):
                 h, c = lstm_step(x[:, t], h, c, l["rnn"])
                 ys[:, t] = h
-            x = bn_eval(ys, l["bn"])                                 # custom_rnn.py:210-213
+                h = self.q(h)
+            x = self.q(bn_eval(ys, l["bn"]))                         # custom_rnn.py:210-213
             new_state.append((h, c))
         return x, new_state                                          # dropout(eval)=id, linear=id
 
     # -- predictor -----------------------------------------------------------------------
     def pred_init_state(self, B=1):
         if self.pred_lstm:
-            return [(np.repeat(l["hs"][0, 0], B, 0).copy(), np.repeat(l["hs"][1, 0], B, 0).copy())
+            return [(self.q(np.repeat(l["hs"][0, 0], B, 0).copy()), np.repeat(l["hs"][1, 0], B, 0).copy())
                     for l in self.pred]
-        return [np.repeat(l["hs"][0, 0], B, 0).copy() for l in self.pred]
+        return [self.q(np.repeat(l["hs"][0, 0], B, 0).copy()) for l in self.pred]
 
     def predictor(self, tok, state=None):
         """Predictor.forward (models.py:181-187) for one token per row.  tok [B] -> ([B,H], state)."""
@@ -221,19 +245,19 @@ class OracleTransducer:
         for l, s in zip(self.pred, state):
             if self.pred_lstm:
                 h, c = lstm_step(x, s[0], s[1], l["rnn"])
-                new_state.append((h, c))
+                new_state.append((self.q(h), c))
             else:
                 h = nbrc_step(x, s, l["rnn"])
-                new_state.append(h)
-            x = bn_eval(h, l["bn"])
+                new_state.append(self.q(h))
+            x = self.q(bn_eval(h, l["bn"]))
         return x, new_state
 
     # -- joint ---------------------------------------------------------------------------
     def joint_logp(self, h_pred, h_enc):
         """Joint.forward 'concat' (models.py:132-140; cat order pred, enc :136) + log_softmax
         (models.py:418).  h_pred, h_enc [B,H] -> log-probs [B,V]."""
-        x = np.concatenate([h_pred, h_enc], axis=-1)
-        a = np.tanh(x @ self.j0_w.T + self.j0_b).astype(F32)
+        x = self.q(np.concatenate([h_pred, h_enc], axis=-1))
+        a = self.q(np.tanh(x @ self.j0_w.T + self.j0_b).astype(F32))
         z = (a @ self.j2_w.T + self.j2_b).astype(F32)
         m = z.max(-1, keepdims=True)
         lse = m + np.log(np.exp(z - m).sum(-1, keepdims=True, dtype=F32))
