@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=8)
     ap.add_argument("--cpu-chunks", type=int, default=100)
+    ap.add_argument("--beam", type=int, default=1,
+                    help="beam width (1 = greedy, the headline config); > 1 runs the synchronous protocol")
     ap.add_argument("--depth", type=int, default=4,
                     help="pipelined mode: model steps in flight before the oldest is collected (1..7)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -151,7 +153,7 @@ def main():
     cfg = synth.model_cfg(args.model)
     sd = synth.synth_state_dict(cfg, seed=0)
     B = args.streams
-    eng = Engine(sd, cfg, max_streams=B, device=local, dtype=args.dtype)
+    eng = Engine(sd, cfg, max_streams=B, device=local, dtype=args.dtype, beam=args.beam)
     my_streams = shard_streams(B * world, world, rank)
     K, W = args.steps, args.warmup
     n_chunks = K + W + 4
@@ -162,7 +164,7 @@ def main():
     slots = [eng.open() for _ in range(B)]
     assert slots == list(range(B))
 
-    pipelined = not args.no_pipeline
+    pipelined = not args.no_pipeline and args.beam == 1
     push_t = {}                                   # chunk index -> host time of its push (latency bookkeeping)
     order = []                                    # model chunks submitted and not yet collected
 
@@ -258,7 +260,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"configs[{1 if args.dtype == 'f32' else 2}]: {B} concurrent 16 kHz streams/GPU, 4x1024 uni-LSTM encoder, "
-                                   f"2xNBRC predictor, J=1024, V=2048, greedy, {'fp32' if args.dtype == 'f32' else 'bf16 operands / f32 accumulate'}, 80 ms chunks, "
+                                   f"2xNBRC predictor, J=1024, V=2048, {'greedy' if args.beam == 1 else 'beam width ' + str(args.beam)}, {'fp32' if args.dtype == 'f32' else 'bf16 operands / f32 accumulate'}, 80 ms chunks, "
                                    "3-chunk window, 2-frame buffer (model every 160 ms)",
                        "streams_per_gpu": B, "chunk_ms": 80, "parallelism": f"dp{world} (independent streams, no collective)",
                        "pipeline": (f"submit/wait, {args.depth} model steps in flight: encoder of later chunks on the main stream, "
@@ -273,7 +275,7 @@ def main():
                                         "encoder": round(float(np.mean(enc_ms)), 4) if enc_ms else None,
                                         "decode": round(float(np.mean(dec_ms)), 4) if dec_ms else None,
                                         "decode_iters": round(float(np.mean(iters)), 2) if iters else None},
-            "tokens_per_frame": round(tokens / max(1, K * B), 4),
+            "tokens_per_frame": round(tokens / max(1, K * B), 4) if args.beam == 1 else None,
             "roofline": {"bound": "mfma", "kernel": "k_gemm<EpiLSTM> (encoder LSTM cell, layer 1, 64 rows)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

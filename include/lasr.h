@@ -64,7 +64,13 @@ typedef struct {
     int32_t max_streams; /* number of stream slots (= batch rows)                        */
     int32_t max_iters_offline; /* 3  (decode_greedy default, models.py:369)             */
     int32_t max_iters_stream;  /* 10 (transcribe_stream default, models.py:458)         */
-    int32_t beam;        /* 1 = greedy (the only decode the reference has)               */
+    int32_t beam;        /* 1 = greedy (the only decode the reference has); 2..8 = beam  */
+                         /* search width W (spec: oracle _beam_frame):     */
+                         /* W hypothesis slots per stream, streams x W <= 1024 rows.     */
+                         /* Synchronous entry points only (not lasr_step_submit); then   */
+                         /* lasr_fetch returns the WHOLE current best hypothesis after   */
+                         /* every model step (it may change retroactively), neg_logp =   */
+                         /* -its score, align = 0.                                       */
 } lasr_model_desc;
 
 /* Fills `d` with the reference defaults listed above (4x1024 encoder, 2xNBRC predictor). */
@@ -137,7 +143,8 @@ int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* fea
  * state, max_iters_stream.  Blocks until the tokens are on the host. */
 int lasr_step_feats(lasr_ctx* c, const int* slots, int n, const float* feats, int T);
 
-/* New tokens of `slot` since the last fetch (int32 ids incl. nothing for blanks).
+/* New tokens of `slot` since the last fetch (int32 ids incl. nothing for blanks); with beam > 1
+ * the complete best hypothesis as of the last model step (empty if no step ran since the last fetch).
  * neg_logp / align (optional): offline metrics of the last lasr_transcribe_* call
  * (-sum log p of every decision, models.py:420-422,455; alignment_score, models.py:445-453). */
 int lasr_fetch(lasr_ctx* c, int slot, int32_t* tokens, int cap, int* n_new, double* neg_logp,

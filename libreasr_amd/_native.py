@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblasr_hip.so")
+LIB_PATH = os.environ.get("LASR_LIB") or os.path.join(_HERE, "csrc", "liblasr_hip.so")   # LASR_LIB: A/B builds
 
 LASR_OK, LASR_EINVAL, LASR_ENOMEM, LASR_EHIP, LASR_ESTATE, LASR_EFULL = 0, -1, -2, -3, -4, -5
 

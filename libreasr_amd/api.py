@@ -66,7 +66,8 @@ class LibreASR:
                     pcm = pad
                 eng.push([slot], pcm[None] if not isinstance(pcm, torch.Tensor) else pcm[None])
                 if eng.step([slot]):
-                    y = y + eng.fetch(slot)[0]
+                    got = eng.fetch(slot)[0]
+                    y = got if eng.beam > 1 else y + got      # beam: the whole best hypothesis
                     yield list(y) if return_ids else self.lang.denumericalize(y)
         finally:
             eng.close_slot(slot)

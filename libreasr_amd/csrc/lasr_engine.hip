@@ -44,7 +44,9 @@ struct lasr_ctx {
     std::vector<void*> dev_allocs;
     std::vector<void*> host_allocs;
 
-    int M = 0, MT = 0;         // padded rows, m-tiles
+    int M = 0, MT = 0;         // padded rows (stream slots), m-tiles
+    int W = 1;                 // beam width (hypothesis slots per stream); 1 = greedy
+    int Md = 0, MTd = 0;       // decoder rows = M * W (row = stream * W + slot), m-tiles
     int bf = 0;                // 1: bf16 operands (weights + GEMM-input activations), f32 accumulate / state / logits
     int kch = 16;              // k per MFMA chunk (16 f32, 32 bf16)
     size_t esz = 4;            // bytes per operand element
@@ -62,6 +64,17 @@ struct lasr_ctx {
     // recurrent state (row == slot)
     std::vector<void*> enc_h[2], pred_h[2], pred_y;      // element-typed (A operands)
     std::vector<float*> enc_c, pred_c;
+    // beam search: c, BN(h) and pp ping-pong like h (every slot may be re-parented each round):
+    // parity 0 = pred_c / pred_y / pp, parity 1 = the *1 buffers; all follow pred_par
+    std::vector<float*> pred_c1;
+    std::vector<void*> pred_y1;
+    float* pp1 = nullptr;
+    double* b_score = nullptr; int *b_alive = nullptr, *b_inB = nullptr, *b_parent = nullptr, *b_trellis = nullptr;
+    std::vector<std::vector<std::vector<int32_t>>> hyp;   // host: token history of every hypothesis slot [M][W]
+    std::vector<std::vector<int32_t>> committed;          // host: best hypothesis at the last predictor reset(s)
+    std::vector<double> committed_score;
+    std::vector<std::vector<int32_t>> best_full;          // host: committed + current best hypothesis
+    int* trellis_host = nullptr; size_t trellis_host_ints = 0;
     int enc_par = 0;
     int pred_par = 0;               // predictor h ping-pong parity (row-major [M][H] buffers)
     void *cvt_a = nullptr, *cvt_b = nullptr;   // [M][H] element-typed staging of f32 op-level inputs
@@ -254,7 +267,8 @@ bool valid_desc(const lasr_model_desc* d) {
     if (d->max_streams < 1 || d->max_streams > 1024) return false;
     if (d->max_iters_offline < 1 || d->max_iters_stream < 1) return false;
     if (d->blank < 0 || d->blank >= d->vocab || d->bos < 0 || d->bos >= d->vocab) return false;
-    if ((d->dtype != 0 && d->dtype != 1) || d->beam != 1) return false;
+    if ((d->dtype != 0 && d->dtype != 1) || d->beam < 1 || d->beam > 8) return false;
+    if ((d->max_streams + 63) / 64 * 64 * d->beam > 1024) return false;      // decoder rows (streams x beam slots)
     if (d->dtype == 1) {   // bf16 operands: 32-wide K chunks
         auto m32 = [](int v) { return v % 32 == 0; };
         if (!m32(d->feat) || !m32(d->hidden) || !m32(d->joint)) return false;
@@ -304,24 +318,30 @@ void launch_enc_cell(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total
 // one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels); predictor
 // state is row-major [M][H]; toggles pred_par
 template <class Ops>
-void launch_predictor_t(lasr_ctx* c) {
+void launch_predictor_t(lasr_ctx* c, bool beam) {
     const int H = c->d.hidden;
-    const int mgroups = c->M / (16 * MTA);
+    const int mgroups = c->Md / (16 * MTA);
     const int p = c->pred_par;
     for (int l = 0; l < c->d.pred_layers; ++l) {
         const Cell& L = c->pred[l];
         GemmArgs g{};
+        // beam: parity p holds the current state; everything is written to parity p ^ 1
+        void* y_out = (beam && !p) ? c->pred_y1[l] : c->pred_y[l];
+        const void* y_in = (beam && p) ? c->pred_y1[l] : c->pred_y[l];
         if (l > 0) {
-            g.A[0] = c->pred_y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA;
+            g.A[0] = (beam && !p) ? c->pred_y1[l - 1] : c->pred_y[l - 1];   // what layer l-1 just wrote
+            g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA;
         }
         g.A[1] = c->pred_h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhA;
-        g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)(1 + std::min(l, 1)) * 4096 * 16 : nullptr;
+        if (beam) { g.parent = c->b_parent; g.beam_w = c->W; }
+        g.compact = c->ds.emit; g.M = c->Md; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)(1 + std::min(l, 1)) * 4096 * 16 : nullptr;
         if (c->d.pred_cell == 1) {
             typename EpiLSTM<Ops, true, true, 4>::Args ea{};
             ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
-            ea.c = c->pred_c[l]; ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l];
-            ea.y = c->pred_y[l]; ea.y_mt_total = 0; ea.y_mt_off = 0;
-            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
+            ea.c = (beam && !p) ? c->pred_c1[l] : c->pred_c[l]; ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l];
+            ea.y = y_out; ea.y_mt_total = 0; ea.y_mt_off = 0;
+            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md; ea.MT = c->MTd;
+            if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.c_in = p ? c->pred_c1[l] : c->pred_c[l]; ea.y_in = y_in; }
             if (l == 0) {
                 launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
@@ -333,8 +353,9 @@ void launch_predictor_t(lasr_ctx* c) {
         } else {
             typename EpiNBRC<Ops, true>::Args ea{};
             ea.bias = L.bias; ea.rbias = L.rbias; ea.tab = L.tab; ea.token = c->ds.token; ea.emit = c->ds.emit;
-            ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = c->pred_y[l];
-            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M;
+            ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = y_out;
+            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md;
+            if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.y_in = y_in; }
             if (l == 0) {
                 launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
@@ -345,29 +366,33 @@ void launch_predictor_t(lasr_ctx* c) {
             }
         }
     }
-    c->pred_par ^= 1;
+    if (!beam) c->pred_par ^= 1;      // beam: launch_ppj (same pass, same parities) toggles
 }
-void launch_predictor(lasr_ctx* c) {
-    if (c->bf) launch_predictor_t<OpsBF16>(c);
-    else launch_predictor_t<OpsF32>(c);
+void launch_predictor(lasr_ctx* c, bool beam = false) {
+    if (c->bf) launch_predictor_t<OpsBF16>(c, beam);
+    else launch_predictor_t<OpsF32>(c, beam);
 }
 
 // pp (for emitting rows) and the joint activation ja = tanh(pe[t_idx] + pp) for all rows still decoding
 template <class Ops>
-void launch_ppj_t(lasr_ctx* c) {
-    const int H = c->d.hidden, J = c->d.joint;
+void launch_ppj_t(lasr_ctx* c, bool beam) {
+    const int H = c->d.hidden, J = c->d.joint, L = c->d.pred_layers, p = c->pred_par;
     GemmArgs g{};
-    g.A[0] = c->pred_y[c->d.pred_layers - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = c->W1p;
-    g.compact = c->ds.emit; g.M = c->M; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 16 : nullptr;
+    g.A[0] = (beam && !p) ? c->pred_y1[L - 1] : c->pred_y[L - 1];      // what the predictor pass just wrote
+    g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = c->W1p;
+    g.compact = c->ds.emit; g.M = c->Md; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 16 : nullptr;
     typename EpiPPJ<Ops>::Args ea{};
-    ea.b1 = c->b1; ea.pp = c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
-    ea.ja = c->ja; ea.J = J; ea.M = c->M; ea.MT = c->MT; ea.ring = c->pe_ring_R;
-    launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MT, g, ea);
+    ea.b1 = c->b1; ea.pp = (beam && !p) ? c->pp1 : c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
+    ea.ja = c->ja; ea.J = J; ea.M = c->Md; ea.MT = c->MTd; ea.ring = c->pe_ring_R;
+    if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.M_enc = c->M; ea.pp_in = p ? c->pp1 : c->pp; }
+    launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
+    if (beam) c->pred_par ^= 1;
 }
-void launch_ppj(lasr_ctx* c) {
-    if (c->bf) launch_ppj_t<OpsBF16>(c);
-    else launch_ppj_t<OpsF32>(c);
+void launch_ppj(lasr_ctx* c, bool beam = false) {
+    if (c->bf) launch_ppj_t<OpsBF16>(c, beam);
+    else launch_ppj_t<OpsF32>(c, beam);
 }
+float* cur_pp(lasr_ctx* c) { return (c->W > 1 && c->pred_par) ? c->pp1 : c->pp; }
 
 // plain linear over element-typed A (fragment-major, or row-major when AROW); f32 row-major output
 template <bool AROW, int D = 3>
@@ -380,11 +405,11 @@ void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, c
 void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     const int J = c->d.joint, V = c->d.vocab;
     GemmArgs g{};
-    g.A[0] = c->ja; g.a_mt_total[0] = c->MT; g.a_mt_off[0] = 0; g.W[0] = c->W2; g.M = c->M;
+    g.A[0] = c->ja; g.a_mt_total[0] = c->MTd; g.a_mt_off[0] = 0; g.W[0] = c->W2; g.M = c->Md;
     g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)4 * 4096 * 16 : nullptr;
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
-    ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M;
+    ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M; ea.W = c->W;
     launch_linear<false, -1>(c, V / 16, (n_rows + 15) / 16, g, J, ea);
 }
 
@@ -460,6 +485,13 @@ int ensure_T(lasr_ctx* c, int T) {
     c->ds.step_tok = c->ds.step_ntok + M;
     c->n_iter_slots = cap * mi + 8;
     RC(dalloc(c, &c->ds.unfinished, (size_t)c->n_iter_slots));
+    if (c->W > 1) {
+        dfree(c, c->b_trellis); c->b_trellis = nullptr;
+        RC(dalloc(c, &c->b_trellis, (size_t)c->n_iter_slots * c->Md));
+        if (c->trellis_host) (void)hipHostFree(c->trellis_host);
+        c->trellis_host_ints = (size_t)c->n_iter_slots * c->Md + 4 * (size_t)c->Md + 16;
+        HIPCHK(c, hipHostMalloc((void**)&c->trellis_host, sizeof(int) * c->trellis_host_ints));
+    }
     HIPCHK(c, hipMemset(c->ybuf[0], 0, (size_t)cap * M * H * c->esz));
     HIPCHK(c, hipMemset(c->ybuf[1], 0, (size_t)cap * M * H * c->esz));
     HIPCHK(c, hipMemset(c->x0, 0, (size_t)cap * M * F * c->esz));
@@ -485,17 +517,20 @@ int ensure_buf(lasr_ctx* c, T** p, size_t* have, size_t need) {
 
 // ---------------------------------------------------------------------------- reset
 // applies c->dc.what (already committed) to the state; runs the predictor on BOS for rows with bit 2
-int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3) {
+// plain_rows: op-level entry points address predictor rows directly (row = batch index, greedy kernels)
+int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3, bool plain_rows = false) {
+    const bool beam = c->W > 1 && !plain_rows;
     ResetArgs a{};
     a.what = c->dc.what; a.mask = mask; a.M = c->M; a.MT = c->MT; a.H = c->d.hidden; a.Le = c->d.enc_layers; a.Lp = c->d.pred_layers;
     a.pred_lstm = c->d.pred_cell; a.bos = c->d.bos; a.bf = c->bf;
+    a.W = beam ? c->W : 1; a.Md = c->Md; a.score = c->b_score; a.alive = c->b_alive; a.inB = c->b_inB; a.parent = c->b_parent;
     for (int l = 0; l < a.Le; ++l) {
         a.enc_h[l] = c->enc_h[c->enc_par][l]; a.enc_c[l] = c->enc_c[l];
         a.enc_h0[l] = c->enc[l].h0; a.enc_c0[l] = c->enc[l].c0;
     }
     for (int l = 0; l < a.Lp; ++l) {
         a.pred_h[l] = c->pred_h[c->pred_par][l];
-        a.pred_c[l] = c->d.pred_cell ? c->pred_c[l] : nullptr;
+        a.pred_c[l] = c->d.pred_cell ? ((beam && c->pred_par) ? c->pred_c1[l] : c->pred_c[l]) : nullptr;
         a.pred_h0[l] = c->pred[l].h0; a.pred_c0[l] = c->pred[l].c0;
     }
     a.token = c->ds.token; a.emit = c->ds.emit;
@@ -505,8 +540,8 @@ int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3) {
         int* keep_dec = c->T_row_dec;
         c->T_row_dec = c->zero_rows;
         HIPCHK(c, hipMemsetAsync(c->ds.t_idx, 0, sizeof(int) * c->M, c->stream));
-        launch_predictor(c);
-        launch_ppj(c);
+        launch_predictor(c, beam);
+        launch_ppj(c, beam);
         c->T_row_dec = keep_dec;
     }
     return LASR_OK;
@@ -540,7 +575,10 @@ void run_encoder(lasr_ctx* c, int T_max) {
 }
 
 // Greedy decode of the current step (T_row_dev, pe ready).  Blocks until done; fills host queues.
+int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows);
+
 int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows) {
+    if (c->W > 1) return run_decode_beam(c, T_max, max_iters, offline, rows);
     const int M = c->M, J = c->d.joint, V = c->d.vocab;
     DecState s = c->ds;
     s.tok_cap = T_max * max_iters;
@@ -567,7 +605,7 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
             hipLaunchKernelGGL(k_step_begin, dim3(grid1(std::max(M, c->n_iter_slots))), dim3(256), 0, c->stream, s, M,
                                c->n_iter_slots, offline ? 1 : 0);
             hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->dec_t_idx,
-                               c->T_row_dec, c->ja, J, M, c->MT, c->pe_ring_R, c->bf);
+                               c->T_row_dec, c->ja, J, M, c->MT, c->pe_ring_R, c->bf, 1, M);
         }
         for (int q = 0; q < n; ++q) {
             const int it = first + q;
@@ -636,6 +674,91 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
         }
     }
     return LASR_OK;
+}
+
+// Beam search over the current step (W > 1): one selection round per iteration for every stream that
+// still has frames; blocks until done.  The per-round (parent, token) records come back in one copy and
+// are replayed on the host into the token history of every hypothesis slot.
+int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows) {
+    const int M = c->M, Md = c->Md, W = c->W, J = c->d.joint;
+    BeamState b{};
+    b.W = W; b.V = c->d.vocab; b.blank = c->d.blank; b.max_iters = max_iters; b.Md = Md;
+    b.t_idx = c->ds.t_idx; b.iters = c->ds.iters; b.T_row = c->T_row_dec;
+    b.score = c->b_score; b.alive = c->b_alive; b.inB = c->b_inB; b.token = c->ds.token; b.emit = c->ds.emit;
+    b.parent = c->b_parent; b.trellis = c->b_trellis; b.unfinished = c->ds.unfinished;
+    const int total_cap = T_max * max_iters;
+    if (total_cap + 1 > c->n_iter_slots) return fail(c, LASR_EINVAL, "decode iteration budget exceeds the trellis");
+    int* res = c->res_host;
+    hipLaunchKernelGGL(k_beam_begin, dim3(grid1(std::max(Md, c->n_iter_slots))), dim3(256), 0, c->stream, b, M, c->n_iter_slots);
+    hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)Md * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)cur_pp(c),
+                       (const int*)c->dec_t_idx, (const int*)c->T_row_dec, c->ja, J, Md, c->MTd, c->pe_ring_R, c->bf, W, M);
+    int iter = 0;
+    int group = offline ? std::min(total_cap, T_max + 16) : std::min(total_cap, T_max + 4);
+    const int next_group = offline ? 32 : 4;
+    c->dbg_gate = false;
+    while (iter < total_cap) {
+        const int n = std::min(group, total_cap - iter);
+        for (int q = 0; q < n; ++q) {
+            launch_logits(c, c->logits, Md, true);
+            hipLaunchKernelGGL(k_beam_select, dim3(M), dim3(256), 0, c->stream, (const float*)c->logits, b, iter + q);
+            launch_predictor(c, true);
+            launch_ppj(c, true);
+        }
+        iter += n;
+        __atomic_store_n(&res[0], -1, __ATOMIC_RELEASE);
+        HIPCHK(c, hipMemcpyAsync(res, c->ds.unfinished + (iter - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        unsigned long long spins = 0;
+        while (__atomic_load_n((volatile int*)&res[0], __ATOMIC_ACQUIRE) == -1) {
+            __builtin_ia32_pause();
+            if (++spins > (1ull << 27)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
+        }
+        if (res[0] == 0) break;
+        group = next_group;
+    }
+    c->stats.decode_iters = iter;
+    // results: the rounds' records + final scores
+    int* tre = c->trellis_host;
+    double* sc = (double*)(tre + (((size_t)iter * Md + 1) & ~size_t(1)));
+    int* alive = (int*)(sc + Md);
+    HIPCHK(c, hipMemcpyAsync(tre, c->b_trellis, sizeof(int) * (size_t)iter * Md, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sc, c->b_score, sizeof(double) * Md, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(alive, c->b_alive, sizeof(int) * Md, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<std::vector<int32_t>> nh(W);
+    for (int r : rows) {
+        auto& H = c->hyp[r];
+        for (int it = 0; it < iter; ++it) {
+            const int* e = tre + (size_t)it * Md + (size_t)r * W;
+            if (e[0] == -1) continue;                          // stream idle in this round
+            for (int j = 0; j < W; ++j) {
+                if (e[j] < 0) { nh[j].clear(); continue; }     // dead slot
+                nh[j] = H[e[j] >> 16];
+                const int tok = e[j] & 0xffff;
+                if (tok) nh[j].push_back(tok - 1);
+            }
+            for (int j = 0; j < W; ++j) H[j].swap(nh[j]);
+        }
+        int best = -1;
+        for (int j = 0; j < W; ++j)
+            if (alive[(size_t)r * W + j] && (best < 0 || sc[(size_t)r * W + j] > sc[(size_t)r * W + best])) best = j;
+        auto& q = c->best_full[r];
+        q = c->committed[r];                                   // what earlier predictor resets froze
+        double score = c->committed_score[r];
+        if (best >= 0) { q.insert(q.end(), H[best].begin(), H[best].end()); score += sc[(size_t)r * W + best]; }
+        c->queue[r] = q;                                       // beam mode: lasr_fetch hands out the whole best hypothesis
+        c->neg_logp[r] = -score;
+        c->align[r] = 0.0;                                     // alignment_score is a greedy-loop metric
+    }
+    return LASR_OK;
+}
+
+// host side of a predictor reset in beam mode: the best hypothesis so far is frozen, the beam restarts
+void beam_host_reset(lasr_ctx* c, int slot, bool forget) {
+    if (c->W <= 1) return;
+    auto& H = c->hyp[slot];
+    if (forget) { c->committed[slot].clear(); c->committed_score[slot] = 0.0; c->best_full[slot].clear(); }
+    else { c->committed[slot] = c->best_full[slot]; c->committed_score[slot] = -c->neg_logp[slot]; }
+    for (auto& h : H) h.clear();
 }
 
 void rec(lasr_ctx* c, int i) {
@@ -807,6 +930,7 @@ void lasr_destroy(lasr_ctx* c) {
     if (c->cmd_host) (void)hipHostFree(c->cmd_host);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->cont_host) (void)hipHostFree(c->cont_host);
+    if (c->trellis_host) (void)hipHostFree(c->trellis_host);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     if (c->ev_ok)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -826,6 +950,8 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     c->M = (d.max_streams + 16 * MTA - 1) / (16 * MTA) * (16 * MTA);   // whole "A"-tiling row groups
     c->MT = c->M / 16;
     const int M = c->M;
+    c->W = d.beam; c->Md = M * c->W; c->MTd = c->Md / 16;
+    const int Md = c->Md;
     c->G_pred = d.pred_cell ? 4 : 3;
     c->bf = d.dtype == 1; c->kch = c->bf ? 32 : 16; c->esz = c->bf ? 2 : 4;
     Reader rd{weights, n_weights};
@@ -936,16 +1062,29 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         RC(dalloc(c, &c->enc_c[l], (size_t)M * H)); HIPCHK(c, hipMemset(c->enc_c[l], 0, (size_t)M * H * 4));
     }
     for (int l = 0; l < d.pred_layers; ++l) {
-        for (int p = 0; p < 2; ++p) { RC(dalloc(c, (char**)&c->pred_h[p][l], (size_t)M * H * c->esz)); HIPCHK(c, hipMemset(c->pred_h[p][l], 0, (size_t)M * H * c->esz)); }
-        if (d.pred_cell) { RC(dalloc(c, &c->pred_c[l], (size_t)M * H)); HIPCHK(c, hipMemset(c->pred_c[l], 0, (size_t)M * H * 4)); }
-        RC(dalloc(c, (char**)&c->pred_y[l], (size_t)M * H * c->esz)); HIPCHK(c, hipMemset(c->pred_y[l], 0, (size_t)M * H * c->esz));
+        for (int p = 0; p < 2; ++p) { RC(dalloc(c, (char**)&c->pred_h[p][l], (size_t)Md * H * c->esz)); HIPCHK(c, hipMemset(c->pred_h[p][l], 0, (size_t)Md * H * c->esz)); }
+        if (d.pred_cell) { RC(dalloc(c, &c->pred_c[l], (size_t)Md * H)); HIPCHK(c, hipMemset(c->pred_c[l], 0, (size_t)Md * H * 4)); }
+        RC(dalloc(c, (char**)&c->pred_y[l], (size_t)Md * H * c->esz)); HIPCHK(c, hipMemset(c->pred_y[l], 0, (size_t)Md * H * c->esz));
     }
-    RC(dalloc(c, &c->pp, (size_t)M * J)); HIPCHK(c, hipMemset(c->pp, 0, (size_t)M * J * 4));
-    RC(dalloc(c, (char**)&c->ja, (size_t)M * J * c->esz)); HIPCHK(c, hipMemset(c->ja, 0, (size_t)M * J * c->esz));
+    RC(dalloc(c, &c->pp, (size_t)Md * J)); HIPCHK(c, hipMemset(c->pp, 0, (size_t)Md * J * 4));
+    if (c->W > 1) {       // second parity of every per-hypothesis buffer + the beam bookkeeping
+        c->pred_c1.assign(d.pred_layers, nullptr); c->pred_y1.assign(d.pred_layers, nullptr);
+        for (int l = 0; l < d.pred_layers; ++l) {
+            if (d.pred_cell) { RC(dalloc(c, &c->pred_c1[l], (size_t)Md * H)); HIPCHK(c, hipMemset(c->pred_c1[l], 0, (size_t)Md * H * 4)); }
+            RC(dalloc(c, (char**)&c->pred_y1[l], (size_t)Md * H * c->esz)); HIPCHK(c, hipMemset(c->pred_y1[l], 0, (size_t)Md * H * c->esz));
+        }
+        RC(dalloc(c, &c->pp1, (size_t)Md * J)); HIPCHK(c, hipMemset(c->pp1, 0, (size_t)Md * J * 4));
+        RC(dalloc(c, &c->b_score, Md)); RC(dalloc(c, &c->b_alive, Md)); RC(dalloc(c, &c->b_inB, Md)); RC(dalloc(c, &c->b_parent, Md));
+        HIPCHK(c, hipMemset(c->b_score, 0, sizeof(double) * Md)); HIPCHK(c, hipMemset(c->b_alive, 0, sizeof(int) * Md));
+        HIPCHK(c, hipMemset(c->b_inB, 0, sizeof(int) * Md)); HIPCHK(c, hipMemset(c->b_parent, 0, sizeof(int) * Md));
+        c->hyp.assign(M, std::vector<std::vector<int32_t>>(c->W));
+        c->committed.assign(M, {}); c->committed_score.assign(M, 0.0); c->best_full.assign(M, {});
+    }
+    RC(dalloc(c, (char**)&c->ja, (size_t)Md * J * c->esz)); HIPCHK(c, hipMemset(c->ja, 0, (size_t)Md * J * c->esz));
     RC(dalloc(c, (char**)&c->cvt_a, (size_t)M * H * c->esz)); RC(dalloc(c, (char**)&c->cvt_b, (size_t)M * H * c->esz));
-    RC(dalloc(c, &c->logits, (size_t)M * V));
-    RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, M));
-    RC(dalloc(c, &c->ds.emit, M)); RC(dalloc(c, &c->ds.logp_sum, M));
+    RC(dalloc(c, &c->logits, (size_t)Md * V));
+    RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, Md));
+    RC(dalloc(c, &c->ds.emit, Md)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->zero_rows, M));
     HIPCHK(c, hipMemset(c->zero_rows, 0, sizeof(int) * M));
     c->T_row_dev = c->zero_rows;
@@ -970,8 +1109,9 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     c->h_frames_sub.assign(M, 0); c->h_fetched.assign(M, 0);
     c->dec_t_idx = c->ds.t_idx;
     c->T_row_dec = c->T_row_dev;
-    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.token, c->ds.emit, c->ds.sum_iters, c->ds.n_ones})
+    for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.sum_iters, c->ds.n_ones})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
+    HIPCHK(c, hipMemset(c->ds.token, 0, sizeof(int) * Md)); HIPCHK(c, hipMemset(c->ds.emit, 0, sizeof(int) * Md));
     HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
     RC(dalloc(c, &c->win, (size_t)M * d.n_window * d.chunk)); HIPCHK(c, hipMemset(c->win, 0, (size_t)M * d.n_window * d.chunk * 4));
     RC(dalloc(c, &c->ring_pos, M)); HIPCHK(c, hipMemset(c->ring_pos, 0, sizeof(int) * M));
@@ -1064,7 +1204,8 @@ int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
         if (std::find(p.rows.begin(), p.rows.end(), slot) != p.rows.end())
             return fail(c, LASR_ESTATE, "slot %d has a submitted step in flight: call lasr_step_wait first", slot);
     HIPCHK(c, hipSetDevice(c->device));
-    if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); }
+    if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); c->neg_logp[slot] = 0.0; }
+    if (what & 2) beam_host_reset(c, slot, (what & 8) != 0);
     if (what & 3) {
         RC(cmd_begin(c));
         c->hc.what[slot] = what & 3;
@@ -1227,6 +1368,7 @@ static void cont_poll(lasr_ctx* c);
 int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     if (!c) return LASR_EINVAL;
     RC(check_slots(c, slots, n, true));
+    if (c->W > 1) return fail(c, LASR_ESTATE, "lasr_step_submit is greedy-only; use lasr_step_stream with beam > 1");
     if ((int)c->pending.size() >= lasr_ctx::NFLY - 1) return fail(c, LASR_ESTATE, "%d steps already in flight: call lasr_step_wait", (int)c->pending.size());
     HIPCHK(c, hipSetDevice(c->device));
     // keep the decode stream busy while the host enqueues (and the GPU runs) this chunk's encoder
@@ -1309,7 +1451,7 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     }
     if (admitted_any)   // rows that were idle need their joint activation for the new frames
         hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
-                           c->c_avail, c->ja, J, M, c->MT, c->pe_ring_R, c->bf);
+                           c->c_avail, c->ja, J, M, c->MT, c->pe_ring_R, c->bf, 1, M);
     if (!P.target_set) {
         int* st = tgt_stage + (size_t)P.idx * M;
         memcpy(st, P.target.data(), sizeof(int) * M);
@@ -1440,6 +1582,8 @@ int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, 
         c->hc.row_N[s] = n_samples[i]; c->hc.row_src_off[s] = off;
         off += n_samples[i];
         c->queue[s].clear();
+        c->neg_logp[s] = 0.0;
+        beam_host_reset(c, s, true);
     }
     RC(cmd_commit(c));
     RC(apply_reset(c, true));
@@ -1487,6 +1631,8 @@ int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* fea
         c->hc.T_row[s] = n_frames[i]; c->hc.what[s] = 3; c->hc.row_feat_off[s] = off;
         off += n_frames[i];
         c->queue[s].clear();
+        c->neg_logp[s] = 0.0;
+        beam_host_reset(c, s, true);
     }
     RC(cmd_commit(c));
     RC(apply_reset(c, true));
@@ -1643,11 +1789,12 @@ int lasr_predictor(lasr_ctx* c, const int32_t* tok, int B, int U, float* out) {
     RC(cmd_begin(c));
     for (int r = 0; r < B; ++r) c->hc.what[r] = 2;
     RC(cmd_commit(c));
-    RC(apply_reset(c, false));
+    RC(apply_reset(c, false, 3, true));
     for (int u = 0; u < U; ++u) {
         RC(cmd_begin(c));
         for (int r = 0; r < B; ++r) { c->hc.token[r] = tok[(size_t)r * U + u]; c->hc.emit[r] = 1; }
         RC(cmd_commit(c));
+        if (c->Md > c->M) HIPCHK(c, hipMemsetAsync(c->ds.emit, 0, sizeof(int) * c->Md, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->ds.token, c->dc.token, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->ds.emit, c->dc.emit, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
         launch_predictor(c);
@@ -1677,7 +1824,7 @@ int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, floa
         launch_linear<true>(c, J / 16, (B + 15) / 16, g, H, ea);
     }
     hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)c->M * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)c->pp,
-                       (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MT, 1 << 30, c->bf);
+                       (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MTd, 1 << 30, c->bf, 1, c->M);
     launch_logits(c, logits, B, false);
     if (logp_max && argmax) {
         DecState s = c->ds;

@@ -90,8 +90,13 @@ struct GemmArgs {
     int a_rows;             // AROW only: loads of rows >= a_rows are clamped (0 = no clamp)
     const int* compact;     // COMPACT epilogues: per-row flag
     int M;                  // rows scanned for compaction
+    const int* parent;      // beam search (AROW, W > 1): phase-1 rows are read from the row's parent hypothesis
+    int beam_w;             //   slot: row r -> (r / W) * W + parent[r]; nullptr / 0: identity (greedy)
     unsigned long long* dbg; // optional per-workgroup phase timestamps [blocks][16] (LASR_DBG_TIMING)
 };
+
+// beam search: physical row of the parent hypothesis of row r (W slots per stream, contiguous)
+__device__ __forceinline__ int beam_prow(const int* parent, int W, int r) { return (r / W) * W + parent[r]; }
 
 template <int MASK>
 struct PopCount {
@@ -131,7 +136,7 @@ struct WLane {
 // Dynamic fallback (any KC): per-phase loop, D-deep ring with clamped (always valid, countable) loads.
 template <class Ops, int TILES, int DEAD, int MT, int MTP, int NT, int NW, int D>
 __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const f32x4* const (&aptr)[MT], size_t a_step,
-                                           const f32x4* __restrict__ Wp, int KC, int jb, int w, int lane) {
+                                           const f32x4* __restrict__ Wp, int KC, int jb, int w, int wu, int lane) {
     constexpr int NS = PopCount<TILES>::value;
     if constexpr (NS == 0) {
         return;
@@ -139,7 +144,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[MT][NT], const f32x4* co
         if (KC <= 0) return;
         const WLane<DEAD> wl(lane);
         const f32x4* wb = Wp + (size_t)jb * NS * KC * WLane<DEAD>::FRU + wl.off;
-        const int n = (KC - w + NW - 1) / NW;          // chunks of this wave (<= 0: none)
+        const int n = (KC - wu + NW - 1) / NW;         // chunks of this wave (<= 0: none); SGPR: real branches
         auto load = [&](Frag<MTP, NS>& f, int i) {
             int c = w + i * NW;
             c = c < KC ? c : KC - 1;                   // clamp: the load stays valid and countable
@@ -250,10 +255,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
     __shared__ float red[NW * ROWS * LD];
     __shared__ int row_map[Epi::COMPACT ? 1024 : 1];
     __shared__ int n_act_s;
-    // w (and everything derived from it: chunk counts, loop bounds) must be wave-uniform FOR THE
-    // COMPILER: a condition it believes divergent is lowered to EXEC masking, and MFMA ignores EXEC
-    // (a masked-off v_mfma still accumulates) -- seen as double-counted K chunks in the bf16 path
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Loop bounds derived from the wave index must be wave-uniform FOR THE COMPILER: a condition it
+    // believes divergent is lowered to EXEC masking, and MFMA ignores EXEC (a masked-off v_mfma still
+    // accumulates) -- seen as double-counted K chunks in the bf16 path.  Addresses keep the VGPR copy
+    // (hipcc schedules the fully unrolled K stream better with vector address math).
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(w);       // the same value, as an SGPR: control flow only
     const int jb = blockIdx.x, mg = blockIdx.y;
     unsigned long long* dbg = g.dbg ? g.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
     if (dbg && tid == 0) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[5] = wall_clock64(); }
@@ -312,8 +319,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
         if constexpr (AROW) {   // row-major: lane (i, g) reads 16 B of row i at element KCH*c + EPL*g
             int rr = orow;
             if (g.a_rows > 0 && rr >= g.a_rows) rr = g.a_rows - 1;
+            const int rp = g.parent ? beam_prow(g.parent, g.beam_w, rr) : rr;     // recurrent state lives in the parent's slot
             ap0[mt] = (const f32x4*)g.A[0] + (size_t)rr * (g.a_mt_total[0] / Ops::EPL) + (lane >> 4);
-            ap1[mt] = g.A[1] ? (const f32x4*)g.A[1] + (size_t)rr * (g.a_mt_total[1] / Ops::EPL) + (lane >> 4) : nullptr;
+            ap1[mt] = g.A[1] ? (const f32x4*)g.A[1] + (size_t)rp * (g.a_mt_total[1] / Ops::EPL) + (lane >> 4) : nullptr;
         } else {
             const size_t in_tile = (size_t)(lane >> 4) * 16 + (orow & 15);
             ap0[mt] = (const f32x4*)g.A[0] + (size_t)(g.a_mt_off[0] + (orow >> 4)) * 64 + in_tile;
@@ -367,8 +375,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
             LASR_TRY(10, 12)
         }
 #undef LASR_TRY
-        gemm_phase<Ops, Epi::PH0_TILES, Epi::PH0_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD)>(acc, ap0, a_step0, (const f32x4*)g.W[0], g.KC[0], jb, w, lane);
-        gemm_phase<Ops, Epi::PH1_TILES, Epi::PH1_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD)>(acc, ap1, a_step1, (const f32x4*)g.W[1], g.KC[1], jb, w, lane);
+        gemm_phase<Ops, Epi::PH0_TILES, Epi::PH0_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD)>(acc, ap0, a_step0, (const f32x4*)g.W[0], g.KC[0], jb, w, wu, lane);
+        gemm_phase<Ops, Epi::PH1_TILES, Epi::PH1_DEAD, MT, MTP, NT, NW, (DD > 4 ? 4 : DD)>(acc, ap1, a_step1, (const f32x4*)g.W[1], g.KC[1], jb, w, wu, lane);
     };
     if constexpr (MT == 1) {
         if (P == 1) run_phases(std::integral_constant<int, 1>{});   // wave-uniform: an idle workgroup streams nothing
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
     }
 
     if (dbg && tid == 0) dbg[2] = __builtin_amdgcn_s_memtime();
-    if (dbg && lane == 0 && w < 8) dbg[8 + w] = __builtin_amdgcn_s_memtime();   // per-wave end of the K loop
+    if (dbg && lane == 0 && wu < 8) dbg[8 + wu] = __builtin_amdgcn_s_memtime();   // per-wave end of the K loop
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -424,7 +432,7 @@ struct EpiLSTM {
         int t;                 // ENC: time step
         unsigned long long tile_mask;   // ENC: bit mt set iff m-tile mt has a row with t < T_row (host-computed:
                                //      no global load sits in front of the first weight load)
-        float* c;              // [H][M] cell state (f32), in place
+        float* c;              // [H][M] cell state (f32), in place (beam: the OTHER parity, see c_in)
         const void* h_in;      // current parity
         void* h_out;           // other parity
         void* y;               // BN(h'); ENC fragment-major (may be nullptr), PRED row-major
@@ -432,11 +440,18 @@ struct EpiLSTM {
         const float* bn_s;
         const float* bn_t;
         int H, M, MT;
+        // beam search (PRED, W > 1): every hypothesis slot may be re-parented each round, so c and y
+        // ping-pong like h, old state is read from the parent's slot and rows that are not extended
+        // carry (h, c, y) of their parent into their own slot of the other parity
+        const int* parent;
+        int W;
+        const float* c_in;
+        const void* y_in;
     };
     struct Pre {
         int r;                 // row this thread finishes (-1: none)
         bool carry;            // PRED: this thread carries h of original row vr (did not emit)
-        float carry_h;
+        float carry_h, carry_c, carry_y;
         bool act;
         float x[4];            // bias or table values per gate
         float c_old, h_old, s, t;
@@ -451,8 +466,13 @@ struct EpiLSTM {
         p.r = -1; p.carry = false; p.act = false;
         if (tid >= 256) return p;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
+        const bool beam = PRED && a.W > 1;
         if (PRED) {
-            if (vr < a.M && !a.flag[vr]) { p.carry = true; p.carry_h = Ops::ld(a.h_in, hidx(a, vr, u)); }
+            if (vr < a.M && !a.flag[vr]) {
+                const int pr = beam ? beam_prow(a.parent, a.W, vr) : vr;
+                p.carry = true; p.carry_h = Ops::ld(a.h_in, hidx(a, pr, u));
+                if (beam) { p.carry_c = a.c_in[(size_t)u * a.M + pr]; p.carry_y = Ops::ld(a.y_in, hidx(a, pr, u)); }
+            }
             if (vr >= n_act) return p;
             p.r = row_map[vr];
             p.act = true;
@@ -467,7 +487,7 @@ struct EpiLSTM {
         } else {
             p.x[0] = a.bias[u]; p.x[1] = a.bias[H + u]; p.x[2] = a.bias[2 * H + u]; p.x[3] = a.bias[3 * H + u];
         }
-        p.c_old = a.c[(size_t)u * a.M + p.r];
+        p.c_old = beam ? a.c_in[(size_t)u * a.M + beam_prow(a.parent, a.W, p.r)] : a.c[(size_t)u * a.M + p.r];
         p.s = a.bn_s[u]; p.t = a.bn_t[u];
         return p;
     }
@@ -477,7 +497,10 @@ struct EpiLSTM {
         constexpr int ROWS = MTB * 16;
         if (tid >= 256) return;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu;
-        if (PRED && p.carry) Ops::st(a.h_out, hidx(a, vr, u), p.carry_h);
+        if (PRED && p.carry) {
+            Ops::st(a.h_out, hidx(a, vr, u), p.carry_h);
+            if (a.W > 1) { a.c[(size_t)u * a.M + vr] = p.carry_c; Ops::st(a.y, hidx(a, vr, u), p.carry_y); }
+        }
         if (p.r < 0) return;
         const size_t ho = hidx(a, p.r, u);
         if (!p.act) {
@@ -521,11 +544,14 @@ struct EpiNBRC {
         const float* bn_s;
         const float* bn_t;
         int H, M;
+        const int* parent;     // beam search (W > 1): see EpiLSTM::Args
+        int W;
+        const void* y_in;
     };
     struct Pre {
         int r;
         bool carry;
-        float carry_h, h, xz, xr, xg, rz, rr, rg, s, t;
+        float carry_h, carry_y, h, xz, xr, xg, rz, rr, rg, s, t;
     };
     template <int MTB>
     __device__ static Pre prefetch(const Args& a, int tid, int jb, int mg, int n_act, const int* row_map) {
@@ -535,10 +561,15 @@ struct EpiNBRC {
         p.r = -1; p.carry = false;
         if (tid >= 256) return p;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
-        if (vr < a.M && !a.emit[vr]) { p.carry = true; p.carry_h = Ops::ld(a.h_in, (size_t)vr * H + u); }
+        const bool beam = a.W > 1;
+        if (vr < a.M && !a.emit[vr]) {
+            const int pr = beam ? beam_prow(a.parent, a.W, vr) : vr;
+            p.carry = true; p.carry_h = Ops::ld(a.h_in, (size_t)pr * H + u);
+            if (beam) p.carry_y = Ops::ld(a.y_in, (size_t)pr * H + u);
+        }
         if (vr >= n_act) return p;
         p.r = row_map[vr];
-        p.h = Ops::ld(a.h_in, (size_t)p.r * H + u);
+        p.h = Ops::ld(a.h_in, (size_t)(beam ? beam_prow(a.parent, a.W, p.r) : p.r) * H + u);
         if (TABLE) {
             const float* tb = a.tab + (size_t)a.token[p.r] * 3 * H + u;
             p.xz = tb[0]; p.xr = tb[H]; p.xg = tb[2 * H];
@@ -555,7 +586,10 @@ struct EpiNBRC {
         constexpr int ROWS = MTB * 16;
         if (tid >= 256) return;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
-        if (p.carry) Ops::st(a.h_out, (size_t)vr * H + u, p.carry_h);
+        if (p.carry) {
+            Ops::st(a.h_out, (size_t)vr * H + u, p.carry_h);
+            if (a.W > 1) Ops::st(a.y, (size_t)vr * H + u, p.carry_y);
+        }
         if (p.r < 0) return;
         const size_t ho = (size_t)p.r * H + u;
         const float vz = red.sum(row, 0 * U + uu), vr_ = red.sum(row, 1 * U + uu), vgh = red.sum(row, 3 * U + uu);
@@ -584,11 +618,12 @@ struct EpiLinear {
         int M;
         const int* ring_base; // optional: GEMM row (t*M + r) is written to row ((ring_base[r] + t) % ring)*M + r
         int ring;
+        int W;                // beam search: row r belongs to stream r / W (t_idx, T_row are per stream)
     };
     __device__ static bool row_on(const Args& a, int r) {
         if (r >= a.n_rows) return false;
         if (!a.t_idx) return true;
-        const int q = r % a.M;
+        const int q = a.W > 1 ? r / a.W : r % a.M;
         return a.t_idx[q] < a.T_row[q];
     }
     __device__ static bool tile_active(const Args& a, int mt, int lane) {
@@ -630,14 +665,19 @@ struct EpiPPJ {
     static constexpr bool COMPACT = true;
     struct Args {
         const float* b1;
-        float* pp;            // [M][J] f32
-        const float* pe;      // [ring][M][J] f32
-        const int* t_idx;
+        float* pp;            // [M][J] f32 (beam: the other parity, see pp_in)
+        const float* pe;      // [ring][M_enc][J] f32
+        const int* t_idx;     // per stream
         const int* T_row;
         const int* emit;
         void* ja;             // fragment-major [J/KCH][MT][64][16 B]
         int J, M, MT;
         int ring;             // pe holds frame t of row r at slot t % ring (ring >= frames of a step)
+        // beam search (W > 1): rows are hypothesis slots, W per stream; a slot that was not extended
+        // takes pp of its parent slot (current parity) into its own slot of the other parity
+        const int* parent;
+        int W, M_enc;
+        const float* pp_in;
     };
     struct Pre {};
     template <int MTB>
@@ -646,6 +686,7 @@ struct EpiPPJ {
     __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
                                const Pre&, int nthr) {
         constexpr int ROWS = MTB * 16;
+        const bool beam = a.W > 1;
         for (int it = tid; it < ROWS * 16; it += nthr) {
             const int col = it & 15, row = it >> 4;
             const int j = jb * 16 + col;
@@ -654,16 +695,27 @@ struct EpiPPJ {
                 const int r = row_map[vr];
                 const float p = red.sum(row, col) + a.b1[j];
                 a.pp[(size_t)r * a.J + j] = p;
-                const int t = a.t_idx[r];
-                if (t < a.T_row[r])
-                    Ops::st(a.ja, Ops::aoff(r, j, a.MT), tanhf(a.pe[((size_t)(t % a.ring) * a.M + r) * a.J + j] + p));
+                const int q = beam ? r / a.W : r;       // stream of the row
+                const int t = a.t_idx[q];
+                if (t < a.T_row[q])
+                    Ops::st(a.ja, Ops::aoff(r, j, a.MT),
+                            tanhf(a.pe[((size_t)(t % a.ring) * (beam ? a.M_enc : a.M) + q) * a.J + j] + p));
             }
             const int r = vr;                           // original row of this range, if it did not emit
             if (r < a.M && !a.emit[r]) {
-                const int t = a.t_idx[r];
-                if (t < a.T_row[r])
+                const int q = beam ? r / a.W : r;
+                const int t = a.t_idx[q];
+                float p;
+                if (beam) {
+                    p = a.pp_in[(size_t)beam_prow(a.parent, a.W, r) * a.J + j];
+                    a.pp[(size_t)r * a.J + j] = p;
+                } else {
+                    if (t >= a.T_row[q]) continue;
+                    p = a.pp[(size_t)r * a.J + j];
+                }
+                if (t < a.T_row[q])
                     Ops::st(a.ja, Ops::aoff(r, j, a.MT),
-                            tanhf(a.pe[((size_t)(t % a.ring) * a.M + r) * a.J + j] + a.pp[(size_t)r * a.J + j]));
+                            tanhf(a.pe[((size_t)(t % a.ring) * (beam ? a.M_enc : a.M) + q) * a.J + j] + p));
             }
         }
     }

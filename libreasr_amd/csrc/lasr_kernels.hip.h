@@ -38,15 +38,18 @@ __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-// joint activation for all rows (start of a step): ja = tanh(pe[t_idx] + pp)
+// joint activation for all rows (start of a step): ja = tanh(pe[t_idx] + pp).
+// W > 1 (beam search): rows are hypothesis slots, W per stream; t_idx / T_row / pe are per stream (M_enc rows)
 __global__ void k_ja(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
-                     const int* __restrict__ T_row, void* __restrict__ ja, int J, int M, int MT, int ring, int bf) {
+                     const int* __restrict__ T_row, void* __restrict__ ja, int J, int M, int MT, int ring, int bf,
+                     int W, int M_enc) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * J) return;
     const int r = idx / J, j = idx - r * J;
-    const int t = t_idx ? t_idx[r] : 0;
-    if (T_row && t >= T_row[r]) return;
-    act_st(bf, ja, act_off(bf, r, j, MT), tanhf(pe[((size_t)(t % ring) * M + r) * J + j] + pp[(size_t)r * J + j]));
+    const int q = W > 1 ? r / W : r;
+    const int t = t_idx ? t_idx[q] : 0;
+    if (T_row && t >= T_row[q]) return;
+    act_st(bf, ja, act_off(bf, r, j, MT), tanhf(pe[((size_t)(t % ring) * M_enc + q) * J + j] + pp[(size_t)r * J + j]));
 }
 
 // fragment-major -> row-major [rows][K] f32
@@ -99,6 +102,11 @@ struct ResetArgs {
     const int* what;          // [M] bit 1: encoder, bit 2: predictor
     int mask;                 // bits of `what` this launch honours
     int M, MT, H, Le, Lp, pred_lstm, bos, bf;
+    int W, Md;                // beam search: predictor rows are hypothesis slots (W per stream, Md = M * W rows);
+    double* score;            //   a reset stream restarts with slot 0 = the BOS hypothesis (score 0), others dead
+    int* alive;
+    int* inB;
+    int* parent;
     void* enc_h[16];          // current-parity fragment buffers (element-typed)
     float* enc_c[16];
     const float* enc_h0[16];  // [H]
@@ -115,9 +123,17 @@ __global__ void k_reset_rows(const ResetArgs a) {
     if (idx >= a.M * a.H) return;
     const int r = idx / a.H, u = idx - r * a.H;
     const int wh = a.what[r] & a.mask;
+    const int W = a.W > 1 ? a.W : 1;
+    const int rp = r * W;                                  // predictor row (slot 0 of the stream)
     if (u == 0 && (a.mask & 2)) {
-        a.emit[r] = (wh & 2) ? 1 : 0;
-        if (wh & 2) a.token[r] = a.bos;
+        a.emit[rp] = (wh & 2) ? 1 : 0;
+        if (wh & 2) a.token[rp] = a.bos;
+        if (W > 1)
+            for (int b = 0; b < W; ++b) {
+                a.parent[rp + b] = b;
+                if (b) a.emit[rp + b] = 0;
+                if (wh & 2) { a.score[rp + b] = b ? -INFINITY : 0.0; a.alive[rp + b] = b ? 0 : 1; a.inB[rp + b] = 0; }
+            }
     }
     const size_t ho = act_off(a.bf, r, u, a.MT);
     if (wh & 1)
@@ -127,8 +143,8 @@ __global__ void k_reset_rows(const ResetArgs a) {
         }
     if (wh & 2)
         for (int l = 0; l < a.Lp; ++l) {
-            act_st(a.bf, a.pred_h[l], (size_t)r * a.H + u, a.pred_h0[l][u]);
-            if (a.pred_lstm) a.pred_c[l][(size_t)u * a.M + r] = a.pred_c0[l][u];
+            act_st(a.bf, a.pred_h[l], (size_t)rp * a.H + u, a.pred_h0[l][u]);
+            if (a.pred_lstm) a.pred_c[l][(size_t)u * (W > 1 ? a.Md : a.M) + rp] = a.pred_c0[l][u];
         }
 }
 
@@ -271,6 +287,154 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     }
     s.iters[r] = it;
     if (s.cont ? (t < s.target[r]) : (t < Tr)) atomicAdd(&s.unfinished[iter_slot], 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Beam search (the reference has none -- the spec is oracle/rnnt_oracle.py:_beam_frame).
+// Rows are hypothesis slots, W per stream (row = stream * W + slot).  One selection round per decode
+// iteration and stream: candidates = slots already done with the frame (B, carried unchanged) +
+// (slot in A) x (token v) with score + log p(v); the W best survive in order (score desc, then
+// source slot asc, carry first, v asc) and become slots 0..W-1: blank extensions join B, non-blank
+// ones are extended (emit = 1: the predictor kernels step them from their PARENT's state) and are
+// evaluated again unless the per-frame cap is reached.  When every slot is in B the stream moves to
+// the next frame.  W = 1 is exactly the greedy machine of k_select.
+// ------------------------------------------------------------------------------------------------
+struct BeamState {
+    int W, V, blank, max_iters, Md;
+    int* t_idx;        // [M] per stream
+    int* iters;        // [M] rounds done on the current frame
+    const int* T_row;  // [M]
+    double* score;     // [Md] sum of log p of every decision (blank included), f64 sum of f32 terms
+    int* alive;        // [Md]
+    int* inB;          // [Md]
+    int* token;        // [Md] token of the extension (predictor input)
+    int* emit;         // [Md] 1 iff the slot was extended by a non-blank token in this round
+    int* parent;       // [Md] slot (0..W-1) whose state this slot continues
+    int* trellis;      // [n_iter_slots][Md]  (parent << 16) | (token + 1 if extended else 0); -1 stream idle, -2 dead slot
+    int* unfinished;   // [n_iter_slots]
+};
+
+__global__ __launch_bounds__(256) void k_beam_select(const float* __restrict__ logits, BeamState s, int iter_slot) {
+    constexpr int MAXW = 8;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int W = s.W, V = s.V, r0 = q * W;
+    int* tre = s.trellis + (size_t)iter_slot * s.Md + r0;
+    const int t = s.t_idx[q], Tr = s.T_row[q];
+    if (t >= Tr) {                                   // stream has nothing to decode: identity round
+        if (tid < W) { s.emit[r0 + tid] = 0; s.parent[r0 + tid] = tid; tre[tid] = -1; }
+        return;
+    }
+    __shared__ double sc[MAXW];
+    __shared__ int al[MAXW], ib[MAXW];
+    __shared__ float rmax[MAXW], rlog[MAXW];         // per A row: max logit, log(sum exp(z - max))
+    __shared__ float redf[4];
+    __shared__ double redd[4];
+    __shared__ int redi[4];
+    __shared__ double sel_sc[MAXW];
+    __shared__ int sel_ord[MAXW];
+    if (tid < W) { sc[tid] = s.score[r0 + tid]; al[tid] = s.alive[r0 + tid]; ib[tid] = s.inB[r0 + tid]; }
+    __syncthreads();
+    // ---- log-softmax statistics of every row still in A
+    for (int b = 0; b < W; ++b) {
+        if (!al[b] || ib[b]) continue;               // uniform over the workgroup
+        const float* z = logits + (size_t)(r0 + b) * V;
+        float m = -INFINITY;
+        for (int v = tid; v < V; v += 256) m = fmaxf(m, z[v]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) redf[w] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+        __syncthreads();
+        float sum = 0.f;
+        for (int v = tid; v < V; v += 256) sum += expf(z[v] - m);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) redf[w] = sum;
+        __syncthreads();
+        if (tid == 0) { rmax[b] = m; rlog[b] = logf(redf[0] + redf[1] + redf[2] + redf[3]); }
+        __syncthreads();
+    }
+    // ---- W ordered argmax passes; pass j only admits candidates strictly after winner j-1 in the total order
+    double last_sc = INFINITY;
+    int last_ord = -1;
+    for (int j = 0; j < W; ++j) {
+        double best = -INFINITY;
+        int bord = 0x7fffffff;
+        auto offer = [&](double val, int ord) {
+            if (!(val > -INFINITY)) return;
+            const bool after = val < last_sc || (val == last_sc && ord > last_ord);
+            if (!after) return;
+            if (val > best || (val == best && ord < bord)) { best = val; bord = ord; }
+        };
+        for (int b = 0; b < W; ++b) {
+            if (!al[b]) continue;
+            if (ib[b]) {
+                if (tid == 0) offer(sc[b], b * (V + 1));
+                continue;
+            }
+            const float* z = logits + (size_t)(r0 + b) * V;
+            const float m = rmax[b], lg = rlog[b];
+            for (int v = tid; v < V; v += 256) offer(sc[b] + (double)((z[v] - m) - lg), b * (V + 1) + 1 + v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o);
+            const int oo = __shfl_xor(bord, o);
+            if (ob > best || (ob == best && oo < bord)) { best = ob; bord = oo; }
+        }
+        if (lane == 0) { redd[w] = best; redi[w] = bord; }
+        __syncthreads();
+        best = redd[0]; bord = redi[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (redd[k] > best || (redd[k] == best && redi[k] < bord)) { best = redd[k]; bord = redi[k]; }
+        __syncthreads();
+        if (tid == 0) { sel_sc[j] = best; sel_ord[j] = bord; }
+        last_sc = best; last_ord = bord;
+        if (!(best > -INFINITY)) {                   // candidates exhausted: the remaining slots are dead
+            if (tid == 0)
+                for (int k = j + 1; k < W; ++k) { sel_sc[k] = -INFINITY; sel_ord[k] = 0x7fffffff; }
+            break;
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const int round = s.iters[q] + 1;
+    bool all_b = true;
+    int nib[MAXW];
+    for (int j = 0; j < W; ++j) {
+        const int r = r0 + j;
+        if (!(sel_sc[j] > -INFINITY)) {
+            s.alive[r] = 0; s.inB[r] = 0; nib[j] = 1; s.emit[r] = 0; s.parent[r] = j; s.score[r] = -INFINITY; tre[j] = -2;
+            continue;
+        }
+        const int b = sel_ord[j] / (V + 1), k = sel_ord[j] - b * (V + 1);
+        s.alive[r] = 1; s.parent[r] = b; s.score[r] = sel_sc[j];
+        int em = 0, inb = 1;
+        if (k > 0 && k - 1 != s.blank) {
+            em = 1;
+            s.token[r] = k - 1;
+            inb = round >= s.max_iters ? 1 : 0;
+        }
+        s.emit[r] = em;
+        nib[j] = inb;
+        tre[j] = (b << 16) | (em ? k : 0);
+        all_b = all_b && inb;
+    }
+    int tn = t, rn = round;
+    if (all_b) { tn = t + 1; rn = 0; }
+    for (int j = 0; j < W; ++j) s.inB[r0 + j] = all_b ? 0 : (sel_sc[j] > -INFINITY ? nib[j] : 0);
+    s.t_idx[q] = tn; s.iters[q] = rn;
+    if (tn < Tr) atomicAdd(&s.unfinished[iter_slot], 1);
+}
+
+// start of a beam decode step: per-stream cursors and the iteration flags
+__global__ void k_beam_begin(BeamState s, int M, int n_iter_slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) { s.t_idx[i] = 0; s.iters[i] = 0; }
+    if (i < s.Md) { s.emit[i] = 0; s.parent[i] = i % s.W; s.inB[i] = 0; }
+    if (i < n_iter_slots) s.unfinished[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ def _ptr(x):
 
 class Engine:
     def __init__(self, state_dict, cfg=None, max_streams=64, device=0, max_iters_offline=3,
-                 max_iters_stream=10, blank=0, bos=2, dtype="f32", **frontend):
+                 max_iters_stream=10, blank=0, bos=2, dtype="f32", beam=1, **frontend):
         self.lib = N.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("libreasr_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
@@ -48,6 +48,8 @@ class Engine:
             raise ValueError("dtype must be 'f32' or 'bf16'")
         d.dtype = 1 if dtype == "bf16" else 0      # bf16: weights + GEMM-input activations, f32 accumulate
         self.dtype = dtype
+        d.beam = int(beam)                         # 1 = greedy; 2..8 = beam search (synchronous entry points)
+        self.beam = int(beam)
         for k, v in fe.items():
             setattr(d, k, int(v))
         d.max_streams = int(max_streams)

@@ -56,7 +56,13 @@ class Transducer:
                 feats = chunk.reshape(1, chunk.shape[0], -1)
                 eng.step_feats([slot], feats)
                 y_seq, _, _ = eng.fetch(slot)
-                y = y + y_seq
+                if eng.beam > 1:               # beam search hands out the whole best hypothesis (it may change)
+                    n_same = 0
+                    while n_same < min(len(y), len(y_seq)) and y[n_same] == y_seq[n_same]:
+                        n_same += 1
+                    y, y_seq = list(y_seq), y_seq[n_same:]
+                else:
+                    y = y + y_seq
                 yield y, denumericalizer(y_seq), reset
         finally:
             eng.close_slot(slot)

@@ -292,10 +292,79 @@ class OracleTransducer:
         res = (y, -log_p, float(score), iters_all)
         return res + (outs,) if return_logits else res
 
+    # -- beam search (ABSENT from the reference -> parity unpinned; this is the spec) --
+    def _beam_frame(self, hyps, enc_t, W, max_iters):
+        """One encoder frame of the slot-synchronous beam.  hyps: list of dicts(score, y, h_pred, pstate),
+        len <= W.  Round r <= max_iters: candidates = hyps already done with this frame (B, unchanged)
+        + every (hyp in A) x (token v) with score + log p(v); the W best survive (score desc; ties:
+        source slot asc, then "already in B" first, then v asc).  Blank extensions join B, non-blank
+        ones are expanded again (predictor stepped) unless the round cap is reached -- exactly the
+        greedy loop of models.py:405-443 when W == 1.  Scores are float64 sums of float32 log-probs
+        (every decision incl. blanks, as log_p at models.py:420-422); no length norm, no merging."""
+        A = [dict(h, inB=False) for h in hyps]
+        for rnd in range(1, max_iters + 1):
+            cands = []
+            for b, h in enumerate(A):
+                if h["inB"]:
+                    cands.append((-h["score"], b, 0, -1, h))
+                    continue
+                lp, _ = self.joint_logp(h["h_pred"], enc_t[None])
+                lp = lp[0]
+                # only the W best tokens of a hyp can make the global top W
+                top = np.argsort(-lp, kind="stable")[:W]
+                for v in top:
+                    cands.append((-(h["score"] + float(lp[v])), b, 1, int(v), h))
+            cands.sort(key=lambda c: c[:4])
+            new = []
+            for negs, b, kind, v, h in cands[:W]:
+                if kind == 0:
+                    new.append(h)
+                elif v == self.blank:
+                    new.append(dict(h, score=-negs, inB=True))
+                else:
+                    hp, ps = self.predictor([v], h["pstate"])
+                    new.append(dict(score=-negs, y=h["y"] + [v], h_pred=hp, pstate=ps, inB=(rnd == max_iters)))
+            A = new
+            if all(h["inB"] for h in A):
+                break
+        return [{k: h[k] for k in ("score", "y", "h_pred", "pstate")} for h in A]
+
+    def beam_init(self):
+        h_pred, pstate = self.predictor([self.bos])
+        return [dict(score=0.0, y=[], h_pred=h_pred, pstate=pstate)]
+
+    def decode_beam(self, feats, W, max_iters=3):
+        """Offline beam search over one utterance: returns (best tokens, best score, all hyps)."""
+        enc, _ = self.encoder(feats[None])
+        hyps = self.beam_init()
+        for t in range(enc.shape[1]):
+            hyps = self._beam_frame(hyps, enc[0, t], W, max_iters)
+        best = min(range(len(hyps)), key=lambda i: (-hyps[i]["score"], i))
+        return hyps[best]["y"], hyps[best]["score"], hyps
+
     def stream_decoder(self, max_iters=10):
         """Transducer.transcribe_stream (models.py:457-577) as a push-style object: call
         .step(chunk[T,F]) per non-None chunk -> new tokens of that chunk; .reset() = reset()."""
         return _StreamDecoder(self, max_iters)
+
+
+class StreamBeamDecoder:
+    """transcribe_stream with the beam of OracleTransducer._beam_frame: .step(chunk) -> best tokens so far."""
+
+    def __init__(self, m, W, max_iters=10):
+        self.m, self.W, self.max_iters = m, W, max_iters
+        self.enc_state = None
+        self.hyps = m.beam_init()
+
+    def step(self, chunk):
+        enc, self.enc_state = self.m.encoder(chunk[None], self.enc_state)
+        for t in range(enc.shape[1]):
+            self.hyps = self.m._beam_frame(self.hyps, enc[0, t], self.W, self.max_iters)
+        return self.best()
+
+    def best(self):
+        i = min(range(len(self.hyps)), key=lambda i: (-self.hyps[i]["score"], i))
+        return self.hyps[i]["y"], self.hyps[i]["score"]
 
 
 class _StreamDecoder:

@@ -1,0 +1,129 @@
+"""Beam search (BASELINE configs[2]/[4]).  The reference has no beam search, so parity is
+UNPINNED against it; the contract is the oracle's spec (oracle/rnnt_oracle.py:_beam_frame):
+  * beam = 1 is the greedy decode token-for-token (the greedy engine is pinned to the reference goldens;
+    here the oracle's W = 1 beam is checked against the oracle's greedy, on CPU in tests/test_oracle.py)
+  * for W in {2, 4, 8}: best hypothesis and its score equal the oracle's beam on the same inputs
+  * the best score of W = 8 is not below the greedy score (not guaranteed per width: pruned search)."""
+import numpy as np
+import pytest
+import torch
+
+from libreasr_amd import synth
+from oracle import rnnt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+_ENGINES = {}
+
+
+def engine(name, beam, dtype="f32", max_streams=8):
+    import __graft_entry__ as graft
+    from libreasr_amd.engine import Engine
+    key = (name, beam, dtype)
+    if key not in _ENGINES:
+        graft.build()
+        cfg = synth.model_cfg(name)
+        sd = synth.synth_state_dict(cfg, seed=0)
+        _ENGINES[key] = (Engine(sd, cfg, max_streams=max_streams, beam=beam, dtype=dtype),
+                         O.OracleTransducer(sd, cfg, operand=dtype), cfg)
+    return _ENGINES[key]
+
+
+@pytest.mark.parametrize("name,W", [("tiny", 2), ("tiny", 4), ("tiny_lstm", 4), ("tiny", 8), ("cfg2", 4)])
+def test_beam_offline_matches_oracle(name, W):
+    eng, m, cfg = engine(name, W)
+    n = 3 if name != "cfg2" else 2
+    secs = 3 if name != "cfg2" else 2
+    pcm = synth.synth_pcm(n, 16000 * secs, seed=1234)
+    slots = [eng.open() for _ in range(n)]
+    eng.transcribe_pcm(slots, [pcm[i] for i in range(n)])
+    for i, s in enumerate(slots):
+        toks, neg_logp, _ = eng.fetch(s)
+        f = O.features_offline(pcm[i])
+        y, score, _ = m.decode_beam(f, W)
+        g = m.decode_greedy(f)
+        print(f"{name} W={W} utt {i}: {len(toks)} tokens score {-neg_logp:.4f} (oracle {score:.4f}, greedy {-g[1]:.4f})")
+        assert toks == y, (toks, y)
+        assert abs(-neg_logp - score) < 2e-3 * max(1.0, abs(score))
+        if W == 8:
+            assert -neg_logp >= -g[1] - 1e-3
+        eng.close_slot(s)
+
+
+def test_beam_streaming_matches_oracle_and_ragged():
+    W = 4
+    eng, m, cfg = engine("tiny_lstm", W)
+    n = 3
+    pcm = synth.synth_pcm(n, 16000 * 3, seed=1234)
+    chunks = [synth.stream_chunks(pcm[i], 1280, lead=1, tail=4) for i in range(n)]
+    slots = [eng.open() for _ in range(n)]
+    got = [[] for _ in range(n)]
+    fes = [O.StreamFrontend() for _ in range(n)]
+    decs = [O.StreamBeamDecoder(m, W) for _ in range(n)]
+    start = [0, 1, 3]                               # streams join at different chunks: ragged steps
+    for k in range(len(chunks[0]) + max(start)):
+        act = [i for i in range(n) if 0 <= k - start[i] < len(chunks[i])]
+        if not act:
+            continue
+        eng.push([slots[i] for i in act], np.stack([chunks[i][k - start[i]] for i in act]))
+        ran = eng.step([slots[i] for i in act])
+        for i in act:
+            o = fes[i].push(chunks[i][k - start[i]])
+            if o is not None:
+                decs[i].step(o)
+        if ran:
+            for i in act:
+                t = eng.fetch(slots[i])[0]
+                if t:
+                    got[i] = t
+    for i in range(n):
+        y, score = decs[i].best()
+        print(f"stream {i}: {len(got[i])} tokens; oracle {len(y)}")
+        assert got[i] == y, (i, got[i], y)
+    # a predictor reset freezes the best hypothesis and restarts the beam
+    eng.reset(slots[0], 1 | 2 | 4)
+    decs[0] = O.StreamBeamDecoder(m, W)
+    fes0 = fes[0]
+    frozen = list(got[0])
+    for ch in synth.stream_chunks(pcm[1], 1280, lead=0, tail=2):
+        eng.push([slots[0]], ch[None])
+        if eng.step([slots[0]]):
+            t = eng.fetch(slots[0])[0]
+            if t:
+                got[0] = t
+        o = fes0.push(ch)
+        if o is not None:
+            decs[0].step(o)
+    assert got[0] == frozen + decs[0].best()[0]
+    for s in slots:
+        eng.close_slot(s)
+
+
+def test_beam_bf16_cfg2_runs_and_tracks_emulation():
+    W = 4
+    eng, m, cfg = engine("cfg2", W, dtype="bf16")
+    pcm = synth.synth_pcm(2, 16000 * 2, seed=1234)
+    slots = [eng.open() for _ in range(2)]
+    eng.transcribe_pcm(slots, [pcm[0], pcm[1]])
+    for i, s in enumerate(slots):
+        toks, neg_logp, _ = eng.fetch(s)
+        y, score, _ = m.decode_beam(O.features_offline(pcm[i]), W)
+        print(f"bf16 W={W} utt {i}: {len(toks)} tokens score {-neg_logp:.4f} (emulation {len(y)} tokens, {score:.4f})")
+        assert len(toks) > 0
+        assert abs(-neg_logp - score) < 0.05 * max(1.0, abs(score))     # bf16 contract: tolerance, not bit parity
+        eng.close_slot(s)
+
+
+def test_beam_rejects_pipeline_and_bad_width():
+    from libreasr_amd import _native as N
+    from libreasr_amd.engine import Engine
+    eng, _, cfg = engine("tiny", 2)
+    s = eng.open()
+    with pytest.raises(N.LasrError):
+        eng.submit([s])
+    eng.close_slot(s)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    with pytest.raises(ValueError):
+        Engine(sd, cfg, max_streams=8, beam=9)
+    with pytest.raises(ValueError):
+        Engine(sd, cfg, max_streams=512, beam=4)      # 512 x 4 decoder rows > 1024

@@ -93,3 +93,25 @@ def test_model_matches_reference(golden_dir, name, n_sec, n_streams):
 def test_should_reset_policy():
     # api-server.py:44-50: 10 ms * downsample 8 * n_buffer 2 * steps >= 4000 ms
     assert not O.should_reset(24) and O.should_reset(25)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_lstm"])
+def test_beam_width_1_is_the_reference_greedy(golden_dir, name):
+    """The beam spec (absent from the reference: parity unpinned) degenerates to the reference's greedy
+    decode at W = 1: tokens and log-prob of the goldens the reference produced."""
+    g = np.load(os.path.join(golden_dir, f"model_{name}.npz"))
+    cfg = synth.model_cfg(name)
+    m = O.OracleTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
+    pcm = synth.synth_pcm(2, 16000 * 3, seed=1234)
+    for s in range(2):
+        f = O.features_offline(pcm[s])
+        y, score, _ = m.decode_beam(f, 1)
+        assert y == list(g[f"off_tokens_{s}"])
+        assert abs(-score - float(g[f"off_neglogp_{s}"])) < 1e-3 * max(1.0, abs(score))
+        y8, s8, hyps = m.decode_beam(f, 8)
+        assert len(hyps) == 8 and s8 >= score - 1e-6          # wider beam: not worse on these inputs
+        # streaming form == offline form when fed the same frames with the offline iteration cap
+        sb = O.StreamBeamDecoder(m, 4, max_iters=3)
+        for t in range(0, f.shape[0], 2):
+            sb.step(f[t:t + 2])
+        assert sb.best()[0] == m.decode_beam(f, 4)[0]
