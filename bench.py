@@ -115,8 +115,8 @@ def main():
                     help="f32 = BASELINE configs[1] (the headline metric); bf16 = configs[2] arithmetic "
                          "(bf16 MFMA operands, f32 accumulate/state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-streams", type=int, default=8)
-    ap.add_argument("--cpu-chunks", type=int, default=100)
+    ap.add_argument("--cpu-streams", type=int, default=16)
+    ap.add_argument("--cpu-chunks", type=int, default=200)
     ap.add_argument("--beam", type=int, default=1,
                     help="beam width (1 = greedy, the headline config); > 1 runs the synchronous protocol")
     ap.add_argument("--depth", type=int, default=4,

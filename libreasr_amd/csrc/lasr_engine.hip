@@ -269,6 +269,7 @@ bool valid_desc(const lasr_model_desc* d) {
     if (d->blank < 0 || d->blank >= d->vocab || d->bos < 0 || d->bos >= d->vocab) return false;
     if ((d->dtype != 0 && d->dtype != 1) || d->beam < 1 || d->beam > 8) return false;
     if ((d->max_streams + 63) / 64 * 64 * d->beam > 1024) return false;      // decoder rows (streams x beam slots)
+    if (d->beam > 1 && d->vocab > 4096) return false;                         // k_beam_select keeps a stream's logits in registers
     if (d->dtype == 1) {   // bf16 operands: 32-wide K chunks
         auto m32 = [](int v) { return v % 32 == 0; };
         if (!m32(d->feat) || !m32(d->hidden) || !m32(d->joint)) return false;
@@ -700,7 +701,9 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
         const int n = std::min(group, total_cap - iter);
         for (int q = 0; q < n; ++q) {
             launch_logits(c, c->logits, Md, true);
-            hipLaunchKernelGGL(k_beam_select, dim3(M), dim3(256), 0, c->stream, (const float*)c->logits, b, iter + q);
+            if (W <= 2) hipLaunchKernelGGL((k_beam_select<2>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter + q);
+            else if (W <= 4) hipLaunchKernelGGL((k_beam_select<4>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter + q);
+            else hipLaunchKernelGGL((k_beam_select<8>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter + q);
             launch_predictor(c, true);
             launch_ppj(c, true);
         }

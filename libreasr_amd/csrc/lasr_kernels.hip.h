@@ -314,46 +314,91 @@ struct BeamState {
     int* unfinished;   // [n_iter_slots]
 };
 
-__global__ __launch_bounds__(256) void k_beam_select(const float* __restrict__ logits, BeamState s, int iter_slot) {
-    constexpr int MAXW = 8;
+// WT: compile-time bound of W (2, 4, 8).  One workgroup of 1024 threads per stream: its W x V logits
+// are read ONCE into registers (KEEP = 4 per thread and row: V <= 4096, issued before anything else);
+// the statistics of all rows are reduced together and the W ordered argmax passes scan 4 W register
+// values per thread, so the kernel is a handful of block reductions deep.
+template <int WT>
+__global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ logits, BeamState s, int iter_slot) {
+    constexpr int KEEP = 4, NT = 1024, NWV = NT / 64;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int W = s.W, V = s.V, r0 = q * W;
+    // ---- the stream's logits -> registers (in flight while the state below is fetched)
+    float zv[WT][KEEP];
+#pragma unroll
+    for (int b = 0; b < WT; ++b) {
+        const float* z = logits + (size_t)(r0 + (b < W ? b : 0)) * V;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int v = tid + NT * k;
+            zv[b][k] = v < V ? z[v] : -INFINITY;
+        }
+    }
     int* tre = s.trellis + (size_t)iter_slot * s.Md + r0;
     const int t = s.t_idx[q], Tr = s.T_row[q];
     if (t >= Tr) {                                   // stream has nothing to decode: identity round
         if (tid < W) { s.emit[r0 + tid] = 0; s.parent[r0 + tid] = tid; tre[tid] = -1; }
         return;
     }
-    __shared__ double sc[MAXW];
-    __shared__ int al[MAXW], ib[MAXW];
-    __shared__ float rmax[MAXW], rlog[MAXW];         // per A row: max logit, log(sum exp(z - max))
-    __shared__ float redf[4];
-    __shared__ double redd[4];
-    __shared__ int redi[4];
-    __shared__ double sel_sc[MAXW];
-    __shared__ int sel_ord[MAXW];
-    if (tid < W) { sc[tid] = s.score[r0 + tid]; al[tid] = s.alive[r0 + tid]; ib[tid] = s.inB[r0 + tid]; }
+    __shared__ double sc[WT];
+    __shared__ int al[WT], ib[WT];
+    __shared__ float redf[NWV][WT];
+    __shared__ double redd[NWV];
+    __shared__ int redi[NWV];
+    __shared__ double sel_sc[WT];
+    __shared__ int sel_ord[WT];
+    if (tid < WT) {
+        const bool in = tid < W;
+        sc[tid] = in ? s.score[r0 + tid] : -INFINITY; al[tid] = in ? s.alive[r0 + tid] : 0; ib[tid] = in ? s.inB[r0 + tid] : 0;
+    }
     __syncthreads();
-    // ---- log-softmax statistics of every row still in A
-    for (int b = 0; b < W; ++b) {
-        if (!al[b] || ib[b]) continue;               // uniform over the workgroup
-        const float* z = logits + (size_t)(r0 + b) * V;
-        float m = -INFINITY;
-        for (int v = tid; v < V; v += 256) m = fmaxf(m, z[v]);
+    bool inA[WT];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if (lane == 0) redf[w] = m;
-        __syncthreads();
-        m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-        __syncthreads();
+    for (int b = 0; b < WT; ++b) {
+        inA[b] = al[b] && !ib[b];                    // uniform over the workgroup
+        if (!inA[b]) {
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) zv[b][k] = -INFINITY;
+        }
+    }
+    // ---- log-softmax statistics: max, then log(sum exp(z - max)), all rows at once
+    float m[WT], lg[WT];
+#pragma unroll
+    for (int b = 0; b < WT; ++b) {
+        float x = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) x = fmaxf(x, zv[b][k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+        if (lane == 0) redf[w][b] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < WT; ++b) {
+        float x = redf[0][b];
+#pragma unroll
+        for (int k = 1; k < NWV; ++k) x = fmaxf(x, redf[k][b]);
+        m[b] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < WT; ++b) {
         float sum = 0.f;
-        for (int v = tid; v < V; v += 256) sum += expf(z[v] - m);
+        if (inA[b]) {
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) sum += expf(zv[b][k] - m[b]);      // exp(-inf) = 0 for the padding
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        if (lane == 0) redf[w] = sum;
-        __syncthreads();
-        if (tid == 0) { rmax[b] = m; rlog[b] = logf(redf[0] + redf[1] + redf[2] + redf[3]); }
-        __syncthreads();
+        if (lane == 0) redf[w][b] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < WT; ++b) {
+        float x = redf[0][b];
+#pragma unroll
+        for (int k = 1; k < NWV; ++k) x += redf[k][b];
+        lg[b] = logf(x);
     }
     // ---- W ordered argmax passes; pass j only admits candidates strictly after winner j-1 in the total order
     double last_sc = INFINITY;
@@ -367,15 +412,16 @@ __global__ __launch_bounds__(256) void k_beam_select(const float* __restrict__ l
             if (!after) return;
             if (val > best || (val == best && ord < bord)) { best = val; bord = ord; }
         };
-        for (int b = 0; b < W; ++b) {
+#pragma unroll
+        for (int b = 0; b < WT; ++b) {
             if (!al[b]) continue;
             if (ib[b]) {
                 if (tid == 0) offer(sc[b], b * (V + 1));
                 continue;
             }
-            const float* z = logits + (size_t)(r0 + b) * V;
-            const float m = rmax[b], lg = rlog[b];
-            for (int v = tid; v < V; v += 256) offer(sc[b] + (double)((z[v] - m) - lg), b * (V + 1) + 1 + v);
+            const double sb = sc[b];
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) offer(sb + (double)((zv[b][k] - m[b]) - lg[b]), b * (V + 1) + 1 + tid + NT * k);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -387,7 +433,7 @@ __global__ __launch_bounds__(256) void k_beam_select(const float* __restrict__ l
         __syncthreads();
         best = redd[0]; bord = redi[0];
 #pragma unroll
-        for (int k = 1; k < 4; ++k)
+        for (int k = 1; k < NWV; ++k)
             if (redd[k] > best || (redd[k] == best && redi[k] < bord)) { best = redd[k]; bord = redi[k]; }
         __syncthreads();
         if (tid == 0) { sel_sc[j] = best; sel_ord[j] = bord; }
@@ -402,11 +448,12 @@ __global__ __launch_bounds__(256) void k_beam_select(const float* __restrict__ l
     if (tid != 0) return;
     const int round = s.iters[q] + 1;
     bool all_b = true;
-    int nib[MAXW];
+    int nib[WT];
     for (int j = 0; j < W; ++j) {
         const int r = r0 + j;
+        nib[j] = 1;
         if (!(sel_sc[j] > -INFINITY)) {
-            s.alive[r] = 0; s.inB[r] = 0; nib[j] = 1; s.emit[r] = 0; s.parent[r] = j; s.score[r] = -INFINITY; tre[j] = -2;
+            s.alive[r] = 0; s.emit[r] = 0; s.parent[r] = j; s.score[r] = -INFINITY; tre[j] = -2;
             continue;
         }
         const int b = sel_ord[j] / (V + 1), k = sel_ord[j] - b * (V + 1);
