@@ -24,6 +24,9 @@ CONFIGS = {
     # tiny shape for fast CPU-side tests (all dims multiples of 16)
     "tiny": dict(feat=1280, embed=32, vocab=64, hidden=64, joint=64, enc_layers=2,
                  pred_layers=2, pred_cell="NBRC", blank_bias=10.8, out_scale=8.0),
+    # flatter joint output: small argmax margins, so LM shallow fusion (alpha = 0.1) overrides tokens
+    "tiny_soft": dict(feat=1280, embed=32, vocab=64, hidden=64, joint=64, enc_layers=2,
+                      pred_layers=2, pred_cell="NBRC", blank_bias=2.6, out_scale=2.0),
     "tiny_lstm": dict(feat=1280, embed=32, vocab=64, hidden=64, joint=64, enc_layers=2,
                       pred_layers=2, pred_cell="LSTM", blank_bias=10.4, out_scale=8.0),
     # configs 2/3/4: 4x1024 LSTM encoder, reference predictor (2x NBRC), J=1024, V=2048
@@ -124,6 +127,43 @@ def synth_state_dict(cfg, seed=0):
     b[blank_row(cfg)] = np.float32(cfg.get("blank_bias", 0.0))
     sd["joint.joint.2.weight"] = w2
     sd["joint.joint.2.bias"] = b
+    return sd
+
+
+# language models for shallow fusion (lm.py:20-40): Embedding -> LSTM stack -> Linear (weights tied to
+# the embedding when embed == hidden, lm.py:27-29) -> log_softmax.  "lm768" is the shipped shape
+# (config/testing.yaml:308-313: 4 x 768).
+LM_CONFIGS = {
+    "tiny_lm": dict(vocab=64, embed=32, hidden=32, layers=2, emb_scale=4.0),
+    "tiny_lm_untied": dict(vocab=64, embed=16, hidden=32, layers=2, emb_scale=1.0, out_scale=40.0),
+    "lm768": dict(vocab=2048, embed=768, hidden=768, layers=4, emb_scale=1.0),
+}
+
+
+def lm_cfg(name_or_cfg):
+    return dict(LM_CONFIGS[name_or_cfg]) if isinstance(name_or_cfg, str) else dict(name_or_cfg)
+
+
+def synth_lm_state_dict(cfg, seed=100):
+    """{lm.py LM state_dict key: float32 ndarray}.  The output layer is scaled so that the log-softmax
+    is peaked: after standardisation (lm.py:50-52) the fuser only sees its shape, and with alpha = 0.1
+    only a peaked LM ever overrides the joint's choice (the tests need overrides to happen)."""
+    cfg = lm_cfg(cfg)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    V, E, H, L = cfg["vocab"], cfg["embed"], cfg["hidden"], cfg["layers"]
+    sd = {}
+    emb = (rng.standard_normal((V, E)) * cfg.get("emb_scale", 1.0)).astype(np.float32)
+    emb[0] = 0.0                                              # padding_idx=0 (lm.py:23)
+    sd["embed.weight"] = emb
+    k = 1.0 / math.sqrt(H)
+    for l in range(L):
+        i_sz = E if l == 0 else H
+        sd[f"rnn.weight_ih_l{l}"] = _uniform(rng, (4 * H, i_sz), k)
+        sd[f"rnn.weight_hh_l{l}"] = _uniform(rng, (4 * H, H), k)
+        sd[f"rnn.bias_ih_l{l}"] = _uniform(rng, (4 * H,), k)
+        sd[f"rnn.bias_hh_l{l}"] = _uniform(rng, (4 * H,), k)
+    sd["linear.weight"] = emb if E == H else _uniform(rng, (V, H), cfg.get("out_scale", 4.0) * k)
+    sd["linear.bias"] = _uniform(rng, (V,), k)
     return sd
 
 

@@ -61,10 +61,12 @@ def golden_frontend():
     print("frontend:", {k: v.shape for k, v in out.items()})
 
 
-def golden_model(name, n_sec, n_streams, store_acts):
+def golden_model(name, n_sec, n_streams, store_acts, lm_name=None):
     cfg = synth.model_cfg(name)
     sd = synth.synth_state_dict(cfg, seed=0)
     m = rf.ref_transducer(cfg, sd)
+    if lm_name:      # config.py:143-157 attaches the LM to the model; LMFuser (lm.py:43-83) uses it in both decoders
+        m.lm = rf.ref_lm(synth.lm_cfg(lm_name), synth.synth_lm_state_dict(lm_name))
     x_tfm, s_tfm, AT = rf.ref_transforms()
     pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
     out = {}
@@ -74,6 +76,11 @@ def golden_model(name, n_sec, n_streams, store_acts):
             # offline greedy (models.py:369-455)
             txt, neg_logp, metrics, extra = m.decode_greedy(feats)
             toks = [int(v) for v in txt.split()] if txt else []
+            if lm_name:  # what the LM changed (for the record): same weights without the LM
+                m_lm, m.lm = m.lm, None
+                t0 = m.decode_greedy(feats)[0]
+                m.lm = m_lm
+                out[f"off_tokens_nolm_{s}"] = np.array([int(v) for v in t0.split()] if t0 else [], dtype=np.int32)
             out[f"off_tokens_{s}"] = np.array(toks, dtype=np.int32)
             out[f"off_neglogp_{s}"] = np.float64(neg_logp)
             out[f"off_align_{s}"] = np.float64(metrics["alignment_score"])
@@ -108,13 +115,13 @@ def golden_model(name, n_sec, n_streams, store_acts):
             per_chunk, y_all = [], []
             for y, y_one, reset_fn in m.transcribe_stream(gen(), m.lang.denumericalize):
                 per_chunk.append(len(y) - len(y_all))
-                y_all = list(y)
+                y_all = [int(v) for v in y]       # with an LM, fuse() hands back 1-element tensors (lm.py:73)
             out[f"st_tokens_{s}"] = np.array(y_all, dtype=np.int32)
             out[f"st_counts_{s}"] = np.array(per_chunk, dtype=np.int32)
             nb = sum(1 for v in extra["iters"] for _ in range(1))
             print(f"  {name} s{s}: T'={feats.shape[0]} offline tokens={len(toks)} "
                   f"evals={int(np.sum(extra['iters']))} stream tokens={len(y_all)} calls={len(per_chunk)}")
-    np.savez_compressed(os.path.join(OUT, f"model_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"model_{name}{'__' + lm_name if lm_name else ''}.npz"), **out)
 
 
 def golden_flac():
@@ -138,7 +145,7 @@ if __name__ == "__main__":
     assert rf.available(), "/root/reference is required to generate goldens"
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["frontend", "tiny", "tiny_lstm", "cfg2", "cfg2_lstm", "ref6", "cfg5", "flac"]
+    which = sys.argv[1:] or ["frontend", "tiny", "tiny_lstm", "cfg2", "cfg2_lstm", "ref6", "cfg5", "flac", "lm"]
     if "frontend" in which:
         golden_frontend()
     if "tiny" in which:
@@ -153,6 +160,10 @@ if __name__ == "__main__":
         golden_model("ref6", 2.0, 1, False)       # the reference's shipped shape (config/testing.yaml:202-229)
     if "cfg5" in which:
         golden_model("cfg5", 2.0, 1, False)       # BASELINE configs[4] model shape, fp32
+    if "lm" in which:                             # LM shallow fusion, fp32 LM
+        golden_model("tiny_soft", 3.0, 3, False, lm_name="tiny_lm")
+        golden_model("tiny_lstm", 3.0, 2, False, lm_name="tiny_lm_untied")
+        golden_model("cfg2", 3.0, 1, False, lm_name="lm768")
     if "flac" in which:
         try:
             golden_flac()

@@ -198,6 +198,18 @@ class IdLang:
         return " ".join(str(int(i)) for i in ids if int(i) != 0)
 
 
+def ref_lm(cfg, state_dict):
+    """The reference's LM class (lm.py:20-40), fp32, eval.  NOT quantised: load_lm (lm.py:86-100) runs
+    torch.quantization.quantize_dynamic(int8) on it, whose numerics are un-vendored (fbgemm) -- the
+    fusion arithmetic (LMFuser, lm.py:43-83) is what the goldens pin."""
+    install_stubs()
+    from libreasr.lib.lm import LM
+    lm = LM(cfg["vocab"], cfg["embed"], cfg["hidden"], cfg["layers"], p=0.2)
+    sd = {k: torch.as_tensor(np.asarray(v)) for k, v in state_dict.items()}
+    lm.load_state_dict(sd, strict=True)
+    return lm.eval()
+
+
 def ref_transducer(cfg, state_dict=None):
     """Instantiate the reference Transducer for an oracle `cfg` dict (see synth.model_cfg)."""
     install_stubs()

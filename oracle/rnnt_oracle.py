@@ -162,6 +162,77 @@ def _sub(sd, prefix):
     return {k[n:]: np.asarray(v, dtype=F32) for k, v in sd.items() if k.startswith(prefix)}
 
 
+# ----------------------------------------------------------------------------- LM shallow fusion
+LM_ALPHA, LM_THETA, LM_MIN_VAL = F32(0.1), F32(1.0), F32(-10.0)       # lm.py:13-15
+
+
+def standardize(t, eps=1e-5):
+    """utils.py:162-164: t -= t.mean(); t /= (t.std() + eps)   (torch .std(): unbiased)."""
+    t = (t - t.mean(dtype=F32)).astype(F32)
+    return (t / (t.std(ddof=1, dtype=F32) + F32(eps))).astype(F32)
+
+
+class OracleLM:
+    """LM.forward (lm.py:20-40) for one token per call, fp32 (the reference quantises it to int8
+    dynamically, lm.py:97 -- un-vendored numerics, not restated): Embedding -> nn.LSTM stack
+    (zero initial state) -> dropout(eval) -> Linear -> log_softmax."""
+
+    def __init__(self, sd):
+        self.embed = np.asarray(sd["embed.weight"], F32)
+        self.layers = []
+        l = 0
+        while f"rnn.weight_ih_l{l}" in sd:
+            self.layers.append({k: np.asarray(sd[f"rnn.{k[:-3]}_l{l}"], F32)
+                                for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")})
+            l += 1
+        self.w = np.asarray(sd["linear.weight"], F32)
+        self.b = np.asarray(sd["linear.bias"], F32)
+        self.H = self.layers[0]["weight_hh_l0"].shape[1]
+
+    def step(self, tok, state):
+        x = self.embed[np.asarray([tok])]
+        if state is None:
+            state = [(np.zeros((1, self.H), F32), np.zeros((1, self.H), F32)) for _ in self.layers]
+        new = []
+        for p, (h, c) in zip(self.layers, state):
+            h, c = lstm_step(x, h, c, p)
+            new.append((h, c))
+            x = h
+        z = (x @ self.w.T + self.b).astype(F32)[0]
+        m = z.max()
+        lp = ((z - m) - np.log(np.exp(z - m).sum(dtype=F32))).astype(F32)
+        return lp, new
+
+
+class LMFuser:
+    """lm.py:43-83.  advance(): LM step on the emitted token, standardise, [0] = MIN_VAL.
+    fuse(): once the LM has logits, standardise the joint log-softmax, [0] = MIN_VAL, and re-pick the
+    token as argmax(alpha * lm + theta * joint).  Only ever called for a non-blank decision
+    (models.py:427-431): the blank/non-blank decision itself is never changed."""
+
+    def __init__(self, lm):
+        self.lm = lm
+        self.reset()
+
+    def reset(self):
+        self.lm_logits, self.lm_state = None, None
+
+    def advance(self, tok):
+        if self.lm is not None:
+            lp, self.lm_state = self.lm.step(tok, self.lm_state)
+            lp = standardize(lp)
+            lp[0] = LM_MIN_VAL
+            self.lm_logits = lp
+
+    def fuse(self, joint_lp, pred):
+        if self.lm is None or self.lm_logits is None:
+            return pred
+        jo = standardize(joint_lp)
+        jo[0] = LM_MIN_VAL
+        fused = (LM_ALPHA * self.lm_logits).astype(F32) + (LM_THETA * jo).astype(F32)
+        return int(fused.argmax())
+
+
 class OracleTransducer:
     """Restatement of Encoder / Predictor / Joint / Transducer.decode_greedy / transcribe_stream
     (models.py:68-187, 369-455, 457-577) + CustomRNN (custom_rnn.py:140-232)."""
@@ -192,6 +263,7 @@ class OracleTransducer:
         self.j0_b = np.asarray(sd["joint.joint.0.bias"], F32)
         self.j2_w = np.asarray(sd["joint.joint.2.weight"], F32)
         self.j2_b = np.asarray(sd["joint.joint.2.bias"], F32)
+        self.lm = None                                   # OracleLM or None (config.py:143-157 attaches it)
         if operand == "bf16":
             for i, l in enumerate(self.enc + self.pred):
                 first_pred = i == self.Le            # predictor layer 0: input side stays f32 (table)
@@ -270,6 +342,7 @@ class OracleTransducer:
         enc, _ = self.encoder(feats[None])
         enc = enc[0]
         h_pred, pstate = self.predictor([self.bos])                  # models.py:397-398
+        fuser = LMFuser(self.lm)                                     # models.py:401
         y, log_p, iters_all, outs = [], 0.0, [], []
         for t in range(enc.shape[0]):
             iters = 0
@@ -282,8 +355,10 @@ class OracleTransducer:
                 log_p += float(lp[0, pred])                          # models.py:420-422
                 if pred == self.blank:
                     break
+                pred = fuser.fuse(lp[0], pred)                       # models.py:431
                 y.append(pred)
                 h_pred, pstate = self.predictor([pred], pstate)      # models.py:437
+                fuser.advance(pred)                                  # models.py:440
             iters_all.append(iters)
         align = np.array(iters_all)
         s = align.sum()
@@ -371,11 +446,13 @@ class _StreamDecoder:
     def __init__(self, m, max_iters):
         self.m, self.max_iters = m, max_iters
         self.y = []
+        self.fuser = LMFuser(m.lm)                                    # models.py:478
         self.reset()
 
     def reset(self):                                                  # models.py:480-500
         self.enc_state = None
         self.h_pred, self.pstate = self.m.predictor([self.m.bos])
+        self.fuser.reset()                                            # models.py:491-492
 
     def step(self, chunk, return_logits=False):
         m = self.m
@@ -392,8 +469,10 @@ class _StreamDecoder:
                 pred = int(lp[0].argmax())
                 if pred == m.blank:
                     break
+                pred = self.fuser.fuse(lp[0], pred)                   # models.py:558
                 y_seq.append(pred)
                 self.h_pred, self.pstate = m.predictor([pred], self.pstate)
+                self.fuser.advance(pred)                              # models.py:569
         self.y = self.y + y_seq
         return (y_seq, outs) if return_logits else y_seq
 

@@ -115,3 +115,35 @@ def test_beam_width_1_is_the_reference_greedy(golden_dir, name):
         for t in range(0, f.shape[0], 2):
             sb.step(f[t:t + 2])
         assert sb.best()[0] == m.decode_beam(f, 4)[0]
+
+
+LM_CASES = [("tiny_soft", "tiny_lm", 3.0, 3), ("tiny_lstm", "tiny_lm_untied", 3.0, 2), ("cfg2", "lm768", 3.0, 1)]
+
+
+@pytest.mark.parametrize("name,lm_name,n_sec,n_streams", LM_CASES)
+def test_lm_shallow_fusion_matches_reference(golden_dir, name, lm_name, n_sec, n_streams):
+    """LMFuser (lm.py:43-83) inside both greedy loops, goldens from the reference with its own LM class
+    attached (fp32; the int8 dynamic quantisation of load_lm is un-vendored numerics: parity unpinned)."""
+    g = load(golden_dir, f"model_{name}__{lm_name}.npz")
+    cfg = synth.model_cfg(name)
+    m = O.OracleTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
+    m.lm = O.OracleLM(synth.synth_lm_state_dict(lm_name))
+    pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
+    changed = 0
+    for s in range(n_streams):
+        feats = O.features_offline(pcm[s])
+        toks, neg_logp, score, iters = m.decode_greedy(feats)
+        assert toks == list(g[f"off_tokens_{s}"])
+        assert iters == list(g[f"off_iters_{s}"])
+        assert abs(neg_logp - float(g[f"off_neglogp_{s}"])) < 1e-2
+        changed += toks != list(g[f"off_tokens_nolm_{s}"])
+        fe, dec = O.StreamFrontend(), m.stream_decoder()
+        counts = []
+        for c in synth.stream_chunks(pcm[s], 1280, lead=1, tail=10):
+            o = fe.push(c)
+            if o is not None:
+                counts.append(len(dec.step(o)))
+        assert dec.y == list(g[f"st_tokens_{s}"])
+        assert counts == list(g[f"st_counts_{s}"])
+    if name != "tiny_lstm":
+        assert changed > 0        # the fixture is only worth something if the LM overrides tokens
