@@ -191,6 +191,24 @@ int lasr_sync(lasr_ctx* c);
  * (0 encoder cell, 1-2 predictor layers, 3 PPJ, 4 logits): out[5][4096][16] (slots 8..15: per-wave end of the K loop). */
 int lasr_debug_timing(lasr_ctx* c, unsigned long long* out);
 
+/* ---- LM shallow fusion.  Replaces LMFuser / LM of lm.py:20-83 as wired into both greedy
+ * loops (models.py:401,431,440 / :478,558,569; attached to the model at config.py:143-157): after a
+ * non-blank decision the token is re-picked as argmax(alpha * standardize(LM log-probs) + theta *
+ * standardize(joint log-softmax)) with entry 0 forced to min_val on both sides; the LM is stepped on every
+ * emitted token.  The blank / non-blank decision and the accumulated log p are those of the joint alone.
+ * fp32 (or the ctx's bf16 operand mode); the reference additionally int8-quantises the LM dynamically
+ * (lm.py:97) -- not reproduced.  Greedy only (beam = 1).  lasr_stream_reset bit 4 resets the LM state
+ * (reset_lm, models.py:491-492); lasr_transcribe_* start every utterance with a fresh LM state.
+ * Weight blob (float32): embed.weight [V,E]; per layer l: rnn.weight_ih_l{l} [4H,I], rnn.weight_hh_l{l}
+ * [4H,H], rnn.bias_ih_l{l} [4H], rnn.bias_hh_l{l} [4H] (torch gate order i,f,g,o); linear.weight [V,H]
+ * (equal to embed.weight when tied, lm.py:27-29); linear.bias [V]. */
+typedef struct {
+    int32_t vocab, embed, hidden, layers;
+    float alpha, theta, min_val;      /* lm.py:13-15: 0.1, 1.0, -10.0 */
+} lasr_lm_desc;
+size_t lasr_lm_weight_count(const lasr_lm_desc* d);
+int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, size_t n_weights);
+
 /* Roofline micro-benchmark of the dominant kernel (one encoder LSTM-cell launch: all rows active,
  * layer `layer`), `iters` back-to-back launches timed with HIP events on the ctx stream.
  * Returns average microseconds per launch in *us. */

@@ -63,7 +63,14 @@ SYMBOLS = [
     ("lasr_sync", C.c_int, [_P]),
     ("lasr_debug_timing", C.c_int, [_P, _P]),
     ("lasr_bench_cell", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    ("lasr_lm_weight_count", C.c_size_t, [_P]),
+    ("lasr_attach_lm", C.c_int, [_P, _P, _P, C.c_size_t]),
 ]
+
+
+class LmDesc(C.Structure):          # lasr_lm_desc
+    _fields_ = [("vocab", C.c_int32), ("embed", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32),
+                ("alpha", C.c_float), ("theta", C.c_float), ("min_val", C.c_float)]
 
 _lib = None
 

@@ -117,6 +117,22 @@ struct lasr_ctx {
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
     bool use_graphs = true;
 
+    // LM shallow fusion (lasr_attach_lm): Embedding -> LSTM stack -> Linear -> log_softmax, stepped once
+    // per emitted token for the rows that emitted (same compacted cell kernels as the predictor)
+    struct LM {
+        bool on = false;
+        int E = 0, H = 0, L = 0;
+        float alpha = 0.1f, theta = 1.0f, min_val = -10.0f;
+        std::vector<Cell> cells;        // tiling "A"; layer 0 input side = per-token table
+        void* Wout = nullptr; float* bout = nullptr;
+        float *ones = nullptr, *zeros = nullptr;       // "BatchNorm fold" of a plain LSTM: y = h
+        std::vector<void*> h[2], y;     // row-major [M][H], element-typed; h ping-pongs
+        std::vector<float*> cst;        // [H][M]
+        int par = 0;
+        float *raw = nullptr, *lmz = nullptr;          // [M][V] output-layer logits / standardised log-probs
+        int* valid = nullptr;
+    } lm;
+
     // time-series buffers (capacity Tcap frames)
     int Tcap = 0;
     void *x0 = nullptr, *ybuf[2] = {nullptr, nullptr};   // element-typed, fragment-major
@@ -395,8 +411,49 @@ void launch_ppj(lasr_ctx* c, bool beam = false) {
 }
 float* cur_pp(lasr_ctx* c) { return (c->W > 1 && c->pred_par) ? c->pp1 : c->pp; }
 
+template <bool AROW, int D>
+void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea);
+
+// LMFuser.advance (lm.py:49-53) for the rows with emit != 0: LM step on the token just emitted, then
+// log_softmax + standardise + [0] = MIN_VAL into lmz (read by the next k_select of that row)
+template <class Ops>
+void launch_lm_t(lasr_ctx* c) {
+    lasr_ctx::LM& m = c->lm;
+    const int H = m.H, M = c->M, V = c->d.vocab, p = m.par;
+    for (int l = 0; l < m.L; ++l) {
+        const Cell& L = m.cells[l];
+        GemmArgs g{};
+        if (l > 0) { g.A[0] = m.y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA; }
+        g.A[1] = m.h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhA;
+        g.compact = c->ds.emit; g.M = M;
+        typename EpiLSTM<Ops, true, true, 4>::Args ea{};
+        ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
+        ea.c = m.cst[l]; ea.h_in = m.h[p][l]; ea.h_out = m.h[p ^ 1][l]; ea.y = m.y[l];
+        ea.bn_s = m.ones; ea.bn_t = m.zeros; ea.H = H; ea.M = M; ea.MT = c->MT;
+        if (l == 0) {
+            launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, M / (16 * MTA), g, ea);
+        } else {
+            typename EpiLSTM<Ops, true, false, 4>::Args eb{};
+            memcpy(&eb, &ea, sizeof(eb));
+            launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, M / (16 * MTA), g, eb);
+        }
+    }
+    m.par ^= 1;
+    GemmArgs g{};
+    g.A[0] = m.y[m.L - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.W[0] = m.Wout; g.a_rows = M;
+    EpiLinear::Args ea{};
+    ea.bias = m.bout; ea.out = m.raw; ea.ldo = V; ea.n_rows = M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
+    launch_linear<true, -1>(c, V / 16, M / 16, g, H, ea);
+    hipLaunchKernelGGL(k_lm_post, dim3(M), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val);
+}
+void launch_lm(lasr_ctx* c) {
+    if (!c->lm.on) return;
+    if (c->bf) launch_lm_t<OpsBF16>(c);
+    else launch_lm_t<OpsF32>(c);
+}
+
 // plain linear over element-typed A (fragment-major, or row-major when AROW); f32 row-major output
-template <bool AROW, int D = 3>
+template <bool AROW, int D>
 void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea) {
     g.KC[0] = K / c->kch;
     if (c->bf) launch_gemm<OpsBF16, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
@@ -536,6 +593,12 @@ int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3, bool plain_rows = fals
     }
     a.token = c->ds.token; a.emit = c->ds.emit;
     hipLaunchKernelGGL(k_reset_rows, dim3(grid1((size_t)c->M * c->d.hidden)), dim3(256), 0, c->stream, a);
+    if (c->lm.on && (mask & 2)) {      // LM state lives on the decode side, like the predictor's
+        LmResetArgs la{};
+        la.what = c->dc.what; la.M = c->M; la.H = c->lm.H; la.L = c->lm.L; la.bf = c->bf; la.lm_valid = c->lm.valid;
+        for (int l = 0; l < c->lm.L; ++l) { la.h[l] = c->lm.h[c->lm.par][l]; la.c[l] = c->lm.cst[l]; }
+        hipLaunchKernelGGL(k_lm_reset, dim3(grid1((size_t)c->M * c->lm.H)), dim3(256), 0, c->stream, la);
+    }
     if (any_pred) {
         // T_row = 0 for every row: EpiPPJ then only refreshes pp (models.py:489: predictor(BOS))
         int* keep_dec = c->T_row_dec;
@@ -572,7 +635,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
     EpiLinear::Args ea{};
     ea.bias = nullptr; ea.out = c->pe; ea.ldo = J; ea.n_rows = T_max * c->M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
     if (c->pe == c->pe_ring) { ea.ring_base = c->c_enc_frames; ea.ring = lasr_ctx::RING; }   // continuous mode: per-row frame ring
-    launch_linear<false>(c, J / 16, T_max * c->MT, g, H, ea);
+    launch_linear<false, 3>(c, J / 16, T_max * c->MT, g, H, ea);
 }
 
 // Greedy decode of the current step (T_row_dev, pe ready).  Blocks until done; fills host queues.
@@ -616,6 +679,7 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
                                c->T_row_dec, s, it, (float*)nullptr, (int*)nullptr);
             launch_predictor(c);
             launch_ppj(c);
+            launch_lm(c);
         }
         // payload first, the "rows still decoding" word last: the host spins on that word
         HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * ((size_t)M + (size_t)M * s.tok_cap), hipMemcpyDeviceToHost, c->stream));
@@ -631,7 +695,7 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
         const int n = std::min(group, total_cap - iter);
         bool launched = false;
         if (graphs && (n % 2) == 0) {
-            const auto key = std::make_tuple(iter, n, buf_idx, c->pred_par, T_max * 1024 + max_iters);
+            const auto key = std::make_tuple(iter, n, buf_idx, c->pred_par + 2 * c->lm.par, T_max * 1024 + max_iters);
             auto it = c->graphs.find(key);
             if (it == c->graphs.end()) {
                 hipGraph_t gr = nullptr;
@@ -1209,22 +1273,22 @@ int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
     HIPCHK(c, hipSetDevice(c->device));
     if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); c->neg_logp[slot] = 0.0; }
     if (what & 2) beam_host_reset(c, slot, (what & 8) != 0);
-    if (what & 3) {
+    if (what & 7) {
         RC(cmd_begin(c));
-        c->hc.what[slot] = what & 3;
+        c->hc.what[slot] = what & 7;
         RC(cmd_commit(c));
         if (c->pending.empty() && !c->group_inflight) {
             RC(apply_reset(c, (what & 2) != 0));
         } else {
             // other streams have steps in flight: the encoder side of the reset is ordered on the main
-            // stream, the predictor side (BOS pass) on the decode stream, between two iteration groups
+            // stream, the predictor / LM side (BOS pass) on the decode stream, between two iteration groups
             if (what & 1) RC(apply_reset(c, false, 1));
-            if (what & 2) {
+            if (what & 6) {
                 HIPCHK(c, hipEventRecord(c->ev_misc, c->stream));
                 hipStream_t keep = c->stream;
                 HIPCHK(c, hipStreamWaitEvent(c->stream_dec, c->ev_misc, 0));
                 c->stream = c->stream_dec;
-                int rc = apply_reset(c, true, 2);
+                int rc = apply_reset(c, (what & 2) != 0, 2);
                 c->stream = keep;
                 if (rc) return rc;
             }
@@ -1471,6 +1535,7 @@ static int cont_launch_group(lasr_ctx* c, int G) {
                            c->c_avail, s, slot, (float*)nullptr, (int*)nullptr);
         launch_predictor(c);
         launch_ppj(c);
+        launch_lm(c);
     }
     __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
     HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1581,7 +1646,7 @@ int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, 
     long long off = 0;
     for (int i = 0; i < n; ++i) {
         const int s = slots[i];
-        c->hc.T_row[s] = Tp[i]; c->hc.what[s] = 3; c->hc.row_frames[s] = Tm[i];
+        c->hc.T_row[s] = Tp[i]; c->hc.what[s] = 7; c->hc.row_frames[s] = Tm[i];
         c->hc.row_N[s] = n_samples[i]; c->hc.row_src_off[s] = off;
         off += n_samples[i];
         c->queue[s].clear();
@@ -1631,7 +1696,7 @@ int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* fea
     long long off = 0;
     for (int i = 0; i < n; ++i) {
         const int s = slots[i];
-        c->hc.T_row[s] = n_frames[i]; c->hc.what[s] = 3; c->hc.row_feat_off[s] = off;
+        c->hc.T_row[s] = n_frames[i]; c->hc.what[s] = 7; c->hc.row_feat_off[s] = off;
         off += n_frames[i];
         c->queue[s].clear();
         c->neg_logp[s] = 0.0;
@@ -1822,9 +1887,9 @@ int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, floa
         }
         GemmArgs g{}; g.A[0] = ap; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.W[0] = c->W1p; g.a_rows = B;
         EpiLinear::Args ea{}; ea.bias = c->b1; ea.out = c->pp; ea.ldo = J; ea.n_rows = B; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
-        launch_linear<true>(c, J / 16, (B + 15) / 16, g, H, ea);
+        launch_linear<true, 3>(c, J / 16, (B + 15) / 16, g, H, ea);
         g.A[0] = ae; g.W[0] = c->W1e; ea.bias = nullptr; ea.out = c->pe;
-        launch_linear<true>(c, J / 16, (B + 15) / 16, g, H, ea);
+        launch_linear<true, 3>(c, J / 16, (B + 15) / 16, g, H, ea);
     }
     hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)c->M * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)c->pp,
                        (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MTd, 1 << 30, c->bf, 1, c->M);
@@ -1835,6 +1900,77 @@ int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, floa
                            (const int*)nullptr, s, 0, logp_max, argmax);
     }
     HIPCHK(c, hipGetLastError());
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- LM shallow fusion
+size_t lasr_lm_weight_count(const lasr_lm_desc* d) {
+    if (!d || d->vocab <= 0 || d->embed <= 0 || d->hidden <= 0 || d->layers < 1 || d->layers > 8) return 0;
+    const size_t V = d->vocab, E = d->embed, H = d->hidden;
+    size_t n = V * E;
+    for (int l = 0; l < d->layers; ++l) n += 4 * H * (l == 0 ? E : H) + 4 * H * H + 8 * H;
+    return n + V * H + V;
+}
+
+int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, size_t n_weights) {
+    if (!c) return LASR_EINVAL;
+    if (c->lm.on) return fail(c, LASR_ESTATE, "an LM is already attached");
+    if (c->W > 1) return fail(c, LASR_ESTATE, "LM shallow fusion is implemented for greedy decoding (beam = 1)");
+    if (!d || !weights || n_weights != lasr_lm_weight_count(d) || n_weights == 0)
+        return fail(c, LASR_EINVAL, "LM weight blob has %zu floats, expected %zu", n_weights, d ? lasr_lm_weight_count(d) : (size_t)0);
+    if (d->vocab != c->d.vocab) return fail(c, LASR_EINVAL, "LM vocabulary %d != model vocabulary %d", d->vocab, c->d.vocab);
+    if (d->vocab > 4096) return fail(c, LASR_EINVAL, "LM fusion keeps a row's log-probs in registers: vocab <= 4096");
+    if (d->embed % 16 || d->hidden % (c->bf ? 32 : 16)) return fail(c, LASR_EINVAL, "LM dims must be multiples of 16 (hidden: 32 for bf16)");
+    RC(require_idle(c));
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    lasr_ctx::LM& m = c->lm;
+    const int V = d->vocab, E = d->embed, H = d->hidden, L = d->layers, M = c->M;
+    m.E = E; m.H = H; m.L = L; m.alpha = d->alpha; m.theta = d->theta; m.min_val = d->min_val;
+    Reader rd{weights, n_weights};
+    const float* embed = rd.take((size_t)V * E);
+    m.cells.resize(L);
+    std::vector<float> in0_w, in0_b;
+    for (int l = 0; l < L; ++l) RC(load_lstm(c, rd, m.cells[l], l == 0 ? E : H, H, true, l == 0 ? &in0_w : nullptr, l == 0 ? &in0_b : nullptr));
+    const float* wout = rd.take((size_t)V * H); const float* bout = rd.take(V);
+    if (!bout || rd.left != 0) return fail(c, LASR_EINVAL, "LM weight blob layout mismatch");
+    {
+        Packed pk;
+        pack_tiles(pk, c->bf, V / 16, H, [&](int t, int ui, int k) { return wout[(size_t)(16 * t + ui) * H + k]; });
+        RC(upload_packed(c, &m.Wout, pk));
+        RC(upload(c, &m.bout, bout, V));
+        std::vector<float> one(H, 1.f), zero(H, 0.f);
+        RC(upload(c, &m.ones, one.data(), H)); RC(upload(c, &m.zeros, zero.data(), H));
+    }
+    {   // layer-0 input table (exact f32, as for the predictor): tab[v] = embed[v] * W_ih0^T + (b_ih + b_hh)
+        float* emb_dev = nullptr; void* wt = nullptr; float* bt = nullptr;
+        RC(upload(c, &emb_dev, embed, (size_t)V * E));
+        Packed pk;
+        pack_tiles(pk, 0, 4 * H / 16, E, [&](int t, int ui, int k) { return in0_w[(size_t)(16 * t + ui) * E + k]; });
+        RC(upload_packed(c, &wt, pk)); RC(upload(c, &bt, in0_b.data(), in0_b.size()));
+        RC(dalloc(c, &m.cells[0].tab, (size_t)V * 4 * H));
+        GemmArgs g{}; g.A[0] = emb_dev; g.a_mt_total[0] = E; g.a_mt_off[0] = 0; g.KC[0] = E / 16; g.W[0] = wt; g.a_rows = V;
+        EpiLinear::Args ea{}; ea.bias = bt; ea.out = m.cells[0].tab; ea.ldo = 4 * H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
+        launch_gemm<OpsF32, EpiLinear, 1, true>(c, 4 * H / 16, V / 16, g, ea);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        dfree(c, emb_dev); dfree(c, wt); dfree(c, bt);
+        // the x-side weights of layer 0 are folded into the table; its packed copy is not needed
+        dfree(c, m.cells[0].WxA); m.cells[0].WxA = nullptr;
+    }
+    for (int p = 0; p < 2; ++p) m.h[p].resize(L);
+    m.y.resize(L); m.cst.resize(L);
+    for (int l = 0; l < L; ++l) {
+        for (int p = 0; p < 2; ++p) { RC(dalloc(c, (char**)&m.h[p][l], (size_t)M * H * c->esz)); HIPCHK(c, hipMemset(m.h[p][l], 0, (size_t)M * H * c->esz)); }
+        RC(dalloc(c, (char**)&m.y[l], (size_t)M * H * c->esz)); HIPCHK(c, hipMemset(m.y[l], 0, (size_t)M * H * c->esz));
+        RC(dalloc(c, &m.cst[l], (size_t)M * H)); HIPCHK(c, hipMemset(m.cst[l], 0, sizeof(float) * (size_t)M * H));
+    }
+    RC(dalloc(c, &m.raw, (size_t)M * V)); RC(dalloc(c, &m.lmz, (size_t)M * V)); RC(dalloc(c, &m.valid, M));
+    HIPCHK(c, hipMemset(m.lmz, 0, sizeof(float) * (size_t)M * V)); HIPCHK(c, hipMemset(m.valid, 0, sizeof(int) * M));
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);   // decode groups change shape
+    c->graphs.clear();
+    c->ds.lmz = m.lmz; c->ds.lm_valid = m.valid; c->ds.lm_alpha = m.alpha; c->ds.lm_theta = m.theta; c->ds.lm_min = m.min_val;
+    m.on = true;
     return LASR_OK;
 }
 

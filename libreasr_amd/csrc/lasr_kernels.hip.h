@@ -169,7 +169,21 @@ struct DecState {
     int* ntok_end;     // [M][end_slots] tokens emitted when row r finished its step j (slot j % end_slots)
     int step_T;        // frames per model step (n_buffer)
     int end_slots;
+    // LM shallow fusion (LMFuser.fuse, lm.py:59-79): standardised LM log-probs of the row's last token
+    const float* lmz;  // [M][V] (nullptr: no LM attached)
+    const int* lm_valid; // [M] the LM has advanced at least once since the last LM reset
+    float lm_alpha, lm_theta, lm_min;
 };
+
+// block-wide sum over 256 threads (4 waves); every thread gets the result
+__device__ __forceinline__ float block_sum_256(float x, float* sh4, int lane, int w) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    __syncthreads();                                 // sh4 may still be read from a previous use
+    if (lane == 0) sh4[w] = x;
+    __syncthreads();
+    return sh4[0] + sh4[1] + sh4[2] + sh4[3];
+}
 
 // frames of newly encoded steps become visible to the decode loop (continuous mode)
 __global__ void k_advance(int* __restrict__ counter, const int* __restrict__ add, int M) {
@@ -253,9 +267,67 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if (lane == 0) ss[w] = sum;
     __syncthreads();
-    if (tid != 0) return;
     sum = ss[0] + ss[1] + ss[2] + ss[3];
     const float logp = -logf(sum);       // log_softmax at the argmax = z_max - logsumexp
+    if (!PLAIN && s.lmz && arg != blank && s.lm_valid[r]) {
+        // LMFuser.fuse (lm.py:59-79), only for a non-blank decision (models.py:427-431; uniform over
+        // the workgroup): standardise the joint log-softmax (utils.py:162-164: subtract the mean,
+        // divide by the unbiased std + 1e-5), entry 0 = MIN_VAL, re-pick argmax(alpha*lm + theta*joint).
+        // V <= 4096 (checked at lasr_attach_lm): every value of the row is in zv[].
+        __shared__ float sh4[4];
+        const float lse = logf(sum);
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) {
+            const int j = tid + 256 * q;
+            zv[q] = j < V ? (zv[q] - best) - lse : 0.f;        // log-softmax; padding contributes nothing
+            part += zv[q];
+        }
+        const float mean = block_sum_256(part, sh4, lane, w) / (float)V;
+        part = 0.f;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) {
+            const int j = tid + 256 * q;
+            zv[q] = j < V ? zv[q] - mean : 0.f;                // t.add_(-t.mean())
+            part += zv[q];
+        }
+        const float mean2 = block_sum_256(part, sh4, lane, w) / (float)V;   // torch.std subtracts its own mean again
+        part = 0.f;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) {
+            const int j = tid + 256 * q;
+            const float d = j < V ? zv[q] - mean2 : 0.f;
+            part += d * d;
+        }
+        const float sd = sqrtf(block_sum_256(part, sh4, lane, w) / (float)(V - 1));
+        const float den = sd + 1e-5f;
+        const float* lz = s.lmz + (size_t)r * V;
+        float fb = -INFINITY;
+        int fa = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) {
+            const int j = tid + 256 * q;
+            if (j >= V) continue;
+            const float jo = j == 0 ? s.lm_min : zv[q] / den;
+            const float f = __fadd_rn(__fmul_rn(s.lm_alpha, lz[j]), __fmul_rn(s.lm_theta, jo));   // no FMA contraction
+            if (f > fb) { fb = f; fa = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(fb, o);
+            const int oa = __shfl_xor(fa, o);
+            if (ob > fb || (ob == fb && oa < fa)) { fb = ob; fa = oa; }
+        }
+        __syncthreads();
+        if (lane == 0) { sv[w] = fb; si[w] = fa; }
+        __syncthreads();
+        fb = sv[0]; fa = si[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (sv[q] > fb || (sv[q] == fb && si[q] < fa)) { fb = sv[q]; fa = si[q]; }
+        arg = fa;                        // the emitted token; log p stays the unfused one (models.py:422)
+    }
+    if (tid != 0) return;
     if (PLAIN) {
         out_logp[r] = logp;
         out_arg[r] = arg;
@@ -287,6 +359,85 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     }
     s.iters[r] = it;
     if (s.cont ? (t < s.target[r]) : (t < Tr)) atomicAdd(&s.unfinished[iter_slot], 1);
+}
+
+// LMFuser.advance (lm.py:49-53) for the rows that just emitted a token: log_softmax of the LM's output
+// layer, standardise (utils.py:162-164), entry 0 = MIN_VAL.  One workgroup per row, V <= 4096.
+__global__ __launch_bounds__(256) void k_lm_post(const float* __restrict__ raw, const int* __restrict__ emit,
+                                                 float* __restrict__ lmz, int* __restrict__ lm_valid, int V, float min_val) {
+    constexpr int KEEP = 16;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (!emit[r]) return;
+    __shared__ float sh4[4];
+    const float* z = raw + (size_t)r * V;
+    float zv[KEEP];
+    float best = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) {
+        const int j = tid + 256 * q;
+        zv[q] = j < V ? z[j] : -INFINITY;
+        best = fmaxf(best, zv[q]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+    if (lane == 0) sh4[w] = best;
+    __syncthreads();
+    best = fmaxf(fmaxf(sh4[0], sh4[1]), fmaxf(sh4[2], sh4[3]));
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) part += expf(zv[q] - best);
+    const float lse = logf(block_sum_256(part, sh4, lane, w));
+    part = 0.f;
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) {
+        const int j = tid + 256 * q;
+        zv[q] = j < V ? (zv[q] - best) - lse : 0.f;
+        part += zv[q];
+    }
+    const float mean = block_sum_256(part, sh4, lane, w) / (float)V;
+    part = 0.f;
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) {
+        const int j = tid + 256 * q;
+        zv[q] = j < V ? zv[q] - mean : 0.f;
+        part += zv[q];
+    }
+    const float mean2 = block_sum_256(part, sh4, lane, w) / (float)V;
+    part = 0.f;
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) {
+        const int j = tid + 256 * q;
+        const float d = j < V ? zv[q] - mean2 : 0.f;
+        part += d * d;
+    }
+    const float den = sqrtf(block_sum_256(part, sh4, lane, w) / (float)(V - 1)) + 1e-5f;
+    float* o = lmz + (size_t)r * V;
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) {
+        const int j = tid + 256 * q;
+        if (j < V) o[j] = j == 0 ? min_val : zv[q] / den;
+    }
+    if (tid == 0) lm_valid[r] = 1;
+}
+
+// LMFuser.reset (lm.py:81-83) for rows flagged with bit 4: no logits, zero LSTM state
+struct LmResetArgs {
+    const int* what;
+    int M, H, L, bf;
+    void* h[8];          // current parity, row-major [M][H]
+    float* c[8];         // [H][M]
+    int* lm_valid;
+};
+__global__ void k_lm_reset(const LmResetArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.M * a.H) return;
+    const int r = idx / a.H, u = idx - r * a.H;
+    if (!(a.what[r] & 4)) return;
+    if (u == 0) a.lm_valid[r] = 0;
+    for (int l = 0; l < a.L; ++l) {
+        act_st(a.bf, a.h[l], (size_t)r * a.H + u, 0.f);
+        a.c[l][(size_t)u * a.M + r] = 0.f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from .weights import flatten_state_dict, infer_cfg
+from .weights import flatten_lm_state_dict, flatten_state_dict, infer_cfg
 
 FRONTEND_DEFAULTS = dict(n_fft=1024, win=400, hop=160, n_mels=128, n_stack=10, stride=8, n_buffer=2,
                          n_window=3, chunk=1280, sample_rate=16000)
@@ -75,6 +75,14 @@ class Engine:
             self.ctx = None
             raise N.LasrError(rc, msg)
         self.max_streams = int(max_streams)
+
+    def attach_lm(self, lm_state_dict, alpha=0.1, theta=1.0, min_val=-10.0):
+        """LM shallow fusion (lm.py LM / LMFuser; constants lm.py:13-15).  fp32 / bf16 operands like the
+        model; the reference's int8 dynamic quantisation of the LM is not reproduced."""
+        cfg, blob = flatten_lm_state_dict(lm_state_dict)
+        d = N.LmDesc(cfg["vocab"], cfg["embed"], cfg["hidden"], cfg["layers"], alpha, theta, min_val)
+        self._chk(self.lib.lasr_attach_lm(self.ctx, C.byref(d), blob.ctypes.data_as(C.c_void_p), blob.size))
+        self.lm_cfg = cfg
 
     # ------------------------------------------------------------------ plumbing
     def _chk(self, rc):

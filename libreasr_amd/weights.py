@@ -78,3 +78,26 @@ def flatten_state_dict(sd, cfg):
     take("joint.joint.2.weight", (V, J))
     take("joint.joint.2.bias", (V,))
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+def flatten_lm_state_dict(sd):
+    """LM (lm.py:20-40) state_dict -> (cfg, float32 blob) in the order lasr_attach_lm expects.  Accepts
+    torch tensors or arrays; `linear.weight` may be absent when it is tied to `embed.weight`."""
+    emb = _np(sd["embed.weight"])
+    V, E = emb.shape
+    parts = [emb.reshape(-1)]
+    l = 0
+    H = None
+    while f"rnn.weight_ih_l{l}" in sd:
+        w_ih, w_hh = _np(sd[f"rnn.weight_ih_l{l}"]), _np(sd[f"rnn.weight_hh_l{l}"])
+        H = w_hh.shape[1]
+        assert w_ih.shape == (4 * H, E if l == 0 else H) and w_hh.shape == (4 * H, H)
+        parts += [w_ih.reshape(-1), w_hh.reshape(-1), _np(sd[f"rnn.bias_ih_l{l}"]).reshape(-1),
+                  _np(sd[f"rnn.bias_hh_l{l}"]).reshape(-1)]
+        l += 1
+    assert l >= 1, "no rnn.weight_ih_l0 in the LM state_dict"
+    w = _np(sd["linear.weight"]) if "linear.weight" in sd else emb
+    assert w.shape == (V, H)
+    parts += [w.reshape(-1), _np(sd["linear.bias"]).reshape(-1)]
+    cfg = dict(vocab=int(V), embed=int(E), hidden=int(H), layers=l)
+    return cfg, np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
