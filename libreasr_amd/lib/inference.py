@@ -24,7 +24,24 @@ def load_state_dict(path):
     return {k: v for k, v in sd.items() if torch.is_tensor(v)}
 
 
-def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_streams=16, device=0):
+def load_lm_state_dict(conf, synthetic_lm=None):
+    """config.py:140-147 + lm.py:86-100: the LM is loaded when `lm.enable` and `lm.path` resolve; a
+    failure to load is not fatal in the reference ("[LM] Failed to load.").  fp32 (no int8 quantisation)."""
+    if synthetic_lm is not None:
+        return synth.synth_lm_state_dict(synthetic_lm)
+    lm = (conf.get("lm", {}) or {}) if conf else {}
+    if not lm.get("enable") or not lm.get("path") or not os.path.exists(lm["path"]):
+        return None
+    try:
+        sd = torch.load(lm["path"], map_location="cpu")
+        return {k: v for k, v in sd.items() if torch.is_tensor(v)}
+    except Exception:
+        print("[LM] Failed to load.")
+        return None
+
+
+def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_streams=16, device=0,
+               synthetic_lm=None, dtype="f32", beam=1):
     torch.set_num_threads(2)                # inference.py:21
     conf, cfg, sd = {}, None, None
     if os.path.exists(config_path):
@@ -38,7 +55,11 @@ def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_st
         cfg = model_cfg_from_conf(conf) if "model" in conf else infer_cfg(sd)
     n_stack, downsample, n_buffer = stream_settings(conf) if conf else (10, 8, 2)
     eng = Engine(sd, cfg, max_streams=max_streams, device=device, n_stack=n_stack, stride=downsample,
-                 n_buffer=n_buffer)
+                 n_buffer=n_buffer, dtype=dtype, beam=beam)
+    lm_sd = load_lm_state_dict(conf, synthetic_lm)
+    if lm_sd is not None and beam == 1:
+        eng.attach_lm(lm_sd)
+        print("[LM] loaded.")
     tok = ((conf.get("tokenizer", {}) or {}).get("model_file")) if conf else None
     language = get_language(tok if tok and os.path.exists(tok) else None)
     model = Transducer(eng, language)

@@ -154,3 +154,18 @@ def test_lm_attach_errors():
     with pytest.raises(N.LasrError):
         eng.attach_lm(synth.synth_lm_state_dict("tiny_lm"))   # greedy only
     eng.close()
+
+
+def test_lm_through_the_facade(golden_dir):
+    """LibreASR.load(..., synthetic_lm=...) == config.py:140-157 attaching the LM at load time."""
+    from libreasr_amd.api import LibreASR
+    g = np.load(os.path.join(golden_dir, "model_tiny_soft__tiny_lm.npz"))
+    asr = LibreASR.load("en", synthetic="tiny_soft", synthetic_lm="tiny_lm", max_streams=4)
+    pcm = synth.synth_pcm(3, 16000 * 3, seed=1234)
+    ids = asr.transcribe([pcm[0], pcm[1]], return_ids=True)
+    assert ids[0] == list(g["off_tokens_0"]) and ids[1] == list(g["off_tokens_1"])
+    last = None
+    for y in asr.stream(synth.stream_chunks(pcm[2], 1280, lead=1, tail=10), return_ids=True):
+        last = y
+    assert last == list(g["st_tokens_2"])
+    asr.engine.close()
