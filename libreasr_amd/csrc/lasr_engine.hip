@@ -47,6 +47,11 @@ struct lasr_ctx {
     int M = 0, MT = 0;         // padded rows (stream slots), m-tiles
     int W = 1;                 // beam width (hypothesis slots per stream); 1 = greedy
     int Md = 0, MTd = 0;       // decoder rows = M * W (row = stream * W + slot), m-tiles
+    static constexpr int LA_MAX = 4;
+    int la = 1;                // greedy lookahead: frames evaluated per row and iteration (1 with an LM or a beam)
+    int la_stream = 1, la_offline = 3;   // measured on configs[1]: streaming steps have 2 frames and the per-iteration
+                               // cost of a wider logits GEMM cancels the saved iterations; offline (258 frames) gains 10 %
+    int MTj = 0;               // m-tiles of the ja / logits row space: max(Md, LA_MAX * M) / 16
     int bf = 0;                // 1: bf16 operands (weights + GEMM-input activations), f32 accumulate / state / logits
     int kch = 16;              // k per MFMA chunk (16 f32, 32 bf16)
     size_t esz = 4;            // bytes per operand element
@@ -112,6 +117,7 @@ struct lasr_ctx {
     long long inflight_for = -1;    // serial of the pending step the in-flight group's flag refers to
     long long done_serial = -1;     // serial of a pending step already known to be fully decoded
     int kick_iters = 0;
+    int kick_n = 4, wait_n = 2;     // iterations per group: kicked from submit / launched while waiting
     // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
     // predictor parity at group start, frames)
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
@@ -400,7 +406,7 @@ void launch_ppj_t(lasr_ctx* c, bool beam) {
     g.compact = c->ds.emit; g.M = c->Md; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 16 : nullptr;
     typename EpiPPJ<Ops>::Args ea{};
     ea.b1 = c->b1; ea.pp = (beam && !p) ? c->pp1 : c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
-    ea.ja = c->ja; ea.J = J; ea.M = c->Md; ea.MT = c->MTd; ea.ring = c->pe_ring_R;
+    ea.ja = c->ja; ea.J = J; ea.M = c->Md; ea.MT = c->MTj; ea.ring = c->pe_ring_R; ea.la = beam ? 1 : c->la;
     if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.M_enc = c->M; ea.pp_in = p ? c->pp1 : c->pp; }
     launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
     if (beam) c->pred_par ^= 1;
@@ -463,7 +469,7 @@ void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, c
 void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     const int J = c->d.joint, V = c->d.vocab;
     GemmArgs g{};
-    g.A[0] = c->ja; g.a_mt_total[0] = c->MTd; g.a_mt_off[0] = 0; g.W[0] = c->W2; g.M = c->Md;
+    g.A[0] = c->ja; g.a_mt_total[0] = c->MTj; g.a_mt_off[0] = 0; g.W[0] = c->W2; g.M = c->Md;
     g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)4 * 4096 * 16 : nullptr;
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
@@ -644,6 +650,7 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
 int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows) {
     if (c->W > 1) return run_decode_beam(c, T_max, max_iters, offline, rows);
     const int M = c->M, J = c->d.joint, V = c->d.vocab;
+    c->la = offline ? c->la_offline : c->la_stream;
     DecState s = c->ds;
     s.tok_cap = T_max * max_iters;
     const int total_cap = T_max * max_iters;
@@ -652,7 +659,8 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
     // its start); after each group the "rows still decoding" counter and the step's tokens so far
     // come back in the same round trip.  In streaming mode every group is a cached hipGraph: one
     // launch instead of 4 kernels per iteration, so the GPU is not fed at host launch speed.
-    int group = offline ? std::min(total_cap, (T_max + 16) & ~1) : std::min(total_cap, (T_max + 4) & ~1);
+    // (with lookahead a row consumes up to `la` blank frames per iteration: fewer iterations up front)
+    int group = offline ? std::min(total_cap, ((T_max + c->la - 1) / c->la + 16) & ~1) : std::min(total_cap, (T_max + 4) & ~1);
     const int next_group = offline ? 32 : 4;
     int* res = c->res_host;
     int* ntok = res + 4;
@@ -669,14 +677,14 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
             hipLaunchKernelGGL(k_step_begin, dim3(grid1(std::max(M, c->n_iter_slots))), dim3(256), 0, c->stream, s, M,
                                c->n_iter_slots, offline ? 1 : 0);
             hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->dec_t_idx,
-                               c->T_row_dec, c->ja, J, M, c->MT, c->pe_ring_R, c->bf, 1, M);
+                               c->T_row_dec, c->ja, J, M, c->MTj, c->pe_ring_R, c->bf, 1, M, c->la);
         }
         for (int q = 0; q < n; ++q) {
             const int it = first + q;
             c->dbg_gate = (it == 0);
-            launch_logits(c, c->logits, M, true);
+            launch_logits(c, c->logits, c->la * M, true);
             hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, max_iters,
-                               c->T_row_dec, s, it, (float*)nullptr, (int*)nullptr);
+                               c->T_row_dec, s, it, (float*)nullptr, (int*)nullptr, c->la, M);
             launch_predictor(c);
             launch_ppj(c);
             launch_lm(c);
@@ -756,7 +764,7 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
     int* res = c->res_host;
     hipLaunchKernelGGL(k_beam_begin, dim3(grid1(std::max(Md, c->n_iter_slots))), dim3(256), 0, c->stream, b, M, c->n_iter_slots);
     hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)Md * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)cur_pp(c),
-                       (const int*)c->dec_t_idx, (const int*)c->T_row_dec, c->ja, J, Md, c->MTd, c->pe_ring_R, c->bf, W, M);
+                       (const int*)c->dec_t_idx, (const int*)c->T_row_dec, c->ja, J, Md, c->MTj, c->pe_ring_R, c->bf, W, M, 1);
     int iter = 0;
     int group = offline ? std::min(total_cap, T_max + 16) : std::min(total_cap, T_max + 4);
     const int next_group = offline ? 32 : 4;
@@ -1019,6 +1027,16 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     const int M = c->M;
     c->W = d.beam; c->Md = M * c->W; c->MTd = c->Md / 16;
     const int Md = c->Md;
+    c->MTj = std::max(c->Md, lasr_ctx::LA_MAX * M) / 16;
+    {   // frames evaluated per row and iteration in the greedy loop (see k_select); measured best on configs[1]
+        const char* e = getenv("LASR_LOOKAHEAD");
+        if (e) c->la_stream = c->la_offline = std::min(lasr_ctx::LA_MAX, std::max(1, atoi(e)));
+        if (c->W > 1) c->la_stream = c->la_offline = 1;
+        c->la = c->la_stream;
+        if (getenv("LASR_KICK")) c->kick_n = std::max(1, atoi(getenv("LASR_KICK")));
+        if (getenv("LASR_GROUP")) c->wait_n = std::max(1, atoi(getenv("LASR_GROUP")));
+    }
+    const size_t Mj = (size_t)c->MTj * 16;
     c->G_pred = d.pred_cell ? 4 : 3;
     c->bf = d.dtype == 1; c->kch = c->bf ? 32 : 16; c->esz = c->bf ? 2 : 4;
     Reader rd{weights, n_weights};
@@ -1147,9 +1165,9 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         c->hyp.assign(M, std::vector<std::vector<int32_t>>(c->W));
         c->committed.assign(M, {}); c->committed_score.assign(M, 0.0); c->best_full.assign(M, {});
     }
-    RC(dalloc(c, (char**)&c->ja, (size_t)Md * J * c->esz)); HIPCHK(c, hipMemset(c->ja, 0, (size_t)Md * J * c->esz));
+    RC(dalloc(c, (char**)&c->ja, Mj * J * c->esz)); HIPCHK(c, hipMemset(c->ja, 0, Mj * J * c->esz));
     RC(dalloc(c, (char**)&c->cvt_a, (size_t)M * H * c->esz)); RC(dalloc(c, (char**)&c->cvt_b, (size_t)M * H * c->esz));
-    RC(dalloc(c, &c->logits, (size_t)Md * V));
+    RC(dalloc(c, &c->logits, Mj * V));
     RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, Md));
     RC(dalloc(c, &c->ds.emit, Md)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->zero_rows, M));
@@ -1441,7 +1459,7 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     // keep the decode stream busy while the host enqueues (and the GPU runs) this chunk's encoder
     cont_poll(c);
     if (!c->pending.empty() && !c->group_inflight) {
-        c->kick_iters = 4;
+        c->kick_iters = c->kick_n;
         RC(cont_launch_group(c, c->kick_iters));
     }
     const int idx = (int)(c->model_steps % lasr_ctx::NFLY);
@@ -1498,6 +1516,7 @@ struct ContScope {
 // the copy of "rows of the oldest pending step still behind" into the pinned flag.  Does not wait.
 static int cont_launch_group(lasr_ctx* c, int G) {
     const int M = c->M, V = c->d.vocab, J = c->d.joint;
+    c->la = c->la_stream;
     ContScope scope(c);
     lasr_ctx::PendingStep& P = c->pending.front();
     DecState s = c->ds;
@@ -1518,7 +1537,7 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     }
     if (admitted_any)   // rows that were idle need their joint activation for the new frames
         hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
-                           c->c_avail, c->ja, J, M, c->MT, c->pe_ring_R, c->bf, 1, M);
+                           c->c_avail, c->ja, J, M, c->MTj, c->pe_ring_R, c->bf, 1, M, c->la);
     if (!P.target_set) {
         int* st = tgt_stage + (size_t)P.idx * M;
         memcpy(st, P.target.data(), sizeof(int) * M);
@@ -1530,9 +1549,9 @@ static int cont_launch_group(lasr_ctx* c, int G) {
         slot = (int)(c->cont_iters & 63);
         c->cont_iters++;
         c->dbg_gate = false;
-        launch_logits(c, c->logits, M, true);
+        launch_logits(c, c->logits, c->la * M, true);
         hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, c->d.max_iters_stream,
-                           c->c_avail, s, slot, (float*)nullptr, (int*)nullptr);
+                           c->c_avail, s, slot, (float*)nullptr, (int*)nullptr, c->la, M);
         launch_predictor(c);
         launch_ppj(c);
         launch_lm(c);
@@ -1566,7 +1585,7 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran) {
     const long long it0 = c->cont_iters - (c->group_inflight ? c->kick_iters : 0);
     const long long serial = c->pending.front().serial;
     for (int guard = 0; c->done_serial != serial; ++guard) {
-        if (!c->group_inflight) RC(cont_launch_group(c, 2));
+        if (!c->group_inflight) RC(cont_launch_group(c, c->wait_n));
         RC(spin_flag(c, flag, c->stream_dec));
         c->group_inflight = false;
         // a group launched while an older step was the target says nothing about this one
@@ -1892,12 +1911,12 @@ int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, floa
         launch_linear<true, 3>(c, J / 16, (B + 15) / 16, g, H, ea);
     }
     hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)c->M * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)c->pp,
-                       (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MTd, 1 << 30, c->bf, 1, c->M);
+                       (const int*)nullptr, (const int*)nullptr, c->ja, J, c->M, c->MTj, 1 << 30, c->bf, 1, c->M, 1);
     launch_logits(c, logits, B, false);
     if (logp_max && argmax) {
         DecState s = c->ds;
         hipLaunchKernelGGL((k_select<true>), dim3(B), dim3(256), 0, c->stream, (const float*)logits, V, c->d.blank, 1,
-                           (const int*)nullptr, s, 0, logp_max, argmax);
+                           (const int*)nullptr, s, 0, logp_max, argmax, 1, c->M);
     }
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
@@ -1969,6 +1988,7 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
     HIPCHK(c, hipMemset(m.lmz, 0, sizeof(float) * (size_t)M * V)); HIPCHK(c, hipMemset(m.valid, 0, sizeof(int) * M));
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);   // decode groups change shape
     c->graphs.clear();
+    c->la = c->la_stream = c->la_offline = 1;   // the fused re-pick needs the LM state of exactly this decision
     c->ds.lmz = m.lmz; c->ds.lm_valid = m.valid; c->ds.lm_alpha = m.alpha; c->ds.lm_theta = m.theta; c->ds.lm_min = m.min_val;
     m.on = true;
     return LASR_OK;

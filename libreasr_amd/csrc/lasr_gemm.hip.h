@@ -623,8 +623,9 @@ struct EpiLinear {
     __device__ static bool row_on(const Args& a, int r) {
         if (r >= a.n_rows) return false;
         if (!a.t_idx) return true;
-        const int q = a.W > 1 ? r / a.W : r % a.M;
-        return a.t_idx[q] < a.T_row[q];
+        if (a.W > 1) return a.t_idx[r / a.W] < a.T_row[r / a.W];
+        const int q = r % a.M;                 // lookahead: rows [k*M, (k+1)*M) evaluate frame t + k
+        return a.t_idx[q] + r / a.M < a.T_row[q];
     }
     __device__ static bool tile_active(const Args& a, int mt, int lane) {
         return any16(lane < 16 && row_on(a, mt * 16 + (lane & 15)), lane);
@@ -678,6 +679,7 @@ struct EpiPPJ {
         const int* parent;
         int W, M_enc;
         const float* pp_in;
+        int la;               // greedy lookahead: ja is also produced for frames t+1 .. t+la-1 (rows k*M + r)
     };
     struct Pre {};
     template <int MTB>
@@ -696,10 +698,15 @@ struct EpiPPJ {
                 const float p = red.sum(row, col) + a.b1[j];
                 a.pp[(size_t)r * a.J + j] = p;
                 const int q = beam ? r / a.W : r;       // stream of the row
-                const int t = a.t_idx[q];
-                if (t < a.T_row[q])
-                    Ops::st(a.ja, Ops::aoff(r, j, a.MT),
-                            tanhf(a.pe[((size_t)(t % a.ring) * (beam ? a.M_enc : a.M) + q) * a.J + j] + p));
+                const int t = a.t_idx[q], Tq = a.T_row[q];
+                if (beam) {
+                    if (t < Tq)
+                        Ops::st(a.ja, Ops::aoff(r, j, a.MT), tanhf(a.pe[((size_t)(t % a.ring) * a.M_enc + q) * a.J + j] + p));
+                } else {
+                    for (int k = 0; k < a.la && t + k < Tq; ++k)
+                        Ops::st(a.ja, Ops::aoff(k * a.M + r, j, a.MT),
+                                tanhf(a.pe[((size_t)((t + k) % a.ring) * a.M + r) * a.J + j] + p));
+                }
             }
             const int r = vr;                           // original row of this range, if it did not emit
             if (r < a.M && !a.emit[r]) {
@@ -709,13 +716,16 @@ struct EpiPPJ {
                 if (beam) {
                     p = a.pp_in[(size_t)beam_prow(a.parent, a.W, r) * a.J + j];
                     a.pp[(size_t)r * a.J + j] = p;
+                    if (t < a.T_row[q])
+                        Ops::st(a.ja, Ops::aoff(r, j, a.MT), tanhf(a.pe[((size_t)(t % a.ring) * a.M_enc + q) * a.J + j] + p));
                 } else {
-                    if (t >= a.T_row[q]) continue;
+                    const int Tq = a.T_row[q];
+                    if (t >= Tq) continue;
                     p = a.pp[(size_t)r * a.J + j];
+                    for (int k = 0; k < a.la && t + k < Tq; ++k)
+                        Ops::st(a.ja, Ops::aoff(k * a.M + r, j, a.MT),
+                                tanhf(a.pe[((size_t)((t + k) % a.ring) * a.M + r) * a.J + j] + p));
                 }
-                if (t < a.T_row[q])
-                    Ops::st(a.ja, Ops::aoff(r, j, a.MT),
-                            tanhf(a.pe[((size_t)(t % a.ring) * (beam ? a.M_enc : a.M) + q) * a.J + j] + p));
             }
         }
     }

@@ -42,14 +42,17 @@ __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(
 // W > 1 (beam search): rows are hypothesis slots, W per stream; t_idx / T_row / pe are per stream (M_enc rows)
 __global__ void k_ja(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
                      const int* __restrict__ T_row, void* __restrict__ ja, int J, int M, int MT, int ring, int bf,
-                     int W, int M_enc) {
+                     int W, int M_enc, int la) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * J) return;
     const int r = idx / J, j = idx - r * J;
     const int q = W > 1 ? r / W : r;
     const int t = t_idx ? t_idx[q] : 0;
-    if (T_row && t >= T_row[q]) return;
-    act_st(bf, ja, act_off(bf, r, j, MT), tanhf(pe[((size_t)(t % ring) * M_enc + q) * J + j] + pp[(size_t)r * J + j]));
+    const float p = pp[(size_t)r * J + j];
+    for (int k = 0; k < la; ++k) {           // greedy lookahead: frames t .. t+la-1 (rows k*M + r); la = 1 otherwise
+        if (T_row && t + k >= T_row[q]) return;
+        act_st(bf, ja, act_off(bf, k * M + r, j, MT), tanhf(pe[((size_t)((t + k) % ring) * M_enc + q) * J + j] + p));
+    }
 }
 
 // fragment-major -> row-major [rows][K] f32
@@ -210,10 +213,17 @@ __global__ void k_step_begin(DecState s, int M, int n_iter_slots, int reset_metr
 // log-softmax + argmax over the vocabulary and the greedy state machine of
 // Transducer.decode_greedy / transcribe_stream (models.py:405-443, 530-571), one workgroup per row.
 // PLAIN: only (argmax, log p) are produced (op-level joint entry point).
+//
+// Lookahead (la > 1): the iteration evaluated frames t, t+1, .. t+la-1 of the row against the SAME
+// predictor state (logits rows r, M + r, 2M + r, ..).  As long as the decision is blank the predictor
+// state does not change, so the next frame's evaluation is exactly what the reference would compute
+// next: the row consumes the whole run of blanks and, if it comes, the first token after it, in one
+// iteration.  The decisions, their order and every metric are those of the one-frame-per-iteration
+// loop; only the number of launches per frame changes.  (With an LM attached la = 1.)
 template <bool PLAIN>
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits, int V, int blank, int max_iters,
                                                 const int* __restrict__ T_row, DecState s, int iter_slot,
-                                                float* __restrict__ out_logp, int* __restrict__ out_arg) {
+                                                float* __restrict__ out_logp, int* __restrict__ out_arg, int la, int M) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (!PLAIN && s.cont && r == 0 && tid == 0) s.unfinished[(iter_slot + 32) & 63] = 0;   // recycle the flag ring
     // state of the row: loaded up front so the latency overlaps the logits reads
@@ -230,134 +240,153 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         }
     }
     constexpr int KEEP = 16;                        // logits kept in registers per thread (V <= 4096)
-    const float* z = logits + (size_t)r * V;
-    float zv[KEEP];
-    float best = -INFINITY;
-    int arg = 0x7fffffff;
-#pragma unroll
-    for (int q = 0; q < KEEP; ++q) {
-        const int j = tid + 256 * q;
-        zv[q] = j < V ? z[j] : -INFINITY;
-        if (zv[q] > best) { best = zv[q]; arg = j; }   // ascending j per thread: first max wins
-    }
-    for (int j = tid + 256 * KEEP; j < V; j += 256) {
-        const float x = z[j];
-        if (x > best) { best = x; arg = j; }
-    }
     __shared__ float sv[4];
     __shared__ int si[4];
     __shared__ float ss[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o);
-        const int oa = __shfl_xor(arg, o);
-        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
-    }
-    if (lane == 0) { sv[w] = best; si[w] = arg; }
-    __syncthreads();
-    best = sv[0]; arg = si[0];
-#pragma unroll
-    for (int q = 1; q < 4; ++q)
-        if (sv[q] > best || (sv[q] == best && si[q] < arg)) { best = sv[q]; arg = si[q]; }
-    float sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < KEEP; ++q) sum += expf(zv[q] - best);      // exp(-inf) = 0 for the padding
-    for (int j = tid + 256 * KEEP; j < V; j += 256) sum += expf(z[j] - best);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0) ss[w] = sum;
-    __syncthreads();
-    sum = ss[0] + ss[1] + ss[2] + ss[3];
-    const float logp = -logf(sum);       // log_softmax at the argmax = z_max - logsumexp
-    if (!PLAIN && s.lmz && arg != blank && s.lm_valid[r]) {
-        // LMFuser.fuse (lm.py:59-79), only for a non-blank decision (models.py:427-431; uniform over
-        // the workgroup): standardise the joint log-softmax (utils.py:162-164: subtract the mean,
-        // divide by the unbiased std + 1e-5), entry 0 = MIN_VAL, re-pick argmax(alpha*lm + theta*joint).
-        // V <= 4096 (checked at lasr_attach_lm): every value of the row is in zv[].
-        __shared__ float sh4[4];
-        const float lse = logf(sum);
-        float part = 0.f;
+    int emitted = 0;
+    for (int k = 0;; ++k) {
+        const float* z = logits + (size_t)(k * M + r) * V;
+        float zv[KEEP];
+        float best = -INFINITY;
+        int arg = 0x7fffffff;
 #pragma unroll
         for (int q = 0; q < KEEP; ++q) {
             const int j = tid + 256 * q;
-            zv[q] = j < V ? (zv[q] - best) - lse : 0.f;        // log-softmax; padding contributes nothing
-            part += zv[q];
+            zv[q] = j < V ? z[j] : -INFINITY;
+            if (zv[q] > best) { best = zv[q]; arg = j; }   // ascending j per thread: first max wins
         }
-        const float mean = block_sum_256(part, sh4, lane, w) / (float)V;
-        part = 0.f;
-#pragma unroll
-        for (int q = 0; q < KEEP; ++q) {
-            const int j = tid + 256 * q;
-            zv[q] = j < V ? zv[q] - mean : 0.f;                // t.add_(-t.mean())
-            part += zv[q];
-        }
-        const float mean2 = block_sum_256(part, sh4, lane, w) / (float)V;   // torch.std subtracts its own mean again
-        part = 0.f;
-#pragma unroll
-        for (int q = 0; q < KEEP; ++q) {
-            const int j = tid + 256 * q;
-            const float d = j < V ? zv[q] - mean2 : 0.f;
-            part += d * d;
-        }
-        const float sd = sqrtf(block_sum_256(part, sh4, lane, w) / (float)(V - 1));
-        const float den = sd + 1e-5f;
-        const float* lz = s.lmz + (size_t)r * V;
-        float fb = -INFINITY;
-        int fa = 0x7fffffff;
-#pragma unroll
-        for (int q = 0; q < KEEP; ++q) {
-            const int j = tid + 256 * q;
-            if (j >= V) continue;
-            const float jo = j == 0 ? s.lm_min : zv[q] / den;
-            const float f = __fadd_rn(__fmul_rn(s.lm_alpha, lz[j]), __fmul_rn(s.lm_theta, jo));   // no FMA contraction
-            if (f > fb) { fb = f; fa = j; }
+        for (int j = tid + 256 * KEEP; j < V; j += 256) {
+            const float x = z[j];
+            if (x > best) { best = x; arg = j; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(fb, o);
-            const int oa = __shfl_xor(fa, o);
-            if (ob > fb || (ob == fb && oa < fa)) { fb = ob; fa = oa; }
+            const float ob = __shfl_xor(best, o);
+            const int oa = __shfl_xor(arg, o);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
         }
+        if (lane == 0) { sv[w] = best; si[w] = arg; }
         __syncthreads();
-        if (lane == 0) { sv[w] = fb; si[w] = fa; }
-        __syncthreads();
-        fb = sv[0]; fa = si[0];
+        best = sv[0]; arg = si[0];
 #pragma unroll
         for (int q = 1; q < 4; ++q)
-            if (sv[q] > fb || (sv[q] == fb && si[q] < fa)) { fb = sv[q]; fa = si[q]; }
-        arg = fa;                        // the emitted token; log p stays the unfused one (models.py:422)
+            if (sv[q] > best || (sv[q] == best && si[q] < arg)) { best = sv[q]; arg = si[q]; }
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) sum += expf(zv[q] - best);      // exp(-inf) = 0 for the padding
+        for (int j = tid + 256 * KEEP; j < V; j += 256) sum += expf(z[j] - best);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) ss[w] = sum;
+        __syncthreads();
+        sum = ss[0] + ss[1] + ss[2] + ss[3];
+        const float logp = -logf(sum);       // log_softmax at the argmax = z_max - logsumexp
+        if (PLAIN) {
+            if (tid == 0) { out_logp[r] = logp; out_arg[r] = arg; }
+            return;
+        }
+        const bool nonblank = arg != blank;      // decided by the joint alone (models.py:424-431)
+        if (s.lmz && nonblank && s.lm_valid[r]) {
+            // LMFuser.fuse (lm.py:59-79), only for a non-blank decision (models.py:427-431; uniform over
+            // the workgroup): standardise the joint log-softmax (utils.py:162-164: subtract the mean,
+            // divide by the unbiased std + 1e-5), entry 0 = MIN_VAL, re-pick argmax(alpha*lm + theta*joint).
+            // V <= 4096 (checked at lasr_attach_lm): every value of the row is in zv[].
+            __shared__ float sh4[4];
+            const float lse = logf(sum);
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < KEEP; ++q) {
+                const int j = tid + 256 * q;
+                zv[q] = j < V ? (zv[q] - best) - lse : 0.f;        // log-softmax; padding contributes nothing
+                part += zv[q];
+            }
+            const float mean = block_sum_256(part, sh4, lane, w) / (float)V;
+            part = 0.f;
+#pragma unroll
+            for (int q = 0; q < KEEP; ++q) {
+                const int j = tid + 256 * q;
+                zv[q] = j < V ? zv[q] - mean : 0.f;                // t.add_(-t.mean())
+                part += zv[q];
+            }
+            const float mean2 = block_sum_256(part, sh4, lane, w) / (float)V;   // torch.std subtracts its own mean again
+            part = 0.f;
+#pragma unroll
+            for (int q = 0; q < KEEP; ++q) {
+                const int j = tid + 256 * q;
+                const float d = j < V ? zv[q] - mean2 : 0.f;
+                part += d * d;
+            }
+            const float sd = sqrtf(block_sum_256(part, sh4, lane, w) / (float)(V - 1));
+            const float den = sd + 1e-5f;
+            const float* lz = s.lmz + (size_t)r * V;
+            float fb = -INFINITY;
+            int fa = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < KEEP; ++q) {
+                const int j = tid + 256 * q;
+                if (j >= V) continue;
+                const float jo = j == 0 ? s.lm_min : zv[q] / den;
+                const float f = __fadd_rn(__fmul_rn(s.lm_alpha, lz[j]), __fmul_rn(s.lm_theta, jo));   // no FMA contraction
+                if (f > fb) { fb = f; fa = j; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(fb, o);
+                const int oa = __shfl_xor(fa, o);
+                if (ob > fb || (ob == fb && oa < fa)) { fb = ob; fa = oa; }
+            }
+            __syncthreads();
+            if (lane == 0) { sv[w] = fb; si[w] = fa; }
+            __syncthreads();
+            fb = sv[0]; fa = si[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (sv[q] > fb || (sv[q] == fb && si[q] < fa)) { fb = sv[q]; fa = si[q]; }
+            arg = fa;                        // the emitted token; log p stays the unfused one (models.py:422)
+        }
+        // ---- the decision (every thread tracks t and the loop control; thread 0 owns the rest of the state)
+        bool frame_done = true;
+        int it = 0;
+        if (tid == 0) {
+            lp0 += (double)logp;
+            it = it0 + 1;
+            si0 += 1;
+        }
+        if (nonblank) {
+            emitted = 1;
+            if (tid == 0) {
+                if (s.cont) s.step_tok[(size_t)r * s.tok_cap + (n0 % s.tok_cap)] = arg;
+                else if (n0 < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n0] = arg;
+                n0 += 1;
+                s.token[r] = arg;
+            }
+            // the per-frame evaluation count lives in thread 0: broadcast "symbol cap reached"
+            __syncthreads();
+            if (tid == 0) sv[0] = (it >= max_iters) ? 1.f : 0.f;
+            __syncthreads();
+            frame_done = sv[0] != 0.f;
+        }
+        if (frame_done) {
+            if (tid == 0) {
+                if (it == 1) no0 += 1;
+                it = 0;
+            }
+            t += 1;
+            if (tid == 0 && s.cont && t % s.step_T == 0)      // the row just finished one of its model steps
+                s.ntok_end[(size_t)r * s.end_slots + ((t / s.step_T - 1) % s.end_slots)] = n0;
+        }
+        if (tid == 0) it0 = it;
+        if (emitted || k + 1 >= la || t >= Tr) break;
+        __syncthreads();                     // sv / si / ss are reused by the next frame's reductions
     }
     if (tid != 0) return;
-    if (PLAIN) {
-        out_logp[r] = logp;
-        out_arg[r] = arg;
-        return;
-    }
-    s.logp_sum[r] = lp0 + (double)logp;
-    int it = it0 + 1;
-    s.sum_iters[r] = si0 + 1;
-    bool frame_done;
-    if (arg == blank) {
-        s.emit[r] = 0;
-        frame_done = true;
-    } else {
-        if (s.cont) s.step_tok[(size_t)r * s.tok_cap + (n0 % s.tok_cap)] = arg;
-        else if (n0 < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n0] = arg;
-        s.step_ntok[r] = n0 + 1;
-        n0 += 1;
-        s.token[r] = arg;
-        s.emit[r] = 1;
-        frame_done = (it >= max_iters);
-    }
-    if (frame_done) {
-        if (it == 1) s.n_ones[r] = no0 + 1;
-        it = 0;
-        t += 1;
-        s.t_idx[r] = t;
-        if (s.cont && t % s.step_T == 0)      // the row just finished one of its model steps
-            s.ntok_end[(size_t)r * s.end_slots + ((t / s.step_T - 1) % s.end_slots)] = n0;
-    }
-    s.iters[r] = it;
+    s.emit[r] = emitted;
+    s.logp_sum[r] = lp0;
+    s.sum_iters[r] = si0;
+    s.n_ones[r] = no0;
+    s.step_ntok[r] = n0;
+    s.t_idx[r] = t;
+    s.iters[r] = it0;
     if (s.cont ? (t < s.target[r]) : (t < Tr)) atomicAdd(&s.unfinished[iter_slot], 1);
 }
 

@@ -390,3 +390,63 @@ def test_config5_shape_against_oracle():
     finally:
         for slot in slots:
             eng.close_slot(slot)
+
+
+@pytest.mark.parametrize("la", [2, 4])
+def test_streaming_lookahead_is_invisible(la, monkeypatch, golden_dir):
+    """Greedy lookahead (k_select evaluating frames t .. t+la-1 against one predictor state and consuming
+    the run of blanks) must not change a single token or per-call count: synchronous steps with 2 and 5
+    frames, the pipelined / continuous loop, and ragged streams (env knob read at engine creation)."""
+    import __graft_entry__ as graft
+    from libreasr_amd.engine import Engine
+    graft.build()
+    monkeypatch.setenv("LASR_LOOKAHEAD", str(la))
+    name = "tiny_lstm"
+    cfg = synth.model_cfg(name)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    eng = Engine(sd, cfg, max_streams=8)
+    m = O.OracleTransducer(sd, cfg)
+    g = np.load(os.path.join(golden_dir, f"model_{name}.npz"))
+    n = 2
+    pcm = synth.synth_pcm(n, 16000 * 3, seed=1234)
+    chunks = [synth.stream_chunks(p, 1280, lead=1, tail=10) for p in pcm]
+    for mode in ("sync", "pipelined"):
+        slots = [eng.open() for _ in range(n)]
+        got, counts = [[] for _ in range(n)], [[] for _ in range(n)]
+
+        def take():
+            for s, t in enumerate(eng.fetch_many(slots, 64)):
+                got[s] += t
+                counts[s].append(len(t))
+
+        for k in range(len(chunks[0])):
+            eng.push(slots, np.stack([c[k] for c in chunks]))
+            if mode == "sync":
+                if eng.step(slots):
+                    take()
+            else:
+                eng.submit(slots)
+                if eng.pending() >= 3 and eng.wait():
+                    take()
+        while eng.pending():
+            if eng.wait():
+                take()
+        for s in range(n):
+            assert got[s] == list(g[f"st_tokens_{s}"]), (mode, s)
+            assert counts[s] == list(g[f"st_counts_{s}"]), (mode, s)
+        for s in slots:
+            eng.close_slot(s)
+    # feature-level steps with 5 frames per call and different lengths of history per stream
+    slots = [eng.open() for _ in range(n)]
+    feats = [O.features_offline(p) for p in pcm]
+    decs = [m.stream_decoder() for _ in range(n)]
+    got = [[] for _ in range(n)]
+    for t0 in range(0, 30, 5):
+        eng.step_feats(slots, np.stack([f[t0:t0 + 5] for f in feats]))
+        for s, t in enumerate(eng.fetch_many(slots, 256)):
+            got[s] += t
+        for s in range(n):
+            decs[s].step(feats[s][t0:t0 + 5])
+    for s in range(n):
+        assert got[s] == decs[s].y
+    eng.close()
