@@ -115,6 +115,8 @@ def main():
                     help="f32 = BASELINE configs[1] (the headline metric); bf16 = configs[2] arithmetic "
                          "(bf16 MFMA operands, f32 accumulate/state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-pcm", action="store_true",
+                    help="hand lasr_push_pcm HOST buffers every chunk (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--cpu-streams", type=int, default=16)
     ap.add_argument("--cpu-chunks", type=int, default=200)
     ap.add_argument("--beam", type=int, default=1,
@@ -161,6 +163,7 @@ def main():
     # laid out [chunk][stream][1280] so that one step reads one contiguous block
     pcm_host = np.stack([synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in my_streams])
     pcm_dev = torch.as_tensor(pcm_host.reshape(B, n_chunks, CHUNK).transpose(1, 0, 2).copy()).to(device)
+    pcm_host_chunks = np.ascontiguousarray(pcm_host.reshape(B, n_chunks, CHUNK).transpose(1, 0, 2)) if args.host_pcm else None
     slots = [eng.open() for _ in range(B)]
     assert slots == list(range(B))
 
@@ -173,7 +176,7 @@ def main():
         push + submit (front-end and encoder of chunk k go to the GPU), then collect the tokens of
         the previous model step, whose decode loop runs on a second HIP stream under encoder(k)."""
         t_push = time.perf_counter()
-        eng.push(slots, pcm_dev[k])
+        eng.push(slots, pcm_host_chunks[k] if args.host_pcm else pcm_dev[k])
         ntok, done = 0, 0
         if not pipelined:
             if eng.step(slots):
@@ -258,7 +261,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic",
+            "data": "synthetic" + (" (PCM handed over in host memory every chunk: PCIe-inclusive)" if args.host_pcm else ""),
             "config": {"workload": f"configs[{1 if args.dtype == 'f32' else 2}]: {B} concurrent 16 kHz streams/GPU, 4x1024 uni-LSTM encoder, "
                                    f"2xNBRC predictor, J=1024, V=2048, {'greedy' if args.beam == 1 else 'beam width ' + str(args.beam)}, {'fp32' if args.dtype == 'f32' else 'bf16 operands / f32 accumulate'}, 80 ms chunks, "
                                    "3-chunk window, 2-frame buffer (model every 160 ms)",

@@ -149,6 +149,10 @@ struct lasr_ctx {
     float* win = nullptr; int* ring_pos = nullptr;
     float* pend = nullptr;          // [M][n_buffer*n_stack][n_mels]
     float* stage_pcm = nullptr; size_t stage_pcm_floats = 0;
+    // streaming pushes from host memory: ring of device staging rows + one event per entry, so a push
+    // never has to drain the stream (the copy of chunk k+1 overlaps the kernels of chunk k)
+    static constexpr int NSTAGE = 16;
+    float* push_stage = nullptr; hipEvent_t push_ev[NSTAGE] = {}; bool push_used[NSTAGE] = {}; int push_next = 0;
     float* lm_buf = nullptr; size_t lm_floats = 0;       // offline log-mel
     float* feat_stage = nullptr; size_t feat_stage_floats = 0;
 
@@ -1006,6 +1010,8 @@ void lasr_destroy(lasr_ctx* c) {
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->cont_host) (void)hipHostFree(c->cont_host);
     if (c->trellis_host) (void)hipHostFree(c->trellis_host);
+    for (auto& e : c->push_ev)
+        if (e) (void)hipEventDestroy(e);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
     if (c->ev_ok)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -1335,11 +1341,20 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
     HIPCHK(c, hipSetDevice(c->device));
     const int CH = c->d.chunk;
     const float* src = pcm;
-    if (!is_device_ptr(pcm)) {
-        RC(ensure_buf(c, &c->stage_pcm, &c->stage_pcm_floats, (size_t)c->M * CH));
+    const bool from_host = !is_device_ptr(pcm);
+    int stage_i = -1;
+    if (from_host) {
+        if (!c->push_stage) {
+            RC(dalloc(c, &c->push_stage, (size_t)lasr_ctx::NSTAGE * c->M * CH));
+            for (auto& e : c->push_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        stage_i = c->push_next;
+        c->push_next = (stage_i + 1) % lasr_ctx::NSTAGE;
+        if (c->push_used[stage_i]) HIPCHK(c, hipEventSynchronize(c->push_ev[stage_i]));   // its last reader (16 pushes ago) is done
+        float* dst = c->push_stage + (size_t)stage_i * c->M * CH;
         // pageable host memory: hipMemcpyAsync stages it synchronously, so the caller's buffer is free on return
-        HIPCHK(c, hipMemcpyAsync(c->stage_pcm, pcm, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream));
-        src = c->stage_pcm;
+        HIPCHK(c, hipMemcpyAsync(dst, pcm, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream));
+        src = dst;
     }
     if (c->M <= 512) {      // slot -> staging-row map by value: no command-block copy for a push
         PushIdx pi;
@@ -1355,10 +1370,9 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
         hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, (const int*)c->dc.src_idx, pi, c->win, c->ring_pos, CH, c->d.n_window);
     }
     for (int i = 0; i < n; ++i) c->n_chunks[slots[i]]++;
-    if (!is_device_ptr(pcm)) {
-        // the staging buffer is reused by the next push: keep ordering simple
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->cmd_inflight = 0;
+    if (from_host) {
+        HIPCHK(c, hipEventRecord(c->push_ev[stage_i], c->stream));
+        c->push_used[stage_i] = true;
     }
     return LASR_OK;
 }
