@@ -308,7 +308,7 @@ def main():
             out["roofline"].update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(gbs / PEAK_HBM_GBS, 4),
                                     "note": "algorithmic bytes = packed bf16 weights of one cell (W_ih + W_hh)"})
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would stall the other ranks' teardown)
             rows = [pcm_host[i] for i in range(min(args.cpu_streams, B))]
             out["cpu_baseline"] = cpu_baseline(cfg, sd, rows, args.cpu_chunks)
         print(json.dumps(out), flush=True)

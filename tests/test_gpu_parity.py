@@ -450,3 +450,71 @@ def test_streaming_lookahead_is_invisible(la, monkeypatch, golden_dir):
     for s in range(n):
         assert got[s] == decs[s].y
     eng.close()
+
+
+def test_full_size_properties_config2():
+    """BASELINE configs[1] at full size (64 streams, 4x1024 encoder): properties that do not need the
+    oracle to run at that size.  (i) batch invariance: a stream's tokens do not depend on which other
+    streams share the batch; (ii) protocol invariance: pipelined/continuous == synchronous, per chunk;
+    (iii) chunking invariance: feeding the same stacked frames 2 or 6 at a time gives the same tokens;
+    (iv) 3 of the streams against the oracle as an anchor."""
+    eng, m, cfg = engine("cfg2", max_streams=64)
+    n = 64
+    n_chunks = 16                                   # 1.28 s of audio per stream
+    pcm = np.stack([synth.synth_pcm(1, n_chunks * 1280, seed=4000 + s)[0] for s in range(n)])
+    chunks = pcm.reshape(n, n_chunks, 1280)
+
+    def run(idx, pipelined):
+        slots = [eng.open() for _ in idx]
+        out = [[] for _ in idx]
+        per_call = [[] for _ in idx]
+
+        def take():
+            for i, t in enumerate(eng.fetch_many(slots, 128)):
+                out[i] += t
+                per_call[i].append(len(t))
+
+        for k in range(n_chunks):
+            eng.push(slots, dev(chunks[idx, k]))
+            if pipelined:
+                eng.submit(slots)
+                if eng.pending() >= 4 and eng.wait():
+                    take()
+            elif eng.step(slots):
+                take()
+        while eng.pending():
+            if eng.wait():
+                take()
+        for s in slots:
+            eng.close_slot(s)
+        return out, per_call
+
+    full_sync, calls_sync = run(list(range(n)), False)
+    full_pipe, calls_pipe = run(list(range(n)), True)
+    assert full_sync == full_pipe and calls_sync == calls_pipe          # (ii)
+    assert sum(len(t) for t in full_sync) > n                            # the workload emits tokens
+    some = [3, 17, 42, 63]
+    solo, _ = run(some, False)
+    for i, s in enumerate(some):
+        assert solo[i] == full_sync[s], s                                # (i)
+    for s in some[:3]:                                                   # (iv)
+        fe, dec = O.StreamFrontend(), m.stream_decoder()
+        for k in range(n_chunks):
+            o = fe.push(chunks[s, k])
+            if o is not None:
+                dec.step(o)
+        assert dec.y == full_sync[s], s
+    # (iii) same frames, different call granularity (encoder / predictor state carried across calls)
+    feats = np.stack([O.features_offline(pcm[s]) for s in range(8)])[:, :12]
+    res = []
+    for step in (2, 6):
+        slots = [eng.open() for _ in range(8)]
+        out = [[] for _ in range(8)]
+        for t0 in range(0, 12, step):
+            eng.step_feats(slots, feats[:, t0:t0 + step])
+            for i, t in enumerate(eng.fetch_many(slots, 256)):
+                out[i] += t
+        res.append(out)
+        for s in slots:
+            eng.close_slot(s)
+    assert res[0] == res[1]
