@@ -1190,13 +1190,20 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     HIPCHK(c, hipMemset(c->pe_ring, 0, sizeof(float) * (size_t)lasr_ctx::RING * M * J));
     RC(dalloc(c, &c->c_cur, M)); RC(dalloc(c, &c->c_avail, M)); RC(dalloc(c, &c->c_iters, M)); RC(dalloc(c, &c->c_target, M));
     RC(dalloc(c, &c->c_ntotal, M)); RC(dalloc(c, &c->c_enc_frames, M)); RC(dalloc(c, &c->c_behind, 64));
-    RC(dalloc(c, &c->c_ntok_end, (size_t)M * lasr_ctx::ENDSLOTS)); RC(dalloc(c, &c->c_tok_ring, (size_t)M * lasr_ctx::TOKRING));
+    // (c_ntok_end / c_tok_ring live in pinned host memory, written by k_select directly: see below)
     for (int* p : {c->c_cur, c->c_avail, c->c_iters, c->c_target, c->c_ntotal, c->c_enc_frames})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->c_behind, 0, sizeof(int) * 64));
-    HIPCHK(c, hipMemset(c->c_ntok_end, 0, sizeof(int) * (size_t)M * lasr_ctx::ENDSLOTS));
-    HIPCHK(c, hipMemset(c->c_tok_ring, 0, sizeof(int) * (size_t)M * lasr_ctx::TOKRING));
     HIPCHK(c, hipHostMalloc((void**)&c->cont_host, sizeof(int) * (16 + (size_t)M * (lasr_ctx::NFLY + lasr_ctx::ENDSLOTS + lasr_ctx::TOKRING))));
+    memset(c->cont_host, 0, sizeof(int) * (16 + (size_t)M * (lasr_ctx::NFLY + lasr_ctx::ENDSLOTS + lasr_ctx::TOKRING)));
+    {   // continuous decode: the token ring and the per-step boundary marks are written by k_select straight
+        // into this pinned block (zero-copy stores over PCIe, flushed at kernel end): a finished step needs
+        // no result copy at all -- the host reads them as soon as the group's "rows behind" word says 0
+        void* dp = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer(&dp, c->cont_host, 0));
+        c->c_ntok_end = (int*)dp + 16 + (size_t)lasr_ctx::NFLY * M;
+        c->c_tok_ring = c->c_ntok_end + (size_t)M * lasr_ctx::ENDSLOTS;
+    }
     c->h_frames_sub.assign(M, 0); c->h_fetched.assign(M, 0);
     c->dec_t_idx = c->ds.t_idx;
     c->T_row_dec = c->T_row_dev;
@@ -1606,17 +1613,10 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran) {
         if (c->inflight_for == serial && *flag == 0) c->done_serial = serial;
         if (guard > 4096) return fail(c, LASR_EHIP, "decode loop did not converge");
     }
-    if (c->group_inflight) {            // drain a group kicked after this step was already known done:
-        RC(spin_flag(c, flag, c->stream_dec));   // the result copies below reuse the pinned flag word
-        c->group_inflight = false;
-    }
-    // results of the oldest step: tokens between the previous and this step boundary of every row
+    // results of the oldest step: tokens between the previous and this step boundary of every row, already
+    // in pinned memory (written by the kernels of the groups that completed before the flag said 0)
     lasr_ctx::PendingStep& P = c->pending.front();
-    HIPCHK(c, hipMemcpyAsync(h_end, c->c_ntok_end, sizeof(int) * (size_t)M * lasr_ctx::ENDSLOTS, hipMemcpyDeviceToHost, c->stream_dec));
-    HIPCHK(c, hipMemcpyAsync(h_ring, c->c_tok_ring, sizeof(int) * (size_t)M * lasr_ctx::TOKRING, hipMemcpyDeviceToHost, c->stream_dec));
-    __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
-    HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + 63, sizeof(int), hipMemcpyDeviceToHost, c->stream_dec));   // any word >= 0: completion marker
-    RC(spin_flag(c, flag, c->stream_dec));
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     for (int r : P.rows) {
         const int j = P.target[r] / P.Tm - 1;
         const long long end = h_end[(size_t)r * lasr_ctx::ENDSLOTS + (j % lasr_ctx::ENDSLOTS)];
