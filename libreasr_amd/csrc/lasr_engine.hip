@@ -108,6 +108,7 @@ struct lasr_ctx {
     float* pe_ring = nullptr;
     int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
     int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr;
+    int *c_done = nullptr, *c_flag_dev = nullptr;   // workgroups finished per iteration; device view of cont_host[0]
     int* cont_host = nullptr;       // pinned: [0] flag, [4..] target staging (NFLY blocks), then ntok_end + token ring
     struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; const int* T_row_ptr; long long serial; };
     std::vector<PendingStep> pending;
@@ -1194,6 +1195,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     for (int* p : {c->c_cur, c->c_avail, c->c_iters, c->c_target, c->c_ntotal, c->c_enc_frames})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->c_behind, 0, sizeof(int) * 64));
+    RC(dalloc(c, &c->c_done, 64)); HIPCHK(c, hipMemset(c->c_done, 0, sizeof(int) * 64));
     HIPCHK(c, hipHostMalloc((void**)&c->cont_host, sizeof(int) * (16 + (size_t)M * (lasr_ctx::NFLY + lasr_ctx::ENDSLOTS + lasr_ctx::TOKRING))));
     memset(c->cont_host, 0, sizeof(int) * (16 + (size_t)M * (lasr_ctx::NFLY + lasr_ctx::ENDSLOTS + lasr_ctx::TOKRING)));
     {   // continuous decode: the token ring and the per-step boundary marks are written by k_select straight
@@ -1201,6 +1203,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         // no result copy at all -- the host reads them as soon as the group's "rows behind" word says 0
         void* dp = nullptr;
         HIPCHK(c, hipHostGetDevicePointer(&dp, c->cont_host, 0));
+        c->c_flag_dev = (int*)dp;
         c->c_ntok_end = (int*)dp + 16 + (size_t)lasr_ctx::NFLY * M;
         c->c_tok_ring = c->c_ntok_end + (size_t)M * lasr_ctx::ENDSLOTS;
     }
@@ -1543,7 +1546,7 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     DecState s = c->ds;
     s.t_idx = c->c_cur; s.iters = c->c_iters; s.step_ntok = c->c_ntotal; s.step_tok = c->c_tok_ring;
     s.tok_cap = lasr_ctx::TOKRING; s.unfinished = c->c_behind; s.cont = 1; s.target = c->c_target;
-    s.ntok_end = c->c_ntok_end; s.step_T = P.Tm; s.end_slots = lasr_ctx::ENDSLOTS;
+    s.ntok_end = c->c_ntok_end; s.step_T = P.Tm; s.end_slots = lasr_ctx::ENDSLOTS; s.done_blocks = c->c_done;
     int* flag = c->cont_host;
     int* tgt_stage = c->cont_host + 16;
     // admit encoded steps in order: the oldest unconditionally, later ones only if their encoder is done
@@ -1566,10 +1569,12 @@ static int cont_launch_group(lasr_ctx* c, int G) {
         P.target_set = true;
     }
     int slot = 0;
+    __atomic_store_n(flag, -1, __ATOMIC_RELEASE);      // before the launch that will overwrite it
     for (int q = 0; q < G; ++q) {
         slot = (int)(c->cont_iters & 63);
         c->cont_iters++;
         c->dbg_gate = false;
+        s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;    // k_select of the last iteration publishes "rows behind"
         launch_logits(c, c->logits, c->la * M, true);
         hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, c->d.max_iters_stream,
                            c->c_avail, s, slot, (float*)nullptr, (int*)nullptr, c->la, M);
@@ -1577,8 +1582,7 @@ static int cont_launch_group(lasr_ctx* c, int G) {
         launch_ppj(c);
         launch_lm(c);
     }
-    __atomic_store_n(flag, -1, __ATOMIC_RELEASE);
-    HIPCHK(c, hipMemcpyAsync(flag, c->c_behind + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    (void)slot;
     c->group_inflight = true;
     c->inflight_for = P.serial;
     HIPCHK(c, hipGetLastError());

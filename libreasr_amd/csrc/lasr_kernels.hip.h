@@ -172,6 +172,10 @@ struct DecState {
     int* ntok_end;     // [M][end_slots] tokens emitted when row r finished its step j (slot j % end_slots)
     int step_T;        // frames per model step (n_buffer)
     int end_slots;
+    // continuous mode, last iteration of a group: the last workgroup to finish publishes the "rows still
+    // behind" count straight into pinned host memory (no copy kernel between the group and the host)
+    int* done_blocks;  // [64] ring, like unfinished
+    int* host_flag;    // nullptr: nothing to publish in this launch
     // LM shallow fusion (LMFuser.fuse, lm.py:59-79): standardised LM log-probs of the row's last token
     const float* lmz;  // [M][V] (nullptr: no LM attached)
     const int* lm_valid; // [M] the LM has advanced at least once since the last LM reset
@@ -225,14 +229,25 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
                                                 const int* __restrict__ T_row, DecState s, int iter_slot,
                                                 float* __restrict__ out_logp, int* __restrict__ out_arg, int la, int M) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (!PLAIN && s.cont && r == 0 && tid == 0) s.unfinished[(iter_slot + 32) & 63] = 0;   // recycle the flag ring
+    if (!PLAIN && s.cont && r == 0 && tid == 0) {                                           // recycle the flag rings
+        s.unfinished[(iter_slot + 32) & 63] = 0;
+        s.done_blocks[(iter_slot + 32) & 63] = 0;
+    }
+    auto publish = [&]() {           // thread 0 of every workgroup, after its last store of this launch
+        if (PLAIN || !s.host_flag) return;
+        __threadfence_system();      // this row's tokens / marks (pinned memory) before the count
+        if (atomicAdd(&s.done_blocks[iter_slot], 1) == (int)gridDim.x - 1) {
+            const int v = atomicAdd(&s.unfinished[iter_slot], 0);
+            __hip_atomic_store(s.host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
     // state of the row: loaded up front so the latency overlaps the logits reads
     int t = 0, Tr = 1, it0 = 0, n0 = 0, si0 = 0, no0 = 0;
     double lp0 = 0.0;
     if (!PLAIN) {
         t = s.t_idx[r]; Tr = T_row[r];
         if (t >= Tr) {
-            if (tid == 0) s.emit[r] = 0;
+            if (tid == 0) { s.emit[r] = 0; publish(); }
             return;
         }
         if (tid == 0) {
@@ -388,6 +403,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     s.t_idx[r] = t;
     s.iters[r] = it0;
     if (s.cont ? (t < s.target[r]) : (t < Tr)) atomicAdd(&s.unfinished[iter_slot], 1);
+    publish();
 }
 
 // LMFuser.advance (lm.py:49-53) for the rows that just emitted a token: log_softmax of the LM's output
