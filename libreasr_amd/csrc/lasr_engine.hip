@@ -118,7 +118,7 @@ struct lasr_ctx {
     long long inflight_for = -1;    // serial of the pending step the in-flight group's flag refers to
     long long done_serial = -1;     // serial of a pending step already known to be fully decoded
     int kick_iters = 0;
-    int kick_n = 4, wait_n = 2;     // iterations per group: kicked from submit / launched while waiting
+    int kick_n = 3, wait_n = 1;     // iterations per group: kicked from submit / launched while waiting (swept on configs[1])
     // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
     // predictor parity at group start, frames)
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
