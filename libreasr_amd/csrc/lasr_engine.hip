@@ -109,6 +109,8 @@ struct lasr_ctx {
     int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
     int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr;
     int *c_done = nullptr, *c_flag_dev = nullptr;   // workgroups finished per iteration; device view of cont_host[0]
+    int* c_iter = nullptr;                          // device-side iteration counter of the continuous loop
+    std::map<std::tuple<int, int, int>, hipGraphExec_t> cgraphs;   // (iterations, predictor parity, LM parity) -> group
     int* cont_host = nullptr;       // pinned: [0] flag, [4..] target staging (NFLY blocks), then ntok_end + token ring
     struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; const int* T_row_ptr; long long serial; };
     std::vector<PendingStep> pending;
@@ -535,6 +537,8 @@ int ensure_T(lasr_ctx* c, int T) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);   // captured pointers become stale
     c->graphs.clear();
+    for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
+    c->cgraphs.clear();
     const int M = c->M, H = c->d.hidden, F = c->d.feat, J = c->d.joint;
     int cap = std::max(T, std::max(2 * c->Tcap, c->d.n_buffer));
     dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe_sync);
@@ -1020,6 +1024,7 @@ void lasr_destroy(lasr_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->ev_misc) (void)hipEventDestroy(c->ev_misc);
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
     if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
     delete c;
 }
@@ -1196,6 +1201,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->c_behind, 0, sizeof(int) * 64));
     RC(dalloc(c, &c->c_done, 64)); HIPCHK(c, hipMemset(c->c_done, 0, sizeof(int) * 64));
+    RC(dalloc(c, &c->c_iter, 4)); HIPCHK(c, hipMemset(c->c_iter, 0, sizeof(int) * 4));
     HIPCHK(c, hipHostMalloc((void**)&c->cont_host, sizeof(int) * (16 + (size_t)M * (lasr_ctx::NFLY + lasr_ctx::ENDSLOTS + lasr_ctx::TOKRING))));
     memset(c->cont_host, 0, sizeof(int) * (16 + (size_t)M * (lasr_ctx::NFLY + lasr_ctx::ENDSLOTS + lasr_ctx::TOKRING)));
     {   // continuous decode: the token ring and the per-step boundary marks are written by k_select straight
@@ -1547,6 +1553,7 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     s.t_idx = c->c_cur; s.iters = c->c_iters; s.step_ntok = c->c_ntotal; s.step_tok = c->c_tok_ring;
     s.tok_cap = lasr_ctx::TOKRING; s.unfinished = c->c_behind; s.cont = 1; s.target = c->c_target;
     s.ntok_end = c->c_ntok_end; s.step_T = P.Tm; s.end_slots = lasr_ctx::ENDSLOTS; s.done_blocks = c->c_done;
+    s.iter_ctr = c->c_iter;
     int* flag = c->cont_host;
     int* tgt_stage = c->cont_host + 16;
     // admit encoded steps in order: the oldest unconditionally, later ones only if their encoder is done
@@ -1568,21 +1575,44 @@ static int cont_launch_group(lasr_ctx* c, int G) {
         HIPCHK(c, hipMemcpyAsync(c->c_target, st, sizeof(int) * M, hipMemcpyHostToDevice, c->stream));
         P.target_set = true;
     }
-    int slot = 0;
     __atomic_store_n(flag, -1, __ATOMIC_RELEASE);      // before the launch that will overwrite it
-    for (int q = 0; q < G; ++q) {
-        slot = (int)(c->cont_iters & 63);
-        c->cont_iters++;
-        c->dbg_gate = false;
-        s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;    // k_select of the last iteration publishes "rows behind"
-        launch_logits(c, c->logits, c->la * M, true);
-        hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, c->d.max_iters_stream,
-                           c->c_avail, s, slot, (float*)nullptr, (int*)nullptr, c->la, M);
-        launch_predictor(c);
-        launch_ppj(c);
-        launch_lm(c);
+    c->dbg_gate = false;
+    // the G iterations are launch-invariant (the flag-ring slot comes from a device counter, the last k_select
+    // publishes the "rows behind" word): replayed as one hipGraph per (G, ping-pong parities)
+    auto enqueue = [&]() {
+        for (int q = 0; q < G; ++q) {
+            s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
+            launch_logits(c, c->logits, c->la * M, true);
+            hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, c->d.max_iters_stream,
+                               c->c_avail, s, 0, (float*)nullptr, (int*)nullptr, c->la, M);
+            launch_predictor(c);
+            launch_ppj(c);
+            launch_lm(c);
+        }
+    };
+    if (c->use_graphs && !c->dbg) {
+        const auto key = std::make_tuple(G, c->pred_par, c->lm.par);
+        auto it = c->cgraphs.find(key);
+        if (it == c->cgraphs.end()) {
+            const int pp0 = c->pred_par, lp0 = c->lm.par;
+            hipGraph_t gr = nullptr;
+            hipGraphExec_t ex = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            enqueue();
+            hipError_t e = hipStreamEndCapture(c->stream, &gr);
+            c->pred_par = pp0; c->lm.par = lp0;            // the capture only recorded; parities advance at launch
+            if (e != hipSuccess || !gr) return fail(c, LASR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(gr);
+            if (e != hipSuccess) return fail(c, LASR_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+            it = c->cgraphs.emplace(key, ex).first;
+        }
+        HIPCHK(c, hipGraphLaunch(it->second, c->stream));
+        if (G & 1) { c->pred_par ^= 1; if (c->lm.on) c->lm.par ^= 1; }
+    } else {
+        enqueue();
     }
-    (void)slot;
+    c->cont_iters += G;
     c->group_inflight = true;
     c->inflight_for = P.serial;
     HIPCHK(c, hipGetLastError());
@@ -2006,6 +2036,8 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
     HIPCHK(c, hipMemset(m.lmz, 0, sizeof(float) * (size_t)M * V)); HIPCHK(c, hipMemset(m.valid, 0, sizeof(int) * M));
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);   // decode groups change shape
     c->graphs.clear();
+    for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
+    c->cgraphs.clear();
     c->la = c->la_stream = c->la_offline = 1;   // the fused re-pick needs the LM state of exactly this decision
     c->ds.lmz = m.lmz; c->ds.lm_valid = m.valid; c->ds.lm_alpha = m.alpha; c->ds.lm_theta = m.theta; c->ds.lm_min = m.min_val;
     m.on = true;

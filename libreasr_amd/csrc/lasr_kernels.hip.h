@@ -176,6 +176,8 @@ struct DecState {
     // behind" count straight into pinned host memory (no copy kernel between the group and the host)
     int* done_blocks;  // [64] ring, like unfinished
     int* host_flag;    // nullptr: nothing to publish in this launch
+    int* iter_ctr;     // continuous mode: device-side iteration counter (the flag-ring slot is iter_ctr & 63), so
+                       // a group of iterations is launch-invariant and can be replayed as a hipGraph
     // LM shallow fusion (LMFuser.fuse, lm.py:59-79): standardised LM log-probs of the row's last token
     const float* lmz;  // [M][V] (nullptr: no LM attached)
     const int* lm_valid; // [M] the LM has advanced at least once since the last LM reset
@@ -226,19 +228,24 @@ __global__ void k_step_begin(DecState s, int M, int n_iter_slots, int reset_metr
 // loop; only the number of launches per frame changes.  (With an LM attached la = 1.)
 template <bool PLAIN>
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits, int V, int blank, int max_iters,
-                                                const int* __restrict__ T_row, DecState s, int iter_slot,
+                                                const int* __restrict__ T_row, DecState s, int iter_slot_in,
                                                 float* __restrict__ out_logp, int* __restrict__ out_arg, int la, int M) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int iter_no = (!PLAIN && s.cont) ? *s.iter_ctr : iter_slot_in;   // same value in every workgroup of the launch
+    const int iter_slot = (!PLAIN && s.cont) ? (iter_no & 63) : iter_slot_in;
     if (!PLAIN && s.cont && r == 0 && tid == 0) {                                           // recycle the flag rings
         s.unfinished[(iter_slot + 32) & 63] = 0;
         s.done_blocks[(iter_slot + 32) & 63] = 0;
     }
     auto publish = [&]() {           // thread 0 of every workgroup, after its last store of this launch
-        if (PLAIN || !s.host_flag) return;
-        __threadfence_system();      // this row's tokens / marks (pinned memory) before the count
-        if (atomicAdd(&s.done_blocks[iter_slot], 1) == (int)gridDim.x - 1) {
-            const int v = atomicAdd(&s.unfinished[iter_slot], 0);
-            __hip_atomic_store(s.host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (PLAIN || !s.cont) return;
+        if (s.host_flag) __threadfence_system();     // this row's tokens / marks (pinned memory) before the count
+        if (atomicAdd(&s.done_blocks[iter_slot], 1) == (int)gridDim.x - 1) {      // last workgroup of the launch
+            if (s.host_flag) {
+                const int v = atomicAdd(&s.unfinished[iter_slot], 0);
+                __hip_atomic_store(s.host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            *s.iter_ctr = iter_no + 1;
         }
     };
     // state of the row: loaded up front so the latency overlaps the logits reads
