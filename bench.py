@@ -246,7 +246,9 @@ def main():
         traffic = None                      # HBM bytes per launch from the committed PMC passes (profiles/)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_cell_pmc.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"] if args.model == "cfg2" and B == 64 and args.dtype == "f32" else None
+                pm = json.load(f)
+                if args.model == "cfg2" and B == 64:
+                    traffic = pm["hbm_bytes_per_launch"] if args.dtype == "f32" else pm.get("bf16", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
         out = {
