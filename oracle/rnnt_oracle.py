@@ -77,9 +77,10 @@ def stack_downsample(spec, n_stack=10, downsample=8):
     return np.ascontiguousarray(uf.transpose(0, 2, 1)).reshape(Tp, M * n_stack).astype(F32)
 
 
-def features_offline(pcm, n_stack=10, downsample=8):
-    """x_tfm pipeline (config/testing.yaml:341-356; api-server.py:74-75): [N] -> [T', 1280]."""
-    return stack_downsample(logmel(pcm), n_stack, downsample)
+def features_offline(pcm, n_stack=10, downsample=8, **mel):
+    """x_tfm pipeline (config/testing.yaml:341-356; api-server.py:74-75): [N] -> [T', 1280].
+    **mel: non-default TransformTime settings (win, hop, n_mels) for shape-generality tests."""
+    return stack_downsample(logmel(pcm, **mel), n_stack, downsample)
 
 
 class StreamFrontend:
@@ -87,8 +88,9 @@ class StreamFrontend:
     BUFFER_N_FRAMES=3 :26) + x_tfm_stream (testing.yaml:358-374) incl. Buffer(n_buffer)
     (transforms.py:455-471).  push(chunk) -> None or [n_buffer*T', 1280]."""
 
-    def __init__(self, n_stack=10, downsample=8, n_buffer=2, n_window=3):
+    def __init__(self, n_stack=10, downsample=8, n_buffer=2, n_window=3, **mel):
         self.n_stack, self.downsample, self.n_buffer, self.n_window = n_stack, downsample, n_buffer, n_window
+        self.mel = mel
         self.frames, self.saved = [], []
 
     def push(self, chunk):
@@ -99,7 +101,7 @@ class StreamFrontend:
         self.called = True
         aud = np.concatenate(self.frames)
         del self.frames[0]
-        spec = stream_postprocess(logmel(aud), self.n_stack)
+        spec = stream_postprocess(logmel(aud, **self.mel), self.n_stack)
         st = stack_downsample(spec, self.n_stack, self.downsample)
         self.saved.append(st)
         if len(self.saved) == self.n_buffer:

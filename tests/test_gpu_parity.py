@@ -518,3 +518,52 @@ def test_full_size_properties_config2():
         for s in slots:
             eng.close_slot(s)
     assert res[0] == res[1]
+
+
+def test_odd_shapes_take_the_generic_paths():
+    """Nothing about the reference shape is baked in: 64 mels x 12 stacked frames (feat 768, the runtime
+    k_stack_ln), stride 6, a 3-frame Buffer, hidden 96 / joint 80 / vocab 48 / embed 48 (no static K
+    schedule, partial waves in the K split), 3 encoder layers, 1-layer LSTM predictor, 5 slots (not a
+    multiple of 16), a 4-chunk window of 960-sample chunks.  Offline + streaming against the oracle."""
+    import __graft_entry__ as graft
+    from libreasr_amd.engine import Engine
+    graft.build()
+    cfg = dict(feat=768, embed=48, vocab=48, hidden=96, joint=80, enc_layers=3, pred_layers=1,
+               pred_cell="LSTM", blank_bias=6.0, out_scale=6.0)
+    sd = synth.synth_state_dict(cfg, seed=3)
+    fe = dict(n_mels=64, n_stack=12, stride=6, n_buffer=3, n_window=4, chunk=960, win=320, hop=120)
+    eng = Engine(sd, cfg, max_streams=5, **fe)
+    m = O.OracleTransducer(sd, cfg)
+    mel = dict(n_mels=64, win=320, hop=120)
+    n = 5
+    pcm = synth.synth_pcm(n, 16000 * 2 + 777, seed=21)
+    slots = [eng.open() for _ in range(n)]
+    lens = [len(pcm[0]), 9000, 16000, 20011, 32000]
+    eng.transcribe_pcm(slots, [pcm[i][:lens[i]] for i in range(n)])
+    n_tok = 0
+    for i, s in enumerate(slots):
+        toks, neg_logp, align = eng.fetch(s)
+        ref = m.decode_greedy(O.features_offline(pcm[i][:lens[i]], n_stack=12, downsample=6, **mel))
+        assert toks == ref[0], (i, toks, ref[0])
+        assert abs(neg_logp - ref[1]) < 1e-2 * max(1.0, abs(ref[1]))
+        assert abs(align - ref[2]) < 1e-6
+        n_tok += len(toks)
+    assert n_tok > 0
+    # streaming: 60 ms chunks, model every 3 calls of the transform
+    for s in slots:
+        eng.reset(s, 15)
+    chunks = [synth.stream_chunks(p[:24000], 960, lead=1, tail=6) for p in pcm]
+    got = [[] for _ in range(n)]
+    for k in range(len(chunks[0])):
+        eng.push(slots, np.stack([c[k] for c in chunks]))
+        if eng.step(slots):
+            for i, t in enumerate(eng.fetch_many(slots, 256)):
+                got[i] += t
+    for i in range(n):
+        f, dec = O.StreamFrontend(n_stack=12, downsample=6, n_buffer=3, n_window=4, **mel), m.stream_decoder()
+        for ch in chunks[i]:
+            o = f.push(ch)
+            if o is not None:
+                dec.step(o)
+        assert got[i] == dec.y, (i, got[i], dec.y)
+    eng.close()
