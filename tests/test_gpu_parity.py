@@ -567,3 +567,56 @@ def test_odd_shapes_take_the_generic_paths():
                 dec.step(o)
         assert got[i] == dec.y, (i, got[i], dec.y)
     eng.close()
+
+
+def test_maximum_stream_count_1024():
+    """max_streams = 1024 (the ABI's maximum: 16 row groups in the predictor / joint kernels, the in-kernel
+    compaction scan at its 1024-row limit, the command-block push path for M > 512): all slots open, 640
+    of them streaming (ragged: the rest idle), synchronous and pipelined; spot-checked against the oracle."""
+    import __graft_entry__ as graft
+    from libreasr_amd._native import LasrError
+    from libreasr_amd.engine import Engine
+    graft.build()
+    cfg = synth.model_cfg("tiny")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    eng = Engine(sd, cfg, max_streams=1024)
+    m = O.OracleTransducer(sd, cfg)
+    slots = [eng.open() for _ in range(1024)]
+    assert slots == list(range(1024))
+    with pytest.raises(LasrError):
+        eng.open()                                   # all slots taken
+    act = list(range(0, 1024, 2))[:320] + list(range(1, 1024, 2))[:320]      # 640 active slots, interleaved
+    base = synth.synth_pcm(8, 16 * 1280, seed=77)
+    chunks = base.reshape(8, 16, 1280)
+    which = np.array([s % 8 for s in act])
+    for mode in ("sync", "pipelined"):
+        got = {s: [] for s in act}
+        for k in range(16):
+            eng.push(act, chunks[which, k])
+            if mode == "sync":
+                if eng.step(act):
+                    for s, t in zip(act, eng.fetch_many(act, 64)):
+                        got[s] += t
+            else:
+                eng.submit(act)
+                if eng.pending() >= 3 and eng.wait():
+                    for s, t in zip(act, eng.fetch_many(act, 64)):
+                        got[s] += t
+        while eng.pending():
+            if eng.wait():
+                for s, t in zip(act, eng.fetch_many(act, 64)):
+                    got[s] += t
+        ref = []
+        for i in range(8):
+            fe, dec = O.StreamFrontend(), m.stream_decoder()
+            for k in range(16):
+                o = fe.push(chunks[i, k])
+                if o is not None:
+                    dec.step(o)
+            ref.append(dec.y)
+        assert sum(len(r) for r in ref) > 0
+        for s in act:
+            assert got[s] == ref[s % 8], (mode, s)
+        for s in act:
+            eng.reset(s, 15)
+    eng.close()
