@@ -461,10 +461,10 @@ struct EpiLSTM {
     template <int MTB>
     __device__ static Pre prefetch(const Args& a, int tid, int jb, int mg, int n_act, const int* row_map) {
         constexpr int ROWS = MTB * 16;
-        static_assert(ROWS * U == 256, "one (row, unit) item per thread");
+        static_assert(ROWS * U <= 256, "at most one (row, unit) item per thread");
         Pre p;
         p.r = -1; p.carry = false; p.act = false;
-        if (tid >= 256) return p;
+        if (tid >= ROWS * U) return p;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
         const bool beam = PRED && a.W > 1;
         if (PRED) {
@@ -495,7 +495,7 @@ struct EpiLSTM {
     __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
                                const Pre& p, int) {
         constexpr int ROWS = MTB * 16;
-        if (tid >= 256) return;
+        if (tid >= ROWS * U) return;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu;
         if (PRED && p.carry) {
             Ops::st(a.h_out, hidx(a, vr, u), p.carry_h);
