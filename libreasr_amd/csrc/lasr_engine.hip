@@ -768,6 +768,7 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
     b.t_idx = c->ds.t_idx; b.iters = c->ds.iters; b.T_row = c->T_row_dec;
     b.score = c->b_score; b.alive = c->b_alive; b.inB = c->b_inB; b.token = c->ds.token; b.emit = c->ds.emit;
     b.parent = c->b_parent; b.trellis = c->b_trellis; b.unfinished = c->ds.unfinished;
+    b.dbg = c->dbg ? c->dbg + (size_t)4 * 4096 * 16 : nullptr;      // reuses the "logits" slot of the debug buffer
     const int total_cap = T_max * max_iters;
     if (total_cap + 1 > c->n_iter_slots) return fail(c, LASR_EINVAL, "decode iteration budget exceeds the trellis");
     int* res = c->res_host;

@@ -515,6 +515,7 @@ struct BeamState {
     int* parent;       // [Md] slot (0..W-1) whose state this slot continues
     int* trellis;      // [n_iter_slots][Md]  (parent << 16) | (token + 1 if extended else 0); -1 stream idle, -2 dead slot
     int* unfinished;   // [n_iter_slots]
+    unsigned long long* dbg;   // LASR_DBG_TIMING: phase timestamps of workgroup 0 (wall_clock64, 10 ns ticks)
 };
 
 // WT: compile-time bound of W (2, 4, 8).  One workgroup of 1024 threads per stream: its W x V logits
@@ -538,6 +539,8 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
         }
     }
     int* tre = s.trellis + (size_t)iter_slot * s.Md + r0;
+    const bool dbg = s.dbg && q == 0 && tid == 0;
+    if (dbg) s.dbg[0] = wall_clock64();
     const int t = s.t_idx[q], Tr = s.T_row[q];
     if (t >= Tr) {                                   // stream has nothing to decode: identity round
         if (tid < W) { s.emit[r0 + tid] = 0; s.parent[r0 + tid] = tid; tre[tid] = -1; }
@@ -555,6 +558,7 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
         sc[tid] = in ? s.score[r0 + tid] : -INFINITY; al[tid] = in ? s.alive[r0 + tid] : 0; ib[tid] = in ? s.inB[r0 + tid] : 0;
     }
     __syncthreads();
+    if (dbg) s.dbg[1] = wall_clock64();
     bool inA[WT];
 #pragma unroll
     for (int b = 0; b < WT; ++b) {
@@ -576,14 +580,19 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
         if (lane == 0) redf[w][b] = x;
     }
     __syncthreads();
+    __shared__ float bc[2][WT];                      // broadcast of the per-row results computed by wave 0
+    if (w == 0) {
 #pragma unroll
-    for (int b = 0; b < WT; ++b) {
-        float x = redf[0][b];
+        for (int b = 0; b < WT; ++b) {
+            float x = lane < NWV ? redf[lane][b] : -INFINITY;
 #pragma unroll
-        for (int k = 1; k < NWV; ++k) x = fmaxf(x, redf[k][b]);
-        m[b] = x;
+            for (int o = NWV / 2; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+            if (lane == 0) bc[0][b] = x;
+        }
     }
     __syncthreads();
+#pragma unroll
+    for (int b = 0; b < WT; ++b) m[b] = bc[0][b];
 #pragma unroll
     for (int b = 0; b < WT; ++b) {
         float sum = 0.f;
@@ -596,36 +605,52 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
         if (lane == 0) redf[w][b] = sum;
     }
     __syncthreads();
-#pragma unroll
-    for (int b = 0; b < WT; ++b) {
-        float x = redf[0][b];
-#pragma unroll
-        for (int k = 1; k < NWV; ++k) x += redf[k][b];
-        lg[b] = logf(x);
-    }
-    // ---- W ordered argmax passes; pass j only admits candidates strictly after winner j-1 in the total order
-    double last_sc = INFINITY;
-    int last_ord = -1;
-    for (int j = 0; j < W; ++j) {
-        double best = -INFINITY;
-        int bord = 0x7fffffff;
-        auto offer = [&](double val, int ord) {
-            if (!(val > -INFINITY)) return;
-            const bool after = val < last_sc || (val == last_sc && ord > last_ord);
-            if (!after) return;
-            if (val > best || (val == best && ord < bord)) { best = val; bord = ord; }
-        };
+    if (w == 0) {
 #pragma unroll
         for (int b = 0; b < WT; ++b) {
-            if (!al[b]) continue;
-            if (ib[b]) {
-                if (tid == 0) offer(sc[b], b * (V + 1));
-                continue;
-            }
-            const double sb = sc[b];
+            float x = 0.f;
+            if (lane == 0) {                          // fixed summation order over the 16 wave partials
 #pragma unroll
-            for (int k = 0; k < KEEP; ++k) offer(sb + (double)((zv[b][k] - m[b]) - lg[b]), b * (V + 1) + 1 + tid + NT * k);
+                for (int k = 0; k < NWV; ++k) x += redf[k][b];
+                bc[1][b] = logf(x);
+            }
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < WT; ++b) lg[b] = bc[1][b];
+    if (dbg) s.dbg[2] = wall_clock64();
+    // ---- W ordered argmax passes.  Pass j only admits candidates strictly after winner j-1 in the total order
+    // (score desc, ord asc).  Every thread caches its local best: it stays valid until it wins, so after the
+    // first pass only the winning thread rescans its candidates; the cross-wave step is done by wave 0 alone.
+    double last_sc = INFINITY;
+    int last_ord = -1;
+    double lbest = -INFINITY;
+    int lord = 0x7fffffff;
+    bool stale = true;
+    for (int j = 0; j < W; ++j) {
+        if (stale) {
+            lbest = -INFINITY; lord = 0x7fffffff;
+            auto offer = [&](double val, int ord) {
+                const bool after = val < last_sc || (val == last_sc && ord > last_ord);
+                const bool better = val > lbest || (val == lbest && ord < lord);
+                if ((val > -INFINITY) && after && better) { lbest = val; lord = ord; }
+            };
+#pragma unroll
+            for (int b = 0; b < WT; ++b) {
+                if (!al[b]) continue;
+                if (ib[b]) {
+                    if (tid == 0) offer(sc[b], b * (V + 1));
+                    continue;
+                }
+                const double sb = sc[b];
+#pragma unroll
+                for (int k = 0; k < KEEP; ++k) offer(sb + (double)((zv[b][k] - m[b]) - lg[b]), b * (V + 1) + 1 + tid + NT * k);
+            }
+            stale = false;
+        }
+        double best = lbest;
+        int bord = lord;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ob = __shfl_xor(best, o);
@@ -634,21 +659,31 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
         }
         if (lane == 0) { redd[w] = best; redi[w] = bord; }
         __syncthreads();
-        best = redd[0]; bord = redi[0];
+        if (w == 0) {                                // 16 wave results -> one, by wave 0
+            best = lane < NWV ? redd[lane] : -INFINITY;
+            bord = lane < NWV ? redi[lane] : 0x7fffffff;
 #pragma unroll
-        for (int k = 1; k < NWV; ++k)
-            if (redd[k] > best || (redd[k] == best && redi[k] < bord)) { best = redd[k]; bord = redi[k]; }
+            for (int o = NWV / 2; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o);
+                const int oo = __shfl_xor(bord, o);
+                if (ob > best || (ob == best && oo < bord)) { best = ob; bord = oo; }
+            }
+            if (lane == 0) { sel_sc[j] = best; sel_ord[j] = bord; }
+        }
         __syncthreads();
-        if (tid == 0) { sel_sc[j] = best; sel_ord[j] = bord; }
-        last_sc = best; last_ord = bord;
+        best = sel_sc[j]; bord = sel_ord[j];
+        if (dbg && j == 0) s.dbg[9] = wall_clock64();
         if (!(best > -INFINITY)) {                   // candidates exhausted: the remaining slots are dead
             if (tid == 0)
                 for (int k = j + 1; k < W; ++k) { sel_sc[k] = -INFINITY; sel_ord[k] = 0x7fffffff; }
             break;
         }
+        if (bord == lord) stale = true;              // this thread's candidate won: find its next one
+        last_sc = best; last_ord = bord;
     }
     __syncthreads();
     if (tid != 0) return;
+    if (dbg) s.dbg[3] = wall_clock64();
     const int round = s.iters[q] + 1;
     bool all_b = true;
     int nib[WT];
@@ -677,6 +712,7 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
     for (int j = 0; j < W; ++j) s.inB[r0 + j] = all_b ? 0 : (sel_sc[j] > -INFINITY ? nib[j] : 0);
     s.t_idx[q] = tn; s.iters[q] = rn;
     if (tn < Tr) atomicAdd(&s.unfinished[iter_slot], 1);
+    if (dbg) s.dbg[4] = wall_clock64();
 }
 
 // start of a beam decode step: per-stream cursors and the iteration flags
