@@ -13,15 +13,13 @@ from ..engine import Engine
 from ..weights import infer_cfg
 from .config import apply_overrides, model_cfg_from_conf, open_config, stream_settings
 from .language import get_language
+from .model_utils import extract_tars, load_lm_state_dict as _load_lm_sd, load_model_state_dict
 from .models import Transducer
 from .transforms import AudioTensor, OfflinePipeline, StreamPipeline  # noqa: F401
 
 
 def load_state_dict(path):
-    sd = torch.load(path, map_location="cpu")
-    if isinstance(sd, dict) and "model" in sd and not any(k.startswith("encoder.") for k in sd):
-        sd = sd["model"]                    # fastai learn.save format (model_utils.py:79-85)
-    return {k: v for k, v in sd.items() if torch.is_tensor(v)}
+    return load_model_state_dict(path)      # plain or fastai learn.save format (model_utils.py:79-85)
 
 
 def load_lm_state_dict(conf, synthetic_lm=None):
@@ -33,8 +31,7 @@ def load_lm_state_dict(conf, synthetic_lm=None):
     if not lm.get("enable") or not lm.get("path") or not os.path.exists(lm["path"]):
         return None
     try:
-        sd = torch.load(lm["path"], map_location="cpu")
-        return {k: v for k, v in sd.items() if torch.is_tensor(v)}
+        return _load_lm_sd(lm["path"])
     except Exception:
         print("[LM] Failed to load.")
         return None
@@ -51,6 +48,8 @@ def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_st
         sd = synth.synth_state_dict(cfg, seed=0)
     else:
         path = ((conf.get("model", {}) or {}).get("path")) or f"./tmp/{lang}/model.pth"
+        if not os.path.exists(path):
+            extract_tars()                  # libreasr-model-*.tar.gz in the working directory (model_utils.py:50-58)
         sd = load_state_dict(path)
         cfg = model_cfg_from_conf(conf) if "model" in conf else infer_cfg(sd)
     n_stack, downsample, n_buffer = stream_settings(conf) if conf else (10, 8, 2)

@@ -84,3 +84,43 @@ def test_bench_multi_gpu_path_over_gloo():
     assert d["world"] == 2 and d["elapsed_max"] == 1.5 and d["units_total"] == 128.0 and d["n_local"] == 64
     import bench
     assert bench.shard_streams(512, 8, 3) == list(range(192, 256))
+
+
+def test_model_archive_round_trip(tmp_path):
+    """libreasr-model-*.tar.gz (model_utils.py:31-58): <lang>/model.pth in fastai learn.save form + tokenizer;
+    extraction, unwrapping and flattening give the blob lasr_create expects; path traversal is refused."""
+    import io
+    import tarfile
+    import torch
+    from libreasr_amd import synth
+    from libreasr_amd.lib import model_utils as mu
+    from libreasr_amd.weights import flatten_lm_state_dict, flatten_state_dict, infer_cfg
+    cfg = synth.model_cfg("tiny")
+    sd = {k: torch.as_tensor(v) for k, v in synth.synth_state_dict(cfg, seed=0).items()}
+    lm = {k: torch.as_tensor(v) for k, v in synth.synth_lm_state_dict("tiny_lm").items()}
+    src = tmp_path / "src" / "en"
+    src.mkdir(parents=True)
+    torch.save({"model": sd, "opt": {"state": []}}, src / "model.pth")
+    torch.save(lm, src / "lm.pth")
+    (src / "tokenizer.yttm-model").write_bytes(b"stub")
+    arc = tmp_path / "libreasr-model-en.tar.gz"
+    with tarfile.open(arc, "w:gz") as tar:
+        for f in ("model.pth", "lm.pth", "tokenizer.yttm-model"):
+            tar.add(src / f, arcname=f"en/{f}")
+    dest = tmp_path / "tmp"
+    names = mu.extract_tars([str(arc)], dest)
+    assert "en/model.pth" in names
+    p = mu.model_paths("en", dest)
+    got = mu.load_model_state_dict(p["model"])
+    assert set(got) == set(sd) and infer_cfg(got) == {k: cfg[k] for k in infer_cfg(got)}
+    blob = flatten_state_dict(got, cfg)
+    assert blob.dtype == np.float32 and blob.size == flatten_state_dict(synth.synth_state_dict(cfg, seed=0), cfg).size
+    lcfg, lblob = flatten_lm_state_dict(mu.load_lm_state_dict(p["lm"]))
+    assert lcfg == dict(vocab=64, embed=32, hidden=32, layers=2) and lblob.size == 64 * 32 + 2 * (4 * 32 * 32 * 2 + 8 * 32) + 64 * 32 + 64
+    evil = tmp_path / "evil.tar.gz"
+    with tarfile.open(evil, "w:gz") as tar:
+        info = tarfile.TarInfo("../escape.txt")
+        info.size = 1
+        tar.addfile(info, io.BytesIO(b"x"))
+    with pytest.raises(ValueError):
+        mu.extract_tars([str(evil)], dest)
