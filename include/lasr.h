@@ -191,6 +191,14 @@ int lasr_sync(lasr_ctx* c);
  * (0 encoder cell, 1-2 predictor layers, 3 PPJ, 4 logits): out[5][4096][16] (slots 8..15: per-wave end of the K loop). */
 int lasr_debug_timing(lasr_ctx* c, unsigned long long* out);
 
+/* ---- Resampling for non-16 kHz clients.  Replaces Resample.encodes, transforms.py:135-144
+ * (torchaudio 0.6.0 transforms.Resample == compliance.kaldi.resample_waveform, lowpass_filter_width 6: a
+ * dependency that is NOT in the reference tree -- restated from its published algorithm, parity unpinned).
+ * pcm / out: device [B][N_in] / [B][*N_out] float32; out == NULL only returns *N_out.  The reference
+ * resamples every transform call separately (the whole utterance, or each 3-chunk window), and so do the
+ * mirrors in libreasr_amd/lib/transforms.py; the fused streaming entry points take 16 kHz PCM. */
+int lasr_resample(lasr_ctx* c, const float* pcm, int B, int64_t N_in, int sr_in, float* out, int64_t* N_out);
+
 /* ---- LM shallow fusion.  Replaces LMFuser / LM of lm.py:20-83 as wired into both greedy
  * loops (models.py:401,431,440 / :478,558,569; attached to the model at config.py:143-157): after a
  * non-blank decision the token is re-picked as argmax(alpha * standardize(LM log-probs) + theta *

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("lasr_sync", C.c_int, [_P]),
     ("lasr_debug_timing", C.c_int, [_P, _P]),
     ("lasr_bench_cell", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    ("lasr_resample", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, C.POINTER(C.c_int64)]),
     ("lasr_lm_weight_count", C.c_size_t, [_P]),
     ("lasr_attach_lm", C.c_int, [_P, _P, _P, C.c_size_t]),
 ]

@@ -142,6 +142,10 @@ struct lasr_ctx {
         int* valid = nullptr;
     } lm;
 
+    // resampling filters per client sample rate (lasr_resample)
+    struct Resampler { int U = 0, taps = 0, in_unit = 0; int* first = nullptr; float* w = nullptr; };
+    std::map<int, Resampler> resamplers;
+
     // time-series buffers (capacity Tcap frames)
     int Tcap = 0;
     void *x0 = nullptr, *ybuf[2] = {nullptr, nullptr};   // element-typed, fragment-major
@@ -1967,6 +1971,71 @@ int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, floa
         hipLaunchKernelGGL((k_select<true>), dim3(B), dim3(256), 0, c->stream, (const float*)logits, V, c->d.blank, 1,
                            (const int*)nullptr, s, 0, logp_max, argmax, 1, c->M);
     }
+    HIPCHK(c, hipGetLastError());
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- resampling
+static long long resample_num_out(long long n_in, int sr_in, int sr_out) {     // kaldi GetNumOutputSamples(flush = true)
+    long long a = sr_in, b = sr_out;
+    while (b) { const long long t = a % b; a = b; b = t; }
+    const long long tick = (long long)sr_in / a * sr_out;
+    const long long ticks_in = tick / sr_in, ticks_out = tick / sr_out;
+    const long long length = n_in * ticks_in;
+    if (length <= 0) return 0;
+    long long last = length / ticks_out;
+    if (last * ticks_out == length) last -= 1;
+    return last + 1;
+}
+
+int lasr_resample(lasr_ctx* c, const float* pcm, int B, int64_t N_in, int sr_in, float* out, int64_t* N_out) {
+    if (!c || !N_out) return LASR_EINVAL;
+    const int sr_out = c->d.sample_rate;
+    if (B < 1 || N_in < 1 || sr_in < 1000 || sr_in > 384000) return fail(c, LASR_EINVAL, "bad argument");
+    *N_out = resample_num_out(N_in, sr_in, sr_out);
+    if (!out) return LASR_OK;                          // size query
+    if (!pcm) return fail(c, LASR_EINVAL, "pcm is null");
+    HIPCHK(c, hipSetDevice(c->device));
+    auto it = c->resamplers.find(sr_in);
+    if (it == c->resamplers.end()) {
+        // one windowed-sinc filter per output phase, float32 arithmetic like torchaudio 0.6.0's
+        // compliance/kaldi.py::_get_LR_indices_and_weights (lowpass_filter_width = 6, cutoff = 0.99 * min(sr) / 2)
+        long long a = sr_in, b = sr_out;
+        while (b) { const long long t = a % b; a = b; b = t; }
+        lasr_ctx::Resampler r;
+        r.in_unit = (int)(sr_in / a); r.U = (int)(sr_out / a);
+        const double cutoff = 0.99 * 0.5 * std::min(sr_in, sr_out);
+        const float width = (float)(6.0 / (2.0 * cutoff));
+        std::vector<float> lo(r.U), hi(r.U), ot(r.U);
+        int taps = 0;
+        for (int p = 0; p < r.U; ++p) {
+            ot[p] = (float)p / (float)sr_out;
+            lo[p] = std::ceil((ot[p] - width) * (float)sr_in);
+            hi[p] = std::floor((ot[p] + width) * (float)sr_in);
+            taps = std::max(taps, (int)(hi[p] - lo[p] + 1.f));
+        }
+        r.taps = taps;
+        std::vector<int> first(r.U);
+        std::vector<float> w((size_t)r.U * taps, 0.f);
+        const float cw = (float)(2.0 * M_PI * cutoff / 6.0), cs = (float)(2.0 * M_PI * cutoff), pi = (float)M_PI;
+        for (int p = 0; p < r.U; ++p) {
+            first[p] = (int)lo[p];
+            for (int j = 0; j < taps; ++j) {
+                const float dt = (lo[p] + (float)j) / (float)sr_in - ot[p];
+                float v = 0.f;
+                if (std::fabs(dt) < width) v = 0.5f * (1.f + std::cos(cw * dt));
+                if (dt != 0.f) v *= std::sin(cs * dt) / (pi * dt);
+                else v *= (float)(2.0 * cutoff);
+                w[(size_t)p * taps + j] = v / (float)sr_in;
+            }
+        }
+        RC(upload(c, &r.first, first.data(), first.size()));
+        RC(upload(c, &r.w, w.data(), w.size()));
+        it = c->resamplers.emplace(sr_in, r).first;
+    }
+    const lasr_ctx::Resampler& r = it->second;
+    hipLaunchKernelGGL(k_resample, dim3((unsigned)((*N_out + 255) / 256), B), dim3(256), 0, c->stream, pcm, (long long)N_in,
+                       (const int*)r.first, (const float*)r.w, r.U, r.taps, r.in_unit, out, (long long)*N_out);
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
 }

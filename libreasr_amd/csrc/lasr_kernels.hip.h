@@ -919,6 +919,27 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     }
 }
 
+// Resample (transforms.py:135-144: torchaudio 0.6.0 transforms.Resample = kaldi LinearResample, un-vendored):
+// polyphase windowed-sinc, one filter per output phase (U = sr_out / gcd phases, `taps` taps):
+//   out[n] = sum_j w[n % U][j] * x[first[n % U] + (n / U) * in_unit + j]     (x = 0 outside [0, N_in))
+// HBM-bound: every input sample is read ~taps * sr_out / sr_in times through L1/L2, written once.
+__global__ void k_resample(const float* __restrict__ x, long long N_in, const int* __restrict__ first,
+                           const float* __restrict__ w, int U, int taps, int in_unit, float* __restrict__ out,
+                           long long N_out) {
+    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N_out) return;
+    const float* xr = x + (size_t)blockIdx.y * N_in;
+    const int ph = (int)(n % U);
+    const long long start = first[ph] + (n / U) * in_unit;
+    const float* wp = w + (size_t)ph * taps;
+    float acc = 0.f;
+    for (int j = 0; j < taps; ++j) {
+        const long long i = start + j;
+        if (i >= 0 && i < N_in) acc += wp[j] * xr[i];
+    }
+    out[(size_t)blockIdx.y * N_out + n] = acc;
+}
+
 // StackDownsample (transforms.py:436-441): feats[row][t'][m*n_stack + k] = logmel[row][f0 + stride*t' + k][m]
 __global__ void k_stack(const float* __restrict__ logmel, int T_frames, int n_mels, int n_stack, int stride,
                         float* __restrict__ feats, int Tp, int F) {

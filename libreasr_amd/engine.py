@@ -218,6 +218,17 @@ class Engine:
         self._chk(self.lib.lasr_logmel(self.ctx, _ptr(pcm), B, Ns, _ptr(out)))
         return out
 
+    def resample(self, pcm, sr_in):
+        """pcm [B, N] float32 cuda at `sr_in` Hz -> [B, N'] at the model's rate (Resample, transforms.py:135-144)."""
+        assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.dim() == 2
+        pcm = pcm.contiguous()
+        B, N = pcm.shape
+        n_out = C.c_int64(0)
+        self._chk(self.lib.lasr_resample(self.ctx, None, B, N, int(sr_in), None, C.byref(n_out)))
+        out = torch.empty(B, n_out.value, device=pcm.device, dtype=torch.float32)
+        self._chk(self.lib.lasr_resample(self.ctx, _ptr(pcm), B, N, int(sr_in), _ptr(out), C.byref(n_out)))
+        return out
+
     def stack(self, logmel):
         logmel = logmel.contiguous()
         B, T, _ = logmel.shape

@@ -28,13 +28,14 @@ class _Base:
 
     def _prep(self, aud):
         sr = getattr(aud, "sr", self.target_sr)
-        if sr != self.target_sr:          # Resample (transforms.py:135-144): only 16 kHz is in scope
-            raise NotImplementedError(f"resampling {sr} -> {self.target_sr} Hz is outside the hot path (SURVEY §8f #5)")
         x = torch.as_tensor(aud).as_subclass(torch.Tensor)
         if x.dim() == 1:
             x = x[None]
         x = x[: self.channels]            # ChannelCut (transforms.py:122-132)
-        return x.to(self.engine.device, torch.float32).contiguous()
+        x = x.to(self.engine.device, torch.float32).contiguous()
+        if sr != self.target_sr:          # Resample (transforms.py:135-144), per call like the reference; equal
+            x = self.engine.resample(x, sr)   # rates are passed through untouched
+        return x
 
 
 class OfflinePipeline(_Base):

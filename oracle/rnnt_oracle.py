@@ -59,6 +59,72 @@ def logmel(pcm, n_fft=1024, win=400, hop=160, n_mels=128, sr=16000):
     return np.log(mel + F32(1e-6)).astype(F32)
 
 
+def resample_num_out(n_in, sr_in, sr_out):
+    """kaldi LinearResample::GetNumOutputSamples(flush=true) as in torchaudio 0.6.0
+    compliance/kaldi.py::_get_num_LR_output_samples: output samples with time in [0, n_in / sr_in)."""
+    import math
+    tick = sr_in * sr_out // math.gcd(sr_in, sr_out)
+    ticks_in, ticks_out = tick // sr_in, tick // sr_out
+    length = n_in * ticks_in
+    if length <= 0:
+        return 0
+    last = length // ticks_out
+    if last * ticks_out == length:
+        last -= 1
+    return last + 1
+
+
+def resample_filters(sr_in, sr_out, lowpass_filter_width=6):
+    """_get_LR_indices_and_weights: one windowed-sinc filter per output phase (sr_out / gcd of them).
+    cutoff = 0.99 * min(sr)/2; Hann window of half-width lowpass_filter_width / (2 cutoff); float32
+    arithmetic like the torch code.  Returns (first_index[phase] int, weights[phase, taps] f32, in_unit, out_unit)."""
+    import math
+    base = math.gcd(sr_in, sr_out)
+    in_unit, out_unit = sr_in // base, sr_out // base
+    cutoff = 0.99 * 0.5 * min(sr_in, sr_out)
+    width = lowpass_filter_width / (2.0 * cutoff)
+    out_t = (np.arange(out_unit, dtype=F32) / F32(sr_out)).astype(F32)
+    min_idx = np.ceil((out_t - F32(width)) * F32(sr_in)).astype(F32)
+    max_idx = np.floor((out_t + F32(width)) * F32(sr_in)).astype(F32)
+    taps = int((max_idx - min_idx + 1).max())
+    j = np.arange(taps, dtype=F32)[None, :]
+    idx = min_idx[:, None] + j
+    dt = (idx / F32(sr_in) - out_t[:, None]).astype(F32)
+    w = np.zeros_like(dt)
+    inside = np.abs(dt) < F32(width)
+    w[inside] = (0.5 * (1 + np.cos(F32(2 * math.pi * cutoff / lowpass_filter_width) * dt[inside]))).astype(F32)
+    nz = dt != 0
+    w[nz] *= (np.sin(F32(2 * math.pi * cutoff) * dt[nz]) / (F32(math.pi) * dt[nz])).astype(F32)
+    w[~nz] *= F32(2 * cutoff)
+    w = (w / F32(sr_in)).astype(F32)
+    return min_idx.astype(np.int64), w, in_unit, out_unit
+
+
+def resample(pcm, sr_in, sr_out=16000):
+    """torchaudio.transforms.Resample(sr_in, sr_out) of torchaudio 0.6.0 = kaldi.resample_waveform
+    (Resample.encodes, transforms.py:141-144; un-vendored -> PARITY UNPINNED, restated from the published
+    algorithm): out[n] = sum_j w[n % U][j] * x[first[n % U] + (n // U) * in_unit + j], zero outside x."""
+    pcm = np.asarray(pcm, dtype=F32)
+    first, w, in_unit, out_unit = resample_filters(sr_in, sr_out)
+    n_out = resample_num_out(len(pcm), sr_in, sr_out)
+    out = np.zeros(n_out, dtype=F32)
+    taps = w.shape[1]
+    xp = np.concatenate([np.zeros(taps + int(max(0, -first.min())), F32), pcm, np.zeros(taps + in_unit, F32)])
+    off = taps + int(max(0, -first.min()))
+    for ph in range(out_unit):
+        n = np.arange(ph, n_out, out_unit)
+        if n.size == 0:
+            continue
+        start = first[ph] + (n // out_unit) * in_unit + off
+        ok = start + taps <= len(xp)
+        seg = np.zeros((n.size, taps), F32)
+        idx = start[:, None] + np.arange(taps)[None, :]
+        idx = np.minimum(idx, len(xp) - 1)
+        seg = xp[idx] * (start[:, None] + np.arange(taps)[None, :] < len(xp))
+        out[n] = (seg.astype(F32) * w[ph][None, :]).sum(axis=1, dtype=F32)
+    return out
+
+
 def stream_postprocess(spec, n_stack=10):
     """StreamPostprocess.encodes (transforms.py:335-342): l = T//3; keep frames [l+1, l+1+n_stack)."""
     a = spec.shape[0] // 3 + 1

@@ -147,3 +147,25 @@ def test_lm_shallow_fusion_matches_reference(golden_dir, name, lm_name, n_sec, n
         assert counts == list(g[f"st_counts_{s}"])
     if name != "tiny_lstm":
         assert changed > 0        # the fixture is only worth something if the LM overrides tokens
+
+
+def test_resample_restatement_properties():
+    """kaldi LinearResample as used by torchaudio 0.6.0 transforms.Resample (un-vendored: parity unpinned).
+    Output length rule, unit gain, tone preservation, and linearity."""
+    assert O.resample_num_out(48000, 48000, 16000) == 16000
+    assert O.resample_num_out(48001, 48000, 16000) == 16001        # one more tick inside [0, N/sr)
+    assert O.resample_num_out(3 * 3840, 48000, 16000) == 3840
+    assert O.resample_num_out(44100, 44100, 16000) == 16000
+    first, w, iu, ou = O.resample_filters(44100, 16000)
+    assert (iu, ou) == (441, 160) and w.shape[0] == 160
+    assert np.abs(w.sum(1) - 1.0).max() < 2e-3                     # DC gain of every phase
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal(9000).astype(np.float32)
+    b = rng.standard_normal(9000).astype(np.float32)
+    lhs = O.resample(a + 2 * b, 44100)
+    rhs = O.resample(a, 44100) + 2 * O.resample(b, 44100)
+    assert np.abs(lhs - rhs).max() < 1e-5                          # linear
+    t = np.arange(48000) / 48000.0
+    y = O.resample(np.sin(2 * np.pi * 1000 * t).astype(np.float32), 48000)
+    ref = np.sin(2 * np.pi * 1000 * np.arange(len(y)) / 16000.0)
+    assert np.abs(y[100:-100] - ref[100:-100]).max() < 2e-3
