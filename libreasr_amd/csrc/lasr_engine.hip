@@ -160,6 +160,9 @@ struct lasr_ctx {
     // never has to drain the stream (the copy of chunk k+1 overlaps the kernels of chunk k)
     static constexpr int NSTAGE = 16;
     float* push_stage = nullptr; hipEvent_t push_ev[NSTAGE] = {}; bool push_used[NSTAGE] = {}; int push_next = 0;
+    float* push_stage_host = nullptr;     // pinned mirror of the ring: caller's (pageable) buffer -> memcpy -> async DMA
+    hipStream_t stream_copy = nullptr;    // the DMA of chunk k+1 runs under the kernels of chunk k; the push kernel waits for it
+    hipEvent_t push_copied[NSTAGE] = {};
     float* lm_buf = nullptr; size_t lm_floats = 0;       // offline log-mel
     float* feat_stage = nullptr; size_t feat_stage_floats = 0;
 
@@ -1020,6 +1023,10 @@ void lasr_destroy(lasr_ctx* c) {
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->cont_host) (void)hipHostFree(c->cont_host);
     if (c->trellis_host) (void)hipHostFree(c->trellis_host);
+    if (c->push_stage_host) (void)hipHostFree(c->push_stage_host);
+    if (c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
+    for (auto& e : c->push_copied)
+        if (e) (void)hipEventDestroy(e);
     for (auto& e : c->push_ev)
         if (e) (void)hipEventDestroy(e);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
@@ -1367,14 +1374,20 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
     if (from_host) {
         if (!c->push_stage) {
             RC(dalloc(c, &c->push_stage, (size_t)lasr_ctx::NSTAGE * c->M * CH));
+            HIPCHK(c, hipHostMalloc((void**)&c->push_stage_host, sizeof(float) * (size_t)lasr_ctx::NSTAGE * c->M * CH));
             for (auto& e : c->push_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& e : c->push_copied) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
         }
         stage_i = c->push_next;
         c->push_next = (stage_i + 1) % lasr_ctx::NSTAGE;
         if (c->push_used[stage_i]) HIPCHK(c, hipEventSynchronize(c->push_ev[stage_i]));   // its last reader (16 pushes ago) is done
         float* dst = c->push_stage + (size_t)stage_i * c->M * CH;
-        // pageable host memory: hipMemcpyAsync stages it synchronously, so the caller's buffer is free on return
-        HIPCHK(c, hipMemcpyAsync(dst, pcm, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream));
+        float* pin = c->push_stage_host + (size_t)stage_i * c->M * CH;
+        memcpy(pin, pcm, sizeof(float) * (size_t)n * CH);      // the caller's buffer is free on return, whatever its kind
+        HIPCHK(c, hipMemcpyAsync(dst, pin, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream_copy));   // truly asynchronous
+        HIPCHK(c, hipEventRecord(c->push_copied[stage_i], c->stream_copy));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->push_copied[stage_i], 0));
         src = dst;
     }
     if (c->M <= 512) {      // slot -> staging-row map by value: no command-block copy for a push

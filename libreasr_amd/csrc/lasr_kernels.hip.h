@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
                                                 const int* __restrict__ T_row, DecState s, int iter_slot_in,
                                                 float* __restrict__ out_logp, int* __restrict__ out_arg, int la, int M) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int iter_no = (!PLAIN && s.cont) ? *s.iter_ctr : iter_slot_in;   // same value in every workgroup of the launch
+    const int iter_no = (!PLAIN && s.cont) ? (int)(*(const unsigned*)s.iter_ctr & 0x3fffffffu) : iter_slot_in;   // same value in every workgroup of the launch
     const int iter_slot = (!PLAIN && s.cont) ? (iter_no & 63) : iter_slot_in;
     if (!PLAIN && s.cont && r == 0 && tid == 0) {                                           // recycle the flag rings
         s.unfinished[(iter_slot + 32) & 63] = 0;
