@@ -70,8 +70,8 @@ class Scheduler(threading.Thread):
     def reset(self, st):
         self._call(lambda: self.eng.reset(st.slot, 1 | 2 | 4))             # models.py:494-497
 
-    def transcribe(self, pcm):
-        return self._call(lambda: self._offline(pcm))
+    def transcribe(self, pcm, sr=16000):
+        return self._call(lambda: self._offline(pcm, sr))
 
     def push(self, st, chunk):
         with self.cv:
@@ -94,9 +94,12 @@ class Scheduler(threading.Thread):
         self.streams.pop(st.slot, None)
         self.eng.close_slot(st.slot)
 
-    def _offline(self, pcm):
+    def _offline(self, pcm, sr=16000):
         slot = self.eng.open()
         try:
+            if sr != self.eng.desc.sample_rate:      # Resample (transforms.py:135-144) of the whole utterance, on the GPU
+                import torch
+                pcm = self.eng.resample(torch.as_tensor(pcm[None]).to(self.eng.device), sr)[0]
             self.eng.transcribe_pcm([slot], [pcm])
             return self.eng.fetch(slot)
         finally:
@@ -148,9 +151,7 @@ class ASRServicer(apg.ASRServicer):
 
     def Transcribe(self, request, context):                                # api-server.py:64-80
         aud = tensorize(request.data)[0].numpy()
-        if request.sr not in (0, 16000):
-            context.abort(grpc.StatusCode.INVALID_ARGUMENT, "only 16 kHz input is in scope")
-        tokens, _, _ = self.sched.transcribe(aud)
+        tokens, _, _ = self.sched.transcribe(aud, request.sr or 16000)
         return ap.Transcript(data=self.lang.denumericalize(tokens))
 
     def TranscribeStream(self, request_iterator, context):                 # api-server.py:82-134
@@ -158,6 +159,8 @@ class ASRServicer(apg.ASRServicer):
         try:
             y, last, last_diff, steps = [], "", "", 0
             for frame in request_iterator:
+                if frame.sr not in (0, 16000):                             # the fused streaming path takes 16 kHz PCM
+                    context.abort(grpc.StatusCode.INVALID_ARGUMENT, "TranscribeStream expects 16 kHz PCM (Transcribe resamples)")
                 pcm = tensorize(frame.data)[0].numpy()
                 if pcm.shape[0] != self.chunk:
                     context.abort(grpc.StatusCode.INVALID_ARGUMENT,

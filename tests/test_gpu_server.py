@@ -79,6 +79,10 @@ def test_grpc_server_batched_streams_and_unary():
             stub = apg.ASRStub(ch)
             text = stub.Transcribe(ap.Audio(data=pcm[0].tobytes(), sr=16000)).data
             assert text == lang.denumericalize(m.decode_greedy(O.features_offline(pcm[0]))[0])
+            # a 48 kHz unary request is resampled on the GPU first (Resample.encodes, transforms.py:135-144)
+            pcm48 = synth.synth_pcm(1, 48000 * 2, seed=9, sr=48000)[0]
+            text48 = stub.Transcribe(ap.Audio(data=pcm48.tobytes(), sr=48000)).data
+            assert text48 == lang.denumericalize(m.decode_greedy(O.features_offline(O.resample(pcm48, 48000)))[0])
             with pytest.raises(grpc.RpcError):                         # wrong chunk size is refused, not mis-decoded
                 list(stub.TranscribeStream(iter([ap.Audio(data=np.zeros(100, np.float32).tobytes(), sr=16000)])))
     finally:
