@@ -620,3 +620,37 @@ def test_maximum_stream_count_1024():
         for s in act:
             eng.reset(s, 15)
     eng.close()
+
+
+def test_long_stream_wraps_every_ring():
+    """40 s of audio per stream through the continuous loop: the per-row token ring (256), the step-mark
+    ring (16), the pe frame ring (32), the flag ring (64 iterations) and the command-block ring (64) all wrap
+    many times; tokens per chunk must still equal the oracle's."""
+    eng, m, cfg = engine("tiny_lstm", max_streams=16)
+    n, n_chunks = 4, 500
+    pcm = np.stack([synth.synth_pcm(1, n_chunks * 1280, seed=900 + s)[0] for s in range(n)])
+    chunks = pcm.reshape(n, n_chunks, 1280)
+    slots = [eng.open() for _ in range(n)]
+    got = [[] for _ in range(n)]
+    for k in range(n_chunks):
+        eng.push(slots, chunks[:, k])
+        eng.submit(slots)
+        if eng.pending() >= 5 and eng.wait():
+            for i, t in enumerate(eng.fetch_many(slots, 128)):
+                got[i] += t
+    while eng.pending():
+        if eng.wait():
+            for i, t in enumerate(eng.fetch_many(slots, 128)):
+                got[i] += t
+    total = 0
+    for i in range(n):
+        fe, dec = O.StreamFrontend(), m.stream_decoder()
+        for k in range(n_chunks):
+            o = fe.push(chunks[i, k])
+            if o is not None:
+                dec.step(o)
+        assert got[i] == dec.y, i
+        total += len(dec.y)
+    assert total > 4 * 256                      # enough tokens to wrap the token ring of a row
+    for s in slots:
+        eng.close_slot(s)
