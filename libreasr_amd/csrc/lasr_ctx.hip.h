@@ -1,0 +1,311 @@
+// lasr_ctx.hip.h -- the engine context (lasr_ctx), error / allocation helpers, operand packing, description checks
+// Part of the single translation unit lasr_engine.hip (textual include, in this order:
+// lasr_ctx, lasr_launch, lasr_decode, lasr_weights); not a stand-alone header.
+#pragma once
+
+namespace {
+
+constexpr int NW = 8;          // waves per GEMM workgroup (K split)
+constexpr int NCMD = 64;       // ring of host->device command blocks
+constexpr int MTA = 4;         // m-tiles per workgroup in the "A" tiling (64 rows)
+
+struct Cell {                  // one recurrent layer (+ its BatchNorm fold and learned initial state)
+    int I = 0;                 // input width
+    void *WxA = nullptr, *WhA = nullptr;  // packed (element-typed), tiling "A" (4 units x gates per tile): predictor
+    void *WxC = nullptr, *WhC = nullptr;  // packed, tiling "C" (8 units x 2 gates per tile, 2 tiles per group): encoder
+    float *bias = nullptr, *rbias = nullptr;
+    float *bn_s = nullptr, *bn_t = nullptr;
+    float *h0 = nullptr, *c0 = nullptr;
+    float *tab = nullptr;      // predictor layer 0: per-token input projection table
+};
+
+}  // namespace
+
+struct lasr_ctx {
+    lasr_model_desc d;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> dev_allocs;
+    std::vector<void*> host_allocs;
+
+    int M = 0, MT = 0;         // padded rows (stream slots), m-tiles
+    int W = 1;                 // beam width (hypothesis slots per stream); 1 = greedy
+    int Md = 0, MTd = 0;       // decoder rows = M * W (row = stream * W + slot), m-tiles
+    static constexpr int LA_MAX = 4;
+    int la = 1;                // greedy lookahead: frames evaluated per row and iteration (1 with an LM or a beam)
+    int la_stream = 1, la_offline = 3;   // measured on configs[1]: streaming steps have 2 frames and the per-iteration
+                               // cost of a wider logits GEMM cancels the saved iterations; offline (258 frames) gains 10 %
+    int MTj = 0;               // m-tiles of the ja / logits row space: max(Md, LA_MAX * M) / 16
+    int bf = 0;                // 1: bf16 operands (weights + GEMM-input activations), f32 accumulate / state / logits
+    int kch = 16;              // k per MFMA chunk (16 f32, 32 bf16)
+    size_t esz = 4;            // bytes per operand element
+    int G_pred = 0;            // gates of the predictor cell (3 NBRC / 4 LSTM)
+
+    // front-end constants
+    float* window = nullptr; float2* tw512 = nullptr; float2* tw1024 = nullptr;
+    int* fb_start = nullptr; int* fb_off = nullptr; float* fb_w = nullptr; int fb_nnz = 0;
+    float *ln_w = nullptr, *ln_b = nullptr;
+
+    std::vector<Cell> enc, pred;
+    void *W1p = nullptr, *W1e = nullptr, *W2 = nullptr;   // packed, element-typed
+    float *b1 = nullptr, *b2 = nullptr;
+
+    // recurrent state (row == slot)
+    std::vector<void*> enc_h[2], pred_h[2], pred_y;      // element-typed (A operands)
+    std::vector<float*> enc_c, pred_c;
+    // beam search: c, BN(h) and pp ping-pong like h (every slot may be re-parented each round):
+    // parity 0 = pred_c / pred_y / pp, parity 1 = the *1 buffers; all follow pred_par
+    std::vector<float*> pred_c1;
+    std::vector<void*> pred_y1;
+    float* pp1 = nullptr;
+    double* b_score = nullptr; int *b_alive = nullptr, *b_inB = nullptr, *b_parent = nullptr, *b_trellis = nullptr;
+    std::vector<std::vector<std::vector<int32_t>>> hyp;   // host: token history of every hypothesis slot [M][W]
+    std::vector<std::vector<int32_t>> committed;          // host: best hypothesis at the last predictor reset(s)
+    std::vector<double> committed_score;
+    std::vector<std::vector<int32_t>> best_full;          // host: committed + current best hypothesis
+    int* trellis_host = nullptr; size_t trellis_host_ints = 0;
+    int enc_par = 0;
+    int pred_par = 0;               // predictor h ping-pong parity (row-major [M][H] buffers)
+    void *cvt_a = nullptr, *cvt_b = nullptr;   // [M][H] element-typed staging of f32 op-level inputs
+    bool dbg_gate = true;           // decode kernels record timestamps only in the first iteration of a step
+    unsigned long long* dbg = nullptr;   // LASR_DBG_TIMING: [5 kinds][4096 blocks][16] phase timestamps
+    std::vector<unsigned long long> tile_masks;   // per step t: m-tiles with an active row (from the host's T_row)
+    float *pp = nullptr, *logits = nullptr;
+    void* ja = nullptr;             // joint activation, fragment-major, element-typed
+    DecState ds{};
+    int n_iter_slots = 0;
+    int* T_row_dev = nullptr;       // [M] current step's frames per row: points INTO the step's device command block
+    int* zero_rows = nullptr;       // [M] zeros (reset passes: "no row is decoding")
+    int* T_row_dec = nullptr;       // what the decode kernels read (T_row_dev; frames-available counters when continuous)
+    int* dec_t_idx = nullptr;       // frame cursor array the decode kernels use (ds.t_idx, or c_cur when continuous)
+    int pe_ring_R = 1 << 30;        // pe frame t lives at slot t % pe_ring_R
+    // continuous decode (lasr_step_submit / lasr_step_wait): front-end + encoder of later chunks run on
+    // the main stream while ONE greedy loop keeps running on stream_dec across chunk boundaries: a row
+    // that finished chunk k moves on to chunk k+1's frames while a bursty row is still on chunk k.
+    hipStream_t stream_dec = nullptr;
+    static constexpr int NFLY = 8;  // steps in flight (ring of events / T_row snapshots)
+    static constexpr int RING = 32; // pe ring, frames per row
+    static constexpr int TOKRING = 256, ENDSLOTS = 16;
+    hipEvent_t ev_enc[NFLY] = {};
+    hipEvent_t ev_misc = nullptr;
+    int* T_row_ring[NFLY] = {};
+    float* pe_ring = nullptr;
+    int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
+    int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr;
+    int *c_done = nullptr, *c_flag_dev = nullptr;   // workgroups finished per iteration; device view of cont_host[0]
+    int* c_iter = nullptr;                          // device-side iteration counter of the continuous loop
+    std::map<std::tuple<int, int, int>, hipGraphExec_t> cgraphs;   // (iterations, predictor parity, LM parity) -> group
+    int* cont_host = nullptr;       // pinned: [0] flag, [4..] target staging (NFLY blocks), then ntok_end + token ring
+    struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; const int* T_row_ptr; long long serial; };
+    std::vector<PendingStep> pending;
+    std::vector<long long> h_frames_sub, h_fetched;
+    long long model_steps = 0, cont_iters = 0;
+    bool group_inflight = false;    // a decode group has been launched and its flag not yet consumed
+    long long inflight_for = -1;    // serial of the pending step the in-flight group's flag refers to
+    long long done_serial = -1;     // serial of a pending step already known to be fully decoded
+    int kick_iters = 0;
+    int kick_n = 3, wait_n = 1;     // iterations per group: kicked from submit / launched while waiting (swept on configs[1])
+    // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
+    // predictor parity at group start, frames)
+    std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+    bool use_graphs = true;
+
+    // LM shallow fusion (lasr_attach_lm): Embedding -> LSTM stack -> Linear -> log_softmax, stepped once
+    // per emitted token for the rows that emitted (same compacted cell kernels as the predictor)
+    struct LM {
+        bool on = false;
+        int E = 0, H = 0, L = 0;
+        float alpha = 0.1f, theta = 1.0f, min_val = -10.0f;
+        std::vector<Cell> cells;        // tiling "A"; layer 0 input side = per-token table
+        void* Wout = nullptr; float* bout = nullptr;
+        float *ones = nullptr, *zeros = nullptr;       // "BatchNorm fold" of a plain LSTM: y = h
+        std::vector<void*> h[2], y;     // row-major [M][H], element-typed; h ping-pongs
+        std::vector<float*> cst;        // [H][M]
+        int par = 0;
+        float *raw = nullptr, *lmz = nullptr;          // [M][V] output-layer logits / standardised log-probs
+        int* valid = nullptr;
+    } lm;
+
+    // resampling filters per client sample rate (lasr_resample)
+    struct Resampler { int U = 0, taps = 0, in_unit = 0; int* first = nullptr; float* w = nullptr; };
+    std::map<int, Resampler> resamplers;
+
+    // time-series buffers (capacity Tcap frames)
+    int Tcap = 0;
+    void *x0 = nullptr, *ybuf[2] = {nullptr, nullptr};   // element-typed, fragment-major
+    float *pe = nullptr, *pe_sync = nullptr;
+    int tok_cap_alloc = 0;
+
+    // front-end buffers
+    float* win = nullptr; int* ring_pos = nullptr;
+    float* pend = nullptr;          // [M][n_buffer*n_stack][n_mels]
+    float* stage_pcm = nullptr; size_t stage_pcm_floats = 0;
+    // streaming pushes from host memory: ring of device staging rows + one event per entry, so a push
+    // never has to drain the stream (the copy of chunk k+1 overlaps the kernels of chunk k)
+    static constexpr int NSTAGE = 16;
+    float* push_stage = nullptr; hipEvent_t push_ev[NSTAGE] = {}; bool push_used[NSTAGE] = {}; int push_next = 0;
+    float* push_stage_host = nullptr;     // pinned mirror of the ring: caller's (pageable) buffer -> memcpy -> async DMA
+    hipStream_t stream_copy = nullptr;    // the DMA of chunk k+1 runs under the kernels of chunk k; the push kernel waits for it
+    hipEvent_t push_copied[NSTAGE] = {};
+    float* lm_buf = nullptr; size_t lm_floats = 0;       // offline log-mel
+    float* feat_stage = nullptr; size_t feat_stage_floats = 0;
+
+    // command blocks (pinned host ring + device ring)
+    struct Cmd {
+        int* T_row; int* what; int* src_idx; int* feat_sel; int* row_frames; int* token; int* emit;
+        long long* row_N; long long* row_src_off; long long* row_feat_off;
+    };
+    char* cmd_host = nullptr; char* cmd_dev = nullptr; size_t cmd_bytes = 0; int cmd_next = 0; int cmd_inflight = 0;
+    Cmd hc{}, dc{};
+
+    // host results
+    int* res_host = nullptr;        // pinned: unfinished flag + ntok + tokens + metrics
+    size_t res_bytes = 0;
+
+    // host mirrors
+    std::vector<char> open_;
+    std::vector<int> n_chunks, n_pend;
+    std::vector<std::vector<int32_t>> queue;
+    std::vector<double> neg_logp, align;
+
+    // stats
+    bool profiling = false;
+    hipEvent_t ev[8];
+    bool ev_ok = false;
+    lasr_step_stats stats{};
+};
+
+namespace {
+
+int fail(lasr_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(c, LASR_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T>
+int dalloc(lasr_ctx* c, T** p, size_t n) {
+    void* q = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) return fail(c, LASR_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    c->dev_allocs.push_back(q);
+    *p = (T*)q;
+    return LASR_OK;
+}
+void dfree(lasr_ctx* c, void* p) {
+    if (!p) return;
+    auto it = std::find(c->dev_allocs.begin(), c->dev_allocs.end(), p);
+    if (it != c->dev_allocs.end()) c->dev_allocs.erase(it);
+    (void)hipFree(p);
+}
+template <class T>
+int upload(lasr_ctx* c, T** p, const T* src, size_t n) {
+    int rc = dalloc(c, p, n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return LASR_OK;
+}
+#define RC(x)                \
+    do {                     \
+        int rc_ = (x);       \
+        if (rc_) return rc_; \
+    } while (0)
+
+unsigned short host_bf16(float x) {            // round to nearest even (same as the device f32_to_bf16)
+    unsigned u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+struct Packed {                                // host image of a packed operand
+    std::vector<char> bytes;
+    int bf = 0;
+    void resize(size_t n_elems, int bf_) { bf = bf_; bytes.assign(n_elems * (bf_ ? 2 : 4), 0); }
+    void set(size_t i, float v) {
+        if (bf) ((unsigned short*)bytes.data())[i] = host_bf16(v);
+        else ((float*)bytes.data())[i] = v;
+    }
+};
+// Weight tile [16 columns][K] -> fragments: elem((tile*KC + c)*64 + lane, e) = get(tile, col = lane&15, k),
+// k = KCH*c + EPL*(lane>>4) + e   (KCH = 16, EPL = 4 for f32;  32, 8 for bf16)
+template <class F>
+void pack_tiles(Packed& dst, int bf, int n_tiles, int K, F get) {
+    const int KCH = bf ? 32 : 16, EPL = bf ? 8 : 4, KC = K / KCH;
+    dst.resize((size_t)n_tiles * KC * 64 * EPL, bf);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int c = 0; c < KC; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < EPL; ++e)
+                    dst.set((((size_t)t * KC + c) * 64 + lane) * EPL + e, get(t, lane & 15, KCH * c + EPL * (lane >> 4) + e));
+}
+// "A" tiling of a pseudo-gated (NBRC) phase: tile = 4 units x {3 live gates}; fragment = [g][12 live cols][EPL]
+// a = live column (gate = a/4, unit = a%4)
+template <class F>
+void pack_tiles12(Packed& dst, int bf, int n_tiles, int K, F get) {
+    const int KCH = bf ? 32 : 16, EPL = bf ? 8 : 4, KC = K / KCH;
+    dst.resize((size_t)n_tiles * KC * 48 * EPL, bf);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int c = 0; c < KC; ++c)
+            for (int g = 0; g < 4; ++g)
+                for (int a = 0; a < 12; ++a)
+                    for (int e = 0; e < EPL; ++e)
+                        dst.set((((size_t)t * KC + c) * 48 + g * 12 + a) * EPL + e, get(t, a, KCH * c + EPL * g + e));
+}
+int upload_packed(lasr_ctx* c, void** p, const Packed& pk) {
+    char* q = nullptr;
+    int rc = dalloc(c, &q, pk.bytes.size());
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(q, pk.bytes.data(), pk.bytes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(c, LASR_EHIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+    *p = q;
+    return LASR_OK;
+}
+
+bool valid_desc(const lasr_model_desc* d) {
+    if (!d) return false;
+    auto m16 = [](int v) { return v > 0 && v % 16 == 0; };
+    if (!m16(d->feat) || !m16(d->hidden) || !m16(d->embed) || !m16(d->joint) || !m16(d->vocab)) return false;
+    if (d->enc_layers < 1 || d->enc_layers > 16 || d->pred_layers < 1 || d->pred_layers > 8) return false;
+    if (d->pred_cell != 0 && d->pred_cell != 1) return false;
+    if (d->n_fft != 1024 || d->win <= 0 || d->win > d->n_fft || d->hop <= 0) return false;
+    if (d->n_mels <= 0 || d->n_stack <= 0 || d->stride <= 0 || d->feat != d->n_mels * d->n_stack) return false;
+    if (d->feat > 64 * 32) return false;
+    if (d->n_buffer < 1 || d->n_window < 1 || d->chunk <= 0) return false;
+    if (d->max_streams < 1 || d->max_streams > 1024) return false;
+    if (d->max_iters_offline < 1 || d->max_iters_stream < 1) return false;
+    if (d->blank < 0 || d->blank >= d->vocab || d->bos < 0 || d->bos >= d->vocab) return false;
+    if ((d->dtype != 0 && d->dtype != 1) || d->beam < 1 || d->beam > 8) return false;
+    if ((d->max_streams + 63) / 64 * 64 * d->beam > 1024) return false;      // decoder rows (streams x beam slots)
+    if (d->beam > 1 && d->vocab > 4096) return false;                         // k_beam_select keeps a stream's logits in registers
+    if (d->dtype == 1) {   // bf16 operands: 32-wide K chunks
+        auto m32 = [](int v) { return v % 32 == 0; };
+        if (!m32(d->feat) || !m32(d->hidden) || !m32(d->joint)) return false;
+    }
+    return true;
+}
+
+// k_stack_ln: the reference shape (1280 = 128 mels x 10 frames) has a fully static instantiation
+#define LAUNCH_STACK_LN(grid, block, shmem, stream, args)                                              \
+    do {                                                                                               \
+        if ((args).F == 1280 && (args).n_stack == 10)                                                  \
+            hipLaunchKernelGGL((k_stack_ln<20, 10>), grid, block, shmem, stream, args);                \
+        else                                                                                           \
+            hipLaunchKernelGGL((k_stack_ln<32, 0>), grid, block, shmem, stream, args);                 \
+    } while (0)
+
+
+}  // namespace

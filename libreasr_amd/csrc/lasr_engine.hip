@@ -18,968 +18,11 @@
 
 using namespace lasr;
 
-namespace {
+#include "lasr_ctx.hip.h"
+#include "lasr_launch.hip.h"
+#include "lasr_decode.hip.h"
+#include "lasr_weights.hip.h"
 
-constexpr int NW = 8;          // waves per GEMM workgroup (K split)
-constexpr int NCMD = 64;       // ring of host->device command blocks
-constexpr int MTA = 4;         // m-tiles per workgroup in the "A" tiling (64 rows)
-
-struct Cell {                  // one recurrent layer (+ its BatchNorm fold and learned initial state)
-    int I = 0;                 // input width
-    void *WxA = nullptr, *WhA = nullptr;  // packed (element-typed), tiling "A" (4 units x gates per tile): predictor
-    void *WxC = nullptr, *WhC = nullptr;  // packed, tiling "C" (8 units x 2 gates per tile, 2 tiles per group): encoder
-    float *bias = nullptr, *rbias = nullptr;
-    float *bn_s = nullptr, *bn_t = nullptr;
-    float *h0 = nullptr, *c0 = nullptr;
-    float *tab = nullptr;      // predictor layer 0: per-token input projection table
-};
-
-}  // namespace
-
-struct lasr_ctx {
-    lasr_model_desc d;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    std::vector<void*> dev_allocs;
-    std::vector<void*> host_allocs;
-
-    int M = 0, MT = 0;         // padded rows (stream slots), m-tiles
-    int W = 1;                 // beam width (hypothesis slots per stream); 1 = greedy
-    int Md = 0, MTd = 0;       // decoder rows = M * W (row = stream * W + slot), m-tiles
-    static constexpr int LA_MAX = 4;
-    int la = 1;                // greedy lookahead: frames evaluated per row and iteration (1 with an LM or a beam)
-    int la_stream = 1, la_offline = 3;   // measured on configs[1]: streaming steps have 2 frames and the per-iteration
-                               // cost of a wider logits GEMM cancels the saved iterations; offline (258 frames) gains 10 %
-    int MTj = 0;               // m-tiles of the ja / logits row space: max(Md, LA_MAX * M) / 16
-    int bf = 0;                // 1: bf16 operands (weights + GEMM-input activations), f32 accumulate / state / logits
-    int kch = 16;              // k per MFMA chunk (16 f32, 32 bf16)
-    size_t esz = 4;            // bytes per operand element
-    int G_pred = 0;            // gates of the predictor cell (3 NBRC / 4 LSTM)
-
-    // front-end constants
-    float* window = nullptr; float2* tw512 = nullptr; float2* tw1024 = nullptr;
-    int* fb_start = nullptr; int* fb_off = nullptr; float* fb_w = nullptr; int fb_nnz = 0;
-    float *ln_w = nullptr, *ln_b = nullptr;
-
-    std::vector<Cell> enc, pred;
-    void *W1p = nullptr, *W1e = nullptr, *W2 = nullptr;   // packed, element-typed
-    float *b1 = nullptr, *b2 = nullptr;
-
-    // recurrent state (row == slot)
-    std::vector<void*> enc_h[2], pred_h[2], pred_y;      // element-typed (A operands)
-    std::vector<float*> enc_c, pred_c;
-    // beam search: c, BN(h) and pp ping-pong like h (every slot may be re-parented each round):
-    // parity 0 = pred_c / pred_y / pp, parity 1 = the *1 buffers; all follow pred_par
-    std::vector<float*> pred_c1;
-    std::vector<void*> pred_y1;
-    float* pp1 = nullptr;
-    double* b_score = nullptr; int *b_alive = nullptr, *b_inB = nullptr, *b_parent = nullptr, *b_trellis = nullptr;
-    std::vector<std::vector<std::vector<int32_t>>> hyp;   // host: token history of every hypothesis slot [M][W]
-    std::vector<std::vector<int32_t>> committed;          // host: best hypothesis at the last predictor reset(s)
-    std::vector<double> committed_score;
-    std::vector<std::vector<int32_t>> best_full;          // host: committed + current best hypothesis
-    int* trellis_host = nullptr; size_t trellis_host_ints = 0;
-    int enc_par = 0;
-    int pred_par = 0;               // predictor h ping-pong parity (row-major [M][H] buffers)
-    void *cvt_a = nullptr, *cvt_b = nullptr;   // [M][H] element-typed staging of f32 op-level inputs
-    bool dbg_gate = true;           // decode kernels record timestamps only in the first iteration of a step
-    unsigned long long* dbg = nullptr;   // LASR_DBG_TIMING: [5 kinds][4096 blocks][16] phase timestamps
-    std::vector<unsigned long long> tile_masks;   // per step t: m-tiles with an active row (from the host's T_row)
-    float *pp = nullptr, *logits = nullptr;
-    void* ja = nullptr;             // joint activation, fragment-major, element-typed
-    DecState ds{};
-    int n_iter_slots = 0;
-    int* T_row_dev = nullptr;       // [M] current step's frames per row: points INTO the step's device command block
-    int* zero_rows = nullptr;       // [M] zeros (reset passes: "no row is decoding")
-    int* T_row_dec = nullptr;       // what the decode kernels read (T_row_dev; frames-available counters when continuous)
-    int* dec_t_idx = nullptr;       // frame cursor array the decode kernels use (ds.t_idx, or c_cur when continuous)
-    int pe_ring_R = 1 << 30;        // pe frame t lives at slot t % pe_ring_R
-    // continuous decode (lasr_step_submit / lasr_step_wait): front-end + encoder of later chunks run on
-    // the main stream while ONE greedy loop keeps running on stream_dec across chunk boundaries: a row
-    // that finished chunk k moves on to chunk k+1's frames while a bursty row is still on chunk k.
-    hipStream_t stream_dec = nullptr;
-    static constexpr int NFLY = 8;  // steps in flight (ring of events / T_row snapshots)
-    static constexpr int RING = 32; // pe ring, frames per row
-    static constexpr int TOKRING = 256, ENDSLOTS = 16;
-    hipEvent_t ev_enc[NFLY] = {};
-    hipEvent_t ev_misc = nullptr;
-    int* T_row_ring[NFLY] = {};
-    float* pe_ring = nullptr;
-    int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
-    int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr;
-    int *c_done = nullptr, *c_flag_dev = nullptr;   // workgroups finished per iteration; device view of cont_host[0]
-    int* c_iter = nullptr;                          // device-side iteration counter of the continuous loop
-    std::map<std::tuple<int, int, int>, hipGraphExec_t> cgraphs;   // (iterations, predictor parity, LM parity) -> group
-    int* cont_host = nullptr;       // pinned: [0] flag, [4..] target staging (NFLY blocks), then ntok_end + token ring
-    struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; const int* T_row_ptr; long long serial; };
-    std::vector<PendingStep> pending;
-    std::vector<long long> h_frames_sub, h_fetched;
-    long long model_steps = 0, cont_iters = 0;
-    bool group_inflight = false;    // a decode group has been launched and its flag not yet consumed
-    long long inflight_for = -1;    // serial of the pending step the in-flight group's flag refers to
-    long long done_serial = -1;     // serial of a pending step already known to be fully decoded
-    int kick_iters = 0;
-    int kick_n = 3, wait_n = 1;     // iterations per group: kicked from submit / launched while waiting (swept on configs[1])
-    // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
-    // predictor parity at group start, frames)
-    std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
-    bool use_graphs = true;
-
-    // LM shallow fusion (lasr_attach_lm): Embedding -> LSTM stack -> Linear -> log_softmax, stepped once
-    // per emitted token for the rows that emitted (same compacted cell kernels as the predictor)
-    struct LM {
-        bool on = false;
-        int E = 0, H = 0, L = 0;
-        float alpha = 0.1f, theta = 1.0f, min_val = -10.0f;
-        std::vector<Cell> cells;        // tiling "A"; layer 0 input side = per-token table
-        void* Wout = nullptr; float* bout = nullptr;
-        float *ones = nullptr, *zeros = nullptr;       // "BatchNorm fold" of a plain LSTM: y = h
-        std::vector<void*> h[2], y;     // row-major [M][H], element-typed; h ping-pongs
-        std::vector<float*> cst;        // [H][M]
-        int par = 0;
-        float *raw = nullptr, *lmz = nullptr;          // [M][V] output-layer logits / standardised log-probs
-        int* valid = nullptr;
-    } lm;
-
-    // resampling filters per client sample rate (lasr_resample)
-    struct Resampler { int U = 0, taps = 0, in_unit = 0; int* first = nullptr; float* w = nullptr; };
-    std::map<int, Resampler> resamplers;
-
-    // time-series buffers (capacity Tcap frames)
-    int Tcap = 0;
-    void *x0 = nullptr, *ybuf[2] = {nullptr, nullptr};   // element-typed, fragment-major
-    float *pe = nullptr, *pe_sync = nullptr;
-    int tok_cap_alloc = 0;
-
-    // front-end buffers
-    float* win = nullptr; int* ring_pos = nullptr;
-    float* pend = nullptr;          // [M][n_buffer*n_stack][n_mels]
-    float* stage_pcm = nullptr; size_t stage_pcm_floats = 0;
-    // streaming pushes from host memory: ring of device staging rows + one event per entry, so a push
-    // never has to drain the stream (the copy of chunk k+1 overlaps the kernels of chunk k)
-    static constexpr int NSTAGE = 16;
-    float* push_stage = nullptr; hipEvent_t push_ev[NSTAGE] = {}; bool push_used[NSTAGE] = {}; int push_next = 0;
-    float* push_stage_host = nullptr;     // pinned mirror of the ring: caller's (pageable) buffer -> memcpy -> async DMA
-    hipStream_t stream_copy = nullptr;    // the DMA of chunk k+1 runs under the kernels of chunk k; the push kernel waits for it
-    hipEvent_t push_copied[NSTAGE] = {};
-    float* lm_buf = nullptr; size_t lm_floats = 0;       // offline log-mel
-    float* feat_stage = nullptr; size_t feat_stage_floats = 0;
-
-    // command blocks (pinned host ring + device ring)
-    struct Cmd {
-        int* T_row; int* what; int* src_idx; int* feat_sel; int* row_frames; int* token; int* emit;
-        long long* row_N; long long* row_src_off; long long* row_feat_off;
-    };
-    char* cmd_host = nullptr; char* cmd_dev = nullptr; size_t cmd_bytes = 0; int cmd_next = 0; int cmd_inflight = 0;
-    Cmd hc{}, dc{};
-
-    // host results
-    int* res_host = nullptr;        // pinned: unfinished flag + ntok + tokens + metrics
-    size_t res_bytes = 0;
-
-    // host mirrors
-    std::vector<char> open_;
-    std::vector<int> n_chunks, n_pend;
-    std::vector<std::vector<int32_t>> queue;
-    std::vector<double> neg_logp, align;
-
-    // stats
-    bool profiling = false;
-    hipEvent_t ev[8];
-    bool ev_ok = false;
-    lasr_step_stats stats{};
-};
-
-namespace {
-
-int fail(lasr_ctx* c, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    if (c) c->err = buf;
-    return code;
-}
-
-#define HIPCHK(c, call)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return fail(c, LASR_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-template <class T>
-int dalloc(lasr_ctx* c, T** p, size_t n) {
-    void* q = nullptr;
-    if (n == 0) n = 1;
-    hipError_t e = hipMalloc(&q, n * sizeof(T));
-    if (e != hipSuccess) return fail(c, LASR_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
-    c->dev_allocs.push_back(q);
-    *p = (T*)q;
-    return LASR_OK;
-}
-void dfree(lasr_ctx* c, void* p) {
-    if (!p) return;
-    auto it = std::find(c->dev_allocs.begin(), c->dev_allocs.end(), p);
-    if (it != c->dev_allocs.end()) c->dev_allocs.erase(it);
-    (void)hipFree(p);
-}
-template <class T>
-int upload(lasr_ctx* c, T** p, const T* src, size_t n) {
-    int rc = dalloc(c, p, n);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
-    return LASR_OK;
-}
-#define RC(x)                \
-    do {                     \
-        int rc_ = (x);       \
-        if (rc_) return rc_; \
-    } while (0)
-
-unsigned short host_bf16(float x) {            // round to nearest even (same as the device f32_to_bf16)
-    unsigned u;
-    memcpy(&u, &x, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-struct Packed {                                // host image of a packed operand
-    std::vector<char> bytes;
-    int bf = 0;
-    void resize(size_t n_elems, int bf_) { bf = bf_; bytes.assign(n_elems * (bf_ ? 2 : 4), 0); }
-    void set(size_t i, float v) {
-        if (bf) ((unsigned short*)bytes.data())[i] = host_bf16(v);
-        else ((float*)bytes.data())[i] = v;
-    }
-};
-// Weight tile [16 columns][K] -> fragments: elem((tile*KC + c)*64 + lane, e) = get(tile, col = lane&15, k),
-// k = KCH*c + EPL*(lane>>4) + e   (KCH = 16, EPL = 4 for f32;  32, 8 for bf16)
-template <class F>
-void pack_tiles(Packed& dst, int bf, int n_tiles, int K, F get) {
-    const int KCH = bf ? 32 : 16, EPL = bf ? 8 : 4, KC = K / KCH;
-    dst.resize((size_t)n_tiles * KC * 64 * EPL, bf);
-    for (int t = 0; t < n_tiles; ++t)
-        for (int c = 0; c < KC; ++c)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < EPL; ++e)
-                    dst.set((((size_t)t * KC + c) * 64 + lane) * EPL + e, get(t, lane & 15, KCH * c + EPL * (lane >> 4) + e));
-}
-// "A" tiling of a pseudo-gated (NBRC) phase: tile = 4 units x {3 live gates}; fragment = [g][12 live cols][EPL]
-// a = live column (gate = a/4, unit = a%4)
-template <class F>
-void pack_tiles12(Packed& dst, int bf, int n_tiles, int K, F get) {
-    const int KCH = bf ? 32 : 16, EPL = bf ? 8 : 4, KC = K / KCH;
-    dst.resize((size_t)n_tiles * KC * 48 * EPL, bf);
-    for (int t = 0; t < n_tiles; ++t)
-        for (int c = 0; c < KC; ++c)
-            for (int g = 0; g < 4; ++g)
-                for (int a = 0; a < 12; ++a)
-                    for (int e = 0; e < EPL; ++e)
-                        dst.set((((size_t)t * KC + c) * 48 + g * 12 + a) * EPL + e, get(t, a, KCH * c + EPL * g + e));
-}
-int upload_packed(lasr_ctx* c, void** p, const Packed& pk) {
-    char* q = nullptr;
-    int rc = dalloc(c, &q, pk.bytes.size());
-    if (rc) return rc;
-    hipError_t e = hipMemcpy(q, pk.bytes.data(), pk.bytes.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return fail(c, LASR_EHIP, "hipMemcpy failed: %s", hipGetErrorString(e));
-    *p = q;
-    return LASR_OK;
-}
-
-bool valid_desc(const lasr_model_desc* d) {
-    if (!d) return false;
-    auto m16 = [](int v) { return v > 0 && v % 16 == 0; };
-    if (!m16(d->feat) || !m16(d->hidden) || !m16(d->embed) || !m16(d->joint) || !m16(d->vocab)) return false;
-    if (d->enc_layers < 1 || d->enc_layers > 16 || d->pred_layers < 1 || d->pred_layers > 8) return false;
-    if (d->pred_cell != 0 && d->pred_cell != 1) return false;
-    if (d->n_fft != 1024 || d->win <= 0 || d->win > d->n_fft || d->hop <= 0) return false;
-    if (d->n_mels <= 0 || d->n_stack <= 0 || d->stride <= 0 || d->feat != d->n_mels * d->n_stack) return false;
-    if (d->feat > 64 * 32) return false;
-    if (d->n_buffer < 1 || d->n_window < 1 || d->chunk <= 0) return false;
-    if (d->max_streams < 1 || d->max_streams > 1024) return false;
-    if (d->max_iters_offline < 1 || d->max_iters_stream < 1) return false;
-    if (d->blank < 0 || d->blank >= d->vocab || d->bos < 0 || d->bos >= d->vocab) return false;
-    if ((d->dtype != 0 && d->dtype != 1) || d->beam < 1 || d->beam > 8) return false;
-    if ((d->max_streams + 63) / 64 * 64 * d->beam > 1024) return false;      // decoder rows (streams x beam slots)
-    if (d->beam > 1 && d->vocab > 4096) return false;                         // k_beam_select keeps a stream's logits in registers
-    if (d->dtype == 1) {   // bf16 operands: 32-wide K chunks
-        auto m32 = [](int v) { return v % 32 == 0; };
-        if (!m32(d->feat) || !m32(d->hidden) || !m32(d->joint)) return false;
-    }
-    return true;
-}
-
-// k_stack_ln: the reference shape (1280 = 128 mels x 10 frames) has a fully static instantiation
-#define LAUNCH_STACK_LN(grid, block, shmem, stream, args)                                              \
-    do {                                                                                               \
-        if ((args).F == 1280 && (args).n_stack == 10)                                                  \
-            hipLaunchKernelGGL((k_stack_ln<20, 10>), grid, block, shmem, stream, args);                \
-        else                                                                                           \
-            hipLaunchKernelGGL((k_stack_ln<32, 0>), grid, block, shmem, stream, args);                 \
-    } while (0)
-
-// ---------------------------------------------------------------------------- launch helpers
-template <class Ops, class Epi, int MT, bool AROW, int D = 3>
-void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g, const typename Epi::Args& ea) {
-    hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NW, AROW, D>), dim3(n_groups, m_groups), dim3(NW * 64), 0, c->stream, g, ea);
-}
-
-int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
-
-// encoder LSTM cell (layer l, step t): x from `xsrc` (fragment-major, K = I); tiling "C"
-template <class Ops>
-void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
-    const Cell& L = c->enc[l];
-    const int H = c->d.hidden;
-    GemmArgs g{};
-    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / Ops::KCH; g.W[0] = L.WxC;
-    g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhC;
-    g.M = c->M; g.dbg = c->dbg;
-    using E = EpiLSTM<Ops, false, false, 8>;
-    typename E::Args ea{};
-    ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t; ea.tile_mask = c->tile_masks.empty() ? ~0ull : c->tile_masks[t];
-    ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
-    ea.y = ydst; ea.y_mt_total = y_mt_total; ea.y_mt_off = t * c->MT;
-    ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
-    launch_gemm<Ops, E, 2, false>(c, H / 8, c->M / 32, g, ea);
-}
-void launch_enc_cell(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
-    if (c->bf) launch_enc_cell_t<OpsBF16>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
-    else launch_enc_cell_t<OpsF32>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
-}
-
-// one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels); predictor
-// state is row-major [M][H]; toggles pred_par
-template <class Ops>
-void launch_predictor_t(lasr_ctx* c, bool beam) {
-    const int H = c->d.hidden;
-    const int mgroups = c->Md / (16 * MTA);
-    const int p = c->pred_par;
-    for (int l = 0; l < c->d.pred_layers; ++l) {
-        const Cell& L = c->pred[l];
-        GemmArgs g{};
-        // beam: parity p holds the current state; everything is written to parity p ^ 1
-        void* y_out = (beam && !p) ? c->pred_y1[l] : c->pred_y[l];
-        const void* y_in = (beam && p) ? c->pred_y1[l] : c->pred_y[l];
-        if (l > 0) {
-            g.A[0] = (beam && !p) ? c->pred_y1[l - 1] : c->pred_y[l - 1];   // what layer l-1 just wrote
-            g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA;
-        }
-        g.A[1] = c->pred_h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhA;
-        if (beam) { g.parent = c->b_parent; g.beam_w = c->W; }
-        g.compact = c->ds.emit; g.M = c->Md; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)(1 + std::min(l, 1)) * 4096 * 16 : nullptr;
-        if (c->d.pred_cell == 1) {
-            typename EpiLSTM<Ops, true, true, 4>::Args ea{};
-            ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
-            ea.c = (beam && !p) ? c->pred_c1[l] : c->pred_c[l]; ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l];
-            ea.y = y_out; ea.y_mt_total = 0; ea.y_mt_off = 0;
-            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md; ea.MT = c->MTd;
-            if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.c_in = p ? c->pred_c1[l] : c->pred_c[l]; ea.y_in = y_in; }
-            if (l == 0) {
-                launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
-            } else {
-                typename EpiLSTM<Ops, true, false, 4>::Args eb{};
-                static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
-                memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
-            }
-        } else {
-            typename EpiNBRC<Ops, true>::Args ea{};
-            ea.bias = L.bias; ea.rbias = L.rbias; ea.tab = L.tab; ea.token = c->ds.token; ea.emit = c->ds.emit;
-            ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = y_out;
-            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md;
-            if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.y_in = y_in; }
-            if (l == 0) {
-                launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
-            } else {
-                typename EpiNBRC<Ops, false>::Args eb{};
-                static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
-                memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
-            }
-        }
-    }
-    if (!beam) c->pred_par ^= 1;      // beam: launch_ppj (same pass, same parities) toggles
-}
-void launch_predictor(lasr_ctx* c, bool beam = false) {
-    if (c->bf) launch_predictor_t<OpsBF16>(c, beam);
-    else launch_predictor_t<OpsF32>(c, beam);
-}
-
-// pp (for emitting rows) and the joint activation ja = tanh(pe[t_idx] + pp) for all rows still decoding
-template <class Ops>
-void launch_ppj_t(lasr_ctx* c, bool beam) {
-    const int H = c->d.hidden, J = c->d.joint, L = c->d.pred_layers, p = c->pred_par;
-    GemmArgs g{};
-    g.A[0] = (beam && !p) ? c->pred_y1[L - 1] : c->pred_y[L - 1];      // what the predictor pass just wrote
-    g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = c->W1p;
-    g.compact = c->ds.emit; g.M = c->Md; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 16 : nullptr;
-    typename EpiPPJ<Ops>::Args ea{};
-    ea.b1 = c->b1; ea.pp = (beam && !p) ? c->pp1 : c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
-    ea.ja = c->ja; ea.J = J; ea.M = c->Md; ea.MT = c->MTj; ea.ring = c->pe_ring_R; ea.la = beam ? 1 : c->la;
-    if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.M_enc = c->M; ea.pp_in = p ? c->pp1 : c->pp; }
-    launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
-    if (beam) c->pred_par ^= 1;
-}
-void launch_ppj(lasr_ctx* c, bool beam = false) {
-    if (c->bf) launch_ppj_t<OpsBF16>(c, beam);
-    else launch_ppj_t<OpsF32>(c, beam);
-}
-float* cur_pp(lasr_ctx* c) { return (c->W > 1 && c->pred_par) ? c->pp1 : c->pp; }
-
-template <bool AROW, int D>
-void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea);
-
-// LMFuser.advance (lm.py:49-53) for the rows with emit != 0: LM step on the token just emitted, then
-// log_softmax + standardise + [0] = MIN_VAL into lmz (read by the next k_select of that row)
-template <class Ops>
-void launch_lm_t(lasr_ctx* c) {
-    lasr_ctx::LM& m = c->lm;
-    const int H = m.H, M = c->M, V = c->d.vocab, p = m.par;
-    for (int l = 0; l < m.L; ++l) {
-        const Cell& L = m.cells[l];
-        GemmArgs g{};
-        if (l > 0) { g.A[0] = m.y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA; }
-        g.A[1] = m.h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhA;
-        g.compact = c->ds.emit; g.M = M;
-        typename EpiLSTM<Ops, true, true, 4>::Args ea{};
-        ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
-        ea.c = m.cst[l]; ea.h_in = m.h[p][l]; ea.h_out = m.h[p ^ 1][l]; ea.y = m.y[l];
-        ea.bn_s = m.ones; ea.bn_t = m.zeros; ea.H = H; ea.M = M; ea.MT = c->MT;
-        if (l == 0) {
-            launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, M / (16 * MTA), g, ea);
-        } else {
-            typename EpiLSTM<Ops, true, false, 4>::Args eb{};
-            memcpy(&eb, &ea, sizeof(eb));
-            launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, M / (16 * MTA), g, eb);
-        }
-    }
-    m.par ^= 1;
-    GemmArgs g{};
-    g.A[0] = m.y[m.L - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.W[0] = m.Wout; g.a_rows = M;
-    EpiLinear::Args ea{};
-    ea.bias = m.bout; ea.out = m.raw; ea.ldo = V; ea.n_rows = M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
-    launch_linear<true, -1>(c, V / 16, M / 16, g, H, ea);
-    hipLaunchKernelGGL(k_lm_post, dim3(M), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val);
-}
-void launch_lm(lasr_ctx* c) {
-    if (!c->lm.on) return;
-    if (c->bf) launch_lm_t<OpsBF16>(c);
-    else launch_lm_t<OpsF32>(c);
-}
-
-// plain linear over element-typed A (fragment-major, or row-major when AROW); f32 row-major output
-template <bool AROW, int D>
-void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea) {
-    g.KC[0] = K / c->kch;
-    if (c->bf) launch_gemm<OpsBF16, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
-    else launch_gemm<OpsF32, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
-}
-
-void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
-    const int J = c->d.joint, V = c->d.vocab;
-    GemmArgs g{};
-    g.A[0] = c->ja; g.a_mt_total[0] = c->MTj; g.a_mt_off[0] = 0; g.W[0] = c->W2; g.M = c->Md;
-    g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)4 * 4096 * 16 : nullptr;
-    EpiLinear::Args ea{};
-    ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
-    ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M; ea.W = c->W;
-    launch_linear<false, -1>(c, V / 16, (n_rows + 15) / 16, g, J, ea);
-}
-
-// ---------------------------------------------------------------------------- command blocks
-size_t cmd_layout(lasr_ctx::Cmd& k, char* base, int M) {
-    size_t o = 0;
-    auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += (bytes + 15) & ~size_t(15); return p; };
-    k.T_row = (int*)take(sizeof(int) * M); k.what = (int*)take(sizeof(int) * M);
-    k.src_idx = (int*)take(sizeof(int) * M); k.feat_sel = (int*)take(sizeof(int) * M);
-    k.row_frames = (int*)take(sizeof(int) * M); k.token = (int*)take(sizeof(int) * M);
-    k.emit = (int*)take(sizeof(int) * M);
-    k.row_N = (long long*)take(sizeof(long long) * M); k.row_src_off = (long long*)take(sizeof(long long) * M);
-    k.row_feat_off = (long long*)take(sizeof(long long) * M);
-    return o;
-}
-
-// next command block: c->hc (host views) / c->dc (device views); zero-initialised
-int cmd_begin(lasr_ctx* c) {
-    if (c->cmd_inflight >= NCMD - 1) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->cmd_inflight = 0;
-    }
-    const int i = c->cmd_next;
-    c->cmd_next = (i + 1) % NCMD;
-    c->cmd_inflight++;
-    cmd_layout(c->hc, c->cmd_host + (size_t)i * c->cmd_bytes, c->M);
-    cmd_layout(c->dc, c->cmd_dev + (size_t)i * c->cmd_bytes, c->M);
-    memset(c->cmd_host + (size_t)i * c->cmd_bytes, 0, c->cmd_bytes);
-    return LASR_OK;
-}
-int cmd_commit(lasr_ctx* c) {
-    HIPCHK(c, hipMemcpyAsync((char*)c->dc.T_row, (char*)c->hc.T_row, c->cmd_bytes, hipMemcpyHostToDevice, c->stream));
-    return LASR_OK;
-}
-
-// device copy of the step's T_row (from the committed command block) + host-side per-step masks of
-// the m-tiles that contain an active row (passed by value to the encoder cell kernels)
-int commit_T_rows(lasr_ctx* c, int T_max) {
-    c->T_row_dev = c->dc.T_row;             // the command ring (NCMD blocks) outlives every step in flight
-    c->T_row_dec = c->T_row_dev;
-    c->tile_masks.assign(std::max(T_max, 1), 0ull);
-    for (int t = 0; t < T_max; ++t) {
-        unsigned long long m = 0;
-        for (int r = 0; r < c->M; ++r)
-            if (t < c->hc.T_row[r]) m |= 1ull << (r >> 4);
-        c->tile_masks[t] = m;
-    }
-    return LASR_OK;
-}
-
-// ---------------------------------------------------------------------------- buffers that grow
-int ensure_T(lasr_ctx* c, int T) {
-    if (T <= c->Tcap) return LASR_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);   // captured pointers become stale
-    c->graphs.clear();
-    for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
-    c->cgraphs.clear();
-    const int M = c->M, H = c->d.hidden, F = c->d.feat, J = c->d.joint;
-    int cap = std::max(T, std::max(2 * c->Tcap, c->d.n_buffer));
-    dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe_sync);
-    c->pe_sync = nullptr;
-    dfree(c, c->ds.step_ntok); dfree(c, c->ds.unfinished);
-    c->x0 = c->ybuf[0] = c->ybuf[1] = c->pe = nullptr; c->ds.step_ntok = nullptr; c->ds.step_tok = nullptr; c->ds.unfinished = nullptr;
-    RC(dalloc(c, (char**)&c->x0, (size_t)cap * M * F * c->esz));
-    RC(dalloc(c, (char**)&c->ybuf[0], (size_t)cap * M * H * c->esz));
-    RC(dalloc(c, (char**)&c->ybuf[1], (size_t)cap * M * H * c->esz));
-    RC(dalloc(c, &c->pe_sync, (size_t)cap * M * J));
-    c->pe = c->pe_sync;
-    const int mi = std::max(c->d.max_iters_offline, c->d.max_iters_stream);
-    c->tok_cap_alloc = cap * mi;
-    // [ntok M][tokens M x tok_cap]: one contiguous block so a group's results reach the host in one copy
-    RC(dalloc(c, &c->ds.step_ntok, (size_t)M + (size_t)M * c->tok_cap_alloc));
-    HIPCHK(c, hipMemset(c->ds.step_ntok, 0, sizeof(int) * M));
-    c->ds.step_tok = c->ds.step_ntok + M;
-    c->n_iter_slots = cap * mi + 8;
-    RC(dalloc(c, &c->ds.unfinished, (size_t)c->n_iter_slots));
-    if (c->W > 1) {
-        dfree(c, c->b_trellis); c->b_trellis = nullptr;
-        RC(dalloc(c, &c->b_trellis, (size_t)c->n_iter_slots * c->Md));
-        if (c->trellis_host) (void)hipHostFree(c->trellis_host);
-        c->trellis_host_ints = (size_t)c->n_iter_slots * c->Md + 4 * (size_t)c->Md + 16;
-        HIPCHK(c, hipHostMalloc((void**)&c->trellis_host, sizeof(int) * c->trellis_host_ints));
-    }
-    HIPCHK(c, hipMemset(c->ybuf[0], 0, (size_t)cap * M * H * c->esz));
-    HIPCHK(c, hipMemset(c->ybuf[1], 0, (size_t)cap * M * H * c->esz));
-    HIPCHK(c, hipMemset(c->x0, 0, (size_t)cap * M * F * c->esz));
-    // pinned result block: [0] unfinished, then ntok[M], sum_iters[M], n_ones[M], logp[M] (double), tokens
-    if (c->res_host) (void)hipHostFree(c->res_host);
-    c->res_bytes = sizeof(int) * (8 + 3 * (size_t)M) + sizeof(double) * M + sizeof(int) * (size_t)M * c->tok_cap_alloc + 64;
-    HIPCHK(c, hipHostMalloc((void**)&c->res_host, c->res_bytes));
-    c->Tcap = cap;
-    return LASR_OK;
-}
-
-template <class T>
-int ensure_buf(lasr_ctx* c, T** p, size_t* have, size_t need) {
-    if (need <= *have) return LASR_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    dfree(c, *p);
-    *p = nullptr;
-    need = need + need / 4;
-    RC(dalloc(c, p, need));
-    *have = need;
-    return LASR_OK;
-}
-
-// ---------------------------------------------------------------------------- reset
-// applies c->dc.what (already committed) to the state; runs the predictor on BOS for rows with bit 2
-// plain_rows: op-level entry points address predictor rows directly (row = batch index, greedy kernels)
-int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3, bool plain_rows = false) {
-    const bool beam = c->W > 1 && !plain_rows;
-    ResetArgs a{};
-    a.what = c->dc.what; a.mask = mask; a.M = c->M; a.MT = c->MT; a.H = c->d.hidden; a.Le = c->d.enc_layers; a.Lp = c->d.pred_layers;
-    a.pred_lstm = c->d.pred_cell; a.bos = c->d.bos; a.bf = c->bf;
-    a.W = beam ? c->W : 1; a.Md = c->Md; a.score = c->b_score; a.alive = c->b_alive; a.inB = c->b_inB; a.parent = c->b_parent;
-    for (int l = 0; l < a.Le; ++l) {
-        a.enc_h[l] = c->enc_h[c->enc_par][l]; a.enc_c[l] = c->enc_c[l];
-        a.enc_h0[l] = c->enc[l].h0; a.enc_c0[l] = c->enc[l].c0;
-    }
-    for (int l = 0; l < a.Lp; ++l) {
-        a.pred_h[l] = c->pred_h[c->pred_par][l];
-        a.pred_c[l] = c->d.pred_cell ? ((beam && c->pred_par) ? c->pred_c1[l] : c->pred_c[l]) : nullptr;
-        a.pred_h0[l] = c->pred[l].h0; a.pred_c0[l] = c->pred[l].c0;
-    }
-    a.token = c->ds.token; a.emit = c->ds.emit;
-    hipLaunchKernelGGL(k_reset_rows, dim3(grid1((size_t)c->M * c->d.hidden)), dim3(256), 0, c->stream, a);
-    if (c->lm.on && (mask & 2)) {      // LM state lives on the decode side, like the predictor's
-        LmResetArgs la{};
-        la.what = c->dc.what; la.M = c->M; la.H = c->lm.H; la.L = c->lm.L; la.bf = c->bf; la.lm_valid = c->lm.valid;
-        for (int l = 0; l < c->lm.L; ++l) { la.h[l] = c->lm.h[c->lm.par][l]; la.c[l] = c->lm.cst[l]; }
-        hipLaunchKernelGGL(k_lm_reset, dim3(grid1((size_t)c->M * c->lm.H)), dim3(256), 0, c->stream, la);
-    }
-    if (any_pred) {
-        // T_row = 0 for every row: EpiPPJ then only refreshes pp (models.py:489: predictor(BOS))
-        int* keep_dec = c->T_row_dec;
-        c->T_row_dec = c->zero_rows;
-        HIPCHK(c, hipMemsetAsync(c->ds.t_idx, 0, sizeof(int) * c->M, c->stream));
-        launch_predictor(c, beam);
-        launch_ppj(c, beam);
-        c->T_row_dec = keep_dec;
-    }
-    return LASR_OK;
-}
-
-// ---------------------------------------------------------------------------- encoder + decode
-// Encoder over T_max frames for rows with T_row > 0 (x0 already holds LayerNorm'ed features).
-void run_encoder(lasr_ctx* c, int T_max) {
-    const int L = c->d.enc_layers;
-    const int mt_total = c->Tcap * c->MT;
-    const int par0 = c->enc_par;
-    // layer-major order: every layer starts from parity par0 and toggles T_max times (enc_h[par][l] is
-    // indexed by the parity at launch time, so all layers end on par0 ^ (T_max & 1))
-    for (int l = 0; l < L; ++l) {
-        c->enc_par = par0;
-        const void* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
-        void* ydst = c->ybuf[l & 1];
-        for (int t = 0; t < T_max; ++t) {
-            launch_enc_cell(c, l, t, xsrc, mt_total, ydst, mt_total);
-            c->enc_par ^= 1;
-        }
-    }
-    // encoder half of the joint for all frames: pe[t][r] = W1e * enc[t][r]
-    const int H = c->d.hidden, J = c->d.joint;
-    GemmArgs g{};
-    g.A[0] = c->ybuf[(L - 1) & 1]; g.a_mt_total[0] = mt_total; g.a_mt_off[0] = 0; g.W[0] = c->W1e;
-    EpiLinear::Args ea{};
-    ea.bias = nullptr; ea.out = c->pe; ea.ldo = J; ea.n_rows = T_max * c->M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
-    if (c->pe == c->pe_ring) { ea.ring_base = c->c_enc_frames; ea.ring = lasr_ctx::RING; }   // continuous mode: per-row frame ring
-    launch_linear<false, 3>(c, J / 16, T_max * c->MT, g, H, ea);
-}
-
-// Greedy decode of the current step (T_row_dev, pe ready).  Blocks until done; fills host queues.
-int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows);
-
-int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows) {
-    if (c->W > 1) return run_decode_beam(c, T_max, max_iters, offline, rows);
-    const int M = c->M, J = c->d.joint, V = c->d.vocab;
-    c->la = offline ? c->la_offline : c->la_stream;
-    DecState s = c->ds;
-    s.tok_cap = T_max * max_iters;
-    const int total_cap = T_max * max_iters;
-    int iter = 0;
-    // iterations are launched in even-sized groups (the predictor ping-pong parity then returns to
-    // its start); after each group the "rows still decoding" counter and the step's tokens so far
-    // come back in the same round trip.  In streaming mode every group is a cached hipGraph: one
-    // launch instead of 4 kernels per iteration, so the GPU is not fed at host launch speed.
-    // (with lookahead a row consumes up to `la` blank frames per iteration: fewer iterations up front)
-    int group = offline ? std::min(total_cap, ((T_max + c->la - 1) / c->la + 16) & ~1) : std::min(total_cap, (T_max + 4) & ~1);
-    const int next_group = offline ? 32 : 4;
-    int* res = c->res_host;
-    int* ntok = res + 4;
-    int* toks = ntok + M;                      // contiguous with ntok, as on the device
-    int* sum_iters = toks + (size_t)M * s.tok_cap;
-    int* n_ones = sum_iters + M;
-    double* logp = (double*)(((uintptr_t)(n_ones + M) + 15) & ~uintptr_t(15));
-    // (the legacy NULL stream cannot be captured: graphs then only serve the pipelined path, whose
-    //  decode loop runs on the ctx-owned stream_dec)
-    const bool graphs = c->use_graphs && !offline && !c->profiling && !c->dbg && c->stream != nullptr;
-    const int buf_idx = 0;
-    auto enqueue_group = [&](int first, int n) -> int {
-        if (first == 0) {
-            hipLaunchKernelGGL(k_step_begin, dim3(grid1(std::max(M, c->n_iter_slots))), dim3(256), 0, c->stream, s, M,
-                               c->n_iter_slots, offline ? 1 : 0);
-            hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->dec_t_idx,
-                               c->T_row_dec, c->ja, J, M, c->MTj, c->pe_ring_R, c->bf, 1, M, c->la);
-        }
-        for (int q = 0; q < n; ++q) {
-            const int it = first + q;
-            c->dbg_gate = (it == 0);
-            launch_logits(c, c->logits, c->la * M, true);
-            hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, max_iters,
-                               c->T_row_dec, s, it, (float*)nullptr, (int*)nullptr, c->la, M);
-            launch_predictor(c);
-            launch_ppj(c);
-            launch_lm(c);
-        }
-        // payload first, the "rows still decoding" word last: the host spins on that word
-        HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * ((size_t)M + (size_t)M * s.tok_cap), hipMemcpyDeviceToHost, c->stream));
-        if (offline) {
-            HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(n_ones, c->ds.n_ones, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(logp, c->ds.logp_sum, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
-        }
-        HIPCHK(c, hipMemcpyAsync(res, c->ds.unfinished + (first + n - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        return LASR_OK;
-    };
-    while (iter < total_cap) {
-        const int n = std::min(group, total_cap - iter);
-        bool launched = false;
-        if (graphs && (n % 2) == 0) {
-            const auto key = std::make_tuple(iter, n, buf_idx, c->pred_par + 2 * c->lm.par, T_max * 1024 + max_iters);
-            auto it = c->graphs.find(key);
-            if (it == c->graphs.end()) {
-                hipGraph_t gr = nullptr;
-                hipGraphExec_t ex = nullptr;
-                HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                int rc = enqueue_group(iter, n);
-                hipError_t e = hipStreamEndCapture(c->stream, &gr);
-                if (rc) return rc;
-                if (e != hipSuccess || !gr) return fail(c, LASR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-                e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(gr);
-                if (e != hipSuccess) return fail(c, LASR_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-                it = c->graphs.emplace(key, ex).first;
-            }
-            HIPCHK(c, hipGraphLaunch(it->second, c->stream));
-            launched = true;
-        }
-        __atomic_store_n(&res[0], -1, __ATOMIC_RELEASE);      // sentinel, overwritten by the last copy of the group
-        if (!launched) RC(enqueue_group(iter, n));
-        iter += n;
-        // spin on the pinned word instead of hipStreamSynchronize (interrupt wake-up costs ~10-20 us per
-        // round trip, and there are 2-4 per step); fall back to a real sync if nothing arrives
-        {
-            unsigned long long spins = 0;
-            while (__atomic_load_n((volatile int*)&res[0], __ATOMIC_ACQUIRE) == -1) {
-                __builtin_ia32_pause();
-                if (++spins > (1ull << 27)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
-            }
-        }
-        if (res[0] == 0) break;
-        group = next_group;
-    }
-    c->stats.decode_iters = iter;
-    for (int r : rows) {
-        const int n = std::min(ntok[r], s.tok_cap);
-        for (int q = 0; q < n; ++q) c->queue[r].push_back(toks[(size_t)r * s.tok_cap + q]);
-        if (offline) {
-            c->neg_logp[r] = -logp[r];
-            // alignment_score = (sum(iters) - #frames with 1 iter) / (sum(iters) + 1e-4)  (models.py:447-453)
-            c->align[r] = ((double)sum_iters[r] - (double)n_ones[r]) / ((double)sum_iters[r] + 1e-4);
-        }
-    }
-    return LASR_OK;
-}
-
-// Beam search over the current step (W > 1): one selection round per iteration for every stream that
-// still has frames; blocks until done.  The per-round (parent, token) records come back in one copy and
-// are replayed on the host into the token history of every hypothesis slot.
-int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows) {
-    const int M = c->M, Md = c->Md, W = c->W, J = c->d.joint;
-    BeamState b{};
-    b.W = W; b.V = c->d.vocab; b.blank = c->d.blank; b.max_iters = max_iters; b.Md = Md;
-    b.t_idx = c->ds.t_idx; b.iters = c->ds.iters; b.T_row = c->T_row_dec;
-    b.score = c->b_score; b.alive = c->b_alive; b.inB = c->b_inB; b.token = c->ds.token; b.emit = c->ds.emit;
-    b.parent = c->b_parent; b.trellis = c->b_trellis; b.unfinished = c->ds.unfinished;
-    b.dbg = c->dbg ? c->dbg + (size_t)4 * 4096 * 16 : nullptr;      // reuses the "logits" slot of the debug buffer
-    const int total_cap = T_max * max_iters;
-    if (total_cap + 1 > c->n_iter_slots) return fail(c, LASR_EINVAL, "decode iteration budget exceeds the trellis");
-    int* res = c->res_host;
-    hipLaunchKernelGGL(k_beam_begin, dim3(grid1(std::max(Md, c->n_iter_slots))), dim3(256), 0, c->stream, b, M, c->n_iter_slots);
-    hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)Md * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)cur_pp(c),
-                       (const int*)c->dec_t_idx, (const int*)c->T_row_dec, c->ja, J, Md, c->MTj, c->pe_ring_R, c->bf, W, M, 1);
-    int iter = 0;
-    int group = offline ? std::min(total_cap, T_max + 16) : std::min(total_cap, T_max + 4);
-    const int next_group = offline ? 32 : 4;
-    c->dbg_gate = false;
-    while (iter < total_cap) {
-        const int n = std::min(group, total_cap - iter);
-        for (int q = 0; q < n; ++q) {
-            launch_logits(c, c->logits, Md, true);
-            if (W <= 2) hipLaunchKernelGGL((k_beam_select<2>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter + q);
-            else if (W <= 4) hipLaunchKernelGGL((k_beam_select<4>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter + q);
-            else hipLaunchKernelGGL((k_beam_select<8>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter + q);
-            launch_predictor(c, true);
-            launch_ppj(c, true);
-        }
-        iter += n;
-        __atomic_store_n(&res[0], -1, __ATOMIC_RELEASE);
-        HIPCHK(c, hipMemcpyAsync(res, c->ds.unfinished + (iter - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        unsigned long long spins = 0;
-        while (__atomic_load_n((volatile int*)&res[0], __ATOMIC_ACQUIRE) == -1) {
-            __builtin_ia32_pause();
-            if (++spins > (1ull << 27)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
-        }
-        if (res[0] == 0) break;
-        group = next_group;
-    }
-    c->stats.decode_iters = iter;
-    // results: the rounds' records + final scores
-    int* tre = c->trellis_host;
-    double* sc = (double*)(tre + (((size_t)iter * Md + 1) & ~size_t(1)));
-    int* alive = (int*)(sc + Md);
-    HIPCHK(c, hipMemcpyAsync(tre, c->b_trellis, sizeof(int) * (size_t)iter * Md, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(sc, c->b_score, sizeof(double) * Md, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(alive, c->b_alive, sizeof(int) * Md, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<std::vector<int32_t>> nh(W);
-    for (int r : rows) {
-        auto& H = c->hyp[r];
-        for (int it = 0; it < iter; ++it) {
-            const int* e = tre + (size_t)it * Md + (size_t)r * W;
-            if (e[0] == -1) continue;                          // stream idle in this round
-            for (int j = 0; j < W; ++j) {
-                if (e[j] < 0) { nh[j].clear(); continue; }     // dead slot
-                nh[j] = H[e[j] >> 16];
-                const int tok = e[j] & 0xffff;
-                if (tok) nh[j].push_back(tok - 1);
-            }
-            for (int j = 0; j < W; ++j) H[j].swap(nh[j]);
-        }
-        int best = -1;
-        for (int j = 0; j < W; ++j)
-            if (alive[(size_t)r * W + j] && (best < 0 || sc[(size_t)r * W + j] > sc[(size_t)r * W + best])) best = j;
-        auto& q = c->best_full[r];
-        q = c->committed[r];                                   // what earlier predictor resets froze
-        double score = c->committed_score[r];
-        if (best >= 0) { q.insert(q.end(), H[best].begin(), H[best].end()); score += sc[(size_t)r * W + best]; }
-        c->queue[r] = q;                                       // beam mode: lasr_fetch hands out the whole best hypothesis
-        c->neg_logp[r] = -score;
-        c->align[r] = 0.0;                                     // alignment_score is a greedy-loop metric
-    }
-    return LASR_OK;
-}
-
-// host side of a predictor reset in beam mode: the best hypothesis so far is frozen, the beam restarts
-void beam_host_reset(lasr_ctx* c, int slot, bool forget) {
-    if (c->W <= 1) return;
-    auto& H = c->hyp[slot];
-    if (forget) { c->committed[slot].clear(); c->committed_score[slot] = 0.0; c->best_full[slot].clear(); }
-    else { c->committed[slot] = c->best_full[slot]; c->committed_score[slot] = -c->neg_logp[slot]; }
-    for (auto& h : H) h.clear();
-}
-
-void rec(lasr_ctx* c, int i) {
-    if (c->profiling && c->ev_ok) (void)hipEventRecord(c->ev[i], c->stream);
-}
-void collect_stats(lasr_ctx* c, int T) {
-    c->stats.frames = T;
-    if (!(c->profiling && c->ev_ok)) return;
-    float a = 0, b = 0, d = 0;
-    (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
-    c->stats.frontend_ms = a; c->stats.encoder_ms = b; c->stats.decode_ms = d;
-    c->stats.cell_ms = b; c->stats.cell_launches = T * c->d.enc_layers;
-}
-
-int check_slots(lasr_ctx* c, const int* slots, int n, bool need_open) {
-    if (!slots || n < 0 || n > c->d.max_streams) return fail(c, LASR_EINVAL, "bad slot list (n=%d)", n);
-    std::vector<char> seen(c->M, 0);
-    for (int i = 0; i < n; ++i) {
-        const int s = slots[i];
-        if (s < 0 || s >= c->d.max_streams) return fail(c, LASR_EINVAL, "slot %d out of range", s);
-        if (seen[s]) return fail(c, LASR_EINVAL, "slot %d listed twice", s);
-        seen[s] = 1;
-        if (need_open && !c->open_[s]) return fail(c, LASR_ESTATE, "slot %d is not open", s);
-    }
-    return LASR_OK;
-}
-
-int require_idle(lasr_ctx* c) {
-    if (!c->pending.empty()) return fail(c, LASR_ESTATE, "%d submitted step(s) not collected: call lasr_step_wait first", (int)c->pending.size());
-    return LASR_OK;
-}
-
-bool is_device_ptr(const void* p) {
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return at.type == hipMemoryTypeDevice;
-}
-
-// HTK mel filterbank (torchaudio 0.6.0 create_fb_matrix semantics), sparse, bin-ascending
-void build_fb(const lasr_model_desc& d, std::vector<int>& start, std::vector<int>& off, std::vector<float>& w) {
-    const int nf = d.n_fft / 2 + 1, nm = d.n_mels;
-    const double fmax = d.sample_rate / 2;
-    auto mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
-    std::vector<double> fpts(nm + 2);
-    const double m0 = mel(0.0), m1 = mel(fmax);
-    for (int i = 0; i < nm + 2; ++i) {
-        const double m = m0 + (m1 - m0) * i / (nm + 1);
-        fpts[i] = 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
-    }
-    start.assign(nm, 0); off.assign(nm + 1, 0); w.clear();
-    for (int m = 0; m < nm; ++m) {
-        int first = -1;
-        std::vector<float> vals;
-        for (int k = 0; k < nf; ++k) {
-            const double f = fmax * k / (nf - 1);
-            const double down = (f - fpts[m]) / (fpts[m + 1] - fpts[m]);
-            const double up = (fpts[m + 2] - f) / (fpts[m + 2] - fpts[m + 1]);
-            const double v = std::max(0.0, std::min(down, up));
-            if (v > 0.0) {
-                if (first < 0) first = k;
-                while ((int)vals.size() < k - first) vals.push_back(0.f);
-                vals.push_back((float)v);
-            }
-        }
-        start[m] = first < 0 ? 0 : first;
-        off[m] = (int)w.size();
-        w.insert(w.end(), vals.begin(), vals.end());
-    }
-    off[nm] = (int)w.size();
-}
-
-// ---------------------------------------------------------------------------- weight loading
-struct Reader {
-    const float* p; size_t left;
-    const float* take(size_t n) {
-        if (n > left) return nullptr;
-        const float* q = p; p += n; left -= n; return q;
-    }
-};
-
-int fold_bn(lasr_ctx* c, Reader& rd, int H, float** s_dev, float** t_dev) {
-    const float* w = rd.take(H); const float* b = rd.take(H); const float* mean = rd.take(H); const float* var = rd.take(H);
-    if (!var) return fail(c, LASR_EINVAL, "weight blob too short (bn)");
-    std::vector<float> s(H), t(H);
-    for (int i = 0; i < H; ++i) {
-        const double sc = (double)w[i] / std::sqrt((double)var[i] + 1e-5);   // BatchNorm1d eps
-        s[i] = (float)sc;
-        t[i] = (float)((double)b[i] - (double)mean[i] * sc);
-    }
-    RC(upload(c, s_dev, s.data(), H));
-    RC(upload(c, t_dev, t.data(), H));
-    return LASR_OK;
-}
-
-// LSTM layer in torch layout: W_ih [4H,I], W_hh [4H,H].
-//   tiling C (encoder): tile t = (jb = t/2, nt = t%2): column col -> gate 2*nt + col/8, unit 8*jb + col%8
-//   tiling A (predictor): tile jb = 4 units x 4 gates (col = gate*4 + unit)
-int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, bool tiling_a, std::vector<float>* keep_wih,
-              std::vector<float>* keep_bias) {
-    L.I = I;
-    const float* wih = rd.take((size_t)4 * H * I); const float* whh = rd.take((size_t)4 * H * H);
-    const float* bih = rd.take(4 * H); const float* bhh = rd.take(4 * H);
-    if (!bhh) return fail(c, LASR_EINVAL, "weight blob too short (lstm)");
-    Packed pk;
-    if (!tiling_a) {
-        pack_tiles(pk, c->bf, (H / 8) * 2, I, [&](int t, int col, int k) { return wih[((size_t)(2 * (t & 1) + (col >> 3)) * H + 8 * (t >> 1) + (col & 7)) * I + k]; });
-        RC(upload_packed(c, &L.WxC, pk));
-        pack_tiles(pk, c->bf, (H / 8) * 2, H, [&](int t, int col, int k) { return whh[((size_t)(2 * (t & 1) + (col >> 3)) * H + 8 * (t >> 1) + (col & 7)) * H + k]; });
-        RC(upload_packed(c, &L.WhC, pk));
-    } else {
-        pack_tiles(pk, c->bf, H / 4, I, [&](int t, int col, int k) { return wih[((size_t)(col >> 2) * H + 4 * t + (col & 3)) * I + k]; });
-        RC(upload_packed(c, &L.WxA, pk));
-        pack_tiles(pk, c->bf, H / 4, H, [&](int t, int col, int k) { return whh[((size_t)(col >> 2) * H + 4 * t + (col & 3)) * H + k]; });
-        RC(upload_packed(c, &L.WhA, pk));
-    }
-    std::vector<float> bias(4 * H);
-    for (int i = 0; i < 4 * H; ++i) bias[i] = bih[i] + bhh[i];
-    RC(upload(c, &L.bias, bias.data(), bias.size()));
-    if (keep_wih) keep_wih->assign(wih, wih + (size_t)4 * H * I);
-    if (keep_bias) *keep_bias = bias;
-    return LASR_OK;
-}
-
-}  // namespace
 
 // =================================================================================================
 // C ABI

@@ -1,0 +1,282 @@
+// lasr_launch.hip.h -- kernel launch helpers (GEMM variants, predictor / joint / LM passes), command blocks, growing buffers
+// Part of the single translation unit lasr_engine.hip (textual include, in this order:
+// lasr_ctx, lasr_launch, lasr_decode, lasr_weights); not a stand-alone header.
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------- launch helpers
+template <class Ops, class Epi, int MT, bool AROW, int D = 3>
+void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g, const typename Epi::Args& ea) {
+    hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NW, AROW, D>), dim3(n_groups, m_groups), dim3(NW * 64), 0, c->stream, g, ea);
+}
+
+int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
+
+// encoder LSTM cell (layer l, step t): x from `xsrc` (fragment-major, K = I); tiling "C"
+template <class Ops>
+void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
+    const Cell& L = c->enc[l];
+    const int H = c->d.hidden;
+    GemmArgs g{};
+    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / Ops::KCH; g.W[0] = L.WxC;
+    g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhC;
+    g.M = c->M; g.dbg = c->dbg;
+    using E = EpiLSTM<Ops, false, false, 8>;
+    typename E::Args ea{};
+    ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t; ea.tile_mask = c->tile_masks.empty() ? ~0ull : c->tile_masks[t];
+    ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
+    ea.y = ydst; ea.y_mt_total = y_mt_total; ea.y_mt_off = t * c->MT;
+    ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
+    launch_gemm<Ops, E, 2, false>(c, H / 8, c->M / 32, g, ea);
+}
+void launch_enc_cell(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
+    if (c->bf) launch_enc_cell_t<OpsBF16>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
+    else launch_enc_cell_t<OpsF32>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
+}
+
+// one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels); predictor
+// state is row-major [M][H]; toggles pred_par
+template <class Ops>
+void launch_predictor_t(lasr_ctx* c, bool beam) {
+    const int H = c->d.hidden;
+    const int mgroups = c->Md / (16 * MTA);
+    const int p = c->pred_par;
+    for (int l = 0; l < c->d.pred_layers; ++l) {
+        const Cell& L = c->pred[l];
+        GemmArgs g{};
+        // beam: parity p holds the current state; everything is written to parity p ^ 1
+        void* y_out = (beam && !p) ? c->pred_y1[l] : c->pred_y[l];
+        const void* y_in = (beam && p) ? c->pred_y1[l] : c->pred_y[l];
+        if (l > 0) {
+            g.A[0] = (beam && !p) ? c->pred_y1[l - 1] : c->pred_y[l - 1];   // what layer l-1 just wrote
+            g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA;
+        }
+        g.A[1] = c->pred_h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhA;
+        if (beam) { g.parent = c->b_parent; g.beam_w = c->W; }
+        g.compact = c->ds.emit; g.M = c->Md; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)(1 + std::min(l, 1)) * 4096 * 16 : nullptr;
+        if (c->d.pred_cell == 1) {
+            typename EpiLSTM<Ops, true, true, 4>::Args ea{};
+            ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
+            ea.c = (beam && !p) ? c->pred_c1[l] : c->pred_c[l]; ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l];
+            ea.y = y_out; ea.y_mt_total = 0; ea.y_mt_off = 0;
+            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md; ea.MT = c->MTd;
+            if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.c_in = p ? c->pred_c1[l] : c->pred_c[l]; ea.y_in = y_in; }
+            if (l == 0) {
+                launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
+            } else {
+                typename EpiLSTM<Ops, true, false, 4>::Args eb{};
+                static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
+                memcpy(&eb, &ea, sizeof(eb));
+                launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
+            }
+        } else {
+            typename EpiNBRC<Ops, true>::Args ea{};
+            ea.bias = L.bias; ea.rbias = L.rbias; ea.tab = L.tab; ea.token = c->ds.token; ea.emit = c->ds.emit;
+            ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = y_out;
+            ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md;
+            if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.y_in = y_in; }
+            if (l == 0) {
+                launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
+            } else {
+                typename EpiNBRC<Ops, false>::Args eb{};
+                static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
+                memcpy(&eb, &ea, sizeof(eb));
+                launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
+            }
+        }
+    }
+    if (!beam) c->pred_par ^= 1;      // beam: launch_ppj (same pass, same parities) toggles
+}
+void launch_predictor(lasr_ctx* c, bool beam = false) {
+    if (c->bf) launch_predictor_t<OpsBF16>(c, beam);
+    else launch_predictor_t<OpsF32>(c, beam);
+}
+
+// pp (for emitting rows) and the joint activation ja = tanh(pe[t_idx] + pp) for all rows still decoding
+template <class Ops>
+void launch_ppj_t(lasr_ctx* c, bool beam) {
+    const int H = c->d.hidden, J = c->d.joint, L = c->d.pred_layers, p = c->pred_par;
+    GemmArgs g{};
+    g.A[0] = (beam && !p) ? c->pred_y1[L - 1] : c->pred_y[L - 1];      // what the predictor pass just wrote
+    g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = c->W1p;
+    g.compact = c->ds.emit; g.M = c->Md; g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)3 * 4096 * 16 : nullptr;
+    typename EpiPPJ<Ops>::Args ea{};
+    ea.b1 = c->b1; ea.pp = (beam && !p) ? c->pp1 : c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
+    ea.ja = c->ja; ea.J = J; ea.M = c->Md; ea.MT = c->MTj; ea.ring = c->pe_ring_R; ea.la = beam ? 1 : c->la;
+    if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.M_enc = c->M; ea.pp_in = p ? c->pp1 : c->pp; }
+    launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
+    if (beam) c->pred_par ^= 1;
+}
+void launch_ppj(lasr_ctx* c, bool beam = false) {
+    if (c->bf) launch_ppj_t<OpsBF16>(c, beam);
+    else launch_ppj_t<OpsF32>(c, beam);
+}
+float* cur_pp(lasr_ctx* c) { return (c->W > 1 && c->pred_par) ? c->pp1 : c->pp; }
+
+template <bool AROW, int D>
+void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea);
+
+// LMFuser.advance (lm.py:49-53) for the rows with emit != 0: LM step on the token just emitted, then
+// log_softmax + standardise + [0] = MIN_VAL into lmz (read by the next k_select of that row)
+template <class Ops>
+void launch_lm_t(lasr_ctx* c) {
+    lasr_ctx::LM& m = c->lm;
+    const int H = m.H, M = c->M, V = c->d.vocab, p = m.par;
+    for (int l = 0; l < m.L; ++l) {
+        const Cell& L = m.cells[l];
+        GemmArgs g{};
+        if (l > 0) { g.A[0] = m.y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA; }
+        g.A[1] = m.h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhA;
+        g.compact = c->ds.emit; g.M = M;
+        typename EpiLSTM<Ops, true, true, 4>::Args ea{};
+        ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
+        ea.c = m.cst[l]; ea.h_in = m.h[p][l]; ea.h_out = m.h[p ^ 1][l]; ea.y = m.y[l];
+        ea.bn_s = m.ones; ea.bn_t = m.zeros; ea.H = H; ea.M = M; ea.MT = c->MT;
+        if (l == 0) {
+            launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, M / (16 * MTA), g, ea);
+        } else {
+            typename EpiLSTM<Ops, true, false, 4>::Args eb{};
+            memcpy(&eb, &ea, sizeof(eb));
+            launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, M / (16 * MTA), g, eb);
+        }
+    }
+    m.par ^= 1;
+    GemmArgs g{};
+    g.A[0] = m.y[m.L - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.W[0] = m.Wout; g.a_rows = M;
+    EpiLinear::Args ea{};
+    ea.bias = m.bout; ea.out = m.raw; ea.ldo = V; ea.n_rows = M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
+    launch_linear<true, -1>(c, V / 16, M / 16, g, H, ea);
+    hipLaunchKernelGGL(k_lm_post, dim3(M), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val);
+}
+void launch_lm(lasr_ctx* c) {
+    if (!c->lm.on) return;
+    if (c->bf) launch_lm_t<OpsBF16>(c);
+    else launch_lm_t<OpsF32>(c);
+}
+
+// plain linear over element-typed A (fragment-major, or row-major when AROW); f32 row-major output
+template <bool AROW, int D>
+void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea) {
+    g.KC[0] = K / c->kch;
+    if (c->bf) launch_gemm<OpsBF16, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
+    else launch_gemm<OpsF32, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
+}
+
+void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
+    const int J = c->d.joint, V = c->d.vocab;
+    GemmArgs g{};
+    g.A[0] = c->ja; g.a_mt_total[0] = c->MTj; g.a_mt_off[0] = 0; g.W[0] = c->W2; g.M = c->Md;
+    g.dbg = (c->dbg && c->dbg_gate) ? c->dbg + (size_t)4 * 4096 * 16 : nullptr;
+    EpiLinear::Args ea{};
+    ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
+    ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M; ea.W = c->W;
+    launch_linear<false, -1>(c, V / 16, (n_rows + 15) / 16, g, J, ea);
+}
+
+// ---------------------------------------------------------------------------- command blocks
+size_t cmd_layout(lasr_ctx::Cmd& k, char* base, int M) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += (bytes + 15) & ~size_t(15); return p; };
+    k.T_row = (int*)take(sizeof(int) * M); k.what = (int*)take(sizeof(int) * M);
+    k.src_idx = (int*)take(sizeof(int) * M); k.feat_sel = (int*)take(sizeof(int) * M);
+    k.row_frames = (int*)take(sizeof(int) * M); k.token = (int*)take(sizeof(int) * M);
+    k.emit = (int*)take(sizeof(int) * M);
+    k.row_N = (long long*)take(sizeof(long long) * M); k.row_src_off = (long long*)take(sizeof(long long) * M);
+    k.row_feat_off = (long long*)take(sizeof(long long) * M);
+    return o;
+}
+
+// next command block: c->hc (host views) / c->dc (device views); zero-initialised
+int cmd_begin(lasr_ctx* c) {
+    if (c->cmd_inflight >= NCMD - 1) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->cmd_inflight = 0;
+    }
+    const int i = c->cmd_next;
+    c->cmd_next = (i + 1) % NCMD;
+    c->cmd_inflight++;
+    cmd_layout(c->hc, c->cmd_host + (size_t)i * c->cmd_bytes, c->M);
+    cmd_layout(c->dc, c->cmd_dev + (size_t)i * c->cmd_bytes, c->M);
+    memset(c->cmd_host + (size_t)i * c->cmd_bytes, 0, c->cmd_bytes);
+    return LASR_OK;
+}
+int cmd_commit(lasr_ctx* c) {
+    HIPCHK(c, hipMemcpyAsync((char*)c->dc.T_row, (char*)c->hc.T_row, c->cmd_bytes, hipMemcpyHostToDevice, c->stream));
+    return LASR_OK;
+}
+
+// device copy of the step's T_row (from the committed command block) + host-side per-step masks of
+// the m-tiles that contain an active row (passed by value to the encoder cell kernels)
+int commit_T_rows(lasr_ctx* c, int T_max) {
+    c->T_row_dev = c->dc.T_row;             // the command ring (NCMD blocks) outlives every step in flight
+    c->T_row_dec = c->T_row_dev;
+    c->tile_masks.assign(std::max(T_max, 1), 0ull);
+    for (int t = 0; t < T_max; ++t) {
+        unsigned long long m = 0;
+        for (int r = 0; r < c->M; ++r)
+            if (t < c->hc.T_row[r]) m |= 1ull << (r >> 4);
+        c->tile_masks[t] = m;
+    }
+    return LASR_OK;
+}
+
+// ---------------------------------------------------------------------------- buffers that grow
+int ensure_T(lasr_ctx* c, int T) {
+    if (T <= c->Tcap) return LASR_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);   // captured pointers become stale
+    c->graphs.clear();
+    for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
+    c->cgraphs.clear();
+    const int M = c->M, H = c->d.hidden, F = c->d.feat, J = c->d.joint;
+    int cap = std::max(T, std::max(2 * c->Tcap, c->d.n_buffer));
+    dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe_sync);
+    c->pe_sync = nullptr;
+    dfree(c, c->ds.step_ntok); dfree(c, c->ds.unfinished);
+    c->x0 = c->ybuf[0] = c->ybuf[1] = c->pe = nullptr; c->ds.step_ntok = nullptr; c->ds.step_tok = nullptr; c->ds.unfinished = nullptr;
+    RC(dalloc(c, (char**)&c->x0, (size_t)cap * M * F * c->esz));
+    RC(dalloc(c, (char**)&c->ybuf[0], (size_t)cap * M * H * c->esz));
+    RC(dalloc(c, (char**)&c->ybuf[1], (size_t)cap * M * H * c->esz));
+    RC(dalloc(c, &c->pe_sync, (size_t)cap * M * J));
+    c->pe = c->pe_sync;
+    const int mi = std::max(c->d.max_iters_offline, c->d.max_iters_stream);
+    c->tok_cap_alloc = cap * mi;
+    // [ntok M][tokens M x tok_cap]: one contiguous block so a group's results reach the host in one copy
+    RC(dalloc(c, &c->ds.step_ntok, (size_t)M + (size_t)M * c->tok_cap_alloc));
+    HIPCHK(c, hipMemset(c->ds.step_ntok, 0, sizeof(int) * M));
+    c->ds.step_tok = c->ds.step_ntok + M;
+    c->n_iter_slots = cap * mi + 8;
+    RC(dalloc(c, &c->ds.unfinished, (size_t)c->n_iter_slots));
+    if (c->W > 1) {
+        dfree(c, c->b_trellis); c->b_trellis = nullptr;
+        RC(dalloc(c, &c->b_trellis, (size_t)c->n_iter_slots * c->Md));
+        if (c->trellis_host) (void)hipHostFree(c->trellis_host);
+        c->trellis_host_ints = (size_t)c->n_iter_slots * c->Md + 4 * (size_t)c->Md + 16;
+        HIPCHK(c, hipHostMalloc((void**)&c->trellis_host, sizeof(int) * c->trellis_host_ints));
+    }
+    HIPCHK(c, hipMemset(c->ybuf[0], 0, (size_t)cap * M * H * c->esz));
+    HIPCHK(c, hipMemset(c->ybuf[1], 0, (size_t)cap * M * H * c->esz));
+    HIPCHK(c, hipMemset(c->x0, 0, (size_t)cap * M * F * c->esz));
+    // pinned result block: [0] unfinished, then ntok[M], sum_iters[M], n_ones[M], logp[M] (double), tokens
+    if (c->res_host) (void)hipHostFree(c->res_host);
+    c->res_bytes = sizeof(int) * (8 + 3 * (size_t)M) + sizeof(double) * M + sizeof(int) * (size_t)M * c->tok_cap_alloc + 64;
+    HIPCHK(c, hipHostMalloc((void**)&c->res_host, c->res_bytes));
+    c->Tcap = cap;
+    return LASR_OK;
+}
+
+template <class T>
+int ensure_buf(lasr_ctx* c, T** p, size_t* have, size_t need) {
+    if (need <= *have) return LASR_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(c, *p);
+    *p = nullptr;
+    need = need + need / 4;
+    RC(dalloc(c, p, need));
+    *have = need;
+    return LASR_OK;
+}
+
+
+}  // namespace
