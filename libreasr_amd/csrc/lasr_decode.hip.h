@@ -86,8 +86,10 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
     // come back in the same round trip.  In streaming mode every group is a cached hipGraph: one
     // launch instead of 4 kernels per iteration, so the GPU is not fed at host launch speed.
     // (with lookahead a row consumes up to `la` blank frames per iteration: fewer iterations up front)
-    int group = offline ? std::min(total_cap, ((T_max + c->la - 1) / c->la + 16) & ~1) : std::min(total_cap, (T_max + 4) & ~1);
-    const int next_group = offline ? 32 : 4;
+    static const int sync_first = getenv("LASR_SYNC_FIRST") ? atoi(getenv("LASR_SYNC_FIRST")) : 4;   // extra iterations of the first group
+    static const int sync_next = getenv("LASR_SYNC_NEXT") ? atoi(getenv("LASR_SYNC_NEXT")) : 2;       // (swept: 4 + 2 best, +2 %)
+    int group = offline ? std::min(total_cap, ((T_max + c->la - 1) / c->la + 16) & ~1) : std::min(total_cap, (T_max + sync_first) & ~1);
+    const int next_group = offline ? 32 : sync_next;
     int* res = c->res_host;
     int* ntok = res + 4;
     int* toks = ntok + M;                      // contiguous with ntok, as on the device
