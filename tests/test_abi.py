@@ -103,3 +103,26 @@ def test_flatten_rejects_bad_shapes():
     del sd["joint.joint.2.weight"]
     with pytest.raises(KeyError):
         flatten_state_dict(sd, cfg)
+
+
+def test_plain_c_consumer_links_and_fails_loudly_without_gpu(tmp_path):
+    """include/lasr.h is C99; a C program linked against liblasr_hip.so sizes the weight blob of the reference
+    shape (53.03 M parameters + BatchNorm statistics) and gets LASR_EHIP from lasr_create on a box without an MI355X."""
+    import shutil
+    import subprocess
+    import __graft_entry__ as graft
+    graft.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "libreasr_amd", "csrc")
+    exe = str(tmp_path / "abi_consumer")
+    cc = shutil.which("gcc")
+    assert cc, "gcc is part of the image"
+    subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "abi_consumer.c"), "-o", exe, "-L", csrc, "-llasr_hip",
+                    "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    import torch
+    has_gpu = torch.cuda.is_available()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert "weights 53039616" in r.stdout, r.stdout + r.stderr
+    assert "lm weights" in r.stdout
+    assert r.returncode == (0 if has_gpu else 10), (r.returncode, r.stdout, r.stderr)
