@@ -49,7 +49,8 @@ def dist_init(world, use_cuda):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+    # LASR_BENCH_BACKEND=gloo: dry run of the multi-rank path where RCCL cannot be used (several ranks on ONE GPU)
+    dist.init_process_group(backend=os.environ.get("LASR_BENCH_BACKEND", "nccl") if use_cuda else "gloo")
     return dist
 
 
@@ -130,6 +131,8 @@ def main():
     args = ap.parse_args()
 
     rank, world, local = dist_env()
+    if os.environ.get("LASR_BENCH_SAME_GPU"):      # dry run: every rank on GPU 0
+        local = 0
     if args.selftest_dist:
         import torch
         dist = dist_init(world, use_cuda=False)
