@@ -206,6 +206,13 @@ def main():
             lat_out.append(time.perf_counter() - push_t.pop(kk))
         return 1, ntok
 
+    # CPython's cyclic GC would stop this (single) host thread for tens of ms in the middle of the timed
+    # region (a full collection walks every container alive in the process, deterministically at the same
+    # chunk): collect now, park the survivors in the permanent generation, keep the collector off while timing
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for k in range(W):
         one_step(k)
     while pipelined and eng.pending():
@@ -217,8 +224,11 @@ def main():
         eng.set_profiling(True)
     lat_model, enc_ms, dec_ms, fe_ms, iters, tokens = [], [], [], [], [], 0
     t0 = time.perf_counter()
+    step_t = []
     for k in range(W, W + K):
+        _t = time.perf_counter()
         ran, ntok = one_step(k, lat_model)
+        step_t.append(time.perf_counter() - _t)
         tokens += ntok
         if ran:
             st = eng.stats()
@@ -232,6 +242,10 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("LASR_BENCH_TRACE"):
+        order_ = np.argsort(step_t)[::-1][:8]
+        print("slowest chunks:", [(int(i), round(1e3 * step_t[i], 2)) for i in order_], "median ms", round(1e3 * float(np.median(step_t)), 3), file=sys.stderr)
     eng.set_profiling(False)
     lat = lat_model
 

@@ -54,6 +54,8 @@ struct lasr_ctx {
     // recurrent state (row == slot)
     std::vector<void*> enc_h[2], pred_h[2], pred_y;      // element-typed (A operands)
     std::vector<float*> enc_c, pred_c;
+    int cell_nw = 0;                // waves per encoder-cell workgroup (0: 4 for f32, 8 for bf16); LASR_CELL_NW
+    int dec_nw_mask = 0;            // LASR_DEC_NW4: bit 1 predictor cells, bit 2 PPJ, bit 4 linear (logits, pe) run with 4 waves
     // beam search: c, BN(h) and pp ping-pong like h (every slot may be re-parented each round):
     // parity 0 = pred_c / pred_y / pp, parity 1 = the *1 buffers; all follow pred_par
     std::vector<float*> pred_c1;

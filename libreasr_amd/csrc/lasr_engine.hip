@@ -109,6 +109,8 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     Reader rd{weights, n_weights};
     {
         if (getenv("LASR_NO_GRAPH")) c->use_graphs = false;
+        if (getenv("LASR_CELL_NW")) c->cell_nw = atoi(getenv("LASR_CELL_NW")) == 4 ? 4 : 8;
+        if (getenv("LASR_DEC_NW4")) c->dec_nw_mask = atoi(getenv("LASR_DEC_NW4"));
         if (getenv("LASR_DBG_TIMING")) {
             RC(dalloc(c, &c->dbg, (size_t)5 * 4096 * 16));
             HIPCHK(c, hipMemset(c->dbg, 0, sizeof(unsigned long long) * 5 * 4096 * 16));

@@ -369,6 +369,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
             LASR_TRY(6, 6)       // K = 1536 / 1536
             LASR_TRY(5, 6)       // K = 1280 / 1536
         } else {
+            LASR_TRY(4, 4)       // (16-wave K split)
+            LASR_TRY(5, 4)
+            LASR_TRY(16, 16)     // (4-wave K split)
+            LASR_TRY(20, 16)
             LASR_TRY(8, 8)
             LASR_TRY(10, 8)
             LASR_TRY(12, 12)

@@ -6,9 +6,9 @@
 namespace {
 
 // ---------------------------------------------------------------------------- launch helpers
-template <class Ops, class Epi, int MT, bool AROW, int D = 3>
+template <class Ops, class Epi, int MT, bool AROW, int D = 3, int NWV = NW>
 void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g, const typename Epi::Args& ea) {
-    hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NW, AROW, D>), dim3(n_groups, m_groups), dim3(NW * 64), 0, c->stream, g, ea);
+    hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NWV, AROW, D>), dim3(n_groups, m_groups), dim3(NWV * 64), 0, c->stream, g, ea);
 }
 
 int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
@@ -28,7 +28,11 @@ void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_tot
     ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
     ea.y = ydst; ea.y_mt_total = y_mt_total; ea.y_mt_off = t * c->MT;
     ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
-    launch_gemm<Ops, E, 2, false>(c, H / 8, c->M / 32, g, ea);
+    // K split over 4 waves for f32 operands (12.8 us against 17.2 us with 8: fewer requests in flight, half the
+    // LDS reduction), 8 waves for bf16 (5.4 us against 6.6 us); LASR_CELL_NW overrides
+    const int nw = c->cell_nw ? c->cell_nw : (Ops::BF ? 8 : 4);
+    if (nw == 4) launch_gemm<Ops, E, 2, false, 3, 4>(c, H / 8, c->M / 32, g, ea);
+    else launch_gemm<Ops, E, 2, false>(c, H / 8, c->M / 32, g, ea);
 }
 void launch_enc_cell(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
     if (c->bf) launch_enc_cell_t<OpsBF16>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
@@ -63,12 +67,12 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md; ea.MT = c->MTd;
             if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.c_in = p ? c->pred_c1[l] : c->pred_c[l]; ea.y_in = y_in; }
             if (l == 0) {
-                launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
+                if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1, 4>(c, H / 4, mgroups, g, ea); else launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 typename EpiLSTM<Ops, true, false, 4>::Args eb{};
                 static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
+                if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1, 4>(c, H / 4, mgroups, g, eb); else launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         } else {
             typename EpiNBRC<Ops, true>::Args ea{};
@@ -77,12 +81,12 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md;
             if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.y_in = y_in; }
             if (l == 0) {
-                launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
+                if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1, 4>(c, H / 4, mgroups, g, ea); else launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 typename EpiNBRC<Ops, false>::Args eb{};
                 static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
-                launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
+                if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1, 4>(c, H / 4, mgroups, g, eb); else launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         }
     }
@@ -105,7 +109,7 @@ void launch_ppj_t(lasr_ctx* c, bool beam) {
     ea.b1 = c->b1; ea.pp = (beam && !p) ? c->pp1 : c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
     ea.ja = c->ja; ea.J = J; ea.M = c->Md; ea.MT = c->MTj; ea.ring = c->pe_ring_R; ea.la = beam ? 1 : c->la;
     if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.M_enc = c->M; ea.pp_in = p ? c->pp1 : c->pp; }
-    launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
+    if (c->dec_nw_mask & 2) launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1, 4>(c, J / 16, c->MTd, g, ea); else launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
     if (beam) c->pred_par ^= 1;
 }
 void launch_ppj(lasr_ctx* c, bool beam = false) {
@@ -159,6 +163,11 @@ void launch_lm(lasr_ctx* c) {
 template <bool AROW, int D>
 void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea) {
     g.KC[0] = K / c->kch;
+    if (c->dec_nw_mask & 4) {
+        if (c->bf) launch_gemm<OpsBF16, EpiLinear, 1, AROW, D, 4>(c, n_groups, m_groups, g, ea);
+        else launch_gemm<OpsF32, EpiLinear, 1, AROW, D, 4>(c, n_groups, m_groups, g, ea);
+        return;
+    }
     if (c->bf) launch_gemm<OpsBF16, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
     else launch_gemm<OpsF32, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
 }
