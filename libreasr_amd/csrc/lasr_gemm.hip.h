@@ -355,7 +355,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
         constexpr int MTP = decltype(mtp_tag)::value;
         constexpr bool P0 = NS0k > 0, P1 = NS1k > 0;
         constexpr int FPC = MTP + NSMk;                                   // fragments per chunk
-        constexpr int DD = D > 0 ? D : (FPC <= 2 ? 9 : FPC <= 3 ? 7 : FPC <= 5 ? 4 : 3);
+        // latency-bound kernels (D < 0): ring depth by fragments per chunk.  f32 operands want a SHALLOW ring
+        // (whole-job +7 % with 3 instead of 9: the memory path degrades with more requests in flight),
+        // bf16 operands (half the bytes per request) keep the deep one (+2 %)
+        constexpr int DD = D > 0 ? D
+                           : Ops::BF ? (FPC <= 2 ? 9 : FPC <= 3 ? 7 : FPC <= 5 ? 4 : 3)
+                                     : (FPC <= 5 && FPC > 3 ? 4 : 3);
         const int k0 = P0 ? g.KC[0] : 0, k1 = P1 ? g.KC[1] : 0;
 #define LASR_TRY(N0, N1)                                                                                              \
     if ((!P0 || k0 == (N0) * NW) && (!P1 || k1 == (N1) * NW)) {                                                       \
