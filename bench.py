@@ -8,18 +8,21 @@ reference-faithful streaming call pattern: 80 ms client chunks, 3-chunk sliding 
 Buffer => the model runs every second chunk on 2 stacked frames (api-server.py:83-115,
 transforms.py:326-342,455-471, models.py:457-577).
 
-A "step" = one 80 ms chunk pushed for every stream of the rank (lasr_push_pcm + lasr_step_stream,
+A "step" = one 80 ms chunk pushed for every stream of the rank (lasr_push_pcm + lasr_step_submit / _wait,
 tokens fetched to the host).  Synthetic PCM is resident in HBM before the timed region.
 Streams are independent: rank r owns streams [64 r, 64 r + 64), there is no data-path collective
 ("scaling": "weak"); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N ...                      # spawns N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +36,9 @@ CHUNK = 1280                 # 80 ms at 16 kHz
 SR = 16000
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PRIME_CHUNKS = 24             # untimed chunks before the W warm-up steps: window fill + hipGraph instantiation
+METRIC = "audio-sec/sec/GPU (16 kHz streaming RNN-T) + p50 per-chunk latency"
 
 
 def dist_env():
@@ -72,25 +78,89 @@ def aggregate(dist, elapsed_local, units_local, device):
     return float(t.item()), float(u.item())
 
 
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU.
+    Refuses (rc 2) when fewer than N devices are visible instead of silently measuring fewer."""
+    if not os.environ.get("LASR_BENCH_SAME_GPU") and "--selftest-dist" not in argv:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def cell_flops(cfg, layer, rows):
     H = cfg["hidden"]
     I = cfg["feat"] if layer == 0 else H
     return 2.0 * rows * 4 * H * (I + H)
 
 
-def cpu_baseline(cfg, sd, pcm_rows, n_chunks):
-    """The oracle (numpy restatement of the reference's CPU path) timed on the host cores on a
-    bounded sample of the same workload: `len(pcm_rows)` streams x n_chunks 80 ms chunks through the
-    reference-faithful streaming pipeline (window -> log-mel -> Buffer -> encoder -> greedy)."""
+def flop_per_frame(cfg, n_tok):
+    """algorithmic FLOP per stacked frame (80 ms of one stream), elementwise work excluded."""
+    F, H, J, V, E = cfg["feat"], cfg["hidden"], cfg["joint"], cfg["vocab"], cfg["embed"]
+    G = 4 if cfg["pred_cell"] == "LSTM" else 3
+    enc = sum(2.0 * 4 * H * ((F if l == 0 else H) + H) for l in range(cfg["enc_layers"]))
+    return enc + 2.0 * H * J + (1.0 + n_tok) * 2.0 * J * V + n_tok * (2.0 * H * J + 2.0 * E * H + cfg["pred_layers"] * 2.0 * G * H * 2 * H)
+
+
+def workload_name(args, cfg, B):
+    base = {"cfg2": 1, "cfg5": 4}.get(args.model)
+    if args.model == "cfg2" and (args.dtype == "bf16" or args.beam > 1):
+        base = 2
+    tag = f"configs[{base}]" if base is not None else f"model '{args.model}' (not a BASELINE config)"
+    exact = (args.model == "cfg2" and args.dtype == "f32" and args.beam == 1 and B == 64) or \
+            (args.model == "cfg2" and args.dtype == "bf16" and args.beam == 4 and B == 64) or \
+            (args.model == "cfg5" and args.dtype == "bf16" and args.beam == 8 and B == 128)
+    if not exact and base is not None:
+        tag += " variant"
+    return (f"{tag}: {B} concurrent 16 kHz streams/GPU, {cfg['enc_layers']}x{cfg['hidden']} uni-LSTM encoder, "
+            f"{cfg['pred_layers']}x{cfg['pred_cell']} predictor, J={cfg['joint']}, V={cfg['vocab']}, "
+            f"{'greedy' if args.beam == 1 else 'beam width ' + str(args.beam)}, "
+            f"{'fp32' if args.dtype == 'f32' else 'bf16 operands / f32 accumulate'}, 80 ms chunks, "
+            "3-chunk window, 2-frame buffer (model every 160 ms)")
+
+
+def cpu_reference_path(cfg, sd, n_streams, n_chunks, threads=2):
+    """The reference's CPU execution path (torch-CPU operators, batch 1 per stream, set_num_threads(2) as
+    inference.py:21) on the host cores, on its OWN bounded sample of the same synthetic workload."""
+    from libreasr_amd import synth
+    from oracle import torch_cpu as TC       # baseline leg only; never on the product path
+    rows = [synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in range(n_streams)]
+    TC.time_stream_path(sd, cfg, rows[:1], min(n_chunks, 12), threads=threads)          # warm-up (thread pools, mkldnn)
+    dt, toks = TC.time_stream_path(sd, cfg, rows, n_chunks, threads=threads)
+    return {"value": round(n_streams * n_chunks * CHUNK / SR / dt, 2), "unit": "audio-sec/sec", "cores": int(threads),
+            "kind": "port",
+            "path": "the reference's torch-CPU execution path restated on the installed torch (oracle/torch_cpu.py: "
+                    "nn.LayerNorm, nn.LSTM + BatchNorm1d per layer, NBRC as torch matmuls, Linear/tanh/Linear, log_softmax, "
+                    "torch.stft front-end), batch 1 per stream, streams one after the other, torch.set_num_threads(2) "
+                    "as libreasr/lib/inference.py:21; tokens pinned to the reference's goldens in tests/test_oracle.py",
+            "sample": f"{n_streams} streams x {n_chunks} chunks of 80 ms ({n_streams * n_chunks * CHUNK / SR:.0f} audio-s)",
+            "seconds": round(dt, 2), "tokens": int(sum(len(t) for t in toks)), "host_cores_available": os.cpu_count()}
+
+
+def cpu_numpy_port(cfg, sd, n_streams, n_chunks):
+    """The numpy oracle (the parity checker) timed the same way: second CPU figure."""
+    from libreasr_amd import synth
     from oracle import rnnt_oracle as O      # baseline leg only; never on the product path
+    rows = [synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in range(n_streams)]
     m = O.OracleTransducer(sd, cfg)
-    B = len(pcm_rows)
-    fes = [O.StreamFrontend() for _ in range(B)]
-    decs = [m.stream_decoder() for _ in range(B)]
+    fes = [O.StreamFrontend() for _ in rows]
+    decs = [m.stream_decoder() for _ in rows]
     t0 = time.perf_counter()
     for k in range(n_chunks):
-        for b in range(B):
-            o = fes[b].push(pcm_rows[b][k * CHUNK:(k + 1) * CHUNK])
+        for b, row in enumerate(rows):
+            o = fes[b].push(row[k * CHUNK:(k + 1) * CHUNK])
             if o is not None:
                 decs[b].step(o)
     dt = time.perf_counter() - t0
@@ -99,9 +169,8 @@ def cpu_baseline(cfg, sd, pcm_rows, n_chunks):
         cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
-    return {"value": round(B * n_chunks * CHUNK / SR / dt, 2), "unit": "audio-sec/sec",
-            "cores": int(cores), "kind": "port",
-            "sample": f"{B} streams x {n_chunks} chunks of 80 ms, numpy oracle, batch 1 per stream (as the reference serves)",
+    return {"value": round(n_streams * n_chunks * CHUNK / SR / dt, 2), "unit": "audio-sec/sec", "cores": int(cores),
+            "kind": "port", "sample": f"{n_streams} streams x {n_chunks} chunks, numpy oracle, batch 1 per stream",
             "seconds": round(dt, 2)}
 
 
@@ -116,10 +185,12 @@ def main():
                     help="f32 = BASELINE configs[1] (the headline metric); bf16 = configs[2] arithmetic "
                          "(bf16 MFMA operands, f32 accumulate/state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the offline and PCIe-inclusive legs")
     ap.add_argument("--host-pcm", action="store_true",
-                    help="hand lasr_push_pcm HOST buffers every chunk (PCIe-inclusive rate; never the headline value)")
-    ap.add_argument("--cpu-streams", type=int, default=16)
-    ap.add_argument("--cpu-chunks", type=int, default=200)
+                    help="hand lasr_push_pcm HOST buffers every chunk in the MAIN timed region (a PCIe-inclusive leg is "
+                         "reported beside the headline anyway)")
+    ap.add_argument("--cpu-streams", type=int, default=12)
+    ap.add_argument("--cpu-chunks", type=int, default=150)
     ap.add_argument("--beam", type=int, default=1,
                     help="beam width (1 = greedy, the headline config); > 1 runs the synchronous protocol")
     ap.add_argument("--depth", type=int, default=6,
@@ -131,6 +202,8 @@ def main():
     args = ap.parse_args()
 
     rank, world, local = dist_env()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if os.environ.get("LASR_BENCH_SAME_GPU"):      # dry run: every rank on GPU 0
         local = 0
     if args.selftest_dist:
@@ -148,9 +221,11 @@ def main():
     import torch
     from libreasr_amd import synth
     from libreasr_amd.engine import Engine
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if not os.environ.get("LASR_BENCH_SAME_GPU") and torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = dist_init(world, use_cuda=True)
@@ -161,12 +236,14 @@ def main():
     eng = Engine(sd, cfg, max_streams=B, device=local, dtype=args.dtype, beam=args.beam)
     my_streams = shard_streams(B * world, world, rank)
     K, W = args.steps, args.warmup
-    n_chunks = K + W + 4
+    P = max(0, PRIME_CHUNKS - W)
+    extras = rank == 0 and not args.no_extras and args.beam == 1 and not args.no_pipeline
+    n_chunks = P + W + K + (K if extras else 0) + 4
     # synthetic PCM for this rank's streams (seeded per global stream id), resident in HBM,
     # laid out [chunk][stream][1280] so that one step reads one contiguous block
     pcm_host = np.stack([synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in my_streams])
     pcm_dev = torch.as_tensor(pcm_host.reshape(B, n_chunks, CHUNK).transpose(1, 0, 2).copy()).to(device)
-    pcm_host_chunks = np.ascontiguousarray(pcm_host.reshape(B, n_chunks, CHUNK).transpose(1, 0, 2)) if args.host_pcm else None
+    pcm_host_chunks = np.ascontiguousarray(pcm_host.reshape(B, n_chunks, CHUNK).transpose(1, 0, 2))
     slots = [eng.open() for _ in range(B)]
     assert slots == list(range(B))
 
@@ -174,12 +251,12 @@ def main():
     push_t = {}                                   # chunk index -> host time of its push (latency bookkeeping)
     order = []                                    # model chunks submitted and not yet collected
 
-    def one_step(k, lat_out=None):
+    def one_step(k, lat_out=None, host=False):
         """One 80 ms chunk for every stream.  Synchronous mode: push + step + fetch.  Pipelined mode:
         push + submit (front-end and encoder of chunk k go to the GPU), then collect the tokens of
-        the previous model step, whose decode loop runs on a second HIP stream under encoder(k)."""
+        the oldest model step once `depth` are in flight; its decode loop runs on a second HIP stream."""
         t_push = time.perf_counter()
-        eng.push(slots, pcm_host_chunks[k] if args.host_pcm else pcm_dev[k])
+        eng.push(slots, pcm_host_chunks[k] if host else pcm_dev[k])
         ntok, done = 0, 0
         if not pipelined:
             if eng.step(slots):
@@ -206,6 +283,30 @@ def main():
             lat_out.append(time.perf_counter() - push_t.pop(kk))
         return 1, ntok
 
+    def drain(lat_out=None):
+        ntok = 0
+        while pipelined and eng.pending():
+            ntok += collect(lat_out)[1]
+        return ntok
+
+    def timed_region(k0, n, lat_out, host=False, stats=None, barrier=True):
+        """barrier + sync | n steps, every token on the host | sync + barrier.  Returns (elapsed, tokens)."""
+        torch.cuda.synchronize(device)
+        if dist is not None and barrier:
+            dist.barrier()
+        tokens = 0
+        t0 = time.perf_counter()
+        for k in range(k0, k0 + n):
+            ran, ntok = one_step(k, lat_out, host)
+            tokens += ntok
+            if ran and stats is not None:
+                stats(eng.stats())
+        tokens += drain(lat_out)
+        torch.cuda.synchronize(device)
+        if dist is not None and barrier:
+            dist.barrier()
+        return time.perf_counter() - t0, tokens
+
     # CPython's cyclic GC would stop this (single) host thread for tens of ms in the middle of the timed
     # region (a full collection walks every container alive in the process, deterministically at the same
     # chunk): collect now, park the survivors in the permanent generation, keep the collector off while timing
@@ -213,63 +314,48 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
-    for k in range(W):
+    for k in range(P + W):                        # P priming chunks (engine start-up), then the W warm-up steps
         one_step(k)
-    while pipelined and eng.pending():
-        collect(None)
-    torch.cuda.synchronize(device)
-    if dist is not None:
-        dist.barrier()
+    drain()
     if not pipelined:
         eng.set_profiling(True)
-    lat_model, enc_ms, dec_ms, fe_ms, iters, tokens = [], [], [], [], [], 0
-    t0 = time.perf_counter()
-    step_t = []
-    for k in range(W, W + K):
-        _t = time.perf_counter()
-        ran, ntok = one_step(k, lat_model)
-        step_t.append(time.perf_counter() - _t)
-        tokens += ntok
-        if ran:
-            st = eng.stats()
-            iters.append(st["decode_iters"])
-            if not pipelined:
-                enc_ms.append(st["encoder_ms"]); dec_ms.append(st["decode_ms"]); fe_ms.append(st["frontend_ms"])
-    while pipelined and eng.pending():            # the timed region ends when every token is on the host
-        ran, ntok = collect(lat_model)
-        tokens += ntok
-    torch.cuda.synchronize(device)
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    if os.environ.get("LASR_BENCH_TRACE"):
-        order_ = np.argsort(step_t)[::-1][:8]
-        print("slowest chunks:", [(int(i), round(1e3 * step_t[i], 2)) for i in order_], "median ms", round(1e3 * float(np.median(step_t)), 3), file=sys.stderr)
+    lat_model, enc_ms, dec_ms, fe_ms, iters = [], [], [], [], []
+
+    def on_stats(st):
+        iters.append(st["decode_iters"])
+        if not pipelined:
+            enc_ms.append(st["encoder_ms"]); dec_ms.append(st["decode_ms"]); fe_ms.append(st["frontend_ms"])
+
+    eng.cell_prof(True)                           # HIP-event pair around every model step's cell sequence, on its stream
+    elapsed, tokens = timed_region(P + W, K, lat_model, host=args.host_pcm, stats=on_stats)
+    cell_us_total, cell_launches = eng.cell_prof_read()
+    eng.cell_prof(False)
     eng.set_profiling(False)
-    lat = lat_model
 
     audio_local = K * B * CHUNK / SR
     elapsed_max, audio_total = aggregate(dist, elapsed, audio_local, device)
 
     if rank == 0:
-        # dominant kernel: the fused LSTM-cell GEMM (k_gemm<EpiLSTM>), measured live with HIP
-        # events on the engine's stream: `iters` back-to-back launches of layer 1, all rows active
-        cell_us = eng.bench_cell(layer=1, iters=300)
-        flops = cell_flops(cfg, 1, B)
-        achieved = flops / (cell_us * 1e-6) / 1e12
-        n_cells = cfg["enc_layers"] * 2
-        wbytes = (4.0 if args.dtype == "f32" else 2.0) * 4 * cfg["hidden"] * 2 * cfg["hidden"]
+        L, H = cfg["enc_layers"], cfg["hidden"]
+        bf = args.dtype == "bf16"
+        n_tok = tokens / max(1, K * B) if args.beam == 1 else 0.0
+        # dominant kernel: the fused LSTM-cell GEMM (k_gemm<EpiLSTM>).  In-job average launch duration from the HIP
+        # events of the timed region; algorithmic work per launch = mean over the layers (layer 0 has K = feat + H)
+        flops_mean = float(np.mean([cell_flops(cfg, l, B) for l in range(L)]))
+        wbytes_mean = float(np.mean([(2.0 if bf else 4.0) * 4 * H * ((cfg["feat"] if l == 0 else H) + H) for l in range(L)]))
+        cell_us = cell_us_total / cell_launches if cell_launches else float("nan")
+        achieved = flops_mean / (cell_us * 1e-6) / 1e12
         traffic = None                      # HBM bytes per launch from the committed PMC passes (profiles/)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_cell_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "cell_pmc.json")) as f:
                 pm = json.load(f)
                 if args.model == "cfg2" and B == 64:
-                    traffic = pm["hbm_bytes_per_launch"] if args.dtype == "f32" else pm.get("bf16", {}).get("hbm_bytes_per_launch")
+                    traffic = pm["hbm_bytes_per_launch"] if not bf else pm.get("bf16", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+        job_tflops = audio_total / elapsed_max * 12.5 * flop_per_frame(cfg, n_tok) / 1e12
         out = {
-            "metric": "audio-sec/sec/GPU (16 kHz streaming RNN-T) + p50 per-chunk latency",
+            "metric": METRIC,
             "value": round(audio_total / elapsed_max, 1),
             "unit": "audio-sec/sec",
             "n_gpus": world,
@@ -281,15 +367,14 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic" + (" (PCM handed over in host memory every chunk: PCIe-inclusive)" if args.host_pcm else ""),
-            "config": {"workload": f"configs[{1 if args.dtype == 'f32' else 2}]: {B} concurrent 16 kHz streams/GPU, 4x1024 uni-LSTM encoder, "
-                                   f"2xNBRC predictor, J=1024, V=2048, {'greedy' if args.beam == 1 else 'beam width ' + str(args.beam)}, {'fp32' if args.dtype == 'f32' else 'bf16 operands / f32 accumulate'}, 80 ms chunks, "
-                                   "3-chunk window, 2-frame buffer (model every 160 ms)",
+            "config": {"workload": workload_name(args, cfg, B),
                        "streams_per_gpu": B, "chunk_ms": 80, "parallelism": f"dp{world} (independent streams, no collective)",
                        "pipeline": (f"submit/wait, {args.depth} model steps in flight: encoder of later chunks on the main stream, "
-                                    "one continuous greedy loop on a second stream") if pipelined else "synchronous"},
+                                    "one continuous greedy loop on a second stream") if pipelined else "synchronous",
+                       "priming_chunks": P},
             "per_gpu_value": round(audio_total / elapsed_max / world, 1),
             "latency_ms": {"definition": "host time from lasr_push_pcm of a model chunk to its tokens on the host"
-                                         + (" (pipelined: includes the overlap with the next chunk's encoder)" if pipelined else ""),
+                                         + (" (pipelined: includes the queueing behind the steps in flight)" if pipelined else ""),
                            "p50_model_chunk": round(1e3 * float(np.median(lat_model)), 4) if lat_model else None,
                            "p95_model_chunk": round(1e3 * float(np.percentile(lat_model, 95)), 4) if lat_model else None,
                            "p50_per_40ms_equiv": round(0.5e3 * float(np.median(lat_model)), 4) if lat_model else None},
@@ -297,39 +382,65 @@ def main():
                                         "encoder": round(float(np.mean(enc_ms)), 4) if enc_ms else None,
                                         "decode": round(float(np.mean(dec_ms)), 4) if dec_ms else None,
                                         "decode_iters": round(float(np.mean(iters)), 2) if iters else None},
-            "tokens_per_frame": round(tokens / max(1, K * B), 4) if args.beam == 1 else None,
-            "roofline": {"bound": "mfma", "kernel": "k_gemm<EpiLSTM> (encoder LSTM cell, layer 1, 64 rows)",
+            "tokens_per_frame": round(n_tok, 4) if args.beam == 1 else None,
+            "roofline": {"bound": "mfma", "kernel": f"k_gemm<EpiLSTM> (encoder LSTM cell, {B} rows, mean over the {L} layers)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "launch_us": round(cell_us, 3), "flops_per_launch": flops,
-                         "weight_bytes_per_launch": wbytes,
-                         "in_situ_encoder_us_per_cell": round(1e3 * float(np.mean(enc_ms)) / n_cells, 3) if enc_ms else None},
+                         "launch_us": round(cell_us, 3), "launches_timed": int(cell_launches),
+                         "timing": "HIP events on the cells' stream around every model step's cell sequence in the timed region "
+                                   "(in-job: next to the decode stream)",
+                         "flops_per_launch": flops_mean, "weight_bytes_per_launch": wbytes_mean,
+                         "whole_job": {"tflops": round(job_tflops, 2),
+                                       "frac": round(job_tflops / (PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS), 4),
+                                       "note": "algorithmic FLOP of SURVEY 8d per frame (measured tokens/frame) x frames/s / MFMA peak"}},
         }
-        # secondary figure: the offline path (Transcribe RPC) on whole 20.65 s utterances (the demo's length)
-        try:
-            n_off = 330400
-            off_pcm = [torch.as_tensor(synth.synth_pcm(1, n_off, seed=5000 + s)[0]).to(device) for s in range(min(B, 64))]
-            eng.transcribe_pcm(slots[:len(off_pcm)], off_pcm)              # warm-up (buffer growth)
-            torch.cuda.synchronize(device)
-            t_off = time.perf_counter()
-            eng.transcribe_pcm(slots[:len(off_pcm)], off_pcm)
-            n_off_tok = sum(len(t) for t in eng.fetch_many(slots[:len(off_pcm)], cap=2048))
-            dt_off = time.perf_counter() - t_off
-            out["offline"] = {"audio_sec_per_sec": round(len(off_pcm) * n_off / SR / dt_off, 1), "utterances": len(off_pcm),
-                              "seconds_each": round(n_off / SR, 2), "wall_ms": round(1e3 * dt_off, 2), "tokens": n_off_tok,
-                              "note": "lasr_transcribe_pcm: fresh state, max_iters 3, synchronous decode loop"}
-        except Exception as e:                                            # never let the extra figure break the contract line
-            out["offline"] = {"error": str(e)[:200]}
-        if args.dtype == "bf16":
+        if bf:
             # 64 rows x 2 flop / 2 B = 64 flop/B is far below the bf16 ridge (2500 TFLOP/s / 8 TB/s = 312):
             # the bf16 cell is bound by streaming its weights, so it is priced against HBM bandwidth
-            gbs = wbytes / (cell_us * 1e-6) / 1e9
+            gbs = wbytes_mean / (cell_us * 1e-6) / 1e9
             out["roofline"].update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(gbs / PEAK_HBM_GBS, 4),
                                     "note": "algorithmic bytes = packed bf16 weights of one cell (W_ih + W_hh)"})
+        try:                                                               # the kernel alone on the GPU (micro-benchmark)
+            out["roofline"]["launch_us_isolated"] = round(eng.bench_cell(layer=1, iters=300), 3)
+        except Exception as e:
+            out["roofline"]["launch_us_isolated"] = None
+        if extras:
+            # PCIe-inclusive leg (SURVEY 8d "from first PCM byte available on host"): the same K steps again with every
+            # chunk handed to lasr_push_pcm as a host array; reported beside the headline, never as `value`
+            try:
+                lat2 = []
+                dt2, _ = timed_region(P + W + K, K, lat2, host=True, barrier=False)
+                out["pcie_inclusive"] = {"value": round(K * B * CHUNK / SR / dt2, 1), "unit": "audio-sec/sec",
+                                         "p50_model_chunk_ms": round(1e3 * float(np.median(lat2)), 4) if lat2 else None,
+                                         "note": "same steps, PCM pushed from host memory every chunk (328 KB/step over PCIe)"}
+            except Exception as e:
+                out["pcie_inclusive"] = {"error": str(e)[:200]}
+            # secondary figure: the offline path (Transcribe RPC) on whole 20.65 s utterances (the demo's length)
+            try:
+                n_off = 330400
+                off_pcm = [torch.as_tensor(synth.synth_pcm(1, n_off, seed=5000 + s)[0]).to(device) for s in range(min(B, 64))]
+                eng.transcribe_pcm(slots[:len(off_pcm)], off_pcm)              # warm-up (buffer growth)
+                torch.cuda.synchronize(device)
+                t_off = time.perf_counter()
+                eng.transcribe_pcm(slots[:len(off_pcm)], off_pcm)
+                n_off_tok = sum(len(t) for t in eng.fetch_many(slots[:len(off_pcm)], cap=2048))
+                dt_off = time.perf_counter() - t_off
+                out["offline"] = {"audio_sec_per_sec": round(len(off_pcm) * n_off / SR / dt_off, 1), "utterances": len(off_pcm),
+                                  "seconds_each": round(n_off / SR, 2), "wall_ms": round(1e3 * dt_off, 2), "tokens": n_off_tok,
+                                  "note": "lasr_transcribe_pcm: fresh state, max_iters 3, synchronous decode loop"}
+            except Exception as e:                                            # never let the extra figure break the contract line
+                out["offline"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would stall the other ranks' teardown)
-            rows = [pcm_host[i] for i in range(min(args.cpu_streams, B))]
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, rows, args.cpu_chunks)
+            gc.enable()
+            try:
+                out["cpu_baseline"] = cpu_reference_path(cfg, sd, args.cpu_streams, args.cpu_chunks)
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "error": str(e)[:300]}
+            try:
+                out["cpu_baseline"]["numpy_port"] = cpu_numpy_port(cfg, sd, 4, 60)
+            except Exception as e:
+                out["cpu_baseline"]["numpy_port"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:

@@ -222,6 +222,14 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
  * Returns average microseconds per launch in *us. */
 int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us);
 
+/* In-job timing of the dominant kernel (bench.py `roofline`): while on, the encoder-cell sequence of every model
+ * step (enc_layers x frames back-to-back launches of the fused LSTM-cell GEMM) is bracketed by one HIP-event pair
+ * on the stream the cells run on.  lasr_cell_prof_read drains the pairs: microseconds and cell launches
+ * accumulated since profiling was switched on (average launch duration = us_total / launches, next to whatever
+ * else shares the GPU -- the number a rocprofv3 kernel trace of the same run shows). */
+int lasr_cell_prof(lasr_ctx* c, int on);
+int lasr_cell_prof_read(lasr_ctx* c, double* us_total, long long* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,6 +171,17 @@ struct lasr_ctx {
     std::vector<std::vector<int32_t>> queue;
     std::vector<double> neg_logp, align;
 
+    // in-job timing of the dominant kernel (lasr_cell_prof): one HIP-event pair around the encoder-cell sequence of
+    // every model step, on the stream the cells are launched on; harvested lazily (ring of pairs)
+    static constexpr int NCELLEV = 64;
+    bool cell_prof = false;
+    hipEvent_t cp_ev[NCELLEV][2] = {};
+    bool cp_ok = false;
+    int cp_head = 0, cp_n = 0;      // ring: cp_n pairs outstanding, oldest at (cp_head - cp_n) mod NCELLEV
+    int cp_cells[NCELLEV] = {};
+    double cp_us = 0.0;
+    long long cp_launches = 0;
+
     // stats
     bool profiling = false;
     hipEvent_t ev[8];

@@ -43,12 +43,37 @@ int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3, bool plain_rows = fals
     return LASR_OK;
 }
 
+// ---------------------------------------------------------------------------- in-job cell timing
+void cell_prof_harvest(lasr_ctx* c, bool all) {
+    while (c->cp_n > 0) {
+        const int i = ((c->cp_head - c->cp_n) % lasr_ctx::NCELLEV + lasr_ctx::NCELLEV) % lasr_ctx::NCELLEV;
+        if (!all && c->cp_n < lasr_ctx::NCELLEV && hipEventQuery(c->cp_ev[i][1]) != hipSuccess) { (void)hipGetLastError(); break; }
+        (void)hipEventSynchronize(c->cp_ev[i][1]);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->cp_ev[i][0], c->cp_ev[i][1]) == hipSuccess) {
+            c->cp_us += 1e3 * (double)ms;
+            c->cp_launches += c->cp_cells[i];
+        } else {
+            (void)hipGetLastError();
+        }
+        c->cp_n--;
+    }
+}
+
 // ---------------------------------------------------------------------------- encoder + decode
 // Encoder over T_max frames for rows with T_row > 0 (x0 already holds LayerNorm'ed features).
 void run_encoder(lasr_ctx* c, int T_max) {
     const int L = c->d.enc_layers;
     const int mt_total = c->Tcap * c->MT;
     const int par0 = c->enc_par;
+    int cp_slot = -1;
+    if (c->cell_prof && c->cp_ok) {
+        if (c->cp_n >= lasr_ctx::NCELLEV) cell_prof_harvest(c, false);
+        cp_slot = c->cp_head;
+        c->cp_head = (c->cp_head + 1) % lasr_ctx::NCELLEV;
+        c->cp_cells[cp_slot] = L * T_max;
+        (void)hipEventRecord(c->cp_ev[cp_slot][0], c->stream);
+    }
     // layer-major order: every layer starts from parity par0 and toggles T_max times (enc_h[par][l] is
     // indexed by the parity at launch time, so all layers end on par0 ^ (T_max & 1))
     for (int l = 0; l < L; ++l) {
@@ -60,6 +85,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
             c->enc_par ^= 1;
         }
     }
+    if (cp_slot >= 0) { (void)hipEventRecord(c->cp_ev[cp_slot][1], c->stream); c->cp_n++; }
     // encoder half of the joint for all frames: pe[t][r] = W1e * enc[t][r]
     const int H = c->d.hidden, J = c->d.joint;
     GemmArgs g{};

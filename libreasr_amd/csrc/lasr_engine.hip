@@ -78,6 +78,9 @@ void lasr_destroy(lasr_ctx* c) {
     for (auto& e : c->ev_enc)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_misc) (void)hipEventDestroy(c->ev_misc);
+    if (c->cp_ok)
+        for (auto& p : c->cp_ev)
+            for (auto& e : p) (void)hipEventDestroy(e);
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
     if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
@@ -1189,6 +1192,29 @@ int lasr_debug_timing(lasr_ctx* c, unsigned long long* out /*[5*4096*8]*/) {
     if (!c->dbg) return fail(c, LASR_ESTATE, "set LASR_DBG_TIMING=1 before lasr_create");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, c->dbg, sizeof(unsigned long long) * 5 * 4096 * 16, hipMemcpyDeviceToHost));
+    return LASR_OK;
+}
+
+// In-job timing of the dominant kernel: while on, every model step's encoder-cell sequence (enc_layers x frames
+// back-to-back launches of k_gemm<EpiLSTM>) is bracketed by a HIP-event pair on the ctx stream.  lasr_cell_prof_read
+// drains the outstanding pairs and returns the accumulated microseconds / cell launches since the last on-switch.
+int lasr_cell_prof(lasr_ctx* c, int on) {
+    if (!c) return LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (on && !c->cp_ok) {
+        for (auto& p : c->cp_ev)
+            for (auto& e : p) HIPCHK(c, hipEventCreate(&e));
+        c->cp_ok = true;
+    }
+    if (on) { cell_prof_harvest(c, true); c->cp_us = 0.0; c->cp_launches = 0; }
+    c->cell_prof = on != 0;
+    return LASR_OK;
+}
+int lasr_cell_prof_read(lasr_ctx* c, double* us_total, long long* launches) {
+    if (!c || !us_total || !launches) return LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    cell_prof_harvest(c, true);
+    *us_total = c->cp_us; *launches = c->cp_launches;
     return LASR_OK;
 }
 

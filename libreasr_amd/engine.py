@@ -280,6 +280,16 @@ class Engine:
     def sync(self):
         self._chk(self.lib.lasr_sync(self.ctx))
 
+    def cell_prof(self, on=True):
+        """In-job HIP-event timing of the encoder-cell launches (see lasr_cell_prof)."""
+        self._chk(self.lib.lasr_cell_prof(self.ctx, 1 if on else 0))
+
+    def cell_prof_read(self):
+        """-> (microseconds, cell launches) accumulated since cell_prof(True)."""
+        us, n = C.c_double(0.0), C.c_longlong(0)
+        self._chk(self.lib.lasr_cell_prof_read(self.ctx, C.byref(us), C.byref(n)))
+        return us.value, n.value
+
     def bench_cell(self, layer=1, iters=200):
         us = C.c_double(0.0)
         self._chk(self.lib.lasr_bench_cell(self.ctx, int(layer), int(iters), C.byref(us)))

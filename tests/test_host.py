@@ -72,18 +72,56 @@ def test_synth_recipe_is_deterministic_and_shaped():
 
 
 def test_bench_multi_gpu_path_over_gloo():
-    """world_size 2 on CPU: contiguous stream sharding, max-over-ranks time, sum-over-ranks units."""
+    """world_size 2 on CPU: contiguous stream sharding, max-over-ranks time, sum-over-ranks units -- once under an
+    external torch.distributed.run (how the driver launches N > 1) and once from plain `python bench.py --gpus 2`
+    (bench.py spawns its own ranks)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--selftest-dist"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert line, out.stdout + out.stderr
-    d = json.loads(line[-1])
-    assert d["world"] == 2 and d["elapsed_max"] == 1.5 and d["units_total"] == 128.0 and d["n_local"] == 64
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmds = [[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+             "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+             "--gpus", "2", "--selftest-dist"],
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-dist"]]
+    for cmd in cmds:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert line, out.stdout + out.stderr
+        d = json.loads(line[-1])
+        assert d["world"] == 2 and d["elapsed_max"] == 1.5 and d["units_total"] == 128.0 and d["n_local"] == 64
     import bench
     assert bench.shard_streams(512, 8, 3) == list(range(192, 256))
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` on a box with fewer than 2 GPUs must fail (rc != 0), not report n_gpus: 1."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LASR_BENCH_SAME_GPU"):
+        env.pop(k, None)
+    env["HIP_VISIBLE_DEVICES"] = ""            # no device visible, whatever the box has
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "GPU(s) visible" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_cpu_legs_and_labels():
+    """The CPU-baseline legs own their PCM (the round-1 crash: slicing past the GPU run's buffer) and the
+    workload label follows the actual model / dtype / beam / streams."""
+    import argparse
+    import bench
+    from libreasr_amd import synth
+    cfg = synth.model_cfg("tiny")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    r = bench.cpu_reference_path(cfg, sd, 2, 30)
+    assert r["value"] > 0 and r["cores"] == 2 and r["kind"] == "port" and r["tokens"] > 0
+    n = bench.cpu_numpy_port(cfg, sd, 2, 30)
+    assert n["value"] > 0
+    ns = argparse.Namespace
+    assert bench.workload_name(ns(model="cfg2", dtype="f32", beam=1), synth.model_cfg("cfg2"), 64).startswith("configs[1]: 64 ")
+    w = bench.workload_name(ns(model="cfg5", dtype="bf16", beam=8), synth.model_cfg("cfg5"), 128)
+    assert w.startswith("configs[4]: 128 ") and "8x1536" in w and "2xLSTM" in w and "beam width 8" in w
+    assert "variant" in bench.workload_name(ns(model="cfg5", dtype="bf16", beam=1), synth.model_cfg("cfg5"), 128)
+    assert abs(bench.flop_per_frame(synth.model_cfg("cfg2"), 0.3) - 85.25e6) < 0.01e6      # SURVEY 8d table
 
 
 def test_model_archive_round_trip(tmp_path):

@@ -169,3 +169,28 @@ def test_resample_restatement_properties():
     y = O.resample(np.sin(2 * np.pi * 1000 * t).astype(np.float32), 48000)
     ref = np.sin(2 * np.pi * 1000 * np.arange(len(y)) / 16000.0)
     assert np.abs(y[100:-100] - ref[100:-100]).max() < 2e-3
+
+
+@pytest.mark.parametrize("name,n_sec,n_streams", [("tiny", 3.0, 3), ("tiny_lstm", 3.0, 2), ("cfg2", 4.0, 2),
+                                                   ("cfg2_lstm", 2.0, 1)])
+def test_torch_cpu_reference_path_matches_reference(golden_dir, name, n_sec, n_streams):
+    """oracle/torch_cpu.py (the reference's torch-CPU execution path restated on the installed torch: the
+    timed CPU neighbour of bench.py) reproduces the goldens the reference's own code produced: offline and
+    streaming token ids, per-call counts, -log p."""
+    from oracle import torch_cpu as TC
+    g = load(golden_dir, f"model_{name}.npz")
+    cfg = synth.model_cfg(name)
+    m = TC.TorchTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
+    pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
+    for s in range(n_streams):
+        y, neg_logp = m.decode_greedy(TC.TorchFrontend().offline(pcm[s]))
+        assert y == list(g[f"off_tokens_{s}"])
+        assert abs(neg_logp - float(g[f"off_neglogp_{s}"])) < 1e-2
+        fe, dec = TC.TorchFrontend(), m.stream_decoder()
+        counts = []
+        for c in synth.stream_chunks(pcm[s], 1280, lead=1, tail=10):
+            o = fe.push(c)
+            if o is not None:
+                counts.append(len(dec.step(o)))
+        assert dec.y == list(g[f"st_tokens_{s}"])
+        assert counts == list(g[f"st_counts_{s}"])
