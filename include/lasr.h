@@ -118,15 +118,21 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm);
 int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran);
 
 /* Pipelined form (throughput mode): lasr_step_submit enqueues this chunk's front-end + encoder on the
- * ctx stream and returns; lasr_step_wait runs the greedy decode loop of the OLDEST submitted model
- * step on a second HIP stream and blocks until its tokens are on the host (n_ran = its slot count,
- * 0 if no model step was pending).  Issue submit(k+1) before wait(k): the encoder of the next chunk
- * then overlaps the latency-bound decode loop of the current one.  At most two steps in flight;
- * every other state-changing call returns LASR_ESTATE while a submitted step is uncollected.
- * Results are identical to lasr_step_stream (same kernels, same order per stream). */
+ * ctx stream and returns; lasr_step_wait keeps ONE greedy decode loop running on a second HIP stream and
+ * blocks until the tokens of the OLDEST submitted model step are on the host (n_ran = its slot count,
+ * 0 if no model step was pending); rows that finish a step early continue with the frames of the later,
+ * already encoded steps.  Issue submit(k+1) ... before wait(k): the encoders of the next chunks then
+ * overlap the latency-bound decode loop.  Up to lasr_max_inflight() model steps may be submitted and not
+ * yet collected: 7 with the reference front-end (n_buffer 2, max_iters_stream 10); fewer when n_buffer *
+ * max_iters_stream is large (the limit keeps the per-row rings of encoder frames (32) and tokens (256) from
+ * wrapping).  At the limit lasr_step_submit returns LASR_ESTATE and changes nothing (the pushed chunk stays
+ * pushed: call lasr_step_wait, then submit again).
+ * Every other state-changing call returns LASR_ESTATE while a submitted step is uncollected.
+ * Results are identical to lasr_step_stream (same kernels, same order per stream).  Greedy only. */
 int lasr_step_submit(lasr_ctx* c, const int* slots, int n);
 int lasr_step_wait(lasr_ctx* c, int* n_ran);
-int lasr_step_pending(lasr_ctx* c);   /* submitted model steps not yet collected (0..2) */
+int lasr_step_pending(lasr_ctx* c);   /* submitted model steps not yet collected (0..lasr_max_inflight()) */
+int lasr_max_inflight(const lasr_ctx* c);
 
 /* ---- offline path (Transcribe RPC, api-server.py:64-80 -> Transducer.transcribe,
  * models.py:365-455): whole utterances, fresh state, max_iters_offline.

@@ -47,6 +47,7 @@ SYMBOLS = [
     ("lasr_step_submit", C.c_int, [_P, _P, C.c_int]),
     ("lasr_step_wait", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("lasr_step_pending", C.c_int, [_P]),
+    ("lasr_max_inflight", C.c_int, [_P]),
     ("lasr_transcribe_pcm", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("lasr_transcribe_feats", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("lasr_step_feats", C.c_int, [_P, _P, C.c_int, _P, C.c_int]),

@@ -79,7 +79,10 @@ struct lasr_ctx {
     int n_iter_slots = 0;
     int* T_row_dev = nullptr;       // [M] current step's frames per row: points INTO the step's device command block
     int* zero_rows = nullptr;       // [M] zeros (reset passes: "no row is decoding")
-    int* T_row_dec = nullptr;       // what the decode kernels read (T_row_dev; frames-available counters when continuous)
+    int* T_row_dec = nullptr;       // what the decode kernels read (T_row_fix; frames-available counters when continuous)
+    int* T_row_fix = nullptr;       // [M] fixed-address copy of the current synchronous step's T_row: the decode kernels are
+                                    // replayed from cached hipGraphs, which bake their pointer arguments in, while the
+                                    // command block (T_row_dev) moves with every step
     int* dec_t_idx = nullptr;       // frame cursor array the decode kernels use (ds.t_idx, or c_cur when continuous)
     int pe_ring_R = 1 << 30;        // pe frame t lives at slot t % pe_ring_R
     // continuous decode (lasr_step_submit / lasr_step_wait): front-end + encoder of later chunks run on

@@ -244,6 +244,8 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->ds.emit, Md)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->zero_rows, M));
     HIPCHK(c, hipMemset(c->zero_rows, 0, sizeof(int) * M));
+    RC(dalloc(c, &c->T_row_fix, M));
+    HIPCHK(c, hipMemset(c->T_row_fix, 0, sizeof(int) * M));
     c->T_row_dev = c->zero_rows;
     for (int q = 0; q < lasr_ctx::NFLY; ++q) {
         RC(dalloc(c, &c->T_row_ring[q], M));
@@ -550,7 +552,14 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     if (!c) return LASR_EINVAL;
     RC(check_slots(c, slots, n, true));
     if (c->W > 1) return fail(c, LASR_ESTATE, "lasr_step_submit is greedy-only; use lasr_step_stream with beam > 1");
-    if ((int)c->pending.size() >= lasr_ctx::NFLY - 1) return fail(c, LASR_ESTATE, "%d steps already in flight: call lasr_step_wait", (int)c->pending.size());
+    {   // in-flight limit: the event / T_row rings (NFLY) and the per-row rings the decode loop runs through --
+        // encoder frames not yet decoded (pe ring), tokens not yet collected (token ring), step boundary marks
+        const int inflight = (int)c->pending.size() + 1, Tm = c->d.n_buffer;
+        if (inflight > lasr_ctx::NFLY - 1 || inflight > lasr_ctx::ENDSLOTS || inflight * Tm > lasr_ctx::RING ||
+            inflight * Tm * c->d.max_iters_stream > lasr_ctx::TOKRING)
+            return fail(c, LASR_ESTATE, "%d steps already in flight (limit %d for n_buffer %d, max_iters_stream %d): call lasr_step_wait",
+                        (int)c->pending.size(), lasr_max_inflight(c), Tm, c->d.max_iters_stream);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     // keep the decode stream busy while the host enqueues (and the GPU runs) this chunk's encoder
     cont_poll(c);
@@ -588,6 +597,15 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
 }
 
 int lasr_step_pending(lasr_ctx* c) { return c ? (int)c->pending.size() : 0; }
+
+int lasr_max_inflight(const lasr_ctx* c) {
+    if (!c) return 0;
+    const int Tm = c->d.n_buffer;
+    int n = std::min(lasr_ctx::NFLY - 1, lasr_ctx::ENDSLOTS);
+    n = std::min(n, lasr_ctx::RING / Tm);
+    n = std::min(n, lasr_ctx::TOKRING / (Tm * c->d.max_iters_stream));
+    return std::max(n, 0);
+}
 
 static int spin_flag(lasr_ctx* c, volatile int* flag, hipStream_t st) {
     unsigned long long spins = 0;

@@ -219,7 +219,9 @@ int cmd_commit(lasr_ctx* c) {
 // the m-tiles that contain an active row (passed by value to the encoder cell kernels)
 int commit_T_rows(lasr_ctx* c, int T_max) {
     c->T_row_dev = c->dc.T_row;             // the command ring (NCMD blocks) outlives every step in flight
-    c->T_row_dec = c->T_row_dev;
+    // decode kernels of the synchronous protocols read a FIXED buffer (cached graphs replay baked-in pointers)
+    HIPCHK(c, hipMemcpyAsync(c->T_row_fix, c->T_row_dev, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+    c->T_row_dec = c->T_row_fix;
     c->tile_masks.assign(std::max(T_max, 1), 0ull);
     for (int t = 0; t < T_max; ++t) {
         unsigned long long m = 0;

@@ -26,23 +26,32 @@ def extract_tars(paths_archive=None, path_dest=_PATH_DEST):
         with tarfile.open(arc) as tar:
             for m in tar.getmembers():
                 target = os.path.realpath(os.path.join(dest, m.name))
-                if not (target == dest or target.startswith(dest + os.sep)) or m.islnk() or m.issym():
-                    raise ValueError(f"unsafe member {m.name!r} in {arc}")
-            tar.extractall(path=dest)
+                if not (target == dest or target.startswith(dest + os.sep)) or not (m.isreg() or m.isdir()):
+                    raise ValueError(f"unsafe member {m.name!r} in {arc}")        # links, devices, FIFOs, escapes
+            try:
+                tar.extractall(path=dest, filter="data")
+            except TypeError:                                                  # Python without extraction filters
+                tar.extractall(path=dest)
             out += [m.name for m in tar.getmembers()]
     return out
 
 
+def _safe_load(path):
+    """Checkpoints come out of an archive found in the working directory: tensors-only unpickling.  The fastai
+    wrapper's "opt" entry is plain containers + tensors and loads under weights_only as well."""
+    return torch.load(str(path), map_location="cpu", weights_only=True)
+
+
 def load_model_state_dict(path):
     """`model.pth`: plain state_dict or the fastai {"model": ..., "opt": ...} wrapper -> {key: tensor}."""
-    sd = torch.load(str(path), map_location="cpu")
+    sd = _safe_load(path)
     if isinstance(sd, dict) and "model" in sd and not any(str(k).startswith("encoder.") for k in sd):
         sd = sd["model"]
     return {k: v for k, v in sd.items() if torch.is_tensor(v)}
 
 
 def load_lm_state_dict(path):
-    sd = torch.load(str(path), map_location="cpu")
+    sd = _safe_load(path)
     return {k: v for k, v in sd.items() if torch.is_tensor(v)}
 
 

@@ -83,6 +83,8 @@ class Scheduler(threading.Thread):
         with self.cv:
             self.stop_flag = True
             self.cv.notify()
+        for st in list(self.streams.values()):      # RPC threads blocked in push() wake up with an error
+            st.outq.put(RuntimeError("scheduler shut down"))
 
     # ---- scheduler thread ------------------------------------------------------------------
     def _open(self):
@@ -112,6 +114,8 @@ class Scheduler(threading.Thread):
                 while not self.stop_flag and not self.ctl and not any(s.inq for s in self.streams.values()):
                     self.cv.wait()
                 if self.stop_flag:
+                    for fn, done in self.ctl:
+                        done.put(RuntimeError("scheduler shut down"))
                     return
                 ctl = list(self.ctl)
                 self.ctl.clear()
@@ -148,14 +152,26 @@ class ASRServicer(apg.ASRServicer):
         self.lang_name, self.sched, self.lang = lang, scheduler, language
         eng = scheduler.eng
         self.downsample, self.n_buffer, self.chunk = eng.desc.stride, eng.desc.n_buffer, eng.desc.chunk
+        self.beam = eng.beam
+
+    @staticmethod
+    def _guard(context, fn):
+        """All stream slots taken (LASR_EFULL) is RESOURCE_EXHAUSTED for the client, not UNKNOWN."""
+        from ._native import LASR_EFULL, LasrError
+        try:
+            return fn()
+        except LasrError as e:
+            if e.code == LASR_EFULL:
+                context.abort(grpc.StatusCode.RESOURCE_EXHAUSTED, "all stream slots are in use")
+            raise
 
     def Transcribe(self, request, context):                                # api-server.py:64-80
         aud = tensorize(request.data)[0].numpy()
-        tokens, _, _ = self.sched.transcribe(aud, request.sr or 16000)
+        tokens, _, _ = self._guard(context, lambda: self.sched.transcribe(aud, request.sr or 16000))
         return ap.Transcript(data=self.lang.denumericalize(tokens))
 
     def TranscribeStream(self, request_iterator, context):                 # api-server.py:82-134
-        st = self.sched.open()
+        st = self._guard(context, self.sched.open)
         try:
             y, last, last_diff, steps = [], "", "", 0
             for frame in request_iterator:
@@ -171,7 +187,15 @@ class ASRServicer(apg.ASRServicer):
                 if res is None:
                     continue                                               # no model call for this chunk
                 steps += 1
-                y = y + res
+                if self.beam > 1:
+                    # beam search: the engine hands out the WHOLE current best hypothesis after every model step (it may
+                    # change retroactively); this chunk's text is what follows the common prefix (lib/models.py does the same)
+                    n = 0
+                    while n < min(len(y), len(res)) and y[n] == res[n]:
+                        n += 1
+                    y, res = list(res), res[n:]
+                else:
+                    y = y + res
                 y_one = self.lang.denumericalize(res)
                 if y_one != "":
                     now = self.lang.denumericalize(y)

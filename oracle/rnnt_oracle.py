@@ -436,7 +436,7 @@ class OracleTransducer:
         return res + (outs,) if return_logits else res
 
     # -- beam search (ABSENT from the reference -> parity unpinned; this is the spec) --
-    def _beam_frame(self, hyps, enc_t, W, max_iters):
+    def _beam_frame(self, hyps, enc_t, W, max_iters, margins=None):
         """One encoder frame of the slot-synchronous beam.  hyps: list of dicts(score, y, h_pred, pstate),
         len <= W.  Round r <= max_iters: candidates = hyps already done with this frame (B, unchanged)
         + every (hyp in A) x (token v) with score + log p(v); the W best survive (score desc; ties:
@@ -458,6 +458,8 @@ class OracleTransducer:
                 for v in top:
                     cands.append((-(h["score"] + float(lp[v])), b, 1, int(v), h))
             cands.sort(key=lambda c: c[:4])
+            if margins is not None and len(cands) > W:      # score gap at the selection boundary (W-th vs next candidate)
+                margins.append(cands[W][0] - cands[W - 1][0])
             new = []
             for negs, b, kind, v, h in cands[:W]:
                 if kind == 0:
@@ -498,11 +500,18 @@ class StreamBeamDecoder:
         self.m, self.W, self.max_iters = m, W, max_iters
         self.enc_state = None
         self.hyps = m.beam_init()
+        self.step_margin = []          # per model step: smallest score gap that decided something (selection
+                                       # boundary of any round, or best vs second-best hypothesis at the end)
 
     def step(self, chunk):
         enc, self.enc_state = self.m.encoder(chunk[None], self.enc_state)
+        margins = []
         for t in range(enc.shape[1]):
-            self.hyps = self.m._beam_frame(self.hyps, enc[0, t], self.W, self.max_iters)
+            self.hyps = self.m._beam_frame(self.hyps, enc[0, t], self.W, self.max_iters, margins)
+        sc = sorted((h["score"] for h in self.hyps), reverse=True)
+        if len(sc) > 1:
+            margins.append(sc[0] - sc[1])
+        self.step_margin.append(min(margins) if margins else float("inf"))
         return self.best()
 
     def best(self):
@@ -514,6 +523,7 @@ class _StreamDecoder:
     def __init__(self, m, max_iters):
         self.m, self.max_iters = m, max_iters
         self.y = []
+        self.decisions = []            # (tokens emitted before the decision, top-1 minus top-2 logit) of every joint evaluation
         self.fuser = LMFuser(m.lm)                                    # models.py:478
         self.reset()
 
@@ -535,6 +545,8 @@ class _StreamDecoder:
                 if return_logits:
                     outs.append(z[0].copy())
                 pred = int(lp[0].argmax())
+                top2 = np.partition(z[0], -2)[-2:]
+                self.decisions.append((len(self.y) + len(y_seq), float(top2[1] - top2[0])))
                 if pred == m.blank:
                     break
                 pred = self.fuser.fuse(lp[0], pred)                   # models.py:558
