@@ -8,12 +8,15 @@ reference-faithful streaming call pattern: 80 ms client chunks, 3-chunk sliding 
 Buffer => the model runs every second chunk on 2 stacked frames (api-server.py:83-115,
 transforms.py:326-342,455-471, models.py:457-577).
 
-A "step" = one 80 ms chunk pushed for every stream of the rank (lasr_push_pcm + lasr_step_submit / _wait,
-tokens fetched to the host).  Synthetic PCM is resident in HBM before the timed region.
+A "step" = one pass of the hot path over one batch of synthetic input: one 1.28 s SEGMENT (16 chunks of 80 ms,
+--chunks-per-step) of every stream of the rank = 81.92 audio-seconds at 64 streams; each chunk is pushed for all
+streams (lasr_push_pcm + lasr_step_submit / _wait) and its tokens are fetched to the host.  (A single 80 ms chunk
+is 0.13 ms of GPU time: 20 of them cannot be timed against a 6-deep software pipeline.)  `value` does not depend
+on the segment length.  Synthetic PCM is resident in HBM before the timed region.
 Streams are independent: rank r owns streams [64 r, 64 r + 64), there is no data-path collective
 ("scaling": "weak"); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python bench.py --gpus N ...                      # spawns N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -38,6 +41,8 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PRIME_CHUNKS = 24             # untimed chunks before the W warm-up steps: window fill + hipGraph instantiation
+CHUNKS_PER_STEP = 16          # one step = a 1.28 s segment of every stream
+PCM_PERIOD = 320              # distinct synthetic chunks per stream (25.6 s); longer runs cycle through them
 METRIC = "audio-sec/sec/GPU (16 kHz streaming RNN-T) + p50 per-chunk latency"
 
 
@@ -177,8 +182,10 @@ def cpu_numpy_port(cfg, sd, n_streams, n_chunks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--chunks-per-step", type=int, default=CHUNKS_PER_STEP,
+                    help="80 ms chunks per stream in one step (default 16 = a 1.28 s segment)")
     ap.add_argument("--model", default="cfg2")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -197,6 +204,7 @@ def main():
                     help="pipelined mode: model steps in flight before the oldest is collected (1..7)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
+    ap.add_argument("--trace", default=None, help="diagnostics: dump the two-stream mark timeline (lasr_trace) of the timed region to this file")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU-only: exercise sharding + aggregation over gloo (no GPU work)")
     args = ap.parse_args()
@@ -235,10 +243,11 @@ def main():
     B = args.streams
     eng = Engine(sd, cfg, max_streams=B, device=local, dtype=args.dtype, beam=args.beam)
     my_streams = shard_streams(B * world, world, rank)
-    K, W = args.steps, args.warmup
+    CPS = max(1, args.chunks_per_step)
+    K, W = args.steps * CPS, args.warmup * CPS            # in chunks from here on
     P = max(0, PRIME_CHUNKS - W)
     extras = rank == 0 and not args.no_extras and args.beam == 1 and not args.no_pipeline
-    n_chunks = P + W + K + (K if extras else 0) + 4
+    n_chunks = min(PCM_PERIOD, P + W + K + (K if extras else 0) + 4)
     # synthetic PCM for this rank's streams (seeded per global stream id), resident in HBM,
     # laid out [chunk][stream][1280] so that one step reads one contiguous block
     pcm_host = np.stack([synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in my_streams])
@@ -256,7 +265,7 @@ def main():
         push + submit (front-end and encoder of chunk k go to the GPU), then collect the tokens of
         the oldest model step once `depth` are in flight; its decode loop runs on a second HIP stream."""
         t_push = time.perf_counter()
-        eng.push(slots, pcm_host_chunks[k] if host else pcm_dev[k])
+        eng.push(slots, pcm_host_chunks[k % n_chunks] if host else pcm_dev[k % n_chunks])
         ntok, done = 0, 0
         if not pipelined:
             if eng.step(slots):
@@ -326,8 +335,15 @@ def main():
         if not pipelined:
             enc_ms.append(st["encoder_ms"]); dec_ms.append(st["decode_ms"]); fe_ms.append(st["frontend_ms"])
 
-    eng.cell_prof(True)                           # HIP-event pair around every model step's cell sequence, on its stream
+    if args.trace:
+        eng.trace(True)
+    else:
+        eng.cell_prof(True)                       # HIP-event pair around every model step's cell sequence, on its stream
     elapsed, tokens = timed_region(P + W, K, lat_model, host=args.host_pcm, stats=on_stats)
+    if args.trace:
+        with open(args.trace, "w") as f:
+            json.dump({"marks": eng.trace_read(), "elapsed_us": 1e6 * elapsed, "chunks": K}, f)
+        eng.trace(False)
     cell_us_total, cell_launches = eng.cell_prof_read()
     eng.cell_prof(False)
     eng.set_profiling(False)
@@ -359,15 +375,18 @@ def main():
             "value": round(audio_total / elapsed_max, 1),
             "unit": "audio-sec/sec",
             "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": round(1e3 * elapsed_max / K, 4),
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed_max / args.steps, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic" + (" (PCM handed over in host memory every chunk: PCIe-inclusive)" if args.host_pcm else ""),
             "config": {"workload": workload_name(args, cfg, B),
+                       "step": f"one {CPS * 80} ms segment ({CPS} chunks of 80 ms) of each of the {B} streams = "
+                               f"{CPS * B * CHUNK / SR:.2f} audio-s per GPU and step",
+                       "chunks_per_step": CPS, "ms_per_chunk": round(1e3 * elapsed_max / K, 4),
                        "streams_per_gpu": B, "chunk_ms": 80, "parallelism": f"dp{world} (independent streams, no collective)",
                        "pipeline": (f"submit/wait, {args.depth} model steps in flight: encoder of later chunks on the main stream, "
                                     "one continuous greedy loop on a second stream") if pipelined else "synchronous",

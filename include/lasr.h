@@ -234,6 +234,12 @@ int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us);
  * accumulated since profiling was switched on (average launch duration = us_total / launches, next to whatever
  * else shares the GPU -- the number a rocprofv3 kernel trace of the same run shows). */
 int lasr_cell_prof(lasr_ctx* c, int on);
+/* Stream timeline of the pipelined protocol (diagnostics): while on, timestamped marks are recorded on the main
+ * stream (tag 1 push, 3 first cell, 4 cells done, 5 model step enqueued) and on the decode stream (10 group reached,
+ * 11 + 100 G [+ 1000: steps admitted] admission done, 12 group done); at most 8192 marks.  lasr_trace_read
+ * synchronises the device and returns the marks in record order with their time in microseconds since lasr_trace(c, 1). */
+int lasr_trace(lasr_ctx* c, int on);
+int lasr_trace_read(lasr_ctx* c, double* us, int* tags, int cap, int* n);
 int lasr_cell_prof_read(lasr_ctx* c, double* us_total, long long* launches);
 
 #ifdef __cplusplus

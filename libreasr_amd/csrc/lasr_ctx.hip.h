@@ -55,6 +55,8 @@ struct lasr_ctx {
     std::vector<void*> enc_h[2], pred_h[2], pred_y;      // element-typed (A operands)
     std::vector<float*> enc_c, pred_c;
     int cell_nw = 0;                // waves per encoder-cell workgroup (0: 4 for f32, 8 for bf16); LASR_CELL_NW
+    int dec_prio = 0, cell_prio = 0;   // s_setprio of the decode-stream GEMMs / of everything else (experiments)
+    int logits_mt = 1;              // m-tiles per workgroup of the logits GEMM (1 | 2 | 4); LASR_LOGITS_MT
     int dec_nw_mask = 0;            // LASR_DEC_NW4: bit 1 predictor cells, bit 2 PPJ, bit 4 linear (logits, pe) run with 4 waves
     // beam search: c, BN(h) and pp ping-pong like h (every slot may be re-parented each round):
     // parity 0 = pred_c / pred_y / pp, parity 1 = the *1 buffers; all follow pred_par
@@ -97,19 +99,19 @@ struct lasr_ctx {
     int* T_row_ring[NFLY] = {};
     float* pe_ring = nullptr;
     int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
+    int* c_hcur_dev = nullptr;      // device view of the pinned per-row frame cursors (cont_host + 16)
     int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr;
     int *c_done = nullptr, *c_flag_dev = nullptr;   // workgroups finished per iteration; device view of cont_host[0]
     int* c_iter = nullptr;                          // device-side iteration counter of the continuous loop
     std::map<std::tuple<int, int, int>, hipGraphExec_t> cgraphs;   // (iterations, predictor parity, LM parity) -> group
-    int* cont_host = nullptr;       // pinned: [0] flag, [4..] target staging (NFLY blocks), then ntok_end + token ring
-    struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; bool target_set; std::vector<int> target; const int* T_row_ptr; long long serial; };
+    int* cont_host = nullptr;       // pinned: [0] flag, [16..16+M) per-row frame cursors, then (after NFLY*M ints) ntok_end + token ring
+    struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; std::vector<int> target; const int* T_row_ptr; long long serial; };
     std::vector<PendingStep> pending;
     std::vector<long long> h_frames_sub, h_fetched;
-    long long model_steps = 0, cont_iters = 0;
+    std::vector<int> h_cur_seen;    // per-row frame cursors as of the last consumed group (step j of row r is decoded iff >= its target)
+    int work_left = 0;              // rows that still had encoded frames to decode when the last consumed group ended
+    long long model_steps = 0, cont_iters = 0, iters_reported = 0;
     bool group_inflight = false;    // a decode group has been launched and its flag not yet consumed
-    long long inflight_for = -1;    // serial of the pending step the in-flight group's flag refers to
-    long long done_serial = -1;     // serial of a pending step already known to be fully decoded
-    int kick_iters = 0;
     int kick_n = 3, wait_n = 1;     // iterations per group: kicked from submit / launched while waiting (swept on configs[1])
     // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
     // predictor parity at group start, frames)
@@ -184,6 +186,17 @@ struct lasr_ctx {
     int cp_cells[NCELLEV] = {};
     double cp_us = 0.0;
     long long cp_launches = 0;
+
+    // stream timeline (lasr_trace): timestamped marks on the main and the decode stream of the pipelined protocol
+    static constexpr int NTRACE = 8192;
+    bool tr_on = false;
+    std::vector<hipEvent_t> tr_ev;
+    std::vector<int> tr_tag;
+    std::vector<double> tr_val;
+    std::vector<int> tr_prev_cur, tr_prev_ntot;    // per-row cursors / token counts at the previous consumed group
+    int tr_last_G = 0;
+    hipEvent_t tr_base = nullptr;
+    int tr_n = 0;
 
     // stats
     bool profiling = false;

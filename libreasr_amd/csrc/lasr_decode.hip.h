@@ -74,6 +74,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
         c->cp_cells[cp_slot] = L * T_max;
         (void)hipEventRecord(c->cp_ev[cp_slot][0], c->stream);
     }
+    tr_mark(c, 3, c->stream);
     // layer-major order: every layer starts from parity par0 and toggles T_max times (enc_h[par][l] is
     // indexed by the parity at launch time, so all layers end on par0 ^ (T_max & 1))
     for (int l = 0; l < L; ++l) {
@@ -86,6 +87,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
         }
     }
     if (cp_slot >= 0) { (void)hipEventRecord(c->cp_ev[cp_slot][1], c->stream); c->cp_n++; }
+    tr_mark(c, 4, c->stream);
     // encoder half of the joint for all frames: pe[t][r] = W1e * enc[t][r]
     const int H = c->d.hidden, J = c->d.joint;
     GemmArgs g{};

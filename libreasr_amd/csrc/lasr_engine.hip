@@ -65,6 +65,8 @@ void lasr_destroy(lasr_ctx* c) {
     if (c->cmd_host) (void)hipHostFree(c->cmd_host);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->cont_host) (void)hipHostFree(c->cont_host);
+    for (auto& e : c->tr_ev) (void)hipEventDestroy(e);
+    if (c->tr_base) (void)hipEventDestroy(c->tr_base);
     if (c->trellis_host) (void)hipHostFree(c->trellis_host);
     if (c->push_stage_host) (void)hipHostFree(c->push_stage_host);
     if (c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
@@ -114,6 +116,9 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         if (getenv("LASR_NO_GRAPH")) c->use_graphs = false;
         if (getenv("LASR_CELL_NW")) c->cell_nw = atoi(getenv("LASR_CELL_NW")) == 4 ? 4 : 8;
         if (getenv("LASR_DEC_NW4")) c->dec_nw_mask = atoi(getenv("LASR_DEC_NW4"));
+        if (getenv("LASR_DEC_PRIO")) c->dec_prio = atoi(getenv("LASR_DEC_PRIO"));
+        if (getenv("LASR_CELL_PRIO")) c->cell_prio = atoi(getenv("LASR_CELL_PRIO"));
+        if (getenv("LASR_LOGITS_MT")) { const int v = atoi(getenv("LASR_LOGITS_MT")); c->logits_mt = (v == 2 || v == 4) ? v : 1; }
         if (getenv("LASR_DBG_TIMING")) {
             RC(dalloc(c, &c->dbg, (size_t)5 * 4096 * 16));
             HIPCHK(c, hipMemset(c->dbg, 0, sizeof(unsigned long long) * 5 * 4096 * 16));
@@ -252,7 +257,13 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         HIPCHK(c, hipMemset(c->T_row_ring[q], 0, sizeof(int) * M));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_enc[q], hipEventDisableTiming));
     }
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
+    if (getenv("LASR_DEC_STREAM_PRIO")) {      // experiment: the latency-critical decode chain on a high-priority HIP stream
+        int lo = 0, hi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->stream_dec, hipStreamNonBlocking, atoi(getenv("LASR_DEC_STREAM_PRIO")) > 0 ? hi : lo));
+    } else {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
+    }
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_misc, hipEventDisableTiming));
     RC(dalloc(c, &c->pe_ring, (size_t)lasr_ctx::RING * M * J));
     HIPCHK(c, hipMemset(c->pe_ring, 0, sizeof(float) * (size_t)lasr_ctx::RING * M * J));
@@ -272,10 +283,11 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         void* dp = nullptr;
         HIPCHK(c, hipHostGetDevicePointer(&dp, c->cont_host, 0));
         c->c_flag_dev = (int*)dp;
+        c->c_hcur_dev = (int*)dp + 16;
         c->c_ntok_end = (int*)dp + 16 + (size_t)lasr_ctx::NFLY * M;
         c->c_tok_ring = c->c_ntok_end + (size_t)M * lasr_ctx::ENDSLOTS;
     }
-    c->h_frames_sub.assign(M, 0); c->h_fetched.assign(M, 0);
+    c->h_frames_sub.assign(M, 0); c->h_fetched.assign(M, 0); c->h_cur_seen.assign(M, 0);
     c->dec_t_idx = c->ds.t_idx;
     c->T_row_dec = c->T_row_dev;
     for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.sum_iters, c->ds.n_ones})
@@ -411,12 +423,15 @@ int lasr_stream_close(lasr_ctx* c, int slot) {
 }
 
 // ---------------------------------------------------------------------------- streaming
+static int cont_pump(lasr_ctx* c, int G);
+
 int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
     if (!c) return LASR_EINVAL;
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
     if (!pcm) return fail(c, LASR_EINVAL, "pcm is null");
     HIPCHK(c, hipSetDevice(c->device));
+    if (!c->pending.empty()) RC(cont_pump(c, c->kick_n));      // steps in flight: keep the decode loop fed
     const int CH = c->d.chunk;
     const float* src = pcm;
     const bool from_host = !is_device_ptr(pcm);
@@ -440,6 +455,7 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->push_copied[stage_i], 0));
         src = dst;
     }
+    tr_mark(c, 1, c->stream);
     if (c->M <= 512) {      // slot -> staging-row map by value: no command-block copy for a push
         PushIdx pi;
         for (int r = 0; r < 512; ++r) pi.idx[r] = -1;
@@ -487,7 +503,10 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             model_rows.push_back(s);
         }
     }
-    RC(cmd_commit(c));
+    // <= 512 rows: the command (frame slot + frames of this model step per row) rides in the log-mel launch's
+    // arguments; otherwise it goes through the command ring (one host->device copy)
+    const bool by_value = any_feat && c->M <= 512 && d.n_buffer * d.n_stack < 32768 && d.n_buffer < 256;
+    if (!by_value) RC(cmd_commit(c));
     rec(c, 0);
     if (any_feat) {
         MelArgs m{};
@@ -497,12 +516,17 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
         m.frames_per_row = d.n_stack; m.out = c->pend; m.out_frames = d.n_buffer * d.n_stack;
         m.row_N = nullptr; m.row_src_off = nullptr; m.row_frames = nullptr;
         m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win; m.fb_nnz = c->fb_nnz;
+        if (by_value) {
+            m.by_value = 1;
+            m.trow_out = model_rows.empty() ? nullptr : c->dc.T_row;
+            for (int r = 0; r < c->M; ++r) { m.sel_v[r] = (short)c->hc.feat_sel[r]; m.trow_v[r] = (unsigned char)c->hc.T_row[r]; }
+        }
         hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), 0, c->stream, m);
     }
     Tm = d.n_buffer;
     if (model_rows.empty()) return LASR_OK;
     RC(ensure_T(c, Tm));
-    RC(commit_T_rows(c, Tm));
+    RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring));    // the continuous loop reads its own frame counters
     {
         StackLnArgs a{};
         a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
@@ -540,12 +564,19 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
 
 static int cont_launch_group(lasr_ctx* c, int G);
 static void cont_poll(lasr_ctx* c);
+static int cont_pump(lasr_ctx* c, int G);
 
 // Pipelined + continuous form of lasr_step_stream.  submit: front-end + encoder of this chunk on the
-// main stream (the encoder half of the joint goes to a per-row frame ring).  wait: keeps ONE greedy
-// loop running on stream_dec until every row of the OLDEST submitted step has consumed that step's
-// frames; rows that are done early continue with the frames of the later, already encoded steps, so
-// the latency-bound tail of a bursty stream overlaps useful work instead of idling 63 rows.
+// main stream (the encoder half of the joint goes to a per-row frame ring).  ONE greedy loop runs on
+// stream_dec across chunk boundaries, in groups of iterations (one hipGraph launch each); rows that are
+// done early continue with the frames of the later, already encoded steps, so the latency-bound tail of
+// a bursty stream overlaps useful work instead of idling 63 rows.  The last k_select of a group stores
+// every row's frame cursor and the number of rows that still have encoded frames into pinned memory:
+// the host derives "step j is decoded" for EVERY step in flight from the cursors (no per-step target on
+// the device), so lasr_step_wait returns at once when the loop is ahead and the host can keep the main
+// stream fed `depth` steps deep; groups are launched from push / submit / wait whenever none is in
+// flight and frames are waiting (or about to be: a group may start with a stream-side wait for the next
+// encoder, so decoding resumes without the host).
 // Tokens are attributed to the step whose frames produced them: per-step results are identical to
 // lasr_step_stream.
 int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
@@ -562,11 +593,7 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     }
     HIPCHK(c, hipSetDevice(c->device));
     // keep the decode stream busy while the host enqueues (and the GPU runs) this chunk's encoder
-    cont_poll(c);
-    if (!c->pending.empty() && !c->group_inflight) {
-        c->kick_iters = c->kick_n;
-        RC(cont_launch_group(c, c->kick_iters));
-    }
+    RC(cont_pump(c, c->kick_n));
     const int idx = (int)(c->model_steps % lasr_ctx::NFLY);
     float* pe_keep = c->pe;
     c->pe = c->pe_ring;                     // run_encoder writes the joint's encoder half into the ring
@@ -584,8 +611,9 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     }
     hipLaunchKernelGGL(k_advance, dim3(grid1(c->M)), dim3(256), 0, c->stream, c->c_enc_frames, (const int*)c->T_row_dev, c->M);
     HIPCHK(c, hipEventRecord(c->ev_enc[idx], c->stream));
+    tr_mark(c, 5, c->stream);
     lasr_ctx::PendingStep p;
-    p.rows = model_rows; p.Tm = Tm; p.idx = idx; p.admitted = false; p.target_set = false;
+    p.rows = model_rows; p.Tm = Tm; p.idx = idx; p.admitted = false;
     p.T_row_ptr = c->T_row_dev;             // lives in the command ring until long after this step is collected
     p.serial = c->model_steps;
     p.target.assign(c->M, 0);
@@ -593,6 +621,9 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     c->pending.push_back(std::move(p));
     c->model_steps++;
     HIPCHK(c, hipGetLastError());
+    // the enqueue above took tens of microseconds of host time: a group may have finished meanwhile.  If nothing is
+    // left to decode the next group is queued behind this step's encoder event (stream-side wait)
+    RC(cont_pump(c, c->kick_n));
     return LASR_OK;
 }
 
@@ -626,25 +657,28 @@ struct ContScope {
     ~ContScope() { c->stream = st; c->pe = pe; c->pe_ring_R = ring; c->dec_t_idx = tidx; c->T_row_dec = trow; }
 };
 
-// One group of G greedy iterations on stream_dec for whatever rows have frames to decode, followed by
-// the copy of "rows of the oldest pending step still behind" into the pinned flag.  Does not wait.
+// One group of G greedy iterations on stream_dec for whatever rows have frames to decode; its last k_select
+// publishes the rows' frame cursors and the "rows with frames left" word to pinned memory.  Does not wait.
 static int cont_launch_group(lasr_ctx* c, int G) {
     const int M = c->M, V = c->d.vocab, J = c->d.joint;
     c->la = c->la_stream;
     ContScope scope(c);
-    lasr_ctx::PendingStep& P = c->pending.front();
     DecState s = c->ds;
     s.t_idx = c->c_cur; s.iters = c->c_iters; s.step_ntok = c->c_ntotal; s.step_tok = c->c_tok_ring;
-    s.tok_cap = lasr_ctx::TOKRING; s.unfinished = c->c_behind; s.cont = 1; s.target = c->c_target;
-    s.ntok_end = c->c_ntok_end; s.step_T = P.Tm; s.end_slots = lasr_ctx::ENDSLOTS; s.done_blocks = c->c_done;
+    s.tok_cap = lasr_ctx::TOKRING; s.unfinished = c->c_behind; s.cont = 1; s.host_cur = c->c_hcur_dev;
+    s.host_ntot = c->tr_on ? c->c_hcur_dev + M : nullptr;
+    s.ntok_end = c->c_ntok_end; s.step_T = c->d.n_buffer; s.end_slots = lasr_ctx::ENDSLOTS; s.done_blocks = c->c_done;
     s.iter_ctr = c->c_iter;
     int* flag = c->cont_host;
-    int* tgt_stage = c->cont_host + 16;
-    // admit encoded steps in order: the oldest unconditionally, later ones only if their encoder is done
+    // admit encoded steps in order.  While rows still have frames to decode only steps whose encoder has finished are
+    // admitted (the loop must not stall behind an encoder); when nothing is left the first one is admitted unconditionally:
+    // the decode stream then waits for that encoder on the GPU and resumes by itself
     bool admitted_any = false;
+    tr_mark(c, 10, c->stream);
     for (auto& q : c->pending) {
         if (q.admitted) continue;
-        if (&q != &P && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
+        const bool must = c->work_left == 0 && !admitted_any;
+        if (!must && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_enc[q.idx], 0));
         hipLaunchKernelGGL(k_advance, dim3(grid1(M)), dim3(256), 0, c->stream, c->c_avail, q.T_row_ptr, M);
         q.admitted = true;
@@ -653,16 +687,11 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     if (admitted_any)   // rows that were idle need their joint activation for the new frames
         hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
                            c->c_avail, c->ja, J, M, c->MTj, c->pe_ring_R, c->bf, 1, M, c->la);
-    if (!P.target_set) {
-        int* st = tgt_stage + (size_t)P.idx * M;
-        memcpy(st, P.target.data(), sizeof(int) * M);
-        HIPCHK(c, hipMemcpyAsync(c->c_target, st, sizeof(int) * M, hipMemcpyHostToDevice, c->stream));
-        P.target_set = true;
-    }
+    tr_mark(c, 11 + 100 * G + (admitted_any ? 1000 : 0), c->stream);
     __atomic_store_n(flag, -1, __ATOMIC_RELEASE);      // before the launch that will overwrite it
     c->dbg_gate = false;
     // the G iterations are launch-invariant (the flag-ring slot comes from a device counter, the last k_select
-    // publishes the "rows behind" word): replayed as one hipGraph per (G, ping-pong parities)
+    // publishes the cursors and the "rows with frames left" word): replayed as one hipGraph per (G, ping-pong parities)
     auto enqueue = [&]() {
         for (int q = 0; q < G; ++q) {
             s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
@@ -696,20 +725,52 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     } else {
         enqueue();
     }
+    tr_mark(c, 12, c->stream);
+    c->tr_last_G = G;
     c->cont_iters += G;
     c->group_inflight = true;
-    c->inflight_for = P.serial;
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
 }
 
-// non-blocking: if the in-flight group has finished, consume its flag
+// non-blocking: if the in-flight group has finished, consume its flag and snapshot the rows' frame cursors
+// (nothing writes them again until the next group is launched)
 static void cont_poll(lasr_ctx* c) {
     if (!c->group_inflight) return;
     const int v = __atomic_load_n((volatile int*)c->cont_host, __ATOMIC_ACQUIRE);
     if (v == -1) return;
     c->group_inflight = false;
-    if (v == 0) c->done_serial = c->inflight_for;
+    c->work_left = v;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    memcpy(c->h_cur_seen.data(), c->cont_host + 16, sizeof(int) * c->M);
+    if (c->tr_on) {     // iterations this group needed = most decisions (frames + tokens) any row made in it; rows that moved
+        const int* nt = c->cont_host + 16 + c->M;
+        int need = 0, rows = 0;
+        for (int r = 0; r < c->M; ++r) {
+            const int dlt = (c->h_cur_seen[r] - c->tr_prev_cur[r]) + (nt[r] - c->tr_prev_ntot[r]);
+            need = std::max(need, dlt);
+            rows += dlt > 0;
+            c->tr_prev_cur[r] = c->h_cur_seen[r]; c->tr_prev_ntot[r] = nt[r];
+        }
+        tr_note(c, 20, need * 1000.0 + c->tr_last_G * 100.0 + v + rows / 1000.0);
+    }
+}
+
+// non-blocking: launch the next group of G iterations if none is in flight and frames are waiting (or the encoder
+// of a submitted step is still to be admitted)
+static int cont_pump(lasr_ctx* c, int G) {
+    cont_poll(c);
+    if (c->group_inflight || c->pending.empty()) return LASR_OK;
+    bool unadmitted = false;
+    for (const auto& q : c->pending) unadmitted |= !q.admitted;
+    if (c->work_left == 0 && !unadmitted) return LASR_OK;        // everything encoded so far is decoded
+    return cont_launch_group(c, G);
+}
+
+static bool cont_step_done(const lasr_ctx* c, const lasr_ctx::PendingStep& P) {
+    for (int r : P.rows)
+        if (c->h_cur_seen[r] < P.target[r]) return false;
+    return true;
 }
 
 int lasr_step_wait(lasr_ctx* c, int* n_ran) {
@@ -721,18 +782,15 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran) {
     int* flag = c->cont_host;
     int* h_end = c->cont_host + 16 + (size_t)lasr_ctx::NFLY * M;
     int* h_ring = h_end + (size_t)M * lasr_ctx::ENDSLOTS;
-    const long long it0 = c->cont_iters - (c->group_inflight ? c->kick_iters : 0);
-    const long long serial = c->pending.front().serial;
-    for (int guard = 0; c->done_serial != serial; ++guard) {
+    for (int guard = 0;; ++guard) {
+        cont_poll(c);
+        if (cont_step_done(c, c->pending.front())) break;
         if (!c->group_inflight) RC(cont_launch_group(c, c->wait_n));
         RC(spin_flag(c, flag, c->stream_dec));
-        c->group_inflight = false;
-        // a group launched while an older step was the target says nothing about this one
-        if (c->inflight_for == serial && *flag == 0) c->done_serial = serial;
         if (guard > 4096) return fail(c, LASR_EHIP, "decode loop did not converge");
     }
     // results of the oldest step: tokens between the previous and this step boundary of every row, already
-    // in pinned memory (written by the kernels of the groups that completed before the flag said 0)
+    // in pinned memory (written by the kernels of the groups that completed before the cursors were published)
     lasr_ctx::PendingStep& P = c->pending.front();
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     for (int r : P.rows) {
@@ -743,10 +801,12 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran) {
         c->h_fetched[r] = end;
     }
     c->stats.frames = P.Tm;
-    c->stats.decode_iters = (int)(c->cont_iters - it0);
+    c->stats.decode_iters = (int)(c->cont_iters - c->iters_reported);
+    c->iters_reported = c->cont_iters;
     if (n_ran) *n_ran = (int)P.rows.size();
     c->pending.erase(c->pending.begin());
     c->cmd_inflight = 0;
+    RC(cont_pump(c, c->wait_n));
     return LASR_OK;
 }
 
@@ -1233,6 +1293,43 @@ int lasr_cell_prof_read(lasr_ctx* c, double* us_total, long long* launches) {
     HIPCHK(c, hipSetDevice(c->device));
     cell_prof_harvest(c, true);
     *us_total = c->cp_us; *launches = c->cp_launches;
+    return LASR_OK;
+}
+
+// Stream timeline of the pipelined protocol: while on, timestamped marks (HIP events) are recorded on the main stream
+// (1 push, 3 first cell, 4 last cell done, 5 model step enqueued) and on the decode stream (10 group reached,
+// 11 + 100 G [+ 1000 if steps were admitted] admission done, 12 group done).  lasr_trace_read synchronises and
+// returns the marks in record order with their time in microseconds since lasr_trace(on).
+int lasr_trace(lasr_ctx* c, int on) {
+    if (!c) return LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (on && c->tr_ev.empty()) {
+        c->tr_ev.resize(lasr_ctx::NTRACE); c->tr_tag.assign(lasr_ctx::NTRACE, 0); c->tr_val.assign(lasr_ctx::NTRACE, 0.0);
+        for (auto& e : c->tr_ev) HIPCHK(c, hipEventCreate(&e));
+        HIPCHK(c, hipEventCreate(&c->tr_base));
+    }
+    if (on) {
+        c->tr_n = 0;
+        HIPCHK(c, hipEventRecord(c->tr_base, c->stream));
+        c->tr_prev_cur = c->h_cur_seen;
+        c->tr_prev_ntot.assign(c->M, 0);        // the first group after the switch reports a bogus token delta
+    }
+    c->tr_on = on != 0;
+    return LASR_OK;
+}
+int lasr_trace_read(lasr_ctx* c, double* us, int* tags, int cap, int* n) {
+    if (!c || !us || !tags || !n) return LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    *n = 0;
+    for (int i = 0; i < c->tr_n && i < cap; ++i) {
+        float ms = 0.f;
+        tags[i] = c->tr_tag[i];
+        if (tags[i] == 20) { us[i] = c->tr_val[i]; *n = i + 1; continue; }      // value record
+        if (hipEventElapsedTime(&ms, c->tr_base, c->tr_ev[i]) != hipSuccess) { (void)hipGetLastError(); ms = -1.f; }
+        us[i] = 1e3 * (double)ms;
+        *n = i + 1;
+    }
     return LASR_OK;
 }
 

@@ -93,6 +93,7 @@ struct GemmArgs {
     const int* parent;      // beam search (AROW, W > 1): phase-1 rows are read from the row's parent hypothesis
     int beam_w;             //   slot: row r -> (r / W) * W + parent[r]; nullptr / 0: identity (greedy)
     unsigned long long* dbg; // optional per-workgroup phase timestamps [blocks][16] (LASR_DBG_TIMING)
+    int prio;                // wave priority for the whole kernel (s_setprio 0..3); experiments: LASR_DEC_PRIO / LASR_CELL_PRIO
 };
 
 // beam search: physical row of the parent hypothesis of row r (W slots per stream, contiguous)
@@ -262,6 +263,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(w);       // the same value, as an SGPR: control flow only
     const int jb = blockIdx.x, mg = blockIdx.y;
+    if (g.prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (g.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (g.prio == 1) __builtin_amdgcn_s_setprio(1);
     unsigned long long* dbg = g.dbg ? g.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
     if (dbg && tid == 0) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[5] = wall_clock64(); }
 

@@ -168,7 +168,9 @@ struct DecState {
     //   t_idx = global frame cursor, T_row = frames available, step_ntok = tokens emitted so far,
     //   step_tok = token ring of tok_cap entries per row
     int cont;
-    const int* target; // [M] frame count the oldest pending step needs from row r (0: not part of it)
+    int* host_cur;     // [M] pinned host memory: the row's frame cursor, stored by the last iteration of a group (the host
+                       //     derives "step j of row r is decoded" for EVERY step in flight from it: no per-step target upload)
+    int* host_ntot;    // [M] pinned (diagnostics, may be nullptr): tokens emitted so far, stored with host_cur
     int* ntok_end;     // [M][end_slots] tokens emitted when row r finished its step j (slot j % end_slots)
     int step_T;        // frames per model step (n_buffer)
     int end_slots;
@@ -254,7 +256,14 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     if (!PLAIN) {
         t = s.t_idx[r]; Tr = T_row[r];
         if (t >= Tr) {
-            if (tid == 0) { s.emit[r] = 0; publish(); }
+            if (tid == 0) {
+                s.emit[r] = 0;
+                if (s.cont && s.host_flag) {                      // progress made in earlier iterations of this group
+                    s.host_cur[r] = t;
+                    if (s.host_ntot) s.host_ntot[r] = s.step_ntok[r];
+                }
+                publish();
+            }
             return;
         }
         if (tid == 0) {
@@ -409,7 +418,11 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     s.step_ntok[r] = n0;
     s.t_idx[r] = t;
     s.iters[r] = it0;
-    if (s.cont ? (t < s.target[r]) : (t < Tr)) atomicAdd(&s.unfinished[iter_slot], 1);
+    if (s.cont && s.host_flag) {
+        s.host_cur[r] = t;
+        if (s.host_ntot) s.host_ntot[r] = n0;
+    }
+    if (t < Tr) atomicAdd(&s.unfinished[iter_slot], 1);     // continuous mode: rows that still have encoded frames to decode
     publish();
 }
 
@@ -780,6 +793,14 @@ struct MelArgs {
     const int* row_frames;
     int win_off, win_len;    // non-zero span of the window inside the n_fft frame
     int fb_nnz;              // total non-zero filter weights (<= 1536: staged in LDS)
+    // streaming, <= 512 rows: the step's per-row command travels BY VALUE with this launch instead of through a
+    // host->device copy of a command block (a copy costs 4-6 us plus a bubble on either side, twice per model step):
+    // sel_v replaces row_sel, and workgroup (0, row) stores the row's frame count of this model step where the
+    // kernels behind this one on the stream (stack + LayerNorm, the cells, the joint GEMM) read it
+    int by_value;
+    int* trow_out;           // [M] (nullptr: this chunk does not run the model)
+    short sel_v[512];
+    unsigned char trow_v[512];
 };
 
 __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
@@ -814,7 +835,8 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     const float* src = a.pcm;
     int head = 0;
     if (a.stream) {
-        const int sel = a.row_sel[row];
+        if (a.by_value && a.trow_out && blockIdx.x == 0 && threadIdx.x == 0) a.trow_out[row] = a.trow_v[row];
+        const int sel = a.by_value ? (int)a.sel_v[row] : a.row_sel[row];
         if (sel < 0) return;                             // uniform over the workgroup (row = blockIdx.y)
         out_frame = sel + fidx;
         t = a.frame0 + fidx;

@@ -7,11 +7,26 @@ namespace {
 
 // ---------------------------------------------------------------------------- launch helpers
 template <class Ops, class Epi, int MT, bool AROW, int D = 3, int NWV = NW>
-void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g, const typename Epi::Args& ea) {
+void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g0, const typename Epi::Args& ea) {
+    GemmArgs g = g0;
+    g.prio = (c->stream == c->stream_dec && c->stream_dec) ? c->dec_prio : c->cell_prio;
     hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NWV, AROW, D>), dim3(n_groups, m_groups), dim3(NWV * 64), 0, c->stream, g, ea);
 }
 
 int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
+
+// lasr_trace: a value record (no event): lasr_trace_read returns `val` in the time field
+void tr_note(lasr_ctx* c, int tag, double val) {
+    if (!c->tr_on || c->tr_n >= lasr_ctx::NTRACE) return;
+    c->tr_val[c->tr_n] = val;
+    c->tr_tag[c->tr_n++] = tag;
+}
+// lasr_trace: one timestamped mark on stream `st` (no-op unless tracing)
+void tr_mark(lasr_ctx* c, int tag, hipStream_t st) {
+    if (!c->tr_on || c->tr_n >= lasr_ctx::NTRACE) return;
+    (void)hipEventRecord(c->tr_ev[c->tr_n], st);
+    c->tr_tag[c->tr_n++] = tag;
+}
 
 // encoder LSTM cell (layer l, step t): x from `xsrc` (fragment-major, K = I); tiling "C"
 template <class Ops>
@@ -172,6 +187,17 @@ void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, c
     else launch_gemm<OpsF32, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
 }
 
+// vocabulary projection of the joint for n_rows rows of ja.  m-tiles per workgroup (c->logits_mt): 1 = a 16-row x
+// 16-column tile per workgroup (every m-tile re-reads the workgroup's 64 KB of W2 from L2); 2 / 4 = 32 / 64 rows per
+// workgroup, W2 fragments fetched once per 2 / 4 m-tiles -- what a lookahead pass (la x M rows) wants
+template <int MTL>
+void launch_logits_t(lasr_ctx* c, const GemmArgs& g0, int n_rows, int K, const EpiLinear::Args& ea) {
+    GemmArgs g = g0;
+    g.KC[0] = K / c->kch;
+    const int ng = c->d.vocab / 16, mg = (n_rows + 16 * MTL - 1) / (16 * MTL);
+    if (c->bf) launch_gemm<OpsBF16, EpiLinear, MTL, false, -1>(c, ng, mg, g, ea);
+    else launch_gemm<OpsF32, EpiLinear, MTL, false, -1>(c, ng, mg, g, ea);
+}
 void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     const int J = c->d.joint, V = c->d.vocab;
     GemmArgs g{};
@@ -180,6 +206,8 @@ void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
     ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M; ea.W = c->W;
+    if (c->logits_mt == 2 && !(c->dec_nw_mask & 4)) { launch_logits_t<2>(c, g, n_rows, J, ea); return; }
+    if (c->logits_mt == 4 && !(c->dec_nw_mask & 4)) { launch_logits_t<4>(c, g, n_rows, J, ea); return; }
     launch_linear<false, -1>(c, V / 16, (n_rows + 15) / 16, g, J, ea);
 }
 
@@ -217,11 +245,13 @@ int cmd_commit(lasr_ctx* c) {
 
 // device copy of the step's T_row (from the committed command block) + host-side per-step masks of
 // the m-tiles that contain an active row (passed by value to the encoder cell kernels)
-int commit_T_rows(lasr_ctx* c, int T_max) {
+int commit_T_rows(lasr_ctx* c, int T_max, bool fixed_copy = true) {
     c->T_row_dev = c->dc.T_row;             // the command ring (NCMD blocks) outlives every step in flight
     // decode kernels of the synchronous protocols read a FIXED buffer (cached graphs replay baked-in pointers)
-    HIPCHK(c, hipMemcpyAsync(c->T_row_fix, c->T_row_dev, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
-    c->T_row_dec = c->T_row_fix;
+    if (fixed_copy) {
+        HIPCHK(c, hipMemcpyAsync(c->T_row_fix, c->T_row_dev, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
+        c->T_row_dec = c->T_row_fix;
+    }
     c->tile_masks.assign(std::max(T_max, 1), 0ull);
     for (int t = 0; t < T_max; ++t) {
         unsigned long long m = 0;

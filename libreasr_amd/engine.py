@@ -284,6 +284,18 @@ class Engine:
         """In-job HIP-event timing of the encoder-cell launches (see lasr_cell_prof)."""
         self._chk(self.lib.lasr_cell_prof(self.ctx, 1 if on else 0))
 
+    def trace(self, on=True):
+        """Timestamped marks on the main / decode streams of the pipelined protocol (see lasr_trace)."""
+        self._chk(self.lib.lasr_trace(self.ctx, 1 if on else 0))
+
+    def trace_read(self, cap=8192):
+        """-> [(tag, microseconds since trace(True)), ...] in record order."""
+        us = (C.c_double * cap)()
+        tags = (C.c_int * cap)()
+        n = C.c_int(0)
+        self._chk(self.lib.lasr_trace_read(self.ctx, us, tags, cap, C.byref(n)))
+        return [(int(tags[i]), float(us[i])) for i in range(n.value)]
+
     def cell_prof_read(self):
         """-> (microseconds, cell launches) accumulated since cell_prof(True)."""
         us, n = C.c_double(0.0), C.c_longlong(0)
