@@ -200,8 +200,8 @@ def main():
     ap.add_argument("--cpu-chunks", type=int, default=150)
     ap.add_argument("--beam", type=int, default=1,
                     help="beam width (1 = greedy, the headline config); > 1 runs the synchronous protocol")
-    ap.add_argument("--depth", type=int, default=6,
-                    help="pipelined mode: model steps in flight before the oldest is collected (1..7)")
+    ap.add_argument("--depth", type=int, default=12,
+                    help="pipelined mode: model steps in flight before the oldest is collected (1..15)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
     ap.add_argument("--trace", default=None, help="diagnostics: dump the two-stream mark timeline (lasr_trace) of the timed region to this file")

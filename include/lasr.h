@@ -123,9 +123,10 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran);
  * 0 if no model step was pending); rows that finish a step early continue with the frames of the later,
  * already encoded steps.  Issue submit(k+1) ... before wait(k): the encoders of the next chunks then
  * overlap the latency-bound decode loop.  Up to lasr_max_inflight() model steps may be submitted and not
- * yet collected: 7 with the reference front-end (n_buffer 2, max_iters_stream 10); fewer when n_buffer *
- * max_iters_stream is large (the limit keeps the per-row rings of encoder frames (32) and tokens (256) from
- * wrapping).  At the limit lasr_step_submit returns LASR_ESTATE and changes nothing (the pushed chunk stays
+ * yet collected: 15 with the reference front-end (n_buffer 2, max_iters_stream 10); fewer when n_buffer *
+ * max_iters_stream is large (the limit keeps the per-row rings of encoder frames (64) and tokens (512) from
+ * wrapping).  A deep pipeline is what absorbs bursty streams: a row that emits many tokens on a few frames falls
+ * behind while the others run ahead on the frames of later steps.  At the limit lasr_step_submit returns LASR_ESTATE and changes nothing (the pushed chunk stays
  * pushed: call lasr_step_wait, then submit again).
  * Every other state-changing call returns LASR_ESTATE while a submitted step is uncollected.
  * Results are identical to lasr_step_stream (same kernels, same order per stream).  Greedy only. */

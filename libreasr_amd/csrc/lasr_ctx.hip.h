@@ -34,8 +34,10 @@ struct lasr_ctx {
     int Md = 0, MTd = 0;       // decoder rows = M * W (row = stream * W + slot), m-tiles
     static constexpr int LA_MAX = 4;
     int la = 1;                // greedy lookahead: frames evaluated per row and iteration (1 with an LM or a beam)
-    int la_stream = 1, la_offline = 3;   // measured on configs[1]: streaming steps have 2 frames and the per-iteration
-                               // cost of a wider logits GEMM cancels the saved iterations; offline (258 frames) gains 10 %
+    int la_sync = 1;           // synchronous per-chunk protocol: 1 (groups are sized for one frame per iteration; 2 measured -4 %)
+    int la_stream = 2, la_offline = 3;   // measured on configs[1] (12 steps in flight, 32-row logits tiling): streaming 2 frames per
+                               // iteration f32 +2 %, bf16 +9 % (2.5 instead of 3.1 iterations per model step; 3 frames: -8 %);
+                               // offline (258 frames) 3 frames +10 %
     int MTj = 0;               // m-tiles of the ja / logits row space: max(Md, LA_MAX * M) / 16
     int bf = 0;                // 1: bf16 operands (weights + GEMM-input activations), f32 accumulate / state / logits
     int kch = 16;              // k per MFMA chunk (16 f32, 32 bf16)
@@ -55,8 +57,8 @@ struct lasr_ctx {
     std::vector<void*> enc_h[2], pred_h[2], pred_y;      // element-typed (A operands)
     std::vector<float*> enc_c, pred_c;
     int cell_nw = 0;                // waves per encoder-cell workgroup (0: 4 for f32, 8 for bf16); LASR_CELL_NW
-    int dec_prio = 0, cell_prio = 0;   // s_setprio of the decode-stream GEMMs / of everything else (experiments)
-    int logits_mt = 1;              // m-tiles per workgroup of the logits GEMM (1 | 2 | 4); LASR_LOGITS_MT
+    int dec_prio = 1, cell_prio = 0;   // s_setprio of the decode-stream GEMMs / of everything else (experiments)
+    int logits_mt = 2;              // m-tiles per workgroup of the logits GEMM (1 | 2 | 4); LASR_LOGITS_MT
     int dec_nw_mask = 0;            // LASR_DEC_NW4: bit 1 predictor cells, bit 2 PPJ, bit 4 linear (logits, pe) run with 4 waves
     // beam search: c, BN(h) and pp ping-pong like h (every slot may be re-parented each round):
     // parity 0 = pred_c / pred_y / pp, parity 1 = the *1 buffers; all follow pred_par
@@ -91,9 +93,9 @@ struct lasr_ctx {
     // the main stream while ONE greedy loop keeps running on stream_dec across chunk boundaries: a row
     // that finished chunk k moves on to chunk k+1's frames while a bursty row is still on chunk k.
     hipStream_t stream_dec = nullptr;
-    static constexpr int NFLY = 8;  // steps in flight (ring of events / T_row snapshots)
-    static constexpr int RING = 32; // pe ring, frames per row
-    static constexpr int TOKRING = 256, ENDSLOTS = 16;
+    static constexpr int NFLY = 16; // steps in flight (ring of encoder-done events)
+    static constexpr int RING = 64; // pe ring, frames per row
+    static constexpr int TOKRING = 512, ENDSLOTS = 32;
     hipEvent_t ev_enc[NFLY] = {};
     hipEvent_t ev_misc = nullptr;
     int* T_row_ring[NFLY] = {};
@@ -145,6 +147,15 @@ struct lasr_ctx {
     int tok_cap_alloc = 0;
 
     // front-end buffers
+    // fused streaming front-end (k_frontend): nothing is computed on a client chunk that does not complete a model
+    // step; the step's launch works through the row's last n_buffer windows, which the PCM ring (ring_chunks =
+    // n_window + n_buffer - 1 chunks) still holds.  pend_serial[s * n_buffer + j] = chunk count of slot s when its
+    // pending frame j was taken; pend_mat = that frame had to be computed early into `pend` (the client pushed more
+    // chunks without stepping, the ring was about to lose its window)
+    bool fe_fused = false;
+    int ring_chunks = 0;
+    std::vector<int> pend_serial;
+    std::vector<char> pend_mat;
     float* win = nullptr; int* ring_pos = nullptr;
     float* pend = nullptr;          // [M][n_buffer*n_stack][n_mels]
     float* stage_pcm = nullptr; size_t stage_pcm_floats = 0;

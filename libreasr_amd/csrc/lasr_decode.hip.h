@@ -104,7 +104,7 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
 int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows) {
     if (c->W > 1) return run_decode_beam(c, T_max, max_iters, offline, rows);
     const int M = c->M, J = c->d.joint, V = c->d.vocab;
-    c->la = offline ? c->la_offline : c->la_stream;
+    c->la = offline ? c->la_offline : c->la_sync;
     DecState s = c->ds;
     s.tok_cap = T_max * max_iters;
     const int total_cap = T_max * max_iters;

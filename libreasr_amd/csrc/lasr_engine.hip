@@ -102,8 +102,8 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     c->MTj = std::max(c->Md, lasr_ctx::LA_MAX * M) / 16;
     {   // frames evaluated per row and iteration in the greedy loop (see k_select); measured best on configs[1]
         const char* e = getenv("LASR_LOOKAHEAD");
-        if (e) c->la_stream = c->la_offline = std::min(lasr_ctx::LA_MAX, std::max(1, atoi(e)));
-        if (c->W > 1) c->la_stream = c->la_offline = 1;
+        if (e) c->la_stream = c->la_offline = c->la_sync = std::min(lasr_ctx::LA_MAX, std::max(1, atoi(e)));
+        if (c->W > 1) c->la_stream = c->la_offline = c->la_sync = 1;
         c->la = c->la_stream;
         if (getenv("LASR_KICK")) c->kick_n = std::max(1, atoi(getenv("LASR_KICK")));
         if (getenv("LASR_GROUP")) c->wait_n = std::max(1, atoi(getenv("LASR_GROUP")));
@@ -294,7 +294,11 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->ds.token, 0, sizeof(int) * Md)); HIPCHK(c, hipMemset(c->ds.emit, 0, sizeof(int) * Md));
     HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
-    RC(dalloc(c, &c->win, (size_t)M * d.n_window * d.chunk)); HIPCHK(c, hipMemset(c->win, 0, (size_t)M * d.n_window * d.chunk * 4));
+    // (the reference front-end: 10 frames of 128 mels per stacked frame; other shapes take the per-chunk kernels)
+    c->fe_fused = M <= 512 && d.n_buffer <= 4 && d.n_stack == 10 && d.n_mels <= 128 && d.feat == 1280 && !getenv("LASR_FE_LEGACY");
+    c->ring_chunks = c->fe_fused ? d.n_window + d.n_buffer - 1 : d.n_window;
+    c->pend_serial.assign((size_t)M * d.n_buffer, 0); c->pend_mat.assign((size_t)M * d.n_buffer, 0);
+    RC(dalloc(c, &c->win, (size_t)M * c->ring_chunks * d.chunk)); HIPCHK(c, hipMemset(c->win, 0, (size_t)M * c->ring_chunks * d.chunk * 4));
     RC(dalloc(c, &c->ring_pos, M)); HIPCHK(c, hipMemset(c->ring_pos, 0, sizeof(int) * M));
     RC(dalloc(c, &c->pend, (size_t)M * d.n_buffer * d.n_stack * d.n_mels));
     HIPCHK(c, hipMemset(c->pend, 0, (size_t)M * d.n_buffer * d.n_stack * d.n_mels * 4));
@@ -425,6 +429,52 @@ int lasr_stream_close(lasr_ctx* c, int slot) {
 // ---------------------------------------------------------------------------- streaming
 static int cont_pump(lasr_ctx* c, int G);
 
+static void fill_mel_args(lasr_ctx* c, MelArgs& m) {
+    const lasr_model_desc& d = c->d;
+    m.window = c->window; m.tw512 = c->tw512; m.tw1024 = c->tw1024; m.fb_start = c->fb_start; m.fb_off = c->fb_off;
+    m.fb_w = c->fb_w; m.n_mels = d.n_mels; m.hop = d.hop;
+    m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win; m.fb_nnz = c->fb_nnz;
+}
+// window geometry of the streaming front-end (api-server.py:95-102 + TransformTime + StreamPostprocess): first frame picked
+static int stream_frame0(lasr_ctx* c, int* nf_out) {
+    const lasr_model_desc& d = c->d;
+    const long long N = (long long)d.n_window * d.chunk;
+    const int T = 1 + (int)(N / d.hop);
+    const int a0 = T / 3 + 1;
+    if (nf_out) *nf_out = std::min(d.n_stack, T - a0);
+    return a0;
+}
+
+// Fused front-end, irregular clients: a slot that is about to be pushed again although it still has a pending frame whose
+// window the ring would lose (more than one chunk pushed per lasr_step_* call) gets that frame computed NOW into `pend`
+// (the per-chunk log-mel kernel, window selected by its age); the step's k_frontend launch then takes it from there.
+static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
+    const lasr_model_desc& d = c->d;
+    const int slack = c->ring_chunks - d.n_window;
+    for (int j = 0; j < d.n_buffer; ++j) {
+        MelArgs m{};
+        bool any = false;
+        for (int i = 0; i < n; ++i) {
+            const int s = slots[i];
+            if (j >= c->n_pend[s] || c->pend_mat[(size_t)s * d.n_buffer + j]) continue;
+            const int age = c->n_chunks[s] - c->pend_serial[(size_t)s * d.n_buffer + j];
+            if (age + 1 <= slack) continue;                      // still in the ring after this push
+            if (!any) { for (int r = 0; r < 512; ++r) m.sel_v[r] = -1; any = true; }
+            m.sel_v[s] = (short)(j * d.n_stack);
+            m.age_v[s] = (unsigned char)age;
+            c->pend_mat[(size_t)s * d.n_buffer + j] = 1;
+        }
+        if (!any) continue;
+        fill_mel_args(c, m);
+        m.pcm = c->win; m.N = (long long)d.n_window * d.chunk; m.stream = 1; m.ring_head = c->ring_pos; m.chunk = d.chunk;
+        m.n_window = d.n_window; m.ring_chunks = c->ring_chunks; m.frame0 = stream_frame0(c, nullptr);
+        m.frames_per_row = d.n_stack; m.out = c->pend; m.out_frames = d.n_buffer * d.n_stack;
+        m.by_value = 1; m.trow_out = nullptr;
+        hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), 0, c->stream, m);
+    }
+    return LASR_OK;
+}
+
 int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
     if (!c) return LASR_EINVAL;
     RC(check_slots(c, slots, n, true));
@@ -456,18 +506,19 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
         src = dst;
     }
     tr_mark(c, 1, c->stream);
+    if (c->fe_fused) RC(materialize_pending(c, slots, n));      // irregular clients only: see there
     if (c->M <= 512) {      // slot -> staging-row map by value: no command-block copy for a push
         PushIdx pi;
         for (int r = 0; r < 512; ++r) pi.idx[r] = -1;
         for (int i = 0; i < n; ++i) pi.idx[slots[i]] = (short)i;
-        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, (const int*)nullptr, pi, c->win, c->ring_pos, CH, c->d.n_window);
+        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, (const int*)nullptr, pi, c->win, c->ring_pos, CH, c->ring_chunks);
     } else {
         RC(cmd_begin(c));
         for (int r = 0; r < c->M; ++r) c->hc.src_idx[r] = -1;
         for (int i = 0; i < n; ++i) c->hc.src_idx[slots[i]] = i;
         RC(cmd_commit(c));
         PushIdx pi;
-        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, (const int*)c->dc.src_idx, pi, c->win, c->ring_pos, CH, c->d.n_window);
+        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, (const int*)c->dc.src_idx, pi, c->win, c->ring_pos, CH, c->ring_chunks);
     }
     for (int i = 0; i < n; ++i) c->n_chunks[slots[i]]++;
     if (from_host) {
@@ -483,13 +534,56 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
     const lasr_model_desc& d = c->d;
     // window geometry (api-server.py:95-102 + TransformTime + StreamPostprocess)
     const long long N = (long long)d.n_window * d.chunk;
-    const int T = 1 + (int)(N / d.hop);
-    const int a0 = T / 3 + 1;
-    const int nf = std::min(d.n_stack, T - a0);
+    int nf = 0;
+    const int a0 = stream_frame0(c, &nf);
     if (nf < d.n_stack) return fail(c, LASR_EINVAL, "chunk of %d samples is too short: window yields %d < n_stack frames", d.chunk, nf);
     if (N <= d.n_fft / 2) return fail(c, LASR_EINVAL, "window shorter than the reflect padding");
     RC(cmd_begin(c));
     model_rows.clear();
+    Tm = d.n_buffer;
+    if (c->fe_fused) {
+        // nothing runs on a chunk that does not complete a model step: the frame is only noted (chunk serial); the step's
+        // single launch works through the last n_buffer windows of every model row
+        for (int i = 0; i < n; ++i) {
+            const int s = slots[i];
+            if (c->n_chunks[s] < d.n_window) continue;          // window not full: the servicer does not call the pipeline
+            const size_t q = (size_t)s * d.n_buffer + c->n_pend[s];
+            c->pend_serial[q] = c->n_chunks[s]; c->pend_mat[q] = 0;
+            if (++c->n_pend[s] == d.n_buffer) {                  // Buffer.encodes: emit when n_buffer collected
+                c->n_pend[s] = 0;
+                c->hc.T_row[s] = d.n_buffer;
+                model_rows.push_back(s);
+            }
+        }
+        rec(c, 0);
+        if (model_rows.empty()) return LASR_OK;
+        RC(ensure_T(c, Tm));
+        FrontArgs f{};
+        f.window = c->window; f.tw512 = c->tw512; f.tw1024 = c->tw1024; f.fb_start = c->fb_start; f.fb_off = c->fb_off; f.fb_w = c->fb_w;
+        f.n_mels = d.n_mels; f.hop = d.hop; f.fb_nnz = c->fb_nnz; f.win_off = (d.n_fft - d.win) / 2; f.win_len = d.win;
+        f.pcm = c->win; f.ring_pos = c->ring_pos; f.chunk = d.chunk; f.n_window = d.n_window; f.ring_chunks = c->ring_chunks; f.frame0 = a0;
+        f.pend = c->pend; f.pend_frames = d.n_buffer * d.n_stack;
+        f.ln_w = c->ln_w; f.ln_b = c->ln_b; f.x0 = c->x0; f.F = d.feat; f.M = c->M; f.MT = c->MT; f.mt_total = c->Tcap * c->MT; f.bf = c->bf;
+        f.trow_out = c->dc.T_row;
+        for (int s : model_rows) {
+            f.trow_v[s] = (unsigned char)d.n_buffer;
+            for (int j = 0; j < d.n_buffer; ++j) {
+                const size_t q = (size_t)s * d.n_buffer + j;
+                const int age = c->n_chunks[s] - c->pend_serial[q];
+                if (!c->pend_mat[q] && age > c->ring_chunks - d.n_window)
+                    return fail(c, LASR_ESTATE, "slot %d: the PCM ring no longer holds the window of pending frame %d", s, j);
+                f.age_v[j][s] = c->pend_mat[q] ? 255 : (unsigned char)age;
+            }
+        }
+        const dim3 grid(d.n_buffer, c->M);
+        hipLaunchKernelGGL((k_frontend<10, 20>), grid, dim3(640), 0, c->stream, f);
+        // (after the launch that stores T_row: the synchronous protocol copies it to a fixed buffer on the stream)
+        RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring));    // the continuous loop reads its own frame counters
+        rec(c, 1);
+        run_encoder(c, Tm);
+        rec(c, 2);
+        return LASR_OK;
+    }
     bool any_feat = false;
     for (int r = 0; r < c->M; ++r) c->hc.feat_sel[r] = -1;
     for (int i = 0; i < n; ++i) {
@@ -510,12 +604,11 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
     rec(c, 0);
     if (any_feat) {
         MelArgs m{};
-        m.window = c->window; m.tw512 = c->tw512; m.tw1024 = c->tw1024; m.fb_start = c->fb_start; m.fb_off = c->fb_off;
-        m.fb_w = c->fb_w; m.n_mels = d.n_mels; m.hop = d.hop; m.pcm = c->win; m.N = N; m.stream = 1;
-        m.ring_head = c->ring_pos; m.chunk = d.chunk; m.n_window = d.n_window; m.row_sel = c->dc.feat_sel; m.frame0 = a0;
+        fill_mel_args(c, m);
+        m.pcm = c->win; m.N = N; m.stream = 1;
+        m.ring_head = c->ring_pos; m.chunk = d.chunk; m.n_window = d.n_window; m.ring_chunks = c->ring_chunks; m.row_sel = c->dc.feat_sel; m.frame0 = a0;
         m.frames_per_row = d.n_stack; m.out = c->pend; m.out_frames = d.n_buffer * d.n_stack;
         m.row_N = nullptr; m.row_src_off = nullptr; m.row_frames = nullptr;
-        m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win; m.fb_nnz = c->fb_nnz;
         if (by_value) {
             m.by_value = 1;
             m.trow_out = model_rows.empty() ? nullptr : c->dc.T_row;
@@ -523,7 +616,6 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
         }
         hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), 0, c->stream, m);
     }
-    Tm = d.n_buffer;
     if (model_rows.empty()) return LASR_OK;
     RC(ensure_T(c, Tm));
     RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring));    // the continuous loop reads its own frame counters

@@ -801,83 +801,33 @@ struct MelArgs {
     int* trow_out;           // [M] (nullptr: this chunk does not run the model)
     short sel_v[512];
     unsigned char trow_v[512];
+    // stream: the PCM ring holds ring_chunks >= n_window chunks per row; the window of a frame ends `age` chunks
+    // before the newest one (by_value: age_v[row], else 0)
+    int ring_chunks;
+    unsigned char age_v[512];
 };
 
-__global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
-    __shared__ float2 sz[4][512 + 8];
-    __shared__ float sp[4][520];
-    __shared__ float s_fbw[1536];
-    __shared__ int s_fbs[128], s_fbo[129];
-    __shared__ float2 s_tw512[512], s_tw1024[513];
-    const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
-    // twiddles + filterbank -> LDS once per workgroup (coalesced, all in flight together): the FFT
-    // passes and the mel loop then have no global loads (each was a dependent ~1 us L2 round trip)
-    for (int q = threadIdx.x; q < 512; q += 256) s_tw512[q] = a.tw512[q];
-    for (int q = threadIdx.x; q <= 512; q += 256) s_tw1024[q] = a.tw1024[q];
-    for (int q = threadIdx.x; q < a.fb_nnz; q += 256) s_fbw[q] = a.fb_w[q];
-    for (int q = threadIdx.x; q < a.n_mels; q += 256) s_fbs[q] = a.fb_start[q];
-    for (int q = threadIdx.x; q <= a.n_mels; q += 256) s_fbo[q] = a.fb_off[q];
-    int fidx = blockIdx.x * 4 + w;                       // frame within the row
-    const int row = blockIdx.y;
-    // a wave without a frame recomputes the last valid one and skips the store: every wave of
-    // the workgroup must reach every __syncthreads()
-    int n_frames = a.frames_per_row;
-    long long N = a.N;
-    if (a.row_frames) {
-        n_frames = a.row_frames[row];
-        if (n_frames <= 0) return;                       // uniform over the workgroup
-        N = a.row_N[row];
-    }
-    const bool valid = fidx < n_frames;
-    if (!valid) fidx = n_frames - 1;
-    int out_frame = fidx;
-    int t = fidx;
-    const float* src = a.pcm;
-    int head = 0;
-    if (a.stream) {
-        if (a.by_value && a.trow_out && blockIdx.x == 0 && threadIdx.x == 0) a.trow_out[row] = a.trow_v[row];
-        const int sel = a.by_value ? (int)a.sel_v[row] : a.row_sel[row];
-        if (sel < 0) return;                             // uniform over the workgroup (row = blockIdx.y)
-        out_frame = sel + fidx;
-        t = a.frame0 + fidx;
-        head = a.ring_head[row];
-        src = a.pcm + (size_t)row * a.n_window * a.chunk;
-    } else if (a.row_frames) {
-        src = a.pcm + a.row_src_off[row];
-    } else {
-        src = a.pcm + (size_t)row * a.N;
-    }
-    const long long base = (long long)t * a.hop - 512;
-    auto sample = [&](int n) -> float {                  // windowed sample n of the 1024-frame
-        // the window is zero outside [win_off, win_off + win_len): decided from the index, so the
-        // window and the PCM loads are independent (no load -> branch -> load chain)
-        if (n < a.win_off || n >= a.win_off + a.win_len) return 0.f;
-        const float wv = a.window[n];
-        long long q = base + n;
-        if (q < 0) q = -q;                               // reflect (torch.stft center=True, pad_mode="reflect")
-        if (q >= N) q = 2 * (N - 1) - q;
-        float x;
-        if (a.stream) {
-            const int qi = (int)q;                       // < n_window * chunk
-            const int ck = qi / a.chunk, wi = qi - ck * a.chunk;
-            int slot = head + ck;
-            if (slot >= a.n_window) slot -= a.n_window;
-            x = src[(size_t)slot * a.chunk + wi];
-        } else {
-            x = src[q];
-        }
-        return x * wv;
-    };
-    // ---- pass 1: z[n] = x[2n] + i x[2n+1]; thread j takes n = j + 64 m
-    cf v[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int n = j + 64 * m;
-        v[m] = cf{sample(2 * n), sample(2 * n + 1)};
-    }
+// staging of the FFT twiddles and the sparse filterbank into LDS (every thread of the block takes part)
+struct MelTables {
+    float* fbw; int* fbs; int* fbo; float2* tw512; float2* tw1024;
+};
+__device__ __forceinline__ void stage_mel_tables(const MelTables& t, const float2* tw512, const float2* tw1024, const float* fb_w,
+                                                 const int* fb_start, const int* fb_off, int fb_nnz, int n_mels) {
+    const int nt = blockDim.x;
+    for (int q = threadIdx.x; q < 512; q += nt) t.tw512[q] = tw512[q];
+    for (int q = threadIdx.x; q <= 512; q += nt) t.tw1024[q] = tw1024[q];
+    for (int q = threadIdx.x; q < fb_nnz; q += nt) t.fbw[q] = fb_w[q];
+    for (int q = threadIdx.x; q < n_mels; q += nt) t.fbs[q] = fb_start[q];
+    for (int q = threadIdx.x; q <= n_mels; q += nt) t.fbo[q] = fb_off[q];
+}
+
+// 1024-point real FFT of one frame as a 512-point complex FFT (radix 8 x 8 x 8 in registers, LDS transposes in the wave's
+// scratch z[512 + 8]) + untangle + power spectrum P[0..512].  v[m] = (x[2n], x[2n+1]) for n = j + 64 m on entry.
+// Contains block-wide barriers: EVERY wave of the workgroup must call it (the first barrier also publishes the
+// staged tables).
+__device__ __forceinline__ void fft1024_power(cf (&v)[8], float2* z, float* P, const float2* s_tw512, const float2* s_tw1024, int j) {
     dft8(v);
     __syncthreads();                                     // staged twiddles / filterbank visible
-    float2* z = sz[w];
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
         const float2 tw = s_tw512[j * k0];
@@ -918,7 +868,6 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     }
     __syncthreads();
     // ---- real-FFT untangle + power: X[k] = (Z[k] + conj Z[512-k])/2 + W1024^k (Z[k] - conj Z[512-k])/(2i)
-    float* P = sp[w];
     for (int k = j; k <= 512; k += 64) {
         const float2 zk = z[k & 511];
         const float2 zn = z[(512 - k) & 511];
@@ -930,14 +879,193 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
         P[k] = X.x * X.x + X.y * X.y;
     }
     __syncthreads();
+}
+// sparse HTK mel of the power spectrum + log(x + 1e-6): lane j takes filters j, j + 64, ..
+__device__ __forceinline__ void mel_log(const float* P, const MelTables& t, int n_mels, int j, float* out) {
+    for (int m = j; m < n_mels; m += 64) {
+        const int s0 = t.fbs[m], o0 = t.fbo[m], cnt = t.fbo[m + 1] - o0;
+        float acc = 0.f;
+        for (int q = 0; q < cnt; ++q) acc += P[s0 + q] * t.fbw[o0 + q];
+        out[m] = logf(acc + 1e-6f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
+    __shared__ float2 sz[4][512 + 8];
+    __shared__ float sp[4][520];
+    __shared__ float s_fbw[1536];
+    __shared__ int s_fbs[128], s_fbo[129];
+    __shared__ float2 s_tw512[512], s_tw1024[513];
+    const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
+    // twiddles + filterbank -> LDS once per workgroup (coalesced, all in flight together): the FFT
+    // passes and the mel loop then have no global loads (each was a dependent ~1 us L2 round trip)
+    const MelTables tab{s_fbw, s_fbs, s_fbo, s_tw512, s_tw1024};
+    stage_mel_tables(tab, a.tw512, a.tw1024, a.fb_w, a.fb_start, a.fb_off, a.fb_nnz, a.n_mels);
+    int fidx = blockIdx.x * 4 + w;                       // frame within the row
+    const int row = blockIdx.y;
+    // a wave without a frame recomputes the last valid one and skips the store: every wave of
+    // the workgroup must reach every __syncthreads()
+    int n_frames = a.frames_per_row;
+    long long N = a.N;
+    if (a.row_frames) {
+        n_frames = a.row_frames[row];
+        if (n_frames <= 0) return;                       // uniform over the workgroup
+        N = a.row_N[row];
+    }
+    const bool valid = fidx < n_frames;
+    if (!valid) fidx = n_frames - 1;
+    int out_frame = fidx;
+    int t = fidx;
+    const float* src = a.pcm;
+    int head = 0;
+    const int NR = a.ring_chunks > 0 ? a.ring_chunks : a.n_window;
+    if (a.stream) {
+        if (a.by_value && a.trow_out && blockIdx.x == 0 && threadIdx.x == 0) a.trow_out[row] = a.trow_v[row];
+        const int sel = a.by_value ? (int)a.sel_v[row] : a.row_sel[row];
+        if (sel < 0) return;                             // uniform over the workgroup (row = blockIdx.y)
+        out_frame = sel + fidx;
+        t = a.frame0 + fidx;
+        // ring_head = next write slot = oldest chunk; the window ends `age` chunks before the newest
+        head = (a.ring_head[row] - (a.by_value ? (int)a.age_v[row] : 0) - a.n_window + 2 * NR) % NR;
+        src = a.pcm + (size_t)row * NR * a.chunk;
+    } else if (a.row_frames) {
+        src = a.pcm + a.row_src_off[row];
+    } else {
+        src = a.pcm + (size_t)row * a.N;
+    }
+    const long long base = (long long)t * a.hop - 512;
+    auto sample = [&](int n) -> float {                  // windowed sample n of the 1024-frame
+        // the window is zero outside [win_off, win_off + win_len): decided from the index, so the
+        // window and the PCM loads are independent (no load -> branch -> load chain)
+        if (n < a.win_off || n >= a.win_off + a.win_len) return 0.f;
+        const float wv = a.window[n];
+        long long q = base + n;
+        if (q < 0) q = -q;                               // reflect (torch.stft center=True, pad_mode="reflect")
+        if (q >= N) q = 2 * (N - 1) - q;
+        float x;
+        if (a.stream) {
+            const int qi = (int)q;                       // < n_window * chunk
+            const int ck = qi / a.chunk, wi = qi - ck * a.chunk;
+            int slot = head + ck;
+            if (slot >= NR) slot -= NR;
+            x = src[(size_t)slot * a.chunk + wi];
+        } else {
+            x = src[q];
+        }
+        return x * wv;
+    };
+    // ---- pass 1: z[n] = x[2n] + i x[2n+1]; thread j takes n = j + 64 m
+    cf v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int n = j + 64 * m;
+        v[m] = cf{sample(2 * n), sample(2 * n + 1)};
+    }
+    fft1024_power(v, sz[w], sp[w], s_tw512, s_tw1024, j);
     // ---- sparse HTK mel + log
     if (!valid) return;
-    float* out = a.out + ((size_t)row * a.out_frames + out_frame) * a.n_mels;
-    for (int m = j; m < a.n_mels; m += 64) {
-        const int s0 = s_fbs[m], o0 = s_fbo[m], cnt = s_fbo[m + 1] - o0;
-        float acc = 0.f;
-        for (int q = 0; q < cnt; ++q) acc += P[s0 + q] * s_fbw[o0 + q];
-        out[m] = logf(acc + 1e-6f);
+    mel_log(sp[w], tab, a.n_mels, j, a.out + ((size_t)row * a.out_frames + out_frame) * a.n_mels);
+}
+
+// Streaming front-end of one model step in ONE launch (<= 512 rows, n_buffer <= 4): for every row that runs the model,
+// the n_buffer x n_stack log-mel frames of its last n_buffer client chunks (StreamPostprocess picks n_stack frames of the
+// 3-chunk window that was current when that chunk arrived: the PCM ring keeps n_window + n_buffer - 1 chunks, so the
+// older windows are still there), StackDownsample and LayerNorm -> fragment-major x0.  Workgroup (t', row) = one stacked
+// frame, one wave per log-mel frame.  Replaces log-mel (per client chunk) + stack/LayerNorm (per model step) = 3 launches
+// and the command-block copies: the per-row command (frames of this step, window ages) is passed by value.
+struct FrontArgs {
+    const float* window; const float2* tw512; const float2* tw1024;
+    const int* fb_start; const int* fb_off; const float* fb_w;
+    int n_mels, hop, fb_nnz, win_off, win_len;
+    const float* pcm;        // [M][ring_chunks][chunk]
+    const int* ring_pos;     // [M] next write slot
+    int chunk, n_window, ring_chunks, frame0;
+    const float* pend;       // [M][n_buffer * n_stack][n_mels]: frames that had to be computed early (age 255)
+    int pend_frames;
+    const float* ln_w; const float* ln_b;
+    void* x0;
+    int F, M, MT, mt_total, bf;
+    int* trow_out;           // [M]: the row's frame count of this step, for the kernels behind this one
+    unsigned char trow_v[512];
+    unsigned char age_v[4][512];   // [t'][row]: chunks pushed since the window of stacked frame t' was current; 255: in pend
+};
+template <int NSTACK, int VPL>
+__global__ __launch_bounds__(64 * NSTACK) void k_frontend(const FrontArgs a) {
+    __shared__ float2 sz[NSTACK][512 + 8];
+    __shared__ float sp[NSTACK][520];
+    __shared__ float smel[NSTACK][128];
+    __shared__ float s_fbw[1536];
+    __shared__ int s_fbs[128], s_fbo[129];
+    __shared__ float2 s_tw512[512], s_tw1024[513];
+    const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
+    const int tp = blockIdx.x, row = blockIdx.y;
+    const int Tr = a.trow_v[row];
+    if (tp == 0 && threadIdx.x == 0) a.trow_out[row] = Tr;
+    if (tp >= Tr) return;                                // uniform over the workgroup
+    const MelTables tab{s_fbw, s_fbs, s_fbo, s_tw512, s_tw1024};
+    stage_mel_tables(tab, a.tw512, a.tw1024, a.fb_w, a.fb_start, a.fb_off, a.fb_nnz, a.n_mels);
+    const int age = a.age_v[tp][row];
+    if (age == 255) {                                    // uniform: this stacked frame's log-mel frames are in pend
+        const float* src = a.pend + ((size_t)row * a.pend_frames + (size_t)tp * NSTACK + w) * a.n_mels;
+        for (int m = j; m < a.n_mels; m += 64) smel[w][m] = src[m];
+        __syncthreads();
+    } else {
+        const int NR = a.ring_chunks;
+        const int head = (a.ring_pos[row] - age - a.n_window + 2 * NR) % NR;
+        const float* src = a.pcm + (size_t)row * NR * a.chunk;
+        const int N = a.n_window * a.chunk;
+        const int base = (a.frame0 + w) * a.hop - 512;
+        auto sample = [&](int n) -> float {
+            if (n < a.win_off || n >= a.win_off + a.win_len) return 0.f;
+            const float wv = a.window[n];
+            int q = base + n;
+            if (q < 0) q = -q;                           // reflect (torch.stft center=True, pad_mode="reflect")
+            if (q >= N) q = 2 * (N - 1) - q;
+            const int ck = q / a.chunk, wi = q - ck * a.chunk;
+            int slot = head + ck;
+            if (slot >= NR) slot -= NR;
+            return src[(size_t)slot * a.chunk + wi] * wv;
+        };
+        cf v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int n = j + 64 * m;
+            v[m] = cf{sample(2 * n), sample(2 * n + 1)};
+        }
+        fft1024_power(v, sz[w], sp[w], s_tw512, s_tw1024, j);
+        mel_log(sp[w], tab, a.n_mels, j, smel[w]);
+        __syncthreads();
+    }
+    // StackDownsample (feat[m * n_stack + k] = mel[k][m]) + LayerNorm by wave 0, in the arithmetic order of k_stack_ln
+    if (w != 0) return;
+    float x[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+        const int f = j + 64 * q;
+        const int m = f / NSTACK, k = f - m * NSTACK;
+        const float val = f < a.F ? smel[k][m] : 0.f;
+        x[q] = val;
+        sum += val;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mu = sum / (float)a.F;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+        const float d = (j + 64 * q < a.F) ? x[q] - mu : 0.f;
+        var += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)a.F + 1e-5f);
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+        const int f = j + 64 * q;
+        if (f >= a.F) continue;
+        const float y = (x[q] - mu) * rstd * a.ln_w[f] + a.ln_b[f];
+        act_st(a.bf, a.x0, act_off(a.bf, tp * a.MT * 16 + row, f, a.mt_total), y);
     }
 }
 

@@ -73,9 +73,9 @@ def test_inflight_limit_is_what_the_header_says():
     from libreasr_amd._native import LASR_ESTATE, LasrError
     eng, sd, cfg = make("tiny", max_streams=16)
     try:
-        assert eng.lib.lasr_max_inflight(eng.ctx) == 7
+        assert eng.lib.lasr_max_inflight(eng.ctx) == 15
         m = O.OracleTransducer(sd, cfg)
-        n = 30
+        n = 60
         pcm = synth.synth_pcm(2, n * 1280, seed=5)
         slots = [eng.open() for _ in range(2)]
         got = [[], []]
@@ -84,14 +84,14 @@ def test_inflight_limit_is_what_the_header_says():
             eng.push(slots, np.stack([p[k * 1280:(k + 1) * 1280] for p in pcm]))
             try:
                 eng.submit(slots)
-            except LasrError as e:                  # the 8th model step in flight
-                assert e.code == LASR_ESTATE and eng.pending() == 7
+            except LasrError as e:                  # the 16th model step in flight
+                assert e.code == LASR_ESTATE and eng.pending() == 15
                 refused += 1
                 assert eng.wait() == 2              # collect the oldest, then the same submit goes through
                 for i, t in enumerate(eng.fetch_many(slots, 64)):
                     got[i] += t
                 eng.submit(slots)
-        assert refused > 0 and eng.pending() == 7
+        assert refused > 0 and eng.pending() == 15
         while eng.pending():
             eng.wait()
             for i, t in enumerate(eng.fetch_many(slots, 64)):
@@ -100,10 +100,10 @@ def test_inflight_limit_is_what_the_header_says():
             assert got[i] == oracle_stream(m, pcm[i], n).y
     finally:
         eng.close()
-    # rings sized for 32 frames / 256 tokens per row: a front-end with more evaluations per step gets a lower limit
+    # rings sized for 64 frames / 512 tokens per row: a front-end with more evaluations per step gets a lower limit
     eng, _, _ = make("tiny", max_streams=16, max_iters_stream=20)
     try:
-        assert eng.lib.lasr_max_inflight(eng.ctx) == 6          # 256 // (2 * 20)
+        assert eng.lib.lasr_max_inflight(eng.ctx) == 12         # 512 // (2 * 20)
     finally:
         eng.close()
 
