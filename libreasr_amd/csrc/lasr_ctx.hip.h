@@ -102,7 +102,7 @@ struct lasr_ctx {
     float* pe_ring = nullptr;
     int *c_cur = nullptr, *c_avail = nullptr, *c_iters = nullptr, *c_target = nullptr, *c_ntotal = nullptr;
     int* c_hcur_dev = nullptr;      // device view of the pinned per-row frame cursors (cont_host + 16)
-    int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr;
+    int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr, *c_enc_base = nullptr;
     int *c_done = nullptr, *c_flag_dev = nullptr;   // workgroups finished per iteration; device view of cont_host[0]
     int* c_iter = nullptr;                          // device-side iteration counter of the continuous loop
     std::map<std::tuple<int, int, int>, hipGraphExec_t> cgraphs;   // (iterations, predictor parity, LM parity) -> group
@@ -110,6 +110,7 @@ struct lasr_ctx {
     struct PendingStep { std::vector<int> rows; int Tm; int idx; bool admitted; std::vector<int> target; const int* T_row_ptr; long long serial; };
     std::vector<PendingStep> pending;
     std::vector<long long> h_frames_sub, h_fetched;
+    std::vector<int> h_avail;       // per-row frames admitted to the decode loop (device copy: c_avail)
     std::vector<int> h_cur_seen;    // per-row frame cursors as of the last consumed group (step j of row r is decoded iff >= its target)
     int work_left = 0;              // rows that still had encoded frames to decode when the last consumed group ended
     long long model_steps = 0, cont_iters = 0, iters_reported = 0;

@@ -94,7 +94,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
     g.A[0] = c->ybuf[(L - 1) & 1]; g.a_mt_total[0] = mt_total; g.a_mt_off[0] = 0; g.W[0] = c->W1e;
     EpiLinear::Args ea{};
     ea.bias = nullptr; ea.out = c->pe; ea.ldo = J; ea.n_rows = T_max * c->M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = c->M;
-    if (c->pe == c->pe_ring) { ea.ring_base = c->c_enc_frames; ea.ring = lasr_ctx::RING; }   // continuous mode: per-row frame ring
+    if (c->pe == c->pe_ring) { ea.ring_base = c->fe_fused ? c->c_enc_base : c->c_enc_frames; ea.ring = lasr_ctx::RING; }   // continuous mode: per-row frame ring
     launch_linear<false, 3>(c, J / 16, T_max * c->MT, g, H, ea);
 }
 

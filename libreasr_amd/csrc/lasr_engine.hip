@@ -115,6 +115,9 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     {
         if (getenv("LASR_NO_GRAPH")) c->use_graphs = false;
         if (getenv("LASR_CELL_NW")) c->cell_nw = atoi(getenv("LASR_CELL_NW")) == 4 ? 4 : 8;
+        // decode-stream GEMMs (predictor cells, PPJ, logits): 4 waves per workgroup with f32 operands (next to the encoder cells
+        // of the main stream fewer waves per CU interfere less: whole job +5 %), 8 with bf16 (4: -3 %)
+        c->dec_nw_mask = c->bf ? 0 : 7;
         if (getenv("LASR_DEC_NW4")) c->dec_nw_mask = atoi(getenv("LASR_DEC_NW4"));
         if (getenv("LASR_DEC_PRIO")) c->dec_prio = atoi(getenv("LASR_DEC_PRIO"));
         if (getenv("LASR_CELL_PRIO")) c->cell_prio = atoi(getenv("LASR_CELL_PRIO"));
@@ -268,7 +271,8 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->pe_ring, (size_t)lasr_ctx::RING * M * J));
     HIPCHK(c, hipMemset(c->pe_ring, 0, sizeof(float) * (size_t)lasr_ctx::RING * M * J));
     RC(dalloc(c, &c->c_cur, M)); RC(dalloc(c, &c->c_avail, M)); RC(dalloc(c, &c->c_iters, M)); RC(dalloc(c, &c->c_target, M));
-    RC(dalloc(c, &c->c_ntotal, M)); RC(dalloc(c, &c->c_enc_frames, M)); RC(dalloc(c, &c->c_behind, 64));
+    RC(dalloc(c, &c->c_ntotal, M)); RC(dalloc(c, &c->c_enc_frames, M)); RC(dalloc(c, &c->c_enc_base, M));
+    HIPCHK(c, hipMemset(c->c_enc_base, 0, sizeof(int) * M)); RC(dalloc(c, &c->c_behind, 64));
     // (c_ntok_end / c_tok_ring live in pinned host memory, written by k_select directly: see below)
     for (int* p : {c->c_cur, c->c_avail, c->c_iters, c->c_target, c->c_ntotal, c->c_enc_frames})
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
@@ -287,7 +291,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         c->c_ntok_end = (int*)dp + 16 + (size_t)lasr_ctx::NFLY * M;
         c->c_tok_ring = c->c_ntok_end + (size_t)M * lasr_ctx::ENDSLOTS;
     }
-    c->h_frames_sub.assign(M, 0); c->h_fetched.assign(M, 0); c->h_cur_seen.assign(M, 0);
+    c->h_frames_sub.assign(M, 0); c->h_fetched.assign(M, 0); c->h_cur_seen.assign(M, 0); c->h_avail.assign(M, 0);
     c->dec_t_idx = c->ds.t_idx;
     c->T_row_dec = c->T_row_dev;
     for (int* p : {c->ds.t_idx, c->ds.iters, c->ds.sum_iters, c->ds.n_ones})
@@ -565,6 +569,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
         f.pend = c->pend; f.pend_frames = d.n_buffer * d.n_stack;
         f.ln_w = c->ln_w; f.ln_b = c->ln_b; f.x0 = c->x0; f.F = d.feat; f.M = c->M; f.MT = c->MT; f.mt_total = c->Tcap * c->MT; f.bf = c->bf;
         f.trow_out = c->dc.T_row;
+        if (c->pe == c->pe_ring) { f.enc_frames = c->c_enc_frames; f.enc_base = c->c_enc_base; }
         for (int s : model_rows) {
             f.trow_v[s] = (unsigned char)d.n_buffer;
             for (int j = 0; j < d.n_buffer; ++j) {
@@ -701,7 +706,8 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
         HIPCHK(c, hipGetLastError());
         return LASR_OK;
     }
-    hipLaunchKernelGGL(k_advance, dim3(grid1(c->M)), dim3(256), 0, c->stream, c->c_enc_frames, (const int*)c->T_row_dev, c->M);
+    if (!c->fe_fused)       // (the fused front-end launch has already advanced the frame counters)
+        hipLaunchKernelGGL(k_advance, dim3(grid1(c->M)), dim3(256), 0, c->stream, c->c_enc_frames, (const int*)c->T_row_dev, c->M);
     HIPCHK(c, hipEventRecord(c->ev_enc[idx], c->stream));
     tr_mark(c, 5, c->stream);
     lasr_ctx::PendingStep p;
@@ -767,18 +773,28 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     // the decode stream then waits for that encoder on the GPU and resumes by itself
     bool admitted_any = false;
     tr_mark(c, 10, c->stream);
+    const bool by_value = M <= 512;
     for (auto& q : c->pending) {
         if (q.admitted) continue;
         const bool must = c->work_left == 0 && !admitted_any;
         if (!must && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_enc[q.idx], 0));
-        hipLaunchKernelGGL(k_advance, dim3(grid1(M)), dim3(256), 0, c->stream, c->c_avail, q.T_row_ptr, M);
+        if (by_value) { for (int r : q.rows) c->h_avail[r] = q.target[r]; }
+        else hipLaunchKernelGGL(k_advance, dim3(grid1(M)), dim3(256), 0, c->stream, c->c_avail, q.T_row_ptr, M);
         q.admitted = true;
         admitted_any = true;
     }
-    if (admitted_any)   // rows that were idle need their joint activation for the new frames
-        hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
-                           c->c_avail, c->ja, J, M, c->MTj, c->pe_ring_R, c->bf, 1, M, c->la);
+    if (admitted_any) {  // rows that were idle need their joint activation for the new frames
+        if (by_value) {
+            AvailV av;
+            for (int r = 0; r < 512; ++r) av.v[r] = r < M ? c->h_avail[r] : 0;
+            hipLaunchKernelGGL(k_ja_admit, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)c->pp,
+                               (const int*)c->c_cur, av, c->c_avail, c->ja, J, M, c->MTj, c->pe_ring_R, c->bf, c->la);
+        } else {
+            hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
+                               c->c_avail, c->ja, J, M, c->MTj, c->pe_ring_R, c->bf, 1, M, c->la);
+        }
+    }
     tr_mark(c, 11 + 100 * G + (admitted_any ? 1000 : 0), c->stream);
     __atomic_store_n(flag, -1, __ATOMIC_RELEASE);      // before the launch that will overwrite it
     c->dbg_gate = false;

@@ -55,6 +55,26 @@ __global__ void k_ja(const float* __restrict__ pe, const float* __restrict__ pp,
     }
 }
 
+// continuous greedy loop, admission of newly encoded steps (<= 512 rows): the rows' new "frames available" counts come BY
+// VALUE (the host knows every row's cumulative frame count), are stored for the kernels behind this one and used here for
+// the joint activation of the rows that were idle -- one launch instead of a counter-advance kernel per admitted step + k_ja
+struct AvailV { int v[512]; };
+__global__ void k_ja_admit(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
+                           const AvailV av, int* __restrict__ avail_out, void* __restrict__ ja, int J, int M, int MT, int ring,
+                           int bf, int la) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * J) return;
+    const int r = idx / J, j = idx - r * J;
+    const int Tav = av.v[r];
+    if (j == 0) avail_out[r] = Tav;
+    const int t = t_idx[r];
+    const float p = pp[(size_t)r * J + j];
+    for (int k = 0; k < la; ++k) {
+        if (t + k >= Tav) return;
+        act_st(bf, ja, act_off(bf, k * M + r, j, MT), tanhf(pe[((size_t)((t + k) % ring) * M + r) * J + j] + p));
+    }
+}
+
 // fragment-major -> row-major [rows][K] f32
 __global__ void k_from_frag(const void* __restrict__ src, int mt_total, int mt_off, float* __restrict__ dst, int ldd,
                             int rows, int K, int bf) {
@@ -986,6 +1006,8 @@ struct FrontArgs {
     void* x0;
     int F, M, MT, mt_total, bf;
     int* trow_out;           // [M]: the row's frame count of this step, for the kernels behind this one
+    int* enc_frames;         // pipelined protocol (else nullptr): [M] frames encoded so far; this launch snapshots it into
+    int* enc_base;           //   enc_base (the ring base of this step's joint GEMM) and advances it by the step's frames
     unsigned char trow_v[512];
     unsigned char age_v[4][512];   // [t'][row]: chunks pushed since the window of stacked frame t' was current; 255: in pend
 };
@@ -1000,7 +1022,10 @@ __global__ __launch_bounds__(64 * NSTACK) void k_frontend(const FrontArgs a) {
     const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
     const int tp = blockIdx.x, row = blockIdx.y;
     const int Tr = a.trow_v[row];
-    if (tp == 0 && threadIdx.x == 0) a.trow_out[row] = Tr;
+    if (tp == 0 && threadIdx.x == 0) {
+        a.trow_out[row] = Tr;
+        if (a.enc_frames) { const int e = a.enc_frames[row]; a.enc_base[row] = e; a.enc_frames[row] = e + Tr; }
+    }
     if (tp >= Tr) return;                                // uniform over the workgroup
     const MelTables tab{s_fbw, s_fbs, s_fbo, s_tw512, s_tw1024};
     stage_mel_tables(tab, a.tw512, a.tw1024, a.fb_w, a.fb_start, a.fb_off, a.fb_nnz, a.n_mels);

@@ -195,6 +195,11 @@ void launch_logits_t(lasr_ctx* c, const GemmArgs& g0, int n_rows, int K, const E
     GemmArgs g = g0;
     g.KC[0] = K / c->kch;
     const int ng = c->d.vocab / 16, mg = (n_rows + 16 * MTL - 1) / (16 * MTL);
+    if (c->dec_nw_mask & 4) {
+        if (c->bf) launch_gemm<OpsBF16, EpiLinear, MTL, false, -1, 4>(c, ng, mg, g, ea);
+        else launch_gemm<OpsF32, EpiLinear, MTL, false, -1, 4>(c, ng, mg, g, ea);
+        return;
+    }
     if (c->bf) launch_gemm<OpsBF16, EpiLinear, MTL, false, -1>(c, ng, mg, g, ea);
     else launch_gemm<OpsF32, EpiLinear, MTL, false, -1>(c, ng, mg, g, ea);
 }
@@ -206,8 +211,8 @@ void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
     ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M; ea.W = c->W;
-    if (c->logits_mt == 2 && !(c->dec_nw_mask & 4)) { launch_logits_t<2>(c, g, n_rows, J, ea); return; }
-    if (c->logits_mt == 4 && !(c->dec_nw_mask & 4)) { launch_logits_t<4>(c, g, n_rows, J, ea); return; }
+    if (c->logits_mt == 2) { launch_logits_t<2>(c, g, n_rows, J, ea); return; }
+    if (c->logits_mt == 4) { launch_logits_t<4>(c, g, n_rows, J, ea); return; }
     launch_linear<false, -1>(c, V / 16, (n_rows + 15) / 16, g, J, ea);
 }
 
