@@ -345,6 +345,7 @@ def main():
             json.dump({"marks": eng.trace_read(), "elapsed_us": 1e6 * elapsed, "chunks": K}, f)
         eng.trace(False)
     cell_us_total, cell_launches = eng.cell_prof_read()
+    cell_kernel_us_total, cell_kernel_launches = eng.cell_prof_kernel() if not args.trace else (0.0, 0)
     eng.cell_prof(False)
     eng.set_profiling(False)
 
@@ -359,7 +360,10 @@ def main():
         # events of the timed region; algorithmic work per launch = mean over the layers (layer 0 has K = feat + H)
         flops_mean = float(np.mean([cell_flops(cfg, l, B) for l in range(L)]))
         wbytes_mean = float(np.mean([(2.0 if bf else 4.0) * 4 * H * ((cfg["feat"] if l == 0 else H) + H) for l in range(L)]))
-        cell_us = cell_us_total / cell_launches if cell_launches else float("nan")
+        cell_us_ev = cell_us_total / cell_launches if cell_launches else float("nan")       # HIP events: includes the launch gaps
+        # the kernel's own duration (max exit - min entry of the device wall clock over its workgroups): what a kernel trace
+        # (rocprofv3 --kernel-trace --stats) reports as the average duration of this kernel
+        cell_us = cell_kernel_us_total / cell_kernel_launches if cell_kernel_launches else cell_us_ev
         achieved = flops_mean / (cell_us * 1e-6) / 1e12
         traffic = None                      # HBM bytes per launch from the committed PMC passes (profiles/)
         try:
@@ -405,9 +409,12 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"k_gemm<EpiLSTM> (encoder LSTM cell, {B} rows, mean over the {L} layers)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "launch_us": round(cell_us, 3), "launches_timed": int(cell_launches),
-                         "timing": "HIP events on the cells' stream around every model step's cell sequence in the timed region "
-                                   "(in-job: next to the decode stream)",
+                         "launch_us": round(cell_us, 3), "launches_timed": int(cell_kernel_launches or cell_launches),
+                         "timing": "in-job (next to the decode stream), every cell launch of the timed region: kernel duration = max exit - "
+                                   "min entry of the device wall clock over the launch's workgroups (the quantity rocprofv3 --kernel-trace "
+                                   "reports); launch_us_events = HIP-event pairs on the cells' stream around each model step's cell sequence "
+                                   "/ cells (adds the launch gaps and the events' own cost)",
+                         "launch_us_events": round(cell_us_ev, 3),
                          "flops_per_launch": flops_mean, "weight_bytes_per_launch": wbytes_mean,
                          "whole_job": {"tflops": round(job_tflops, 2),
                                        "frac": round(job_tflops / (PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS), 4),

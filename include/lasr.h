@@ -242,6 +242,10 @@ int lasr_cell_prof(lasr_ctx* c, int on);
 int lasr_trace(lasr_ctx* c, int on);
 int lasr_trace_read(lasr_ctx* c, double* us, int* tags, int cap, int* n);
 int lasr_cell_prof_read(lasr_ctx* c, double* us_total, long long* launches);
+/* ... and the kernels' own durations over the same period (at most 32768 launches): per cell launch, max exit - min
+ * entry of the device's constant wall clock over the kernel's workgroups -- what a kernel trace reports as the kernel's
+ * duration (no launch gaps, no event overhead).  Synchronises the device. */
+int lasr_cell_prof_kernel(lasr_ctx* c, double* us_total, long long* launches);
 
 #ifdef __cplusplus
 }

@@ -198,6 +198,12 @@ struct lasr_ctx {
     int cp_cells[NCELLEV] = {};
     double cp_us = 0.0;
     long long cp_launches = 0;
+    // ... and the kernels' own durations: every cell launch gets a slot {min entry, max exit} of the device's constant
+    // wall clock over its workgroups (what a kernel trace calls the kernel's duration: no launch gaps, no event overhead)
+    static constexpr int NCELLSLOT = 1 << 15;
+    unsigned long long* cp_slots = nullptr;   // device [NCELLSLOT][2]
+    long long cp_slot_next = 0;
+    double cp_clock_mhz = 100.0;
 
     // stream timeline (lasr_trace): timestamped marks on the main and the decode stream of the pipelined protocol
     static constexpr int NTRACE = 8192;

@@ -1393,7 +1393,36 @@ int lasr_cell_prof(lasr_ctx* c, int on) {
         c->cp_ok = true;
     }
     if (on) { cell_prof_harvest(c, true); c->cp_us = 0.0; c->cp_launches = 0; }
+    if (on) {
+        if (!c->cp_slots) {
+            RC(dalloc(c, &c->cp_slots, (size_t)2 * lasr_ctx::NCELLSLOT));
+            int khz = 0;
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) c->cp_clock_mhz = khz / 1e3;
+            else (void)hipGetLastError();
+        }
+        std::vector<unsigned long long> init((size_t)2 * lasr_ctx::NCELLSLOT);
+        for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0ull; }
+        HIPCHK(c, hipMemcpy(c->cp_slots, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        c->cp_slot_next = 0;
+    }
     c->cell_prof = on != 0;
+    return LASR_OK;
+}
+// the cell kernels' own durations since lasr_cell_prof(c, 1): per launch, max exit - min entry of the device's constant
+// wall clock over the kernel's workgroups (comparable with a kernel trace's duration column)
+int lasr_cell_prof_kernel(lasr_ctx* c, double* us_total, long long* launches) {
+    if (!c || !us_total || !launches) return LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    *us_total = 0.0; *launches = 0;
+    if (!c->cp_slots || c->cp_slot_next == 0) return LASR_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)2 * c->cp_slot_next);
+    HIPCHK(c, hipMemcpy(h.data(), c->cp_slots, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (long long i = 0; i < c->cp_slot_next; ++i) {
+        if (h[2 * i] == ~0ull || h[2 * i + 1] < h[2 * i]) continue;
+        *us_total += (double)(h[2 * i + 1] - h[2 * i]) / c->cp_clock_mhz;
+        *launches += 1;
+    }
     return LASR_OK;
 }
 int lasr_cell_prof_read(lasr_ctx* c, double* us_total, long long* launches) {

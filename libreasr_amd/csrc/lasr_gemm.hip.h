@@ -93,6 +93,7 @@ struct GemmArgs {
     const int* parent;      // beam search (AROW, W > 1): phase-1 rows are read from the row's parent hypothesis
     int beam_w;             //   slot: row r -> (r / W) * W + parent[r]; nullptr / 0: identity (greedy)
     unsigned long long* dbg; // optional per-workgroup phase timestamps [blocks][16] (LASR_DBG_TIMING)
+    unsigned long long* prof; // optional [2]: min entry / max exit wall_clock64() over the workgroups = the kernel's own duration
     int prio;                // wave priority for the whole kernel (s_setprio 0..3); experiments: LASR_DEC_PRIO / LASR_CELL_PRIO
 };
 
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
     else if (g.prio == 1) __builtin_amdgcn_s_setprio(1);
     unsigned long long* dbg = g.dbg ? g.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
     if (dbg && tid == 0) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[5] = wall_clock64(); }
+    if (g.prof && tid == 0) atomicMin(&g.prof[0], (unsigned long long)wall_clock64());
 
     // (0) this wave's first weight fragment does not depend on flags / compaction: put it in flight
     //     before anything else (first-touch latency of the weight stream is the long pole)
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
     if (dbg && tid == 0) dbg[3] = __builtin_amdgcn_s_memtime();
     Epi::template run<MT>(ea, RedView<NW, ROWS, LD>{red}, tid, jb, mg, n_act, row_map, pre, NW * 64);
     if (dbg && tid == 0) { dbg[4] = __builtin_amdgcn_s_memtime(); dbg[6] = wall_clock64(); }
+    if (g.prof && tid == 0) atomicMax(&g.prof[1], (unsigned long long)wall_clock64());
 }
 
 // ------------------------------------------------------------------------------------------------

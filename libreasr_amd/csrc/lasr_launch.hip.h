@@ -37,6 +37,7 @@ void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_tot
     g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / Ops::KCH; g.W[0] = L.WxC;
     g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhC;
     g.M = c->M; g.dbg = c->dbg;
+    if (c->cell_prof && c->cp_slots && c->cp_slot_next < lasr_ctx::NCELLSLOT) g.prof = c->cp_slots + 2 * (c->cp_slot_next++);
     using E = EpiLSTM<Ops, false, false, 8>;
     typename E::Args ea{};
     ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t; ea.tile_mask = c->tile_masks.empty() ? ~0ull : c->tile_masks[t];

@@ -284,6 +284,12 @@ class Engine:
         """In-job HIP-event timing of the encoder-cell launches (see lasr_cell_prof)."""
         self._chk(self.lib.lasr_cell_prof(self.ctx, 1 if on else 0))
 
+    def cell_prof_kernel(self):
+        """-> (microseconds, cell launches): the cell kernels' own durations since cell_prof(True) (in-kernel wall clock)."""
+        us, n = C.c_double(0.0), C.c_longlong(0)
+        self._chk(self.lib.lasr_cell_prof_kernel(self.ctx, C.byref(us), C.byref(n)))
+        return float(us.value), int(n.value)
+
     def trace(self, on=True):
         """Timestamped marks on the main / decode streams of the pipelined protocol (see lasr_trace)."""
         self._chk(self.lib.lasr_trace(self.ctx, 1 if on else 0))
