@@ -117,6 +117,17 @@ int lasr_stream_close(lasr_ctx* c, int slot);
 int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm);
 int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran);
 
+/* Generic streaming clients (any chunk length, any sample rate; the browser client sends 44.1 / 48 kHz,
+ * apps/web/src/App.js:68): one call per servicer iteration with the window the servicer has concatenated from the
+ * last 3 client frames (api-server.py:83-115).  pcm = [n][N] float32, host or device, one window per listed slot, at
+ * `sr` Hz.  Does what x_tfm_stream does per call: Resample of the whole window to 16 kHz (transforms.py:141-144;
+ * skipped when sr is 16000), log-mel of the window (reflect padding at both ends), frames T//3 + 1 .. + n_stack
+ * (transforms.py:335-342), stack, Buffer(n_buffer); when a slot's buffer is full the model runs (synchronous protocol,
+ * like lasr_step_stream; n_ran = slots that ran it; tokens through lasr_fetch).  LASR_EINVAL if the window is too short
+ * for n_stack frames after the cut.  A slot uses EITHER this form OR lasr_push_pcm + lasr_step_* (LASR_ESTATE when a slot
+ * that still has frames pending from the other form is passed).  At most 512 stream slots. */
+int lasr_step_window(lasr_ctx* c, const int* slots, int n, const float* pcm, int64_t N, int sr, int* n_ran);
+
 /* Pipelined form (throughput mode): lasr_step_submit enqueues this chunk's front-end + encoder on the
  * ctx stream and returns; lasr_step_wait keeps ONE greedy decode loop running on a second HIP stream and
  * blocks until the tokens of the OLDEST submitted model step are on the host (n_ran = its slot count,

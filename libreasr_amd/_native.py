@@ -44,6 +44,7 @@ SYMBOLS = [
     ("lasr_stream_close", C.c_int, [_P, C.c_int]),
     ("lasr_push_pcm", C.c_int, [_P, _P, C.c_int, _P]),
     ("lasr_step_stream", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    ("lasr_step_window", C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     ("lasr_step_submit", C.c_int, [_P, _P, C.c_int]),
     ("lasr_step_wait", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("lasr_step_pending", C.c_int, [_P]),

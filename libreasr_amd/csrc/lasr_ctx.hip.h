@@ -160,6 +160,7 @@ struct lasr_ctx {
     float* win = nullptr; int* ring_pos = nullptr;
     float* pend = nullptr;          // [M][n_buffer*n_stack][n_mels]
     float* stage_pcm = nullptr; size_t stage_pcm_floats = 0;
+    float* win_rs = nullptr; size_t win_rs_floats = 0;       // resampled client windows (lasr_step_window)
     // streaming pushes from host memory: ring of device staging rows + one event per entry, so a push
     // never has to drain the stream (the copy of chunk k+1 overlaps the kernels of chunk k)
     static constexpr int NSTAGE = 16;

@@ -1235,6 +1235,91 @@ static long long resample_num_out(long long n_in, int sr_in, int sr_out) {     /
     return last + 1;
 }
 
+int lasr_resample(lasr_ctx* c, const float* pcm, int B, int64_t N_in, int sr_in, float* out, int64_t* N_out);
+
+// Generic client windows (any chunk length, any sample rate): what ASRServicer.TranscribeStream + x_tfm_stream do per call
+// (api-server.py:83-115; transforms.py:141-144 Resample of the WHOLE window, :306-323 log-mel of the window with reflect
+// padding, :335-342 frames T//3 + 1 .. + n_stack, :436-441 stack, :463-471 Buffer) for windows the caller has concatenated:
+// pcm = [n][N] float32 (host or device) at `sr` Hz, one window per listed slot.  Synchronous protocol; the fast path
+// (lasr_push_pcm + lasr_step_*) is the same computation specialised to 16 kHz / fixed chunks with the window kept on the GPU.
+int lasr_step_window(lasr_ctx* c, const int* slots, int n, const float* pcm, int64_t N, int sr, int* n_ran) {
+    if (!c) return LASR_EINVAL;
+    if (n_ran) *n_ran = 0;
+    RC(check_slots(c, slots, n, true));
+    RC(require_idle(c));
+    if (n == 0) return LASR_OK;
+    if (!pcm || N < 1) return fail(c, LASR_EINVAL, "bad window");
+    if (c->M > 512) return fail(c, LASR_EINVAL, "lasr_step_window supports up to 512 stream slots");
+    HIPCHK(c, hipSetDevice(c->device));
+    const lasr_model_desc& d = c->d;
+    const float* src = pcm;
+    if (!is_device_ptr(pcm)) {
+        RC(ensure_buf(c, &c->stage_pcm, &c->stage_pcm_floats, (size_t)n * N));
+        HIPCHK(c, hipMemcpyAsync(c->stage_pcm, pcm, sizeof(float) * (size_t)n * N, hipMemcpyHostToDevice, c->stream));
+        src = c->stage_pcm;
+    }
+    long long Nw = N;
+    if (sr != d.sample_rate) {                              // Resample.encodes on the whole window (transforms.py:141-144)
+        int64_t No = 0;
+        RC(lasr_resample(c, src, n, N, sr, nullptr, &No));
+        RC(ensure_buf(c, &c->win_rs, &c->win_rs_floats, (size_t)n * No));
+        RC(lasr_resample(c, src, n, N, sr, c->win_rs, &No));
+        src = c->win_rs; Nw = No;
+    }
+    const int T = 1 + (int)(Nw / d.hop);
+    const int a0 = T / 3 + 1;                               // StreamPostprocess (transforms.py:335-342)
+    if (T - a0 < d.n_stack) return fail(c, LASR_EINVAL, "window of %lld samples at 16 kHz yields %d < n_stack frames after the cut", Nw, T - a0);
+    if (Nw <= d.n_fft / 2) return fail(c, LASR_EINVAL, "window shorter than the reflect padding");
+    RC(cmd_begin(c));
+    std::vector<int> model_rows;
+    MelArgs m{};
+    fill_mel_args(c, m);
+    for (int i = 0; i < n; ++i) {
+        const int s = slots[i];
+        for (int j = 0; j < c->n_pend[s]; ++j)
+            if (c->fe_fused && !c->pend_mat[(size_t)s * d.n_buffer + j])
+                return fail(c, LASR_ESTATE, "slot %d has frames pending from lasr_push_pcm steps: do not mix the two streaming forms", s);
+        m.dst_row_v[i] = (short)s;
+        m.sel_v[i] = (short)(c->n_pend[s] * d.n_stack);
+        c->pend_mat[(size_t)s * d.n_buffer + c->n_pend[s]] = 1;
+        c->pend_serial[(size_t)s * d.n_buffer + c->n_pend[s]] = c->n_chunks[s];
+        if (++c->n_pend[s] == d.n_buffer) {
+            c->n_pend[s] = 0;
+            c->hc.T_row[s] = d.n_buffer;
+            model_rows.push_back(s);
+        }
+    }
+    RC(cmd_commit(c));
+    rec(c, 0);
+    m.pcm = src; m.N = Nw; m.stream = 0; m.by_value = 1; m.frame0 = a0; m.frames_per_row = d.n_stack;
+    m.out = c->pend; m.out_frames = d.n_buffer * d.n_stack; m.chunk = d.chunk; m.n_window = d.n_window;
+    hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, n), dim3(256), 0, c->stream, m);
+    if (model_rows.empty()) {
+        HIPCHK(c, hipGetLastError());
+        return LASR_OK;
+    }
+    const int Tm = d.n_buffer;
+    RC(ensure_T(c, Tm));
+    RC(commit_T_rows(c, Tm));
+    {
+        StackLnArgs a{};
+        a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
+        a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
+        a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.bf = c->bf; a.Tmax = Tm;
+        LAUNCH_STACK_LN( dim3((Tm + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+    }
+    rec(c, 1);
+    run_encoder(c, Tm);
+    rec(c, 2);
+    RC(run_decode(c, Tm, d.max_iters_stream, false, model_rows));
+    rec(c, 3);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    collect_stats(c, Tm);
+    if (n_ran) *n_ran = (int)model_rows.size();
+    return LASR_OK;
+}
+
 int lasr_resample(lasr_ctx* c, const float* pcm, int B, int64_t N_in, int sr_in, float* out, int64_t* N_out) {
     if (!c || !N_out) return LASR_EINVAL;
     const int sr_out = c->d.sample_rate;

@@ -825,6 +825,9 @@ struct MelArgs {
     // before the newest one (by_value: age_v[row], else 0)
     int ring_chunks;
     unsigned char age_v[512];
+    // whole-window mode (stream == 0, by_value): launch row i reads pcm + i * N (reflect padded, like offline) and writes
+    // frames frame0 .. frame0 + frames_per_row - 1 to row dst_row_v[i] of `out`, frame slot sel_v[i] + k (lasr_step_window)
+    short dst_row_v[512];
 };
 
 // staging of the FFT twiddles and the sparse filterbank into LDS (every thread of the block takes part)
@@ -952,7 +955,9 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
         src = a.pcm + a.row_src_off[row];
     } else {
         src = a.pcm + (size_t)row * a.N;
+        if (a.by_value) { out_frame = (int)a.sel_v[row] + fidx; t = a.frame0 + fidx; }
     }
+    const int out_row = (!a.stream && a.by_value) ? (int)a.dst_row_v[row] : row;
     const long long base = (long long)t * a.hop - 512;
     auto sample = [&](int n) -> float {                  // windowed sample n of the 1024-frame
         // the window is zero outside [win_off, win_off + win_len): decided from the index, so the
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     fft1024_power(v, sz[w], sp[w], s_tw512, s_tw1024, j);
     // ---- sparse HTK mel + log
     if (!valid) return;
-    mel_log(sp[w], tab, a.n_mels, j, a.out + ((size_t)row * a.out_frames + out_frame) * a.n_mels);
+    mel_log(sp[w], tab, a.n_mels, j, a.out + ((size_t)out_row * a.out_frames + out_frame) * a.n_mels);
 }
 
 // Streaming front-end of one model step in ONE launch (<= 512 rows, n_buffer <= 4): for every row that runs the model,

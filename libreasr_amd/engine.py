@@ -135,6 +135,20 @@ class Engine:
         self._chk(self.lib.lasr_step_stream(self.ctx, p, n, C.byref(ran)))
         return ran.value
 
+    def step_window(self, slots, windows, sr=16000):
+        """Generic clients (any chunk length / sample rate): windows = [n, N] float32 (the last 3 client frames of every
+        listed slot, concatenated as the servicer does); returns the number of slots whose model ran (lasr_step_window)."""
+        a, p, n = self._slots(slots)
+        if isinstance(windows, torch.Tensor):
+            windows = windows.contiguous()
+            assert windows.dtype == torch.float32 and windows.shape[0] == n
+        else:
+            windows = np.ascontiguousarray(windows, dtype=np.float32)
+            assert windows.shape[0] == n
+        ran = C.c_int(0)
+        self._chk(self.lib.lasr_step_window(self.ctx, p, n, _ptr(windows), int(windows.shape[1]), int(sr), C.byref(ran)))
+        return ran.value
+
     def submit(self, slots):
         """Pipelined step: enqueue front-end + encoder of the chunk just pushed; returns immediately."""
         a, p, n = self._slots(slots)

@@ -1,9 +1,10 @@
 """Mirror of libreasr/lib/language.py (inference subset): token ids -> text.
 
-The reference decodes with a YouTokenToMe BPE model (language.py:115-155).  Neither the package
-nor a tokenizer model file is available here (they ship with the model release, docs/docs.md:139),
-so parity is defined on token ids; `IdLanguage` is the stand-in and `TokenizedLanguage` is used
-when youtokentome and a model file exist."""
+The reference decodes with a YouTokenToMe BPE model (language.py:115-155).  The package is not
+installed here and no tokenizer model ships with the reference tree (it comes with the model
+release, docs/docs.md:139): `TokenizedLanguage` uses the real package when it is importable and
+otherwise the restated model reader in `yttm.py` (parity unpinned, see there); without a model
+file parity is defined on token ids and `IdLanguage` is the stand-in."""
 
 
 class IdLanguage:
@@ -20,19 +21,39 @@ class IdLanguage:
 
 
 class TokenizedLanguage:
-    def __init__(self, model_file, ignore_ids=(0,)):
-        import youtokentome as yttm      # not installed in this image; raises ImportError
-        self.bpe = yttm.BPE(model=model_file)
+    """language.py:115-155: numericalize / denumericalize / get_idx / get_token / len on a YTTM BPE model."""
+    SOS, EOS = "<s>", "</s>"                         # language.py:20-21 (stripped before encoding)
+
+    def __init__(self, model_file="tmp/tokenizer.yttm-model", ignore_ids=(0,)):
+        try:
+            import youtokentome as yttm          # the reference's dependency, when present
+        except ImportError:
+            from . import yttm                   # restated model reader / decoder
+        self._yttm = yttm
+        self.mf = model_file
+        self.tokenizer = yttm.BPE(model=model_file)
         self.ignore_ids = list(ignore_ids)
 
-    def denumericalize(self, ids):
-        return self.bpe.decode([int(i) for i in ids], ignore_ids=self.ignore_ids)[0]
+    def numericalize(self, text, sos=False, dropout=0):
+        text = text.lower().strip().replace(self.SOS, "").replace(self.EOS, "")
+        return self.tokenizer.encode([text], output_type=self._yttm.OutputType.ID, dropout_prob=dropout)[0]
+
+    def denumericalize(self, nummed, strip_zeros=True):
+        if not isinstance(nummed, (list, tuple)):
+            nummed = [nummed]
+        return self.tokenizer.decode([[int(i) for i in nummed]], ignore_ids=self.ignore_ids)[0]
+
+    def get_idx(self, tok):
+        return self.numericalize(tok)[0]
+
+    def get_token(self, num, strip_zeros=False):
+        return self.denumericalize(num)[0]
+
+    def __len__(self):
+        return self.tokenizer.vocab_size()
 
 
 def get_language(model_file=None):
     if model_file:
-        try:
-            return TokenizedLanguage(model_file)
-        except ImportError:
-            pass
+        return TokenizedLanguage(model_file)
     return IdLanguage()

@@ -8,6 +8,10 @@ Reference behaviour kept (api-server.py:16-26, 44-50, 64-135):
     after every model call: if the chunk produced text, re-denumericalize the whole hypothesis and
     send only the characters that changed (zip_longest diff), skipping a repeat of the previous
     diff; otherwise, after >= 4000 ms of empty output (10 ms * downsample * n_buffer * steps), reset().
+  * clients with another sample rate or frame length (the browser sends 44.1 / 48 kHz, apps/web/src/App.js:68):
+    the last 3 frames are concatenated and the WINDOW is resampled + transformed per call, exactly the
+    servicer's sequence (api-server.py:83-115, transforms.py:141-144, 335-342) -> `lasr_step_window`;
+    16 kHz / 80 ms clients take the fused path that keeps the window on the GPU.
 What differs: the reference shares one model + one stateful `Buffer` transform between 4 worker
 threads at batch 1 (a race).  Here RPC threads only queue PCM; ONE scheduler thread
 owns the engine (a lasr_ctx is single-caller) and steps every stream that has a chunk ready in a
@@ -38,6 +42,8 @@ class _Stream:
     def __init__(self, slot):
         self.slot, self.inq, self.outq = slot, collections.deque(), queue.Queue()
         self.n_chunks, self.n_pend = 0, 0
+        self.generic = None                 # decided by the first frame: False = 16 kHz / 80 ms fused path, True = window form
+        self.frames = []                    # generic form: the last (up to) 3 client frames (api-server.py:85-99)
 
 
 class Scheduler(threading.Thread):
@@ -73,9 +79,9 @@ class Scheduler(threading.Thread):
     def transcribe(self, pcm, sr=16000):
         return self._call(lambda: self._offline(pcm, sr))
 
-    def push(self, st, chunk):
+    def push(self, st, chunk, sr=16000):
         with self.cv:
-            st.inq.append(chunk)
+            st.inq.append((chunk, int(sr) or 16000))
             self.cv.notify()
         return st.outq.get()                # None = model did not run for this chunk, else list of new token ids
 
@@ -128,23 +134,57 @@ class Scheduler(threading.Thread):
                     done.put(e)
             if not ready:
                 continue
+            fast, generic = [], collections.OrderedDict()
+            for s, (pcm, sr) in zip(ready, chunks):
+                if s.generic is None:
+                    s.generic = not (sr == d.sample_rate and pcm.shape[0] == d.chunk)
+                if not s.generic:
+                    if sr != d.sample_rate or pcm.shape[0] > d.chunk:
+                        s.outq.put(ValueError(f"stream opened with {d.chunk}-sample {d.sample_rate} Hz frames: got {pcm.shape[0]} samples at {sr} Hz"))
+                        continue
+                    if pcm.shape[0] < d.chunk:                  # api-client.py:40-41 pads the last slice with zeros
+                        pcm = np.concatenate([pcm, np.zeros(d.chunk - pcm.shape[0], np.float32)])
+                    fast.append((s, pcm))
+                else:                                           # api-server.py:85-99: window of the last 3 frames
+                    s.frames.append(pcm)
+                    if len(s.frames) != d.n_window:
+                        s.outq.put(None)
+                        continue
+                    win = np.concatenate(s.frames)
+                    del s.frames[0]
+                    generic.setdefault((win.shape[0], sr), []).append((s, win))
             try:
-                slots = [s.slot for s in ready]
-                self.eng.push(slots, np.stack(chunks))
-                self.eng.step(slots)
-                toks = self.eng.fetch_many(slots, cap=256)
-                self.batches.append(len(ready))
-                for s, t in zip(ready, toks):
-                    s.n_chunks += 1
-                    ran = False
-                    if s.n_chunks >= d.n_window:            # window full -> one more frame in the Buffer
-                        s.n_pend += 1
-                        if s.n_pend == d.n_buffer:
-                            s.n_pend, ran = 0, True
-                    s.outq.put(t if ran else None)
+                if fast:
+                    slots = [s.slot for s, _ in fast]
+                    self.eng.push(slots, np.stack([p for _, p in fast]))
+                    self.eng.step(slots)
+                    toks = self.eng.fetch_many(slots, cap=256)
+                    self.batches.append(len(fast))
+                    for (s, _), t in zip(fast, toks):
+                        s.n_chunks += 1
+                        ran = False
+                        if s.n_chunks >= d.n_window:            # window full -> one more frame in the Buffer
+                            s.n_pend += 1
+                            if s.n_pend == d.n_buffer:
+                                s.n_pend, ran = 0, True
+                        s.outq.put(t if ran else None)
             except Exception as e:
-                for s in ready:
+                for s, _ in fast:
                     s.outq.put(e)
+            for (N, sr), group in generic.items():              # same window length and rate: one batched call
+                try:
+                    slots = [s.slot for s, _ in group]
+                    self.eng.step_window(slots, np.stack([w for _, w in group]), sr)
+                    toks = self.eng.fetch_many(slots, cap=256)
+                    for (s, _), t in zip(group, toks):
+                        s.n_pend += 1
+                        ran = s.n_pend == d.n_buffer
+                        if ran:
+                            s.n_pend = 0
+                        s.outq.put(t if ran else None)
+                except Exception as e:
+                    for s, _ in group:
+                        s.outq.put(e)
 
 
 class ASRServicer(apg.ASRServicer):
@@ -175,13 +215,10 @@ class ASRServicer(apg.ASRServicer):
         try:
             y, last, last_diff, steps = [], "", "", 0
             for frame in request_iterator:
-                if frame.sr not in (0, 16000):                             # the fused streaming path takes 16 kHz PCM
-                    context.abort(grpc.StatusCode.INVALID_ARGUMENT, "TranscribeStream expects 16 kHz PCM (Transcribe resamples)")
                 pcm = tensorize(frame.data)[0].numpy()
-                if pcm.shape[0] != self.chunk:
-                    context.abort(grpc.StatusCode.INVALID_ARGUMENT,
-                                  f"chunks must be {self.chunk} samples (80 ms at 16 kHz), got {pcm.shape[0]}")
-                res = self.sched.push(st, pcm)
+                res = self.sched.push(st, pcm, frame.sr or 16000)
+                if isinstance(res, ValueError):
+                    context.abort(grpc.StatusCode.INVALID_ARGUMENT, str(res))
                 if isinstance(res, Exception):
                     raise res
                 if res is None:

@@ -154,8 +154,9 @@ class StreamFrontend:
     BUFFER_N_FRAMES=3 :26) + x_tfm_stream (testing.yaml:358-374) incl. Buffer(n_buffer)
     (transforms.py:455-471).  push(chunk) -> None or [n_buffer*T', 1280]."""
 
-    def __init__(self, n_stack=10, downsample=8, n_buffer=2, n_window=3, **mel):
+    def __init__(self, n_stack=10, downsample=8, n_buffer=2, n_window=3, sr=16000, **mel):
         self.n_stack, self.downsample, self.n_buffer, self.n_window = n_stack, downsample, n_buffer, n_window
+        self.sr = sr                             # client sample rate: Resample (order 2, transforms.py:135-144) of the WINDOW
         self.mel = mel
         self.frames, self.saved = [], []
 
@@ -167,6 +168,8 @@ class StreamFrontend:
         self.called = True
         aud = np.concatenate(self.frames)
         del self.frames[0]
+        if self.sr != 16000:
+            aud = resample(aud, self.sr)
         spec = stream_postprocess(logmel(aud, **self.mel), self.n_stack)
         st = stack_downsample(spec, self.n_stack, self.downsample)
         self.saved.append(st)

@@ -223,3 +223,52 @@ def test_config2_bf16_beam4_streaming():
 def test_config4_cfg5_bf16_beam8_128_streams():
     """BASELINE configs[4] per-GPU shape: 8x1536 encoder, 2xLSTM predictor, bf16, beam 8, 128 streams."""
     _beam_stream_case("cfg5", 8, 128, 12, list(range(0, 128, 32)))
+
+
+def test_fused_frontend_irregular_pushes_equal_the_per_chunk_kernels():
+    """The fused front-end (one launch per model step over the PCM ring) against the per-chunk log-mel + stack/LayerNorm
+    kernels (LASR_FE_LEGACY=1) when clients push several chunks per step call -- frames whose window would leave the ring
+    are computed early (materialize_pending).  Property: identical tokens for any push / step interleaving."""
+    import os
+    cfgname = "tiny"
+    pcm = synth.synth_pcm(3, 16000 * 3, seed=31)
+    chunks = [synth.stream_chunks(pcm[i], 1280, lead=1, tail=4) for i in range(3)]
+    n = len(chunks[0])
+    rng = np.random.default_rng(5)
+    # per call: which rows push (possibly several times before the next step), which rows step
+    plan = []
+    pos = [0, 0, 0]
+    while min(pos) < n:
+        pushes = [int(rng.integers(0, 3)) if i else 1 for i in range(3)]      # row 0 regular, rows 1-2 push 0..2 chunks
+        pushes = [min(p, n - pos[i]) for i, p in enumerate(pushes)]
+        step_rows = [i for i in range(3) if pushes[i] > 0 and rng.random() < 0.8]
+        plan.append((pushes, step_rows))
+        pos = [pos[i] + pushes[i] for i in range(3)]
+
+    def run(legacy):
+        if legacy:
+            os.environ["LASR_FE_LEGACY"] = "1"
+        try:
+            eng, _, _ = make(cfgname, max_streams=16)
+        finally:
+            os.environ.pop("LASR_FE_LEGACY", None)
+        try:
+            slots = [eng.open() for _ in range(3)]
+            got = [[], [], []]
+            p = [0, 0, 0]
+            for pushes, step_rows in plan:
+                for rep in range(max(pushes)):
+                    rows = [i for i in range(3) if pushes[i] > rep]
+                    eng.push([slots[i] for i in rows], np.stack([chunks[i][p[i] + rep] for i in rows]))
+                p = [p[i] + pushes[i] for i in range(3)]
+                if step_rows:
+                    eng.step([slots[i] for i in step_rows])
+                    for i in step_rows:
+                        got[i] += eng.fetch(slots[i])[0]
+            return got
+        finally:
+            eng.close()
+
+    fused, legacy = run(False), run(True)
+    assert fused == legacy
+    assert sum(len(g) for g in fused) > 0

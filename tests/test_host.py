@@ -162,3 +162,51 @@ def test_model_archive_round_trip(tmp_path):
         tar.addfile(info, io.BytesIO(b"x"))
     with pytest.raises(ValueError):
         mu.extract_tars([str(evil)], dest)
+
+
+def _tiny_yttm_model(path):
+    """A hand-made YouTokenToMe model file (format of BPEState::dump): pad 0, unk 1, bos 2, eos 3, then the characters
+    "▁ a b c ä" as ids 4..8, then merges in priority order."""
+    chars = {0x2581: 4, ord("a"): 5, ord("b"): 6, ord("c"): 7, ord("ä"): 8}
+    rules = [(5, 6, 9),      # a b   -> ab
+             (4, 9, 10),     # ▁ ab  -> ▁ab
+             (7, 7, 11),     # c c   -> cc
+             (4, 7, 12),     # ▁ c   -> ▁c
+             (10, 11, 13)]   # ▁ab cc -> ▁abcc
+    with open(path, "w", encoding="utf-8") as f:
+        f.write(f"{len(chars)} {len(rules)}\n")
+        for cp, i in chars.items():
+            f.write(f"{cp} {i}\n")
+        for x, y, z in rules:
+            f.write(f"{x} {y} {z}\n")
+        f.write("1 0 2 3\n")
+
+
+def test_yttm_model_reader_decodes_like_the_reference_call(tmp_path):
+    """language.py:135-142: tokenizer.decode([ids], ignore_ids=[0])[0] on a YTTM model (restated reader, lib/yttm.py)."""
+    from libreasr_amd.lib import yttm
+    from libreasr_amd.lib.language import TokenizedLanguage, get_language
+    mf = str(tmp_path / "tokenizer.yttm-model")
+    _tiny_yttm_model(mf)
+    bpe = yttm.BPE(model=mf)
+    assert bpe.vocab_size() == 14
+    assert bpe.vocab()[:4] == ["<PAD>", "<UNK>", "<BOS>", "<EOS>"] and bpe.vocab()[13] == "▁abcc" and bpe.vocab()[8] == "ä"
+    # word-start marker -> space, leading space of the sentence dropped, blank (0) ignored, specials printed by name
+    assert bpe.decode([[13, 0, 12, 0, 0, 10]], ignore_ids=[0]) == ["abcc c ab"]
+    assert bpe.decode([10, 11, 8]) == ["abccä"]
+    assert bpe.decode([[5, 4, 6]]) == ["a b"]                      # a bare ▁ token is a space
+    assert bpe.decode([[2, 10, 3, 1]], ignore_ids=[0]) == ["<BOS> ab<EOS><UNK>"]
+    assert bpe.decode([[0, 0]], ignore_ids=[0]) == [""]
+    with pytest.raises(ValueError):
+        bpe.decode([[99]])
+    # dropout-free BPE encode: lowest rule rank first; unknown characters -> unk
+    assert bpe.encode(["abcc c ab"]) == [[13, 12, 10]]
+    assert bpe.encode("cab x", output_type=yttm.OutputType.SUBWORD) == ["▁c", "ab", "▁", "<UNK>"]
+    assert bpe.subword_to_id("▁ab") == 10 and bpe.subword_to_id("zz") == 1
+    lang = get_language(mf)
+    assert isinstance(lang, TokenizedLanguage) and len(lang) == 14
+    assert lang.denumericalize([13, 0, 12]) == "abcc c"
+    assert lang.numericalize(" ABCC c </s>") == [13, 12]
+    assert lang.denumericalize(lang.numericalize("ab cc ab")) == "ab cc ab"
+    with pytest.raises(ValueError):
+        yttm.BPE(model=__file__.replace("test_host.py", "conftest.py"))
