@@ -76,6 +76,8 @@ class Engine:
             raise N.LasrError(rc, msg)
         self.max_streams = int(max_streams)
 
+    lm_cfg = None          # set by attach_lm
+
     def attach_lm(self, lm_state_dict, alpha=0.1, theta=1.0, min_val=-10.0):
         """LM shallow fusion (lm.py LM / LMFuser; constants lm.py:13-15).  fp32 / bf16 operands like the
         model; the reference's int8 dynamic quantisation of the LM is not reproduced."""

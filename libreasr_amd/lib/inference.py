@@ -30,6 +30,8 @@ def load_lm_state_dict(conf, synthetic_lm=None):
     lm = (conf.get("lm", {}) or {}) if conf else {}
     if not lm.get("enable") or not lm.get("path") or not os.path.exists(lm["path"]):
         return None
+    if not lm.get("path", "").endswith(".pth"):
+        return None
     try:
         return _load_lm_sd(lm["path"])
     except Exception:
@@ -56,11 +58,20 @@ def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_st
     eng = Engine(sd, cfg, max_streams=max_streams, device=device, n_stack=n_stack, stride=downsample,
                  n_buffer=n_buffer, dtype=dtype, beam=beam)
     lm_sd = load_lm_state_dict(conf, synthetic_lm)
+    if lm_sd is None and synthetic is None and os.path.exists(f"./tmp/{lang}/lm.pth") and not conf:
+        try:                                 # no config file: the archive layout decides (testing.yaml:310-311 -> ./tmp/<lang>/lm.pth)
+            lm_sd = _load_lm_sd(f"./tmp/{lang}/lm.pth")
+        except Exception:
+            print("[LM] Failed to load.")
     if lm_sd is not None and beam == 1:
         eng.attach_lm(lm_sd)
         print("[LM] loaded.")
+    # tokenizer: the configured file (testing.yaml:153-154, per-language override :320-321), else where the model archive
+    # puts it (model_utils.py:31-47: <lang>/tokenizer.yttm-model under ./tmp)
     tok = ((conf.get("tokenizer", {}) or {}).get("model_file")) if conf else None
-    language = get_language(tok if tok and os.path.exists(tok) else None)
+    if not (tok and os.path.exists(tok)):
+        tok = f"./tmp/{lang}/tokenizer.yttm-model"
+    language = get_language(tok if os.path.exists(tok) else None)
     model = Transducer(eng, language)
     sr = conf.get("sr", 16000) if conf else 16000
     ch = conf.get("channels", 1) if conf else 1
