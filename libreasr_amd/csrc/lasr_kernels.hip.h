@@ -848,6 +848,15 @@ __device__ __forceinline__ void stage_mel_tables(const MelTables& t, const float
 // scratch z[512 + 8]) + untangle + power spectrum P[0..512].  v[m] = (x[2n], x[2n+1]) for n = j + 64 m on entry.
 // Contains block-wide barriers: EVERY wave of the workgroup must call it (the first barrier also publishes the
 // staged tables).
+// ordering of one wave's own LDS traffic: writes by some lanes, then reads of those addresses by other lanes of the SAME wave.
+// The LDS unit serves a wave's instructions in issue order; what is needed is that the compiler keeps the order and that
+// the writes have been issued (lgkmcnt) before the dependent reads are
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0), vmcnt / expcnt untouched
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ void fft1024_power(cf (&v)[8], float2* z, float* P, const float2* s_tw512, const float2* s_tw1024, int j) {
     dft8(v);
     __syncthreads();                                     // staged twiddles / filterbank visible
@@ -857,7 +866,7 @@ __device__ __forceinline__ void fft1024_power(cf (&v)[8], float2* z, float* P, c
         const cf u = cmul(v[k0], cf{tw.x, tw.y});
         z[k0 * 64 + j] = float2{u.x, u.y};
     }
-    __syncthreads();
+    wave_sync_lds();
     // ---- pass 2: thread (k0 = j>>3, b = j&7): DFT over a of u_k0[8a + b], twiddle W64^{b k1}
     {
         const int k0 = j >> 3, b = j & 7;
@@ -867,7 +876,7 @@ __device__ __forceinline__ void fft1024_power(cf (&v)[8], float2* z, float* P, c
             v[aa] = cf{q.x, q.y};
         }
         dft8(v);
-        __syncthreads();
+        wave_sync_lds();
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1) {
             const float2 tw = s_tw512[8 * b * k1];
@@ -875,7 +884,7 @@ __device__ __forceinline__ void fft1024_power(cf (&v)[8], float2* z, float* P, c
             z[k0 * 64 + k1 * 8 + b] = float2{u.x, u.y};
         }
     }
-    __syncthreads();
+    wave_sync_lds();
     // ---- pass 3: thread (k0, k1): DFT over b -> Z[k0 + 8 k1 + 64 k2]
     {
         const int k0 = j >> 3, k1 = j & 7;
@@ -885,11 +894,11 @@ __device__ __forceinline__ void fft1024_power(cf (&v)[8], float2* z, float* P, c
             v[b] = cf{q.x, q.y};
         }
         dft8(v);
-        __syncthreads();
+        wave_sync_lds();
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) z[k0 + 8 * k1 + 64 * k2] = float2{v[k2].x, v[k2].y};
     }
-    __syncthreads();
+    wave_sync_lds();
     // ---- real-FFT untangle + power: X[k] = (Z[k] + conj Z[512-k])/2 + W1024^k (Z[k] - conj Z[512-k])/(2i)
     for (int k = j; k <= 512; k += 64) {
         const float2 zk = z[k & 511];
@@ -901,7 +910,7 @@ __device__ __forceinline__ void fft1024_power(cf (&v)[8], float2* z, float* P, c
         const cf X = cadd(e, o);
         P[k] = X.x * X.x + X.y * X.y;
     }
-    __syncthreads();
+    wave_sync_lds();
 }
 // sparse HTK mel of the power spectrum + log(x + 1e-6): lane j takes filters j, j + 64, ..
 __device__ __forceinline__ void mel_log(const float* P, const MelTables& t, int n_mels, int j, float* out) {
