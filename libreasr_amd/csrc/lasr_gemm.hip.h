@@ -419,7 +419,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
 }
 
 // ------------------------------------------------------------------------------------------------
-// Epilogues.  A tile column of (gate g, unit uu) is g*U + uu.  Buffers that are A operands of another
+// Epilogues.  prefetch / run are force-inlined: left to itself hipcc emitted EpiNBRC<f32, non-table>::run out of line
+// (kernel arguments copied to scratch, a call, flat loads through the argument pointer: +2 % whole job when inlined).  A tile column of (gate g, unit uu) is g*U + uu.  Buffers that are A operands of another
 // GEMM (h, BN(h), the joint activation) hold Ops::elem; everything else is f32.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool any16(bool flag, int lane) {
@@ -475,7 +476,7 @@ struct EpiLSTM {
     __device__ static bool tile_active(const Args& a, int mt, int lane) { return (a.tile_mask >> mt) & 1ull; }
     __device__ static size_t hidx(const Args& a, int r, int u) { return PRED ? (size_t)r * a.H + u : Ops::aoff(r, u, a.MT); }
     template <int MTB>
-    __device__ static Pre prefetch(const Args& a, int tid, int jb, int mg, int n_act, const int* row_map) {
+    __device__ static __forceinline__ Pre prefetch(const Args& a, int tid, int jb, int mg, int n_act, const int* row_map) {
         constexpr int ROWS = MTB * 16;
         static_assert(ROWS * U <= 256, "at most one (row, unit) item per thread");
         Pre p;
@@ -508,7 +509,7 @@ struct EpiLSTM {
         return p;
     }
     template <int MTB, class Red>
-    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
+    __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
                                const Pre& p, int) {
         constexpr int ROWS = MTB * 16;
         if (tid >= ROWS * U) return;
@@ -570,7 +571,7 @@ struct EpiNBRC {
         float carry_h, carry_y, h, xz, xr, xg, rz, rr, rg, s, t;
     };
     template <int MTB>
-    __device__ static Pre prefetch(const Args& a, int tid, int jb, int mg, int n_act, const int* row_map) {
+    __device__ static __forceinline__ Pre prefetch(const Args& a, int tid, int jb, int mg, int n_act, const int* row_map) {
         constexpr int ROWS = MTB * 16;
         static_assert(ROWS * U == 256, "one (row, unit) item per thread");
         Pre p;
@@ -597,7 +598,7 @@ struct EpiNBRC {
         return p;
     }
     template <int MTB, class Red>
-    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
+    __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
                                const Pre& p, int) {
         constexpr int ROWS = MTB * 16;
         if (tid >= 256) return;
@@ -648,9 +649,9 @@ struct EpiLinear {
     }
     struct Pre {};
     template <int MTB>
-    __device__ static Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
+    __device__ static __forceinline__ Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
     template <int MTB, class Red>
-    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int, const int*, const Pre&,
+    __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int, const int*, const Pre&,
                                int nthr) {
         constexpr int ROWS = MTB * 16;
         for (int it = tid; it < ROWS * 16; it += nthr) {
@@ -699,9 +700,9 @@ struct EpiPPJ {
     };
     struct Pre {};
     template <int MTB>
-    __device__ static Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
+    __device__ static __forceinline__ Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
     template <int MTB, class Red>
-    __device__ static void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
+    __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
                                const Pre&, int nthr) {
         constexpr int ROWS = MTB * 16;
         const bool beam = a.W > 1;
