@@ -61,12 +61,13 @@ def golden_frontend():
     print("frontend:", {k: v.shape for k, v in out.items()})
 
 
-def golden_model(name, n_sec, n_streams, store_acts, lm_name=None):
+def golden_model(name, n_sec, n_streams, store_acts, lm_name=None, lm_int8=False):
     cfg = synth.model_cfg(name)
     sd = synth.synth_state_dict(cfg, seed=0)
     m = rf.ref_transducer(cfg, sd)
     if lm_name:      # config.py:143-157 attaches the LM to the model; LMFuser (lm.py:43-83) uses it in both decoders
-        m.lm = rf.ref_lm(synth.lm_cfg(lm_name), synth.synth_lm_state_dict(lm_name))
+        make = rf.ref_lm_int8 if lm_int8 else rf.ref_lm          # int8: what load_lm serves (lm.py:97)
+        m.lm = make(synth.lm_cfg(lm_name), synth.synth_lm_state_dict(lm_name))
     x_tfm, s_tfm, AT = rf.ref_transforms()
     pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
     out = {}
@@ -121,7 +122,13 @@ def golden_model(name, n_sec, n_streams, store_acts, lm_name=None):
             nb = sum(1 for v in extra["iters"] for _ in range(1))
             print(f"  {name} s{s}: T'={feats.shape[0]} offline tokens={len(toks)} "
                   f"evals={int(np.sum(extra['iters']))} stream tokens={len(y_all)} calls={len(per_chunk)}")
-    np.savez_compressed(os.path.join(OUT, f"model_{name}{'__' + lm_name if lm_name else ''}.npz"), **out)
+    if lm_name and lm_int8:      # a few raw LM outputs of the quantised reference LM, to pin the int8 emulation itself
+        with torch.no_grad():
+            lp, st = m.lm(torch.LongTensor([[5]]))
+            lp2, _ = m.lm(torch.LongTensor([[7]]), st)
+        out["lm_logp_tok5"] = lp.reshape(-1).numpy().astype(np.float32)
+        out["lm_logp_tok5_7"] = lp2.reshape(-1).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, f"model_{name}{'__' + lm_name if lm_name else ''}{'_int8' if lm_int8 else ''}.npz"), **out)
 
 
 def golden_flac():
@@ -164,6 +171,10 @@ if __name__ == "__main__":
         golden_model("tiny_soft", 3.0, 3, False, lm_name="tiny_lm")
         golden_model("tiny_lstm", 3.0, 2, False, lm_name="tiny_lm_untied")
         golden_model("cfg2", 3.0, 1, False, lm_name="lm768")
+    if "lm_int8" in which:                        # the LM as the reference serves it: int8 dynamic quantisation (lm.py:97)
+        golden_model("tiny_soft", 3.0, 3, False, lm_name="tiny_lm", lm_int8=True)
+        golden_model("tiny_lstm", 3.0, 2, False, lm_name="tiny_lm_untied", lm_int8=True)
+        golden_model("cfg2", 3.0, 1, False, lm_name="lm768", lm_int8=True)
     if "flac" in which:
         try:
             golden_flac()

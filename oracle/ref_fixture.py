@@ -198,6 +198,19 @@ class IdLang:
         return " ".join(str(int(i)) for i in ids if int(i) != 0)
 
 
+def ref_lm_int8(cfg, state_dict):
+    """The LM as load_lm serves it (lm.py:86-100): the reference's own maybe_quantize (utils.py:197-210 =
+    torch.quantization.quantize_dynamic({LSTM, Linear}, qint8)) applied to its LM class, on the installed torch."""
+    import warnings
+    lm = ref_lm(cfg, state_dict)
+    from libreasr.lib.utils import maybe_quantize
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        q = maybe_quantize(lm, debug=False)
+    assert "dynamic" in type(q.rnn).__module__, "quantize_dynamic did not convert the LSTM"
+    return q.eval()
+
+
 def ref_lm(cfg, state_dict):
     """The reference's LM class (lm.py:20-40), fp32, eval.  NOT quantised: load_lm (lm.py:86-100) runs
     torch.quantization.quantize_dynamic(int8) on it, whose numerics are un-vendored (fbgemm) -- the

@@ -243,12 +243,50 @@ def standardize(t, eps=1e-5):
     return (t / (t.std(ddof=1, dtype=F32) + F32(eps))).astype(F32)
 
 
-class OracleLM:
-    """LM.forward (lm.py:20-40) for one token per call, fp32 (the reference quantises it to int8
-    dynamically, lm.py:97 -- un-vendored numerics, not restated): Embedding -> nn.LSTM stack
-    (zero initial state) -> dropout(eval) -> Linear -> log_softmax."""
+def dq_choose_qparams(mn, mx, qmin=0, qmax=127):
+    """fbgemm ChooseQuantizationParams as torch's dynamic quantisation calls it (x86 / fbgemm engines, reduce_range:
+    7-bit activations): min / max widened to contain 0, scale in double -> float32, zero point nudged to an integer."""
+    mn, mx = min(float(mn), 0.0), max(float(mx), 0.0)
+    scale = (np.float64(mx) - np.float64(mn)) / (qmax - qmin)
+    if scale == 0.0 or np.isinf(1.0 / scale):
+        scale = 0.1
+    zp_min, zp_max = qmin - mn / scale, qmax - mx / scale
+    izp = zp_min if abs(qmin) + abs(mn / scale) < abs(qmax) + abs(mx / scale) else zp_max
+    zp = qmin if izp < qmin else qmax if izp > qmax else int(np.rint(izp))
+    return np.float32(scale), int(zp)
 
-    def __init__(self, sd):
+
+def dq_weight(w):
+    """quantize_dynamic's weight side (default_dynamic_qconfig: MinMaxObserver qint8 per_tensor_symmetric):
+    scale = max|w| / 127.5, zero point 0, q = clamp(rint(w * (1 / scale)), -128, 127)."""
+    w = np.asarray(w, F32)
+    sw = np.float32(max(float(np.abs(w).max()), 0.0) / 127.5)
+    if sw < np.finfo(np.float32).eps:
+        sw = np.float32(np.finfo(np.float32).eps)      # MinMaxObserver clamps the scale to eps
+    q = np.clip(np.rint(w * (np.float32(1.0) / sw)), -128, 127).astype(np.int32)
+    return q, sw
+
+
+def dq_linear(x, qw, sw, b):
+    """quantized::linear_dynamic(x, packed, reduce_range=True) for one row: per-call activation quantisation,
+    int32 accumulation, dequantisation, float bias."""
+    x = np.asarray(x, F32).reshape(-1)
+    s, zp = dq_choose_qparams(x.min(), x.max())
+    qx = np.clip(np.rint(x * (np.float32(1.0) / s)) + zp, 0, 127).astype(np.int64)
+    acc = (qx - zp) @ qw.astype(np.int64).T
+    return (acc.astype(F32) * np.float32(s * sw) + np.asarray(b, F32)).astype(F32)
+
+
+class OracleLM:
+    """LM.forward (lm.py:20-40) for one token per call: Embedding -> nn.LSTM stack (zero initial state) ->
+    dropout(eval) -> Linear -> log_softmax.  fp32, or with `quantized=True` what load_lm serves (lm.py:97
+    maybe_quantize -> utils.py:197-210 torch.quantization.quantize_dynamic({LSTM, Linear}, qint8)): every LSTM gate
+    matmul and the output layer become dynamically quantised int8 GEMVs (dq_linear); the Embedding stays fp32.  fbgemm is
+    un-vendored: the int8 numerics are those of the INSTALLED torch (2.10, x86 engine), checked against it in
+    tests/test_oracle.py (torch 1.6's differ in details: parity unpinned against the pinned version)."""
+
+    def __init__(self, sd, quantized=False):
+        self.quantized = quantized
         self.embed = np.asarray(sd["embed.weight"], F32)
         self.layers = []
         l = 0
@@ -256,20 +294,32 @@ class OracleLM:
             self.layers.append({k: np.asarray(sd[f"rnn.{k[:-3]}_l{l}"], F32)
                                 for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")})
             l += 1
-        self.w = np.asarray(sd["linear.weight"], F32)
+        self.w = np.asarray(sd["linear.weight"] if "linear.weight" in sd else sd["embed.weight"], F32)
         self.b = np.asarray(sd["linear.bias"], F32)
         self.H = self.layers[0]["weight_hh_l0"].shape[1]
+        if quantized:
+            self.q = [(dq_weight(p["weight_ih_l0"]), dq_weight(p["weight_hh_l0"])) for p in self.layers]
+            self.qo = dq_weight(self.w)
+
+    def _qstep(self, x, h, c, l):
+        p, ((qi, si), (qh, sh)) = self.layers[l], self.q[l]
+        g = dq_linear(x[0], qi, si, p["bias_ih_l0"]) + dq_linear(h[0], qh, sh, p["bias_hh_l0"])
+        H = self.H
+        i, f, gg, o = sigmoid(g[:H]), sigmoid(g[H:2 * H]), np.tanh(g[2 * H:3 * H]).astype(F32), sigmoid(g[3 * H:])
+        c2 = (f * c[0] + i * gg).astype(F32)
+        h2 = (o * np.tanh(c2)).astype(F32)
+        return h2[None], c2[None]
 
     def step(self, tok, state):
         x = self.embed[np.asarray([tok])]
         if state is None:
             state = [(np.zeros((1, self.H), F32), np.zeros((1, self.H), F32)) for _ in self.layers]
         new = []
-        for p, (h, c) in zip(self.layers, state):
-            h, c = lstm_step(x, h, c, p)
+        for l, (p, (h, c)) in enumerate(zip(self.layers, state)):
+            h, c = self._qstep(x, h, c, l) if self.quantized else lstm_step(x, h, c, p)
             new.append((h, c))
             x = h
-        z = (x @ self.w.T + self.b).astype(F32)[0]
+        z = dq_linear(x[0], self.qo[0], self.qo[1], self.b) if self.quantized else (x @ self.w.T + self.b).astype(F32)[0]
         m = z.max()
         lp = ((z - m) - np.log(np.exp(z - m).sum(dtype=F32))).astype(F32)
         return lp, new

@@ -169,3 +169,33 @@ def test_lm_through_the_facade(golden_dir):
         last = y
     assert last == list(g["st_tokens_2"])
     asr.engine.close()
+
+
+@pytest.mark.parametrize("name,lm_name,n_sec,n_streams", CASES)
+def test_fp32_lm_against_the_int8_served_reference(name, lm_name, n_sec, n_streams, golden_dir):
+    """The reference SERVES its LM int8-dynamically-quantised (load_lm, lm.py:97); the engine runs the LM in fp32.  Goldens
+    from the reference's own maybe_quantize'd LM (oracle/ref_fixture.py:ref_lm_int8; the oracle's int8 emulation reproduces
+    them exactly, tests/test_oracle.py).  The quantisation noise enters the decision through 0.1 x the standardised LM
+    log-probs: on these fixtures it flips no fused decision, so the fp32 engine must give the int8 reference's tokens."""
+    eng, m, cfg = engine(name, lm_name)
+    g = np.load(os.path.join(golden_dir, f"model_{name}__{lm_name}_int8.npz"))
+    pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
+    slots = [eng.open() for _ in range(n_streams)]
+    try:
+        eng.transcribe_pcm(slots, [pcm[i] for i in range(n_streams)])
+        for i, s in enumerate(slots):
+            assert eng.fetch(s)[0] == list(g[f"off_tokens_{i}"]), i
+        for s in slots:
+            eng.reset(s, 15)
+        chunks = [synth.stream_chunks(pcm[i], 1280, lead=1, tail=10) for i in range(n_streams)]
+        got = [[] for _ in range(n_streams)]
+        for k in range(len(chunks[0])):
+            eng.push(slots, np.stack([chunks[i][k] for i in range(n_streams)]))
+            if eng.step(slots):
+                for i, t in enumerate(eng.fetch_many(slots, 64)):
+                    got[i] += t
+        for i in range(n_streams):
+            assert got[i] == list(g[f"st_tokens_{i}"]), i
+    finally:
+        for s in slots:
+            eng.close_slot(s)

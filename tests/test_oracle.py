@@ -149,6 +149,41 @@ def test_lm_shallow_fusion_matches_reference(golden_dir, name, lm_name, n_sec, n
         assert changed > 0        # the fixture is only worth something if the LM overrides tokens
 
 
+@pytest.mark.parametrize("name,lm_name,n_sec,n_streams", LM_CASES)
+def test_int8_lm_shallow_fusion_matches_reference(golden_dir, name, lm_name, n_sec, n_streams):
+    """The LM as the reference SERVES it (load_lm, lm.py:97: maybe_quantize = quantize_dynamic({LSTM, Linear}, qint8)): goldens
+    from the reference's own maybe_quantize on its LM class (oracle/ref_fixture.py:ref_lm_int8, installed torch 2.10, x86
+    engine).  The oracle's emulation (dq_linear: 7-bit per-call activations, int8 per-tensor weights) must reproduce the
+    quantised LM's raw outputs and every fused decision."""
+    g = load(golden_dir, f"model_{name}__{lm_name}_int8.npz")
+    cfg = synth.model_cfg(name)
+    m = O.OracleTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
+    lm = O.OracleLM(synth.synth_lm_state_dict(lm_name), quantized=True)
+    lp, st = lm.step(5, None)
+    np.testing.assert_allclose(lp, g["lm_logp_tok5"], atol=2e-4, rtol=0)
+    lp2, _ = lm.step(7, st)
+    np.testing.assert_allclose(lp2, g["lm_logp_tok5_7"], atol=2e-4, rtol=0)
+    m.lm = lm
+    pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
+    g32 = load(golden_dir, f"model_{name}__{lm_name}.npz")
+    differs = 0
+    for s in range(n_streams):
+        feats = O.features_offline(pcm[s])
+        toks, neg_logp, score, iters = m.decode_greedy(feats)
+        assert toks == list(g[f"off_tokens_{s}"])
+        assert iters == list(g[f"off_iters_{s}"])
+        differs += list(g[f"off_tokens_{s}"]) != list(g32[f"off_tokens_{s}"])
+        fe, dec = O.StreamFrontend(), m.stream_decoder()
+        counts = []
+        for c in synth.stream_chunks(pcm[s], 1280, lead=1, tail=10):
+            o = fe.push(c)
+            if o is not None:
+                counts.append(len(dec.step(o)))
+        assert dec.y == list(g[f"st_tokens_{s}"])
+        assert counts == list(g[f"st_counts_{s}"])
+    print(f"{name}/{lm_name}: int8 LM changes the offline transcript of {differs} of {n_streams} utterances vs the fp32 LM")
+
+
 def test_resample_restatement_properties():
     """kaldi LinearResample as used by torchaudio 0.6.0 transforms.Resample (un-vendored: parity unpinned).
     Output length rule, unit gain, tone preservation, and linearity."""
