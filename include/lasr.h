@@ -234,6 +234,12 @@ typedef struct {
 } lasr_lm_desc;
 size_t lasr_lm_weight_count(const lasr_lm_desc* d);
 int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, size_t n_weights);
+/* The same LM as the reference SERVES it: load_lm (lm.py:86-100) applies maybe_quantize (utils.py:197-210) =
+ * torch.quantization.quantize_dynamic({nn.LSTM, nn.Linear}, qint8).  Same weight blob; the engine quantises the weights
+ * (per tensor, symmetric int8) and, per row and per matmul at run time, the activations (7 bits), accumulates in exact
+ * integer arithmetic and dequantises -- the numerics of the installed torch's x86 / fbgemm engine (un-vendored upstream;
+ * restated in oracle/rnnt_oracle.py and pinned there to the reference's own quantised LM).  embed, hidden <= 1024. */
+int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, size_t n_weights);
 
 /* Roofline micro-benchmark of the dominant kernel (one encoder LSTM-cell launch: all rows active,
  * layer `layer`), `iters` back-to-back launches timed with HIP events on the ctx stream.

@@ -73,6 +73,7 @@ SYMBOLS = [
     ("lasr_cell_prof_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     ("lasr_lm_weight_count", C.c_size_t, [_P]),
     ("lasr_attach_lm", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("lasr_attach_lm_int8", C.c_int, [_P, _P, _P, C.c_size_t]),
 ]
 
 

@@ -135,6 +135,15 @@ struct lasr_ctx {
         int par = 0;
         float *raw = nullptr, *lmz = nullptr;          // [M][V] output-layer logits / standardised log-probs
         int* valid = nullptr;
+        // int8-served form (lasr_attach_lm_int8): integer-valued bf16 weights (row-major tiles of 16 outputs, K padded to 32),
+        // per-tensor weight scales, separate biases; fp32 state (h[0][l] == h[1][l] row-major [M][H], cst[l] as [H][M])
+        bool q8 = false;
+        std::vector<void*> qWih, qWhh; void* qWout = nullptr;
+        std::vector<float> s_ih, s_hh; float s_out = 0.f;
+        std::vector<float*> b_ih, b_hh;
+        std::vector<int> Kp_ih; int Kp_h = 0;          // padded K of the x side per layer / of every H-wide operand
+        float *gx = nullptr, *gh = nullptr;            // [M][4H]
+        unsigned short* qa = nullptr; float* sx = nullptr;   // quantised activations [M][Kmax], per-row scales [M]
     } lm;
 
     // resampling filters per client sample rate (lasr_resample)

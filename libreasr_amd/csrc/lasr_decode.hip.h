@@ -27,7 +27,7 @@ int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3, bool plain_rows = fals
     hipLaunchKernelGGL(k_reset_rows, dim3(grid1((size_t)c->M * c->d.hidden)), dim3(256), 0, c->stream, a);
     if (c->lm.on && (mask & 2)) {      // LM state lives on the decode side, like the predictor's
         LmResetArgs la{};
-        la.what = c->dc.what; la.M = c->M; la.H = c->lm.H; la.L = c->lm.L; la.bf = c->bf; la.lm_valid = c->lm.valid;
+        la.what = c->dc.what; la.M = c->M; la.H = c->lm.H; la.L = c->lm.L; la.bf = c->lm.q8 ? 0 : c->bf; la.lm_valid = c->lm.valid;
         for (int l = 0; l < c->lm.L; ++l) { la.h[l] = c->lm.h[c->lm.par][l]; la.c[l] = c->lm.cst[l]; }
         hipLaunchKernelGGL(k_lm_reset, dim3(grid1((size_t)c->M * c->lm.H)), dim3(256), 0, c->stream, la);
     }

@@ -1440,8 +1440,101 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
     c->graphs.clear();
     for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
     c->cgraphs.clear();
-    c->la = c->la_stream = c->la_offline = 1;   // the fused re-pick needs the LM state of exactly this decision
+    c->la = c->la_stream = c->la_offline = c->la_sync = 1;   // the fused re-pick needs the LM state of exactly this decision
     c->ds.lmz = m.lmz; c->ds.lm_valid = m.valid; c->ds.lm_alpha = m.alpha; c->ds.lm_theta = m.theta; c->ds.lm_min = m.min_val;
+    m.on = true;
+    return LASR_OK;
+}
+
+// The LM as the reference serves it: load_lm (lm.py:86-100) runs maybe_quantize (utils.py:197-210) =
+// torch.quantization.quantize_dynamic({nn.LSTM, nn.Linear}, qint8) on it.  Same blob as lasr_attach_lm; the weights are
+// quantised here (per tensor, symmetric: scale = max|w| / 127.5, q = clamp(rint(w * (1 / scale)), -128, 127)), activations per
+// row and per matmul at run time (k_lm_quant).  Numerics of the installed torch's x86 / fbgemm engine (restated in
+// oracle/rnnt_oracle.py:dq_linear and pinned to the reference's quantised LM there).
+int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, size_t n_weights) {
+    if (!c) return LASR_EINVAL;
+    if (c->lm.on) return fail(c, LASR_ESTATE, "an LM is already attached");
+    if (c->W > 1) return fail(c, LASR_ESTATE, "LM shallow fusion is implemented for greedy decoding (beam = 1)");
+    if (!d || !weights || n_weights != lasr_lm_weight_count(d) || n_weights == 0)
+        return fail(c, LASR_EINVAL, "LM weight blob has %zu floats, expected %zu", n_weights, d ? lasr_lm_weight_count(d) : (size_t)0);
+    if (d->vocab != c->d.vocab) return fail(c, LASR_EINVAL, "LM vocabulary %d != model vocabulary %d", d->vocab, c->d.vocab);
+    if (d->vocab > 4096 || d->vocab % 16) return fail(c, LASR_EINVAL, "LM fusion keeps a row's log-probs in registers: vocab <= 4096, multiple of 16");
+    if (d->hidden % 4 || d->hidden > 1024 || d->embed > 1024 || d->embed < 1 || d->layers < 1 || d->layers > 8)
+        return fail(c, LASR_EINVAL, "int8 LM: hidden a multiple of 4, embed / hidden <= 1024 (exact integer accumulation), 1..8 layers");
+    RC(require_idle(c));
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    lasr_ctx::LM& m = c->lm;
+    const int V = d->vocab, E = d->embed, H = d->hidden, L = d->layers, M = c->M;
+    m.E = E; m.H = H; m.L = L; m.alpha = d->alpha; m.theta = d->theta; m.min_val = d->min_val;
+    auto pad32 = [](int k) { return (k + 31) / 32 * 32; };
+    m.Kp_h = pad32(H);
+    Reader rd{weights, n_weights};
+    const float* embed = rd.take((size_t)V * E);
+    // one quantised matrix [N][K] -> integer-valued bf16 tiles (16 outputs x padded K), its scale
+    auto quantise = [&](const float* w, int N, int K, void** dev, float* scale) -> int {
+        float amax = 0.f;
+        for (size_t i = 0; i < (size_t)N * K; ++i) amax = std::max(amax, std::fabs(w[i]));
+        float sw = (float)((double)amax / 127.5);
+        if (sw < 1.1920928955078125e-07f) sw = 1.1920928955078125e-07f;           // MinMaxObserver: scale >= eps
+        const float inv = 1.0f / sw;
+        const int Kp = pad32(K);
+        Packed pk;
+        pack_tiles(pk, 1, N / 16, Kp, [&](int t, int ui, int k) {
+            if (k >= K) return 0.f;
+            const float q = std::nearbyint(w[(size_t)(16 * t + ui) * K + k] * inv);
+            return std::min(127.f, std::max(-128.f, q));
+        });
+        *scale = sw;
+        return upload_packed(c, dev, pk);
+    };
+    m.cells.assign(L, Cell{});
+    m.qWih.assign(L, nullptr); m.qWhh.assign(L, nullptr); m.s_ih.assign(L, 0.f); m.s_hh.assign(L, 0.f);
+    m.b_ih.assign(L, nullptr); m.b_hh.assign(L, nullptr); m.Kp_ih.assign(L, 0);
+    for (int l = 0; l < L; ++l) {
+        const int I = l == 0 ? E : H;
+        const float* wih = rd.take((size_t)4 * H * I); const float* whh = rd.take((size_t)4 * H * H);
+        const float* bih = rd.take(4 * H); const float* bhh = rd.take(4 * H);
+        if (!bhh) return fail(c, LASR_EINVAL, "LM weight blob too short");
+        m.Kp_ih[l] = pad32(I);
+        RC(quantise(wih, 4 * H, I, &m.qWih[l], &m.s_ih[l]));
+        RC(quantise(whh, 4 * H, H, &m.qWhh[l], &m.s_hh[l]));
+        RC(upload(c, &m.b_ih[l], bih, 4 * H)); RC(upload(c, &m.b_hh[l], bhh, 4 * H));
+    }
+    const float* wout = rd.take((size_t)V * H); const float* bout = rd.take(V);
+    if (!bout || rd.left != 0) return fail(c, LASR_EINVAL, "LM weight blob layout mismatch");
+    RC(quantise(wout, V, H, &m.qWout, &m.s_out));
+    RC(upload(c, &m.bout, bout, V));
+    const int Kmax = std::max(m.Kp_h, m.Kp_ih[0]);
+    {   // layer-0 input table: tab[v] = linear_dynamic(embed[v]; W_ih0) + b_ih0 -- a pure function of the token, quantisation included
+        float* emb_dev = nullptr; unsigned short* qa = nullptr; float* sx = nullptr;
+        RC(upload(c, &emb_dev, embed, (size_t)V * E));
+        RC(dalloc(c, &qa, (size_t)V * m.Kp_ih[0])); RC(dalloc(c, &sx, V));
+        RC(dalloc(c, &m.cells[0].tab, (size_t)V * 4 * H));
+        lm_q_gemv(c, emb_dev, E, E, m.Kp_ih[0], m.qWih[0], m.s_ih[0], m.b_ih[0], m.cells[0].tab, 4 * H, V, qa, sx);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        dfree(c, emb_dev); dfree(c, qa); dfree(c, sx);
+    }
+    for (int p = 0; p < 2; ++p) m.h[p].resize(L);
+    m.y.assign(L, nullptr); m.cst.resize(L);
+    for (int l = 0; l < L; ++l) {
+        float* h = nullptr;
+        RC(dalloc(c, &h, (size_t)M * H)); HIPCHK(c, hipMemset(h, 0, sizeof(float) * (size_t)M * H));
+        m.h[0][l] = m.h[1][l] = h;                              // row-local in-place update: no ping-pong
+        RC(dalloc(c, &m.cst[l], (size_t)M * H)); HIPCHK(c, hipMemset(m.cst[l], 0, sizeof(float) * (size_t)M * H));
+    }
+    RC(dalloc(c, &m.gx, (size_t)M * 4 * H)); RC(dalloc(c, &m.gh, (size_t)M * 4 * H));
+    RC(dalloc(c, &m.qa, (size_t)M * Kmax)); RC(dalloc(c, &m.sx, M));
+    RC(dalloc(c, &m.raw, (size_t)M * V)); RC(dalloc(c, &m.lmz, (size_t)M * V)); RC(dalloc(c, &m.valid, M));
+    HIPCHK(c, hipMemset(m.lmz, 0, sizeof(float) * (size_t)M * V)); HIPCHK(c, hipMemset(m.valid, 0, sizeof(int) * M));
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);   // decode groups change shape
+    c->graphs.clear();
+    for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
+    c->cgraphs.clear();
+    c->la = c->la_stream = c->la_offline = c->la_sync = 1;   // the fused re-pick needs the LM state of exactly this decision
+    c->ds.lmz = m.lmz; c->ds.lm_valid = m.valid; c->ds.lm_alpha = m.alpha; c->ds.lm_theta = m.theta; c->ds.lm_min = m.min_val;
+    m.q8 = true;
     m.on = true;
     return LASR_OK;
 }

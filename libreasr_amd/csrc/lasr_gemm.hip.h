@@ -636,6 +636,8 @@ struct EpiLinear {
         const int* ring_base; // optional: GEMM row (t*M + r) is written to row ((ring_base[r] + t) % ring)*M + r
         int ring;
         int W;                // beam search: row r belongs to stream r / W (t_idx, T_row are per stream)
+        const float* row_scale;   // optional (int8-served LM): out = acc * (row_scale[r] * w_scale) + bias
+        float w_scale;
     };
     __device__ static bool row_on(const Args& a, int r) {
         if (r >= a.n_rows) return false;
@@ -664,7 +666,9 @@ struct EpiLinear {
                 const int t = r / a.M, q = r - t * a.M;
                 orow = (size_t)((a.ring_base[q] + t) % a.ring) * a.M + q;
             }
-            a.out[orow * a.ldo + n] = red.sum(row, col) + (a.bias ? a.bias[n] : 0.f);
+            float v = red.sum(row, col);
+            if (a.row_scale) v = __fmul_rn(v, __fmul_rn(a.row_scale[r], a.w_scale));     // dequantise, then the float bias (no FMA)
+            a.out[orow * a.ldo + n] = __fadd_rn(v, a.bias ? a.bias[n] : 0.f);
         }
     }
 };

@@ -525,6 +525,63 @@ __global__ void k_lm_reset(const LmResetArgs a) {
     }
 }
 
+// ---- LM served as the reference serves it (load_lm, lm.py:97: quantize_dynamic({LSTM, Linear}, qint8)): every gate matmul
+// and the output layer are dynamically quantised int8 GEMVs.  Per row (= per call of the batch-1 reference):
+//   (scale, zp) = ChooseQuantizationParams(min(x, 0), max(x, 0), 0, 127)      7-bit activations (reduce_range)
+//   q = clamp(rint(x * (1 / scale)) + zp, 0, 127);   acc = sum_k (q_k - zp) * qw[n][k]   (int32);   y = acc * (scale * sw) + b
+// (q - zp) and the int8 weights are small integers: stored as bf16 they are exact, and so is their f32-accumulated MFMA
+// dot product below K = 1032, i.e. the integer arithmetic of fbgemm is reproduced bit for bit by the bf16 GEMM core.
+// One workgroup per row; dst row stride ldd >= K (columns [K, ldd) are zero padding up to the 32-wide MFMA chunk).
+__global__ __launch_bounds__(256) void k_lm_quant(const float* __restrict__ src, int lds, int K, unsigned short* __restrict__ dst,
+                                                  int ldd, float* __restrict__ scale_out) {
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* x = src + (size_t)r * lds;
+    float mn = 0.f, mx = 0.f;                                  // the range always contains 0
+    for (int k = tid; k < K; k += 256) { const float v = x[k]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    __shared__ float smn[4], smx[4], sqp[2];
+    if (lane == 0) { smn[w] = mn; smx[w] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        double scale = ((double)mx - (double)mn) / 127.0;
+        if ((float)scale == 0.f || isinf(1.0f / (float)scale)) scale = 0.1;
+        const double zmin = 0.0 - (double)mn / scale, zmax = 127.0 - (double)mx / scale;
+        const double emin = fabs((double)mn / scale), emax = 127.0 + fabs((double)mx / scale);
+        const double izp = emin < emax ? zmin : zmax;
+        const float zp = izp < 0.0 ? 0.f : izp > 127.0 ? 127.f : (float)rint(izp);
+        sqp[0] = (float)scale; sqp[1] = zp;
+        scale_out[r] = (float)scale;
+    }
+    __syncthreads();
+    const float inv = 1.0f / sqp[0], zp = sqp[1];
+    unsigned short* d = dst + (size_t)r * ldd;
+    for (int k = tid; k < ldd; k += 256) {
+        float q = 0.f;
+        if (k < K) q = fminf(fmaxf(rintf(__fmul_rn(x[k], inv)) + zp, 0.f), 127.f) - zp;     // an integer in [-127, 127]
+        d[k] = f32_to_bf16(q);
+    }
+}
+
+// LSTM cell of the int8-served LM for the rows that emitted: gates = (layer 0: tab[token] | x-side GEMV) + h-side GEMV (each
+// already dequantised + its bias, torch gate order i, f, g, o); fp32 state, h row-major [M][H], c [H][M].
+__global__ __launch_bounds__(256) void k_lm_cell_q(const float* __restrict__ gx, const float* __restrict__ tab, const int* __restrict__ token,
+                                                   const float* __restrict__ gh, const int* __restrict__ emit, float* __restrict__ h,
+                                                   float* __restrict__ c, int H, int M) {
+    const int r = blockIdx.x;
+    if (!emit[r]) return;
+    const float* a = tab ? tab + (size_t)token[r] * 4 * H : gx + (size_t)r * 4 * H;
+    const float* b = gh + (size_t)r * 4 * H;
+    for (int u = threadIdx.x; u < H; u += 256) {
+        const float gi = a[u] + b[u], gf = a[H + u] + b[H + u], gg = a[2 * H + u] + b[2 * H + u], go = a[3 * H + u] + b[3 * H + u];
+        const float c2 = sigmoid_(gf) * c[(size_t)u * M + r] + sigmoid_(gi) * tanhf(gg);
+        c[(size_t)u * M + r] = c2;
+        h[(size_t)r * H + u] = sigmoid_(go) * tanhf(c2);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Beam search (the reference has none -- the spec is oracle/rnnt_oracle.py:_beam_frame).
 // Rows are hypothesis slots, W per stream (row = stream * W + slot).  One selection round per decode

@@ -78,12 +78,13 @@ class Engine:
 
     lm_cfg = None          # set by attach_lm
 
-    def attach_lm(self, lm_state_dict, alpha=0.1, theta=1.0, min_val=-10.0):
-        """LM shallow fusion (lm.py LM / LMFuser; constants lm.py:13-15).  fp32 / bf16 operands like the
-        model; the reference's int8 dynamic quantisation of the LM is not reproduced."""
+    def attach_lm(self, lm_state_dict, alpha=0.1, theta=1.0, min_val=-10.0, int8=False):
+        """LM shallow fusion (lm.py LM / LMFuser; constants lm.py:13-15).  int8=False: fp32 / bf16 operands like the
+        model; int8=True: the LM as the reference serves it (load_lm -> quantize_dynamic qint8, lm.py:97)."""
         cfg, blob = flatten_lm_state_dict(lm_state_dict)
         d = N.LmDesc(cfg["vocab"], cfg["embed"], cfg["hidden"], cfg["layers"], alpha, theta, min_val)
-        self._chk(self.lib.lasr_attach_lm(self.ctx, C.byref(d), blob.ctypes.data_as(C.c_void_p), blob.size))
+        fn = self.lib.lasr_attach_lm_int8 if int8 else self.lib.lasr_attach_lm
+        self._chk(fn(self.ctx, C.byref(d), blob.ctypes.data_as(C.c_void_p), blob.size))
         self.lm_cfg = cfg
 
     # ------------------------------------------------------------------ plumbing

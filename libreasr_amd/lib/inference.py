@@ -40,7 +40,7 @@ def load_lm_state_dict(conf, synthetic_lm=None):
 
 
 def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_streams=16, device=0,
-               synthetic_lm=None, dtype="f32", beam=1):
+               synthetic_lm=None, dtype="f32", beam=1, lm_int8=True):
     torch.set_num_threads(2)                # inference.py:21
     conf, cfg, sd = {}, None, None
     if os.path.exists(config_path):
@@ -64,7 +64,7 @@ def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_st
         except Exception:
             print("[LM] Failed to load.")
     if lm_sd is not None and beam == 1:
-        eng.attach_lm(lm_sd)
+        eng.attach_lm(lm_sd, int8=lm_int8)      # lm_int8: as load_lm serves it (maybe_quantize, lm.py:97); False: fp32 / bf16 LM
         print("[LM] loaded.")
     # tokenizer: the configured file (testing.yaml:153-154, per-language override :320-321), else where the model archive
     # puts it (model_utils.py:31-47: <lang>/tokenizer.yttm-model under ./tmp)

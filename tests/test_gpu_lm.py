@@ -15,19 +15,19 @@ CASES = [("tiny_soft", "tiny_lm", 3.0, 3), ("tiny_lstm", "tiny_lm_untied", 3.0, 
 _ENGINES = {}
 
 
-def engine(name, lm_name, dtype="f32"):
+def engine(name, lm_name, dtype="f32", int8=False):
     import __graft_entry__ as graft
     from libreasr_amd.engine import Engine
-    key = (name, lm_name, dtype)
+    key = (name, lm_name, dtype, int8)
     if key not in _ENGINES:
         graft.build()
         cfg = synth.model_cfg(name)
         sd = synth.synth_state_dict(cfg, seed=0)
         lsd = synth.synth_lm_state_dict(lm_name)
         eng = Engine(sd, cfg, max_streams=8, dtype=dtype)
-        eng.attach_lm(lsd)
+        eng.attach_lm(lsd, int8=int8)
         m = O.OracleTransducer(sd, cfg, operand=dtype)
-        m.lm = O.OracleLM(lsd)
+        m.lm = O.OracleLM(lsd, quantized=int8)
         _ENGINES[key] = (eng, m, cfg)
     return _ENGINES[key]
 
@@ -199,3 +199,79 @@ def test_fp32_lm_against_the_int8_served_reference(name, lm_name, n_sec, n_strea
     finally:
         for s in slots:
             eng.close_slot(s)
+
+
+@pytest.mark.parametrize("name,lm_name,n_sec,n_streams", CASES)
+def test_int8_lm_engine_matches_the_int8_served_reference(name, lm_name, n_sec, n_streams, golden_dir):
+    """lasr_attach_lm_int8: the LM quantised as load_lm does (quantize_dynamic qint8), integer arithmetic on the MFMA
+    (integer-valued bf16 operands, exact).  Tokens == the goldens of the reference's own quantised LM, offline and streaming;
+    pipelined protocol == the oracle's int8 emulation per stream."""
+    eng, m, cfg = engine(name, lm_name, int8=True)
+    g = np.load(os.path.join(golden_dir, f"model_{name}__{lm_name}_int8.npz"))
+    pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
+    slots = [eng.open() for _ in range(n_streams)]
+    try:
+        eng.transcribe_pcm(slots, [pcm[i] for i in range(n_streams)])
+        for i, s in enumerate(slots):
+            toks, neg_logp, _ = eng.fetch(s)
+            assert toks == list(g[f"off_tokens_{i}"]), i
+            ref = float(g[f"off_neglogp_{i}"])
+            assert abs(neg_logp - ref) < 1e-2 * max(1.0, abs(ref))
+        for s in slots:
+            eng.reset(s, 15)
+        chunks = [synth.stream_chunks(pcm[i], 1280, lead=1, tail=10) for i in range(n_streams)]
+        got = [[] for _ in range(n_streams)]
+        counts = [[] for _ in range(n_streams)]
+        for k in range(len(chunks[0])):
+            eng.push(slots, np.stack([chunks[i][k] for i in range(n_streams)]))
+            if eng.step(slots):
+                for i, t in enumerate(eng.fetch_many(slots, 512)):
+                    got[i] += t
+                    counts[i].append(len(t))
+        for i in range(n_streams):
+            assert got[i] == list(g[f"st_tokens_{i}"]), i
+            assert counts[i] == list(g[f"st_counts_{i}"])
+        # pipelined protocol on fresh audio against the oracle's emulation
+        for s in slots:
+            eng.reset(s, 15)
+        pcm2 = synth.synth_pcm(n_streams, 16000 * 2, seed=99)
+        chunks = [synth.stream_chunks(pcm2[i], 1280, lead=1, tail=6) for i in range(n_streams)]
+        got = [[] for _ in range(n_streams)]
+        for k in range(len(chunks[0])):
+            eng.push(slots, np.stack([chunks[i][k] for i in range(n_streams)]))
+            eng.submit(slots)
+            if eng.pending() >= 3 and eng.wait():
+                for i, t in enumerate(eng.fetch_many(slots, 512)):
+                    got[i] += t
+        while eng.pending():
+            if eng.wait():
+                for i, t in enumerate(eng.fetch_many(slots, 512)):
+                    got[i] += t
+        for i in range(n_streams):
+            fe, dec = O.StreamFrontend(), m.stream_decoder()
+            for ch in chunks[i]:
+                o = fe.push(ch)
+                if o is not None:
+                    dec.step(o)
+            assert got[i] == dec.y, (i, got[i][:20], dec.y[:20])
+    finally:
+        for s in slots:
+            eng.close_slot(s)
+
+
+def test_int8_lm_is_not_the_fp32_lm():
+    """An utterance on which the quantisation noise DOES flip a fused re-pick (found by a seed search on the oracle): the int8
+    engine must follow the oracle's int8 emulation, the fp32 engine the fp32 LM, and the two transcripts differ."""
+    pcm = synth.synth_pcm(1, 16000 * 3, seed=328)[0]
+    feats = O.features_offline(pcm)
+    out = {}
+    for int8 in (False, True):
+        eng, m, cfg = engine("tiny_soft", "tiny_lm", int8=int8)
+        s = eng.open()
+        try:
+            eng.transcribe_pcm([s], [pcm])
+            out[int8] = eng.fetch(s)[0]
+        finally:
+            eng.close_slot(s)
+        assert out[int8] == m.decode_greedy(feats)[0], int8
+    assert out[False] != out[True]
