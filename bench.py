@@ -345,7 +345,7 @@ def main():
             json.dump({"marks": eng.trace_read(), "elapsed_us": 1e6 * elapsed, "chunks": K}, f)
         eng.trace(False)
     cell_us_total, cell_launches = eng.cell_prof_read()
-    cell_kernel_us_total, cell_kernel_launches = eng.cell_prof_kernel() if not args.trace else (0.0, 0)
+    cell_kernel_us_total, cell_kernel_launches, cell_kernel_cells = eng.cell_prof_kernel() if not args.trace else (0.0, 0, 0)
     eng.cell_prof(False)
     eng.set_profiling(False)
 
@@ -364,6 +364,11 @@ def main():
         # the kernel's own duration (max exit - min entry of the device wall clock over its workgroups): what a kernel trace
         # (rocprofv3 --kernel-trace --stats) reports as the average duration of this kernel
         cell_us = cell_kernel_us_total / cell_kernel_launches if cell_kernel_launches else cell_us_ev
+        # the encoder pass is a layer wavefront: a launch holds the independent cells of one anti-diagonal (1.6 on average
+        # for 4 layers x 2 frames); algorithmic work per launch = cells per launch x the mean cell
+        cells_per_launch = cell_kernel_cells / cell_kernel_launches if cell_kernel_launches else 1.0
+        flops_mean *= cells_per_launch
+        wbytes_mean *= cells_per_launch
         achieved = flops_mean / (cell_us * 1e-6) / 1e12
         traffic = None                      # HBM bytes per launch from the committed PMC passes (profiles/)
         try:
@@ -373,6 +378,8 @@ def main():
                     traffic = pm["hbm_bytes_per_launch"] if not bf else pm.get("bf16", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+        if traffic is not None:
+            traffic = int(traffic * cells_per_launch)        # the PMC passes measured a one-cell launch
         job_tflops = audio_total / elapsed_max * 12.5 * flop_per_frame(cfg, n_tok) / 1e12
         out = {
             "metric": METRIC,
@@ -406,7 +413,10 @@ def main():
                                         "decode": round(float(np.mean(dec_ms)), 4) if dec_ms else None,
                                         "decode_iters": round(float(np.mean(iters)), 2) if iters else None},
             "tokens_per_frame": round(n_tok, 4) if args.beam == 1 else None,
-            "roofline": {"bound": "mfma", "kernel": f"k_gemm<EpiLSTM> (encoder LSTM cell, {B} rows, mean over the {L} layers)",
+            "roofline": {"bound": "mfma", "kernel": (f"k_gemm<EpiLSTM> (encoder LSTM cell, {B} rows, mean over the {L} layers)" if cells_per_launch <= 1.0 else
+                                                    f"k_gemm_multi<EpiLSTM> (encoder LSTM cells of one layer-wavefront diagonal, {B} rows; "
+                                                    f"{cells_per_launch:.2f} cells per launch on average, mean cell over the {L} layers)"),
+                         "cells_per_launch": round(cells_per_launch, 3),
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(cell_us, 3), "launches_timed": int(cell_kernel_launches or cell_launches),

@@ -261,8 +261,9 @@ int lasr_trace_read(lasr_ctx* c, double* us, int* tags, int cap, int* n);
 int lasr_cell_prof_read(lasr_ctx* c, double* us_total, long long* launches);
 /* ... and the kernels' own durations over the same period (at most 32768 launches): per cell launch, max exit - min
  * entry of the device's constant wall clock over the kernel's workgroups -- what a kernel trace reports as the kernel's
- * duration (no launch gaps, no event overhead).  Synchronises the device. */
-int lasr_cell_prof_kernel(lasr_ctx* c, double* us_total, long long* launches);
+ * duration (no launch gaps, no event overhead).  *cells (may be NULL) = LSTM cells those launches computed: the encoder
+ * pass runs as a layer wavefront, a launch holds the independent cells (l, t) of one anti-diagonal.  Synchronises the device. */
+int lasr_cell_prof_kernel(lasr_ctx* c, double* us_total, long long* launches, long long* cells);
 
 #ifdef __cplusplus
 }

@@ -213,6 +213,8 @@ struct lasr_ctx {
     static constexpr int NCELLSLOT = 1 << 15;
     unsigned long long* cp_slots = nullptr;   // device [NCELLSLOT][2]
     long long cp_slot_next = 0;
+    std::vector<unsigned char> cp_slot_cells;  // cells computed by the launch of slot i (layer-wavefront launches: up to 8)
+    int enc_wave = 0;               // encoder pass as a layer wavefront (cells of an anti-diagonal share a launch): default on for bf16; LASR_ENC_WAVE
     double cp_clock_mhz = 100.0;
 
     // stream timeline (lasr_trace): timestamped marks on the main and the decode stream of the pipelined protocol

@@ -75,6 +75,21 @@ void run_encoder(lasr_ctx* c, int T_max) {
         (void)hipEventRecord(c->cp_ev[cp_slot][0], c->stream);
     }
     tr_mark(c, 3, c->stream);
+    // layer wavefront: the cells (l, t) with l + t = d depend only on diagonal d - 1, so a diagonal is ONE launch
+    // (k_gemm_multi, up to NPMAX cells): L + T - 1 launches instead of L * T, and the per-launch fixed costs of a cell
+    // overlap its neighbours' K loops.  Cell (l, t) reads h parity par0 ^ (t & 1); all layers end on par0 ^ (T & 1).
+    if (c->enc_wave && L > 1 && T_max > 1) {
+        EncCellRef cells[NPMAX];
+        for (int d = 0; d < L + T_max - 1; ++d) {
+            int n = 0;
+            for (int l = std::min(d, L - 1); l >= 0 && d - l < T_max; --l) {
+                cells[n++] = EncCellRef{l, d - l};
+                if (n == NPMAX) { launch_enc_wave(c, cells, n, par0, mt_total); n = 0; }
+            }
+            if (n) launch_enc_wave(c, cells, n, par0, mt_total);
+        }
+        c->enc_par = par0 ^ (T_max & 1);
+    } else
     // layer-major order: every layer starts from parity par0 and toggles T_max times (enc_h[par][l] is
     // indexed by the parity at launch time, so all layers end on par0 ^ (T_max & 1))
     for (int l = 0; l < L; ++l) {

@@ -115,6 +115,10 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     {
         if (getenv("LASR_NO_GRAPH")) c->use_graphs = false;
         if (getenv("LASR_CELL_NW")) c->cell_nw = atoi(getenv("LASR_CELL_NW")) == 4 ? 4 : 8;
+        // encoder pass as a layer wavefront: bf16 cells are load-paced with idle MFMA time, two of them per CU overlap (streaming
+        // +4 %, offline +14 %); f32 cells are MFMA-paced, two per CU only contend (-4 %)
+        c->enc_wave = c->bf ? 1 : 0;
+        if (getenv("LASR_ENC_WAVE")) c->enc_wave = atoi(getenv("LASR_ENC_WAVE"));
         // decode-stream GEMMs (predictor cells, PPJ, logits): 4 waves per workgroup with f32 operands (next to the encoder cells
         // of the main stream fewer waves per CU interfere less: whole job +5 %), 8 with bf16 (4: -3 %)
         c->dec_nw_mask = c->bf ? 0 : 7;
@@ -1582,16 +1586,18 @@ int lasr_cell_prof(lasr_ctx* c, int on) {
         for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0ull; }
         HIPCHK(c, hipMemcpy(c->cp_slots, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
         c->cp_slot_next = 0;
+        c->cp_slot_cells.assign(lasr_ctx::NCELLSLOT, 0);
     }
     c->cell_prof = on != 0;
     return LASR_OK;
 }
 // the cell kernels' own durations since lasr_cell_prof(c, 1): per launch, max exit - min entry of the device's constant
 // wall clock over the kernel's workgroups (comparable with a kernel trace's duration column)
-int lasr_cell_prof_kernel(lasr_ctx* c, double* us_total, long long* launches) {
+int lasr_cell_prof_kernel(lasr_ctx* c, double* us_total, long long* launches, long long* cells) {
     if (!c || !us_total || !launches) return LASR_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     *us_total = 0.0; *launches = 0;
+    if (cells) *cells = 0;
     if (!c->cp_slots || c->cp_slot_next == 0) return LASR_OK;
     HIPCHK(c, hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)2 * c->cp_slot_next);
@@ -1600,6 +1606,7 @@ int lasr_cell_prof_kernel(lasr_ctx* c, double* us_total, long long* launches) {
         if (h[2 * i] == ~0ull || h[2 * i + 1] < h[2 * i]) continue;
         *us_total += (double)(h[2 * i + 1] - h[2 * i]) / c->cp_clock_mhz;
         *launches += 1;
+        if (cells) *cells += c->cp_slot_cells[i];
     }
     return LASR_OK;
 }

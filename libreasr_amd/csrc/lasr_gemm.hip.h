@@ -251,23 +251,22 @@ struct RedView {
 
 // One workgroup = (n-group jb = blockIdx.x, m-group mg = blockIdx.y of MT m-tiles).
 // D > 0: ring depth; D < 0: latency-bound kernel, depth from the register budget.
+// gemm_body: the workgroup's work with its LDS handed in (k_gemm: one problem per launch; k_gemm_multi: several independent
+// problems of the same kind in one launch, blockIdx.z selects the problem).
 template <class Ops, class Epi, int MT, int NW, bool AROW, int D>
-__global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typename Epi::Args ea) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi::Args& ea, const int jb, const int mg,
+                                          float* red, int* row_map, int& n_act_s) {
     constexpr int NT = Epi::NT, ROWS = MT * 16, LD = NT * 16 + 1;
-    __shared__ float red[NW * ROWS * LD];
-    __shared__ int row_map[Epi::COMPACT ? 1024 : 1];
-    __shared__ int n_act_s;
     // Loop bounds derived from the wave index must be wave-uniform FOR THE COMPILER: a condition it
     // believes divergent is lowered to EXEC masking, and MFMA ignores EXEC (a masked-off v_mfma still
     // accumulates) -- seen as double-counted K chunks in the bf16 path.  Addresses keep the VGPR copy
     // (hipcc schedules the fully unrolled K stream better with vector address math).
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(w);       // the same value, as an SGPR: control flow only
-    const int jb = blockIdx.x, mg = blockIdx.y;
     if (g.prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (g.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (g.prio == 1) __builtin_amdgcn_s_setprio(1);
-    unsigned long long* dbg = g.dbg ? g.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
+    unsigned long long* dbg = g.dbg ? g.dbg + ((size_t)mg * gridDim.x + jb) * 16 : nullptr;
     if (dbg && tid == 0) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[5] = wall_clock64(); }
     if (g.prof && tid == 0) atomicMin(&g.prof[0], (unsigned long long)wall_clock64());
 
@@ -416,6 +415,34 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typena
     Epi::template run<MT>(ea, RedView<NW, ROWS, LD>{red}, tid, jb, mg, n_act, row_map, pre, NW * 64);
     if (dbg && tid == 0) { dbg[4] = __builtin_amdgcn_s_memtime(); dbg[6] = wall_clock64(); }
     if (g.prof && tid == 0) atomicMax(&g.prof[1], (unsigned long long)wall_clock64());
+}
+
+template <class Ops, class Epi, int MT, int NW, bool AROW, int D>
+__global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs g, const typename Epi::Args ea) {
+    constexpr int NT = Epi::NT, ROWS = MT * 16, LD = NT * 16 + 1;
+    __shared__ float red[NW * ROWS * LD];
+    __shared__ int row_map[Epi::COMPACT ? 1024 : 1];
+    __shared__ int n_act_s;
+    gemm_body<Ops, Epi, MT, NW, AROW, D>(g, ea, blockIdx.x, blockIdx.y, red, row_map, n_act_s);
+}
+
+// Up to NPMAX independent problems of one kind in ONE launch (grid.z = problems): the encoder's layer wavefront -- cell (l, t)
+// and cell (l + 1, t - 1) depend on nothing of each other, so the cells of an anti-diagonal share a launch and its fixed
+// costs (launch gap, prologue, LDS reduction, epilogue overlap the other cells' K loops).
+constexpr int NPMAX = 8;
+template <class Epi>
+struct MultiArgs {
+    GemmArgs g[NPMAX];
+    typename Epi::Args ea[NPMAX];
+};
+template <class Ops, class Epi, int MT, int NW, bool AROW, int D>
+__global__ __launch_bounds__(NW * 64) void k_gemm_multi(const MultiArgs<Epi> m) {
+    constexpr int NT = Epi::NT, ROWS = MT * 16, LD = NT * 16 + 1;
+    __shared__ float red[NW * ROWS * LD];
+    __shared__ int row_map[Epi::COMPACT ? 1024 : 1];
+    __shared__ int n_act_s;
+    const int p = blockIdx.z;
+    gemm_body<Ops, Epi, MT, NW, AROW, D>(m.g[p], m.ea[p], blockIdx.x, blockIdx.y, red, row_map, n_act_s);
 }
 
 // ------------------------------------------------------------------------------------------------

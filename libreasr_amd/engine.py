@@ -302,10 +302,11 @@ class Engine:
         self._chk(self.lib.lasr_cell_prof(self.ctx, 1 if on else 0))
 
     def cell_prof_kernel(self):
-        """-> (microseconds, cell launches): the cell kernels' own durations since cell_prof(True) (in-kernel wall clock)."""
-        us, n = C.c_double(0.0), C.c_longlong(0)
-        self._chk(self.lib.lasr_cell_prof_kernel(self.ctx, C.byref(us), C.byref(n)))
-        return float(us.value), int(n.value)
+        """-> (microseconds, launches, cells): the cell kernels' own durations since cell_prof(True) (in-kernel wall clock)
+        and the LSTM cells they computed (a layer-wavefront launch holds several independent cells)."""
+        us, n, k = C.c_double(0.0), C.c_longlong(0), C.c_longlong(0)
+        self._chk(self.lib.lasr_cell_prof_kernel(self.ctx, C.byref(us), C.byref(n), C.byref(k)))
+        return float(us.value), int(n.value), int(k.value)
 
     def trace(self, on=True):
         """Timestamped marks on the main / decode streams of the pipelined protocol (see lasr_trace)."""
