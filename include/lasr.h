@@ -108,7 +108,10 @@ int lasr_stream_close(lasr_ctx* c, int slot);
 
 /* ---- streaming hot path, batched over n slots ------------------------------------------------
  * lasr_push_pcm: one client chunk of `chunk` float32 samples per listed slot (replaces
- * tensorize + the window cat of api-server.py:88-102).  pcm: [n, chunk] host or device.
+ * tensorize + the window cat of api-server.py:88-102).  pcm: [n, chunk] host or device.  Pageable host memory is
+ * copied before the call returns; device memory and PINNED host memory (hipHostMalloc / hipHostRegister / a torch
+ * pin_memory() tensor) are read by a kernel in stream order, like hipMemcpyAsync would: keep them untouched until the
+ * stream has got there (e.g. until the lasr_step_* call that consumes the chunk has returned).
  * lasr_step_stream: for every listed slot whose window is full, computes the log-mel frames of
  * the window's middle (TransformTime + StreamPostprocess + StackDownsample, transforms.py:
  * 306-342,436-441), buffers them (Buffer), and for slots whose buffer reached n_buffer runs

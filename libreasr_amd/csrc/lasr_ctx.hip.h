@@ -174,6 +174,7 @@ struct lasr_ctx {
     // never has to drain the stream (the copy of chunk k+1 overlaps the kernels of chunk k)
     static constexpr int NSTAGE = 64;     // > 2 pushes x 15 model steps in flight: a push never waits for its ring entry
     float* push_stage = nullptr; hipEvent_t push_ev[NSTAGE] = {}; bool push_used[NSTAGE] = {}; int push_next = 0;
+    float* push_stage_host_dev = nullptr; bool push_zero_copy = true;   // device view of the pinned ring; LASR_PUSH_DMA=1: DMA + event instead
     float* push_stage_host = nullptr;     // pinned mirror of the ring: caller's (pageable) buffer -> memcpy -> async DMA
     hipStream_t stream_copy = nullptr;    // the DMA of chunk k+1 runs under the kernels of chunk k; the push kernel waits for it
     hipEvent_t push_copied[NSTAGE] = {};

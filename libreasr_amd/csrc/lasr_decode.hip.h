@@ -349,6 +349,17 @@ bool is_device_ptr(const void* p) {
     return at.type == hipMemoryTypeDevice;
 }
 
+// pinned (page-locked, device-mapped) host memory: returns the address the device can read it at, else nullptr
+const void* pinned_host_dev_ptr(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    return at.devicePointer;
+}
+
 // HTK mel filterbank (torchaudio 0.6.0 create_fb_matrix semantics), sparse, bin-ascending
 void build_fb(const lasr_model_desc& d, std::vector<int>& start, std::vector<int>& off, std::vector<float>& w) {
     const int nf = d.n_fft / 2 + 1, nm = d.n_mels;

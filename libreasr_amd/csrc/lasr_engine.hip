@@ -492,12 +492,23 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
     if (!c->pending.empty()) RC(cont_pump(c, c->kick_n));      // steps in flight: keep the decode loop fed
     const int CH = c->d.chunk;
     const float* src = pcm;
-    const bool from_host = !is_device_ptr(pcm);
+    // three kinds of caller memory: device (read by the ring-append kernel in stream order), PINNED host (the same: the kernel
+    // reads it over PCIe in stream order, like hipMemcpyAsync would -- the buffer must stay untouched until the stream gets
+    // there), pageable host (copied into the engine's pinned ring before the call returns)
+    const void* pinned = is_device_ptr(pcm) ? nullptr : pinned_host_dev_ptr(pcm);
+    const bool from_host = !is_device_ptr(pcm) && !pinned;
+    if (pinned) src = (const float*)pinned;
     int stage_i = -1;
     if (from_host) {
         if (!c->push_stage) {
             RC(dalloc(c, &c->push_stage, (size_t)lasr_ctx::NSTAGE * c->M * CH));
             HIPCHK(c, hipHostMalloc((void**)&c->push_stage_host, sizeof(float) * (size_t)lasr_ctx::NSTAGE * c->M * CH));
+            {
+                void* dp = nullptr;
+                HIPCHK(c, hipHostGetDevicePointer(&dp, c->push_stage_host, 0));
+                c->push_stage_host_dev = (float*)dp;
+                c->push_zero_copy = !(getenv("LASR_PUSH_DMA") && atoi(getenv("LASR_PUSH_DMA")) != 0);
+            }
             for (auto& e : c->push_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             for (auto& e : c->push_copied) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
@@ -507,11 +518,19 @@ int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
         if (c->push_used[stage_i]) HIPCHK(c, hipEventSynchronize(c->push_ev[stage_i]));   // its last reader (16 pushes ago) is done
         float* dst = c->push_stage + (size_t)stage_i * c->M * CH;
         float* pin = c->push_stage_host + (size_t)stage_i * c->M * CH;
+        if (c->push_zero_copy) {
+            // zero-copy: the ring-append kernel reads the pinned ring entry over PCIe itself (328 KB at 64 streams: a few
+            // microseconds on the stream) -- no DMA call, no copy stream, no cross-stream event (three driver calls and a
+            // cross-queue dependency per push less; the single host thread is what limits the PCIe-inclusive rate)
+            memcpy(pin, pcm, sizeof(float) * (size_t)n * CH);
+            src = c->push_stage_host_dev + (size_t)stage_i * c->M * CH;
+        } else {
         memcpy(pin, pcm, sizeof(float) * (size_t)n * CH);      // the caller's buffer is free on return, whatever its kind
         HIPCHK(c, hipMemcpyAsync(dst, pin, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream_copy));   // truly asynchronous
         HIPCHK(c, hipEventRecord(c->push_copied[stage_i], c->stream_copy));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->push_copied[stage_i], 0));
         src = dst;
+        }
     }
     tr_mark(c, 1, c->stream);
     if (c->fe_fused) RC(materialize_pending(c, slots, n));      // irregular clients only: see there

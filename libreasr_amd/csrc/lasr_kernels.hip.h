@@ -1273,7 +1273,13 @@ __global__ void k_push_pcm(const float* __restrict__ src, const int* __restrict_
     const int pos = ring_pos[row];
     float* d = win + ((size_t)row * n_window + pos) * chunk;
     const float* s = src + (size_t)si * chunk;
-    for (int i = threadIdx.x; i < chunk; i += blockDim.x) d[i] = s[i];
+    if ((chunk & 3) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {     // 16-byte requests (the source may sit across PCIe)
+        const float4* s4 = (const float4*)s;
+        float4* d4 = (float4*)d;
+        for (int i = threadIdx.x; i < chunk / 4; i += blockDim.x) d4[i] = s4[i];
+    } else {
+        for (int i = threadIdx.x; i < chunk; i += blockDim.x) d[i] = s[i];
+    }
     __syncthreads();
     if (threadIdx.x == 0) ring_pos[row] = (pos + 1) % n_window;
 }
