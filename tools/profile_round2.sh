@@ -28,3 +28,14 @@ except Exception as e: print("$f ERR", e)
 PY
 done
 cat $O/timeline_f32.txt $O/timeline_bf16.txt
+# PMC passes on the isolated cell (one counter group per pass; gpurun refuses --pmc together with the hip / hsa trace domains)
+if [ -n "$LASR_PROFILE_PMC" ]; then
+  cd /tmp
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+    n=$(echo $grp | tr ' ' '_' | cut -c1-40)
+    LASR_BENCH_LAYERS=1 timeout 200 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc_f32_$n -o pmc -- python3 $R/tools/cellbench.py cfg2 30 > /dev/null 2>&1
+    LASR_DTYPE=bf16 LASR_BENCH_LAYERS=1 timeout 200 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc_bf16_$n -o pmc -- python3 $R/tools/cellbench.py cfg2 30 > /dev/null 2>&1
+  done
+  cd $R
+  for f in $O/pmc_*/pmc_results.db; do python3 tools/rocpd_pmc.py $f --filter EpiLSTM; done
+fi
