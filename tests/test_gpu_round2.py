@@ -272,3 +272,50 @@ def test_fused_frontend_irregular_pushes_equal_the_per_chunk_kernels():
     fused, legacy = run(False), run(True)
     assert fused == legacy
     assert sum(len(g) for g in fused) > 0
+
+
+@pytest.mark.parametrize("n_buffer", [1, 3, 4])
+def test_fused_frontend_other_buffer_depths(n_buffer):
+    """The fused front-end (k_frontend) with Buffer(n_buffer) != 2: the PCM ring holds n_window + n_buffer - 1 chunks and the
+    step's launch works through the last n_buffer windows.  Three streams, one chunk out of phase with the others (their
+    model steps fall on different calls), synchronous and pipelined protocol, against the oracle."""
+    eng, sd, cfg = make("tiny", max_streams=16, n_buffer=n_buffer)
+    try:
+        m = O.OracleTransducer(sd, cfg)
+        n, n_chunks = 3, 40
+        pcm = synth.synth_pcm(n, n_chunks * 1280, seed=8 + n_buffer)
+        ref = []
+        for i in range(n):
+            fe, dec = O.StreamFrontend(n_buffer=n_buffer), m.stream_decoder()
+            for k in range(n_chunks):
+                o = fe.push(pcm[i][k * 1280:(k + 1) * 1280])
+                if o is not None:
+                    dec.step(o)
+            ref.append(dec.y)
+        assert sum(len(r) for r in ref) > 0
+        for mode in ("sync", "pipelined"):
+            slots = [eng.open() for _ in range(n)]
+            got = [[] for _ in range(n)]
+            for k in range(n_chunks + 1):
+                rows = [i for i in range(n) if 0 <= k - (i == 2) < n_chunks]         # stream 2 starts one call late
+                chunk = np.stack([pcm[i][(k - (i == 2)) * 1280:(k - (i == 2) + 1) * 1280] for i in rows])
+                eng.push([slots[i] for i in rows], chunk)
+                if mode == "sync":
+                    if eng.step([slots[i] for i in rows]):
+                        for i, t in zip(rows, eng.fetch_many([slots[i] for i in rows], 64)):
+                            got[i] += t
+                else:
+                    eng.submit([slots[i] for i in rows])
+                    if eng.pending() >= 5 and eng.wait():
+                        for i, t in enumerate(eng.fetch_many(slots, 64)):
+                            got[i] += t
+            while eng.pending():
+                if eng.wait():
+                    for i, t in enumerate(eng.fetch_many(slots, 64)):
+                        got[i] += t
+            for i in range(n):
+                assert got[i] == ref[i], (mode, n_buffer, i)
+            for s in slots:
+                eng.close_slot(s)
+    finally:
+        eng.close()
