@@ -647,6 +647,107 @@ struct EpiNBRC {
     }
 };
 
+// ---- wide predictor tilings (many decoder rows: beam search, > 256 streams): 16 units x all gates x 64 rows per workgroup
+// (NT = 4 of the 4-unit tiles of tiling A: same packed weights).  With hundreds of rows the A operand, not the weights, is what
+// moves: a 4-unit workgroup reads its 64 rows' whole [x, h] for 4 units' worth of outputs, a 16-unit one for 16 (1/4 of the
+// L2 -> CU traffic: configs[4] at beam 8 has 1024 rows x 3072 x 2 B per row group and 384 n-groups).  Column of (pseudo-gate
+// pg, unit uu of 16) in the 64-column workgroup tile: (uu / 4) * 16 + pg * 4 + uu % 4.  Item loop instead of one item per
+// thread, operands loaded in the epilogue (at these sizes the K loop is tens of microseconds).  Same arithmetic per item as
+// EpiLSTM<PRED> / EpiNBRC.
+template <class Ops, bool TABLE>
+struct EpiLSTMw {
+    static constexpr int U = 16, NT = 4;
+    static constexpr int PH0_TILES = TABLE ? 0 : 15, PH1_TILES = 15;
+    static constexpr int PH0_DEAD = -1, PH1_DEAD = -1;
+    static constexpr bool COMPACT = true;
+    using Args = typename EpiLSTM<Ops, true, TABLE, 4>::Args;
+    struct Pre {};
+    template <int MTB>
+    __device__ static __forceinline__ Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
+    template <int MTB, class Red>
+    __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
+                                               const Pre&, int nthr) {
+        constexpr int ROWS = MTB * 16;
+        const int H = a.H;
+        const bool beam = a.W > 1;
+        for (int item = tid; item < ROWS * U; item += nthr) {
+            const int row = item % ROWS, uu = item / ROWS, vr = mg * ROWS + row, u = jb * U + uu;
+            if (vr < a.M && !a.flag[vr]) {          // a row that did not emit: carried to the other parity
+                const int pr = beam ? beam_prow(a.parent, a.W, vr) : vr;
+                Ops::st(a.h_out, (size_t)vr * H + u, Ops::ld(a.h_in, (size_t)pr * H + u));
+                if (beam) {
+                    a.c[(size_t)u * a.M + vr] = a.c_in[(size_t)u * a.M + pr];
+                    Ops::st(a.y, (size_t)vr * H + u, Ops::ld(a.y_in, (size_t)pr * H + u));
+                }
+            }
+            if (vr >= n_act) continue;
+            const int r = row_map[vr];
+            float x[4];
+            if (TABLE) {
+                const float* tb = a.tab + (size_t)a.token[r] * 4 * H + u;
+                x[0] = tb[0]; x[1] = tb[H]; x[2] = tb[2 * H]; x[3] = tb[3 * H];
+            } else {
+                x[0] = a.bias[u]; x[1] = a.bias[H + u]; x[2] = a.bias[2 * H + u]; x[3] = a.bias[3 * H + u];
+            }
+            const float c_old = beam ? a.c_in[(size_t)u * a.M + beam_prow(a.parent, a.W, r)] : a.c[(size_t)u * a.M + r];
+            const int cb = (uu >> 2) * 16 + (uu & 3);
+            const float gi = red.sum(row, cb) + x[0], gf = red.sum(row, cb + 4) + x[1];
+            const float gg = red.sum(row, cb + 8) + x[2], go = red.sum(row, cb + 12) + x[3];
+            const float c2 = sigmoid_(gf) * c_old + sigmoid_(gi) * tanhf(gg);
+            const float h2 = sigmoid_(go) * tanhf(c2);
+            a.c[(size_t)u * a.M + r] = c2;
+            Ops::st(a.h_out, (size_t)r * H + u, h2);
+            Ops::st(a.y, (size_t)r * H + u, h2 * a.bn_s[u] + a.bn_t[u]);
+        }
+    }
+};
+
+template <class Ops, bool TABLE>
+struct EpiNBRCw {
+    static constexpr int U = 16, NT = 4;
+    static constexpr int PH0_TILES = TABLE ? 0 : 15, PH1_TILES = 15;
+    static constexpr int PH0_DEAD = 12, PH1_DEAD = 8;
+    static constexpr bool COMPACT = true;
+    using Args = typename EpiNBRC<Ops, TABLE>::Args;
+    struct Pre {};
+    template <int MTB>
+    __device__ static __forceinline__ Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
+    template <int MTB, class Red>
+    __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
+                                               const Pre&, int nthr) {
+        constexpr int ROWS = MTB * 16;
+        const int H = a.H;
+        const bool beam = a.W > 1;
+        for (int item = tid; item < ROWS * U; item += nthr) {
+            const int row = item % ROWS, uu = item / ROWS, vr = mg * ROWS + row, u = jb * U + uu;
+            if (vr < a.M && !a.emit[vr]) {
+                const int pr = beam ? beam_prow(a.parent, a.W, vr) : vr;
+                Ops::st(a.h_out, (size_t)vr * H + u, Ops::ld(a.h_in, (size_t)pr * H + u));
+                if (beam) Ops::st(a.y, (size_t)vr * H + u, Ops::ld(a.y_in, (size_t)pr * H + u));
+            }
+            if (vr >= n_act) continue;
+            const int r = row_map[vr];
+            const float h = Ops::ld(a.h_in, (size_t)(beam ? beam_prow(a.parent, a.W, r) : r) * H + u);
+            float xz, xr, xg;
+            if (TABLE) {
+                const float* tb = a.tab + (size_t)a.token[r] * 3 * H + u;
+                xz = tb[0]; xr = tb[H]; xg = tb[2 * H];
+            } else {
+                xz = a.bias[u]; xr = a.bias[H + u]; xg = a.bias[2 * H + u];
+            }
+            const int cb = (uu >> 2) * 16 + (uu & 3);
+            const float vz = red.sum(row, cb), vr_ = red.sum(row, cb + 4), vgh = red.sum(row, cb + 12);
+            if (!TABLE) xg = red.sum(row, cb + 8) + xg;
+            const float z = sigmoid_(vz + xz + a.rbias[u]);
+            const float rr = sigmoid_(vr_ + xr + a.rbias[H + u]);
+            const float gc = tanhf(xg + rr * (vgh + a.rbias[2 * H + u]));
+            const float h2 = z * h + (1.0f - z) * gc;
+            Ops::st(a.h_out, (size_t)r * H + u, h2);
+            Ops::st(a.y, (size_t)r * H + u, h2 * a.bn_s[u] + a.bn_t[u]);
+        }
+    }
+};
+
 // ---- plain linear: out[row][col] = acc + bias[col], row-major f32.
 struct EpiLinear {
     static constexpr int NT = 1;
