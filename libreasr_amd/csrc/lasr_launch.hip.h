@@ -173,7 +173,10 @@ void launch_ppj_t(lasr_ctx* c, bool beam) {
     ea.b1 = c->b1; ea.pp = (beam && !p) ? c->pp1 : c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
     ea.ja = c->ja; ea.J = J; ea.M = c->Md; ea.MT = c->MTj; ea.ring = c->pe_ring_R; ea.la = beam ? 1 : c->la;
     if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.M_enc = c->M; ea.pp_in = p ? c->pp1 : c->pp; }
-    if (c->dec_nw_mask & 2) launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1, 4>(c, J / 16, c->MTd, g, ea); else launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
+    static const int ppj_wide_env = getenv("LASR_PPJ_WIDE") ? atoi(getenv("LASR_PPJ_WIDE")) : -1;
+    const bool ppj_wide = (ppj_wide_env >= 0 ? ppj_wide_env != 0 : c->Md >= 512) && c->MTd % 4 == 0;   // 64-row workgroups for many decoder rows
+    if (ppj_wide) launch_gemm<Ops, EpiPPJ<Ops>, 4, true, -1, 4>(c, J / 16, c->MTd / 4, g, ea);
+    else if (c->dec_nw_mask & 2) launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1, 4>(c, J / 16, c->MTd, g, ea); else launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
     if (beam) c->pred_par ^= 1;
 }
 void launch_ppj(lasr_ctx* c, bool beam = false) {
@@ -287,8 +290,9 @@ void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
     ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M; ea.W = c->W;
+    static const int lw_env = getenv("LASR_LOGITS_WIDE") ? atoi(getenv("LASR_LOGITS_WIDE")) : -1;
+    if (c->logits_mt == 4 || (c->logits_mt == 2 && (lw_env >= 0 ? lw_env != 0 : n_rows >= 512))) { launch_logits_t<4>(c, g, n_rows, J, ea); return; }
     if (c->logits_mt == 2) { launch_logits_t<2>(c, g, n_rows, J, ea); return; }
-    if (c->logits_mt == 4) { launch_logits_t<4>(c, g, n_rows, J, ea); return; }
     launch_linear<false, -1>(c, V / 16, (n_rows + 15) / 16, g, J, ea);
 }
 
