@@ -258,6 +258,7 @@ def main():
     assert slots == list(range(B))
 
     pipelined = not args.no_pipeline and args.beam == 1
+    FETCH_CAP = 64 if args.beam == 1 else 8192      # beam: every fetch hands out the whole current best hypothesis
     push_t = {}                                   # chunk index -> host time of its push (latency bookkeeping)
     order = []                                    # model chunks submitted and not yet collected
 
@@ -271,7 +272,7 @@ def main():
         ntok, done = 0, 0
         if not pipelined:
             if eng.step(slots):
-                ntok = sum(len(t) for t in eng.fetch_many(slots, cap=64))
+                ntok = sum(len(t) for t in eng.fetch_many(slots, cap=FETCH_CAP))
                 done = 1
                 if lat_out is not None:
                     lat_out.append(time.perf_counter() - t_push)
@@ -288,7 +289,7 @@ def main():
     def collect(lat_out):
         if not eng.wait():
             return 0, 0
-        ntok = sum(len(t) for t in eng.fetch_many(slots, cap=64))
+        ntok = sum(len(t) for t in eng.fetch_many(slots, cap=FETCH_CAP))
         kk = order.pop(0)
         if lat_out is not None:
             lat_out.append(time.perf_counter() - push_t.pop(kk))

@@ -654,10 +654,10 @@ struct EpiNBRC {
 // pg, unit uu of 16) in the 64-column workgroup tile: (uu / 4) * 16 + pg * 4 + uu % 4.  Item loop instead of one item per
 // thread, operands loaded in the epilogue (at these sizes the K loop is tens of microseconds).  Same arithmetic per item as
 // EpiLSTM<PRED> / EpiNBRC.
-template <class Ops, bool TABLE>
+template <class Ops, bool TABLE, int NTW = 4>
 struct EpiLSTMw {
-    static constexpr int U = 16, NT = 4;
-    static constexpr int PH0_TILES = TABLE ? 0 : 15, PH1_TILES = 15;
+    static constexpr int U = 4 * NTW, NT = NTW;
+    static constexpr int PH0_TILES = TABLE ? 0 : (1 << NTW) - 1, PH1_TILES = (1 << NTW) - 1;
     static constexpr int PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = true;
     using Args = typename EpiLSTM<Ops, true, TABLE, 4>::Args;
@@ -702,10 +702,10 @@ struct EpiLSTMw {
     }
 };
 
-template <class Ops, bool TABLE>
+template <class Ops, bool TABLE, int NTW = 4>
 struct EpiNBRCw {
-    static constexpr int U = 16, NT = 4;
-    static constexpr int PH0_TILES = TABLE ? 0 : 15, PH1_TILES = 15;
+    static constexpr int U = 4 * NTW, NT = NTW;
+    static constexpr int PH0_TILES = TABLE ? 0 : (1 << NTW) - 1, PH1_TILES = (1 << NTW) - 1;
     static constexpr int PH0_DEAD = 12, PH1_DEAD = 8;
     static constexpr bool COMPACT = true;
     using Args = typename EpiNBRC<Ops, TABLE>::Args;

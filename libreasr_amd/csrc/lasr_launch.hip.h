@@ -105,7 +105,9 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
     // many decoder rows (beam 8 x 64+ streams, >= 512 streams): 16-unit workgroups, a quarter of the activation traffic
     // (configs[4], 1024 rows: predictor cells 135 -> ~50 us, whole job +60 %; at 256 rows: bf16 equal, f32 -22 %; at 64: -20 %)
     static const int wide_env = getenv("LASR_PRED_WIDE") ? atoi(getenv("LASR_PRED_WIDE")) : -1;
-    const bool wide = wide_env >= 0 ? wide_env != 0 : c->Md >= 512;
+    const bool wide = wide_env >= 0 ? wide_env == 1 : c->Md >= 512;
+    const int w8_min = getenv("LASR_W8_MIN") ? atoi(getenv("LASR_W8_MIN")) : 256;
+    const bool wide8 = wide_env >= 0 ? wide_env == 2 : (c->bf && c->Md >= w8_min && c->Md < 512);   // 8 units per workgroup, 8 waves
     for (int l = 0; l < c->d.pred_layers; ++l) {
         const Cell& L = c->pred[l];
         GemmArgs g{};
@@ -127,13 +129,15 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md; ea.MT = c->MTd;
             if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.c_in = p ? c->pred_c1[l] : c->pred_c[l]; ea.y_in = y_in; }
             if (l == 0) {
-                if (wide) launch_gemm<Ops, EpiLSTMw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
+                if (wide8) launch_gemm<Ops, EpiLSTMw<Ops, true, 2>, MTA, true, -1>(c, H / 8, mgroups, g, ea);
+                else if (wide) launch_gemm<Ops, EpiLSTMw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
                 else if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1, 4>(c, H / 4, mgroups, g, ea); else launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 typename EpiLSTM<Ops, true, false, 4>::Args eb{};
                 static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
-                if (wide) launch_gemm<Ops, EpiLSTMw<Ops, false>, MTA, true, -1, 4>(c, H / 16, mgroups, g, eb);
+                if (wide8) launch_gemm<Ops, EpiLSTMw<Ops, false, 2>, MTA, true, -1>(c, H / 8, mgroups, g, eb);
+                else if (wide) launch_gemm<Ops, EpiLSTMw<Ops, false>, MTA, true, -1, 4>(c, H / 16, mgroups, g, eb);
                 else if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1, 4>(c, H / 4, mgroups, g, eb); else launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         } else {
@@ -143,13 +147,15 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md;
             if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.y_in = y_in; }
             if (l == 0) {
-                if (wide) launch_gemm<Ops, EpiNBRCw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
+                if (wide8) launch_gemm<Ops, EpiNBRCw<Ops, true, 2>, MTA, true, -1>(c, H / 8, mgroups, g, ea);
+                else if (wide) launch_gemm<Ops, EpiNBRCw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
                 else if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1, 4>(c, H / 4, mgroups, g, ea); else launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 typename EpiNBRC<Ops, false>::Args eb{};
                 static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
-                if (wide) launch_gemm<Ops, EpiNBRCw<Ops, false>, MTA, true, -1, 4>(c, H / 16, mgroups, g, eb);
+                if (wide8) launch_gemm<Ops, EpiNBRCw<Ops, false, 2>, MTA, true, -1>(c, H / 8, mgroups, g, eb);
+                else if (wide) launch_gemm<Ops, EpiNBRCw<Ops, false>, MTA, true, -1, 4>(c, H / 16, mgroups, g, eb);
                 else if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1, 4>(c, H / 4, mgroups, g, eb); else launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         }
