@@ -39,3 +39,4 @@ if [ -n "$LASR_PROFILE_PMC" ]; then
   cd $R
   for f in $O/pmc_*/pmc_results.db; do python3 tools/rocpd_pmc.py $f --filter EpiLSTM; done
 fi
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
