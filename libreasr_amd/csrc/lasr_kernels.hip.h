@@ -971,11 +971,15 @@ __device__ __forceinline__ void fft1024_power(cf (&v)[8], float2* z, float* P, c
 }
 // sparse HTK mel of the power spectrum + log(x + 1e-6): lane j takes filters j, j + 64, ..
 __device__ __forceinline__ void mel_log(const float* P, const MelTables& t, int n_mels, int j, float* out) {
-    for (int m = j; m < n_mels; m += 64) {
-        const int s0 = t.fbs[m], o0 = t.fbo[m], cnt = t.fbo[m + 1] - o0;
+    // HTK filters widen with the mel index (3 bins at the bottom, ~35 at the top): with n_mels == 128 lane j takes filters
+    // j and 127 - j, so every lane walks about the same number of taps (lane 63 used to walk the two widest ones)
+    const bool paired = n_mels == 128;
+    for (int i = 0, m = j; m < n_mels; ++i, m += 64) {
+        const int mm = (paired && i == 1) ? 127 - j : m;
+        const int s0 = t.fbs[mm], o0 = t.fbo[mm], cnt = t.fbo[mm + 1] - o0;
         float acc = 0.f;
         for (int q = 0; q < cnt; ++q) acc += P[s0 + q] * t.fbw[o0 + q];
-        out[m] = logf(acc + 1e-6f);
+        out[mm] = logf(acc + 1e-6f);
     }
 }
 
