@@ -154,6 +154,27 @@ def cpu_reference_path(cfg, sd, n_streams, n_chunks, threads=2):
             "seconds": round(dt, 2), "tokens": int(sum(len(t) for t in toks)), "host_cores_available": os.cpu_count()}
 
 
+def cpu_best_effort(cfg, sd, n_streams, n_chunks):
+    """SURVEY 8d (ii) "best-effort CPU": every host core, the encoder batched over all the streams of the GPU batch, the
+    greedy loop per stream, torch.backends.mkldnn on and off.  Still a PORT of the reference's operators (oracle/torch_cpu.py)."""
+    import torch
+    from libreasr_amd import synth
+    from oracle import torch_cpu as TC       # baseline leg only; never on the product path
+    rows = [synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in range(n_streams)]
+    cores = os.cpu_count() or 1
+    res = {}
+    for mk in (True, False):
+        with torch.backends.mkldnn.flags(enabled=mk):
+            TC.time_stream_path_batched(sd, cfg, rows[:8], min(n_chunks, 8), threads=cores)      # warm-up
+            dt, toks = TC.time_stream_path_batched(sd, cfg, rows, n_chunks, threads=cores)
+        res["mkldnn_on" if mk else "mkldnn_off"] = {"value": round(n_streams * n_chunks * CHUNK / SR / dt, 1), "seconds": round(dt, 2),
+                                                    "tokens": int(sum(len(t) for t in toks))}
+    best = max(res.values(), key=lambda v: v["value"])
+    return {"value": best["value"], "unit": "audio-sec/sec", "cores": int(cores), "kind": "port", **res,
+            "sample": f"{n_streams} streams x {n_chunks} chunks of 80 ms, encoder batched over the {n_streams} streams "
+                      f"(nn.LSTM, batch {n_streams}), front-end batched, greedy loop per stream; torch.set_num_threads({cores})"}
+
+
 def cpu_numpy_port(cfg, sd, n_streams, n_chunks):
     """The numpy oracle (the parity checker) timed the same way: second CPU figure."""
     from libreasr_amd import synth
@@ -198,12 +219,23 @@ def main():
                          "reported beside the headline anyway)")
     ap.add_argument("--cpu-streams", type=int, default=12)
     ap.add_argument("--cpu-chunks", type=int, default=150)
+    ap.add_argument("--cpu-be-chunks", type=int, default=60,
+                    help="chunks per stream of the best-effort CPU leg (all host cores, encoder batched over the streams)")
     ap.add_argument("--beam", type=int, default=1,
                     help="beam width (1 = greedy, the headline config); > 1 runs the synchronous protocol")
     ap.add_argument("--depth", type=int, default=12,
                     help="pipelined mode: model steps in flight before the oldest is collected (1..15)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
+    ap.add_argument("--prof-steps", type=int, default=0,
+                    help="steps of an extra PROFILED region behind the timed one (only used with --cell-prof-in-timed 0)")
+    ap.add_argument("--cell-prof-in-timed", type=int, default=1,
+                    help="timers of the dominant kernel inside the timed region: 1 = HIP-event pair per model step on the cells' stream + "
+                         "per-workgroup clock stores in the cell kernels (measured: no effect on `value`), 2 = clocks only, 0 = none")
+    ap.add_argument("--check-rows", type=int, default=8,
+                    help="self-check: rows replayed through the synchronous protocol after the timed region (0 = off)")
+    ap.add_argument("--split-push", action="store_true",
+                    help="lasr_push_pcm + lasr_step_submit as two calls instead of lasr_push_submit (A/B)")
     ap.add_argument("--trace", default=None, help="diagnostics: dump the two-stream mark timeline (lasr_trace) of the timed region to this file")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU-only: exercise sharding + aggregation over gloo (no GPU work)")
@@ -247,7 +279,7 @@ def main():
     K, W = args.steps * CPS, args.warmup * CPS            # in chunks from here on
     P = max(0, PRIME_CHUNKS - W)
     extras = rank == 0 and not args.no_extras and args.beam == 1 and not args.no_pipeline
-    n_chunks = min(PCM_PERIOD, P + W + K + (K if extras else 0) + 4)
+    n_chunks = min(PCM_PERIOD, P + W + K + (2 * K if extras else 0) + max(0, min(args.steps, args.prof_steps)) * CPS + 4)
     # synthetic PCM for this rank's streams (seeded per global stream id), resident in HBM,
     # laid out [chunk][stream][1280] so that one step reads one contiguous block
     pcm_host = np.stack([synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in my_streams])
@@ -261,35 +293,70 @@ def main():
     FETCH_CAP = 64 if args.beam == 1 else 8192      # beam: every fetch hands out the whole current best hypothesis
     push_t = {}                                   # chunk index -> host time of its push (latency bookkeeping)
     order = []                                    # model chunks submitted and not yet collected
+    NCHK = min(B, max(0, args.check_rows)) if args.beam == 1 else 0
+    rec_steps = [[] for _ in range(NCHK)]         # self-check: per checked row, the token list of every model step so far
+    recording = [True]
+    host_us = {"push": 0.0, "submit": 0.0, "wait": 0.0, "fetch": 0.0, "n_model_steps": 0}   # host time per call kind (timed region)
+
+    def record(tok_lists):
+        if recording[0]:
+            for r in range(NCHK):
+                rec_steps[r].append(tok_lists[r])
 
     def one_step(k, lat_out=None, host=False):
         """One 80 ms chunk for every stream.  Synchronous mode: push + step + fetch.  Pipelined mode:
         push + submit (front-end and encoder of chunk k go to the GPU), then collect the tokens of
         the oldest model step once `depth` are in flight; its decode loop runs on a second HIP stream."""
         t_push = time.perf_counter()
-        src = pcm_dev if not host else (pcm_pinned_chunks if host == "pinned" else pcm_host_chunks)
-        eng.push(slots, src[k % n_chunks])
+        src = pcm_dev if not host else (pcm_pinned_chunks if host in ("pinned", "pinned_nocopy") else pcm_host_chunks)
+        nocopy = host == "pinned_nocopy"
+        if pipelined and not args.split_push:
+            # push + submit in one call: the front-end launch of a model step appends the newest chunk itself
+            before = eng.pending()
+            eng.push_submit(slots, src[k % n_chunks], pinned_nocopy=nocopy)
+            host_us["push"] += time.perf_counter() - t_push
+            ntok, done = 0, 0
+            if eng.pending() > before:
+                order.append(k)
+                push_t[k] = t_push
+                host_us["n_model_steps"] += 1
+            if eng.pending() >= args.depth:
+                done, ntok = collect(lat_out)
+            return done, ntok
+        eng.push(slots, src[k % n_chunks], pinned_nocopy=nocopy)
+        t1 = time.perf_counter()
+        host_us["push"] += t1 - t_push
         ntok, done = 0, 0
         if not pipelined:
             if eng.step(slots):
-                ntok = sum(len(t) for t in eng.fetch_many(slots, cap=FETCH_CAP))
+                toks = eng.fetch_many(slots, cap=FETCH_CAP)
+                record(toks)
+                ntok = sum(len(t) for t in toks)
                 done = 1
                 if lat_out is not None:
                     lat_out.append(time.perf_counter() - t_push)
             return done, ntok
         before = eng.pending()
         eng.submit(slots)
+        host_us["submit"] += time.perf_counter() - t1
         if eng.pending() > before:
             order.append(k)
             push_t[k] = t_push
+            host_us["n_model_steps"] += 1
         if eng.pending() >= args.depth:
             done, ntok = collect(lat_out)
         return done, ntok
 
     def collect(lat_out):
+        t0 = time.perf_counter()
         if not eng.wait():
             return 0, 0
-        ntok = sum(len(t) for t in eng.fetch_many(slots, cap=FETCH_CAP))
+        t1 = time.perf_counter()
+        toks = eng.fetch_many(slots, cap=FETCH_CAP)
+        host_us["wait"] += t1 - t0
+        host_us["fetch"] += time.perf_counter() - t1
+        record(toks)
+        ntok = sum(len(t) for t in toks)
         kk = order.pop(0)
         if lat_out is not None:
             lat_out.append(time.perf_counter() - push_t.pop(kk))
@@ -338,23 +405,54 @@ def main():
         if not pipelined:
             enc_ms.append(st["encoder_ms"]); dec_ms.append(st["decode_ms"]); fe_ms.append(st["frontend_ms"])
 
+    # The dominant kernel is timed INSIDE the timed region: one HIP-event pair per model step around the cell sequence (on the
+    # cells' stream) and, in the cell kernels, one plain store of the device wall clock per workgroup at entry and exit.  Both
+    # are free at the resolution of this bench (round 2's timers used two atomics on one word per workgroup: they cost the
+    # job 10 % and inflated the cell's own duration by 2 us; profiles/r03/r03b_timer_cost.txt).
     if args.trace:
         eng.trace(True)
-    else:
-        eng.cell_prof(True)                       # HIP-event pair around every model step's cell sequence, on its stream
+    elif args.cell_prof_in_timed:
+        eng.cell_prof(args.cell_prof_in_timed)
+    for k in host_us:
+        host_us[k] = 0.0 if k != "n_model_steps" else 0
     elapsed, tokens = timed_region(P + W, K, lat_model, host=args.host_pcm, stats=on_stats)
+    host_timed = dict(host_us)
+    recording[0] = False                          # the self-check compares everything up to the end of the timed region
     if args.trace:
         with open(args.trace, "w") as f:
             json.dump({"marks": eng.trace_read(), "elapsed_us": 1e6 * elapsed, "chunks": K}, f)
         eng.trace(False)
-    cell_us_total, cell_launches = eng.cell_prof_read()
-    cell_kernel_us_total, cell_kernel_launches, cell_kernel_cells = eng.cell_prof_kernel() if not args.trace else (0.0, 0, 0)
+    k_next = P + W + K
+    prof_value = None
+    if args.cell_prof_in_timed and not args.trace:
+        Kp = K
+        prof_elapsed = elapsed
+    else:
+        Kp = max(0, min(args.steps, args.prof_steps)) * CPS
+        if Kp and not args.trace:
+            eng.cell_prof(True)                   # HIP-event pair around every model step's cell sequence + in-kernel clocks
+            prof_elapsed, _ = timed_region(k_next, Kp, None, host=args.host_pcm, barrier=False)
+            k_next += Kp
+            prof_value = Kp * B * CHUNK / SR / prof_elapsed
+    cell_us_total, cell_launches = eng.cell_prof_read() if (Kp and not args.trace and args.cell_prof_in_timed != 2) else (0.0, 0)
+    cell_kernel_us_total, cell_kernel_launches, cell_kernel_cells = eng.cell_prof_kernel() if (Kp and not args.trace) else (0.0, 0, 0)
     eng.cell_prof(False)
     eng.set_profiling(False)
 
     audio_local = K * B * CHUNK / SR
     elapsed_max, audio_total = aggregate(dist, elapsed, audio_local, device)
+    # per-rank figures on rank 0 (a straggler is visible in the driver's N-GPU line): value, elapsed, host time per model step
+    nms = max(1, host_timed["n_model_steps"])
+    mine = [float(rank), audio_local / elapsed, elapsed, 1e6 * host_timed["push"] / nms, 1e6 * host_timed["submit"] / nms,
+            1e6 * host_timed["wait"] / nms, 1e6 * host_timed["fetch"] / nms]
+    per_rank = [mine]
+    if dist is not None:
+        t = torch.tensor(mine, dtype=torch.float64, device=device)
+        bufs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t)
+        per_rank = [b.tolist() for b in bufs]
 
+    rc_final = 0
     if rank == 0:
         L, H = cfg["enc_layers"], cfg["hidden"]
         bf = args.dtype == "bf16"
@@ -406,6 +504,9 @@ def main():
                                     "one continuous greedy loop on a second stream") if pipelined else "synchronous",
                        "priming_chunks": P},
             "per_gpu_value": round(audio_total / elapsed_max / world, 1),
+            "per_rank": [{"rank": int(v[0]), "value": round(v[1], 1), "elapsed_s": round(v[2], 5),
+                          "host_us_per_model_step": {"push": round(v[3], 1), "submit": round(v[4], 1), "wait_incl_spin": round(v[5], 1),
+                                                     "fetch": round(v[6], 1)}} for v in per_rank],
             "latency_ms": {"definition": "host time from lasr_push_pcm of a model chunk to its tokens on the host"
                                          + (" (pipelined: includes the queueing behind the steps in flight)" if pipelined else ""),
                            "p50_model_chunk": round(1e3 * float(np.median(lat_model)), 4) if lat_model else None,
@@ -423,6 +524,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(cell_us, 3), "launches_timed": int(cell_kernel_launches or cell_launches),
+                         "measured_in": ("the timed region itself (--cell-prof-in-timed)" if args.cell_prof_in_timed else
+                                         f"a separate profiled region of {Kp // CPS} steps right behind the timed one (same streams, same "
+                                         "pipeline, cell timers on): the timed region itself carries no event records or in-kernel timers"),
+                         "value_profiled": round(prof_value, 1) if prof_value else None,
                          "timing": "in-job (next to the decode stream), every cell launch of the timed region: kernel duration = max exit - "
                                    "min entry of the device wall clock over the launch's workgroups (the quantity rocprofv3 --kernel-trace "
                                    "reports); launch_us_events = HIP-event pairs on the cells' stream around each model step's cell sequence "
@@ -449,16 +554,18 @@ def main():
             # chunk handed to lasr_push_pcm as a host array; reported beside the headline, never as `value`
             try:
                 lat2 = []
-                dt2, _ = timed_region(P + W + K, K, lat2, host="pinned", barrier=False)
+                dt2, _ = timed_region(k_next, K, lat2, host="pinned_nocopy", barrier=False)
                 lat3 = []
-                dt3, _ = timed_region(P + W + 2 * K, K, lat3, host=True, barrier=False)
-                out["pcie_inclusive"] = {"value": round(K * B * CHUNK / SR / dt2, 1), "unit": "audio-sec/sec",
-                                         "pageable": {"value": round(K * B * CHUNK / SR / dt3, 1),
-                                                      "note": "chunks handed over as pageable numpy arrays: lasr_push_pcm first copies them "
-                                                              "into its pinned ring (one more 328 KB memcpy per push on the single host thread)"},
-                                         "p50_model_chunk_ms": round(1e3 * float(np.median(lat2)), 4) if lat2 else None,
-                                         "note": "same steps, every chunk handed to lasr_push_pcm in PINNED host memory (the ring-append kernel reads it over PCIe: "
-                                                 "328 KB per chunk)"}
+                dt3, _ = timed_region(k_next + K, K, lat3, host=True, barrier=False)
+                out["pcie_inclusive"] = {"value": round(K * B * CHUNK / SR / dt3, 1), "unit": "audio-sec/sec",
+                                         "p50_model_chunk_ms": round(1e3 * float(np.median(lat3)), 4) if lat3 else None,
+                                         "note": "same steps, every chunk handed over as a PAGEABLE host array (what a server's receive path has): "
+                                                 "copied into the engine's pinned staging ring before the call returns (helper threads), read "
+                                                 "from there over PCIe by the front-end / ring-append kernel: 328 KB per chunk",
+                                         "pinned_nocopy": {"value": round(K * B * CHUNK / SR / dt2, 1),
+                                                           "p50_model_chunk_ms": round(1e3 * float(np.median(lat2)), 4) if lat2 else None,
+                                                           "note": "opt-in LASR_PUSH_PINNED_NOCOPY: the kernel reads the caller's pinned buffer "
+                                                                   "over PCIe, nothing is copied (buffer lifetime: lasr_push_consumed)"}}
             except Exception as e:
                 out["pcie_inclusive"] = {"error": str(e)[:200]}
             # secondary figure: the offline path (Transcribe RPC) on whole 20.65 s utterances (the demo's length)
@@ -476,6 +583,34 @@ def main():
                                   "note": "lasr_transcribe_pcm: fresh state, max_iters 3, synchronous decode loop"}
             except Exception as e:                                            # never let the extra figure break the contract line
                 out["offline"] = {"error": str(e)[:200]}
+        if NCHK:
+            # self-check: the first NCHK streams again, from their first chunk, on freshly reset slots through the SYNCHRONOUS
+            # protocol (push -> step -> fetch per chunk); per model step the tokens must equal what the run above fetched
+            try:
+                rows = slots[:NCHK]
+                for s_ in rows:
+                    eng.reset(s_, 15)
+                sync_steps = [[] for _ in rows]
+                for k in range(P + W + K):
+                    eng.push(rows, pcm_dev[k % n_chunks][:NCHK])
+                    if eng.step(rows):
+                        toks = eng.fetch_many(rows, cap=FETCH_CAP)
+                        for r in range(NCHK):
+                            sync_steps[r].append(toks[r])
+                n_tok_chk = sum(len(t) for r in range(NCHK) for t in sync_steps[r])
+                bad = [(r, j) for r in range(NCHK) for j in range(max(len(sync_steps[r]), len(rec_steps[r])))
+                       if j >= len(sync_steps[r]) or j >= len(rec_steps[r]) or sync_steps[r][j] != rec_steps[r][j]]
+                out["tokens_checked"] = int(n_tok_chk)
+                out["tokens_equal"] = not bad
+                out["self_check"] = {"rows": NCHK, "model_steps_per_row": len(sync_steps[0]), "chunks": P + W + K,
+                                     "what": "streams 0..rows-1 replayed from chunk 0 through lasr_step_stream on reset slots; per model step "
+                                             "the token lists must equal those the " + ("pipelined " if pipelined else "") + "run fetched "
+                                             "(priming + warm-up + timed region)",
+                                     "first_mismatch": [int(bad[0][0]), int(bad[0][1])] if bad else None}
+            except Exception as e:
+                out["tokens_checked"] = 0
+                out["tokens_equal"] = False
+                out["self_check"] = {"error": str(e)[:300]}
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would stall the other ranks' teardown)
             gc.enable()
             try:
@@ -486,11 +621,20 @@ def main():
                 out["cpu_baseline"]["numpy_port"] = cpu_numpy_port(cfg, sd, 4, 60)
             except Exception as e:
                 out["cpu_baseline"]["numpy_port"] = {"error": str(e)[:200]}
+            try:
+                out["cpu_baseline"]["best_effort"] = cpu_best_effort(cfg, sd, B, args.cpu_be_chunks)
+            except Exception as e:
+                out["cpu_baseline"]["best_effort"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
+        if out.get("tokens_equal") is False:
+            print("bench.py: SELF-CHECK FAILED: " + json.dumps(out.get("self_check")), file=sys.stderr, flush=True)
+            rc_final = 3
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rc_final:
+        raise SystemExit(rc_final)
 
 
 if __name__ == "__main__":

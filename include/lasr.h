@@ -101,22 +101,30 @@ const char* lasr_last_error(const lasr_ctx* c);
  * Transducer.transcribe_stream, models.py:466-500, the Buffer transform's `saved` list,
  * transforms.py:461-471, and the servicer's 3-chunk `frames` list, api-server.py:85-102). */
 int lasr_stream_open(lasr_ctx* c, int* slot);
-/* what: 1 = encoder state, 2 = predictor (re-run on BOS), 4 = lm (no-op: no LM), 8 = front-end
+/* what: 1 = encoder state, 2 = predictor (re-run on BOS), 4 = LM state (reset_lm, models.py:491-492; no-op without an attached LM), 8 = front-end
  * window + frame buffer; OR-able.  reset() of models.py:494-497 == 1|2|4. */
 int lasr_stream_reset(lasr_ctx* c, int slot, int what);
 int lasr_stream_close(lasr_ctx* c, int slot);
 
 /* ---- streaming hot path, batched over n slots ------------------------------------------------
  * lasr_push_pcm: one client chunk of `chunk` float32 samples per listed slot (replaces
- * tensorize + the window cat of api-server.py:88-102).  pcm: [n, chunk] host or device.  Pageable host memory is
- * copied before the call returns; device memory and PINNED host memory (hipHostMalloc / hipHostRegister / a torch
- * pin_memory() tensor) are read by a kernel in stream order, like hipMemcpyAsync would: keep them untouched until the
- * stream has got there (e.g. until the lasr_step_* call that consumes the chunk has returned).
+ * tensorize + the window cat of api-server.py:88-102).  pcm: [n, chunk] host or device.
+ *   - HOST memory (pageable or pinned): copied into the engine's pinned staging ring BEFORE the call returns (helper
+ *     threads: LASR_PUSH_THREADS, default 2); the caller's buffer is free on return.
+ *   - DEVICE memory: read by a kernel in stream order on the ctx stream, like hipMemcpyAsync(D2D) would.
+ *   - lasr_push_pcm_ex with LASR_PUSH_PINNED_NOCOPY (opt-in): pcm must be PINNED host memory (hipHostMalloc /
+ *     hipHostRegister / a torch pin_memory() tensor); nothing is copied, a kernel reads the buffer over PCIe AFTER the call
+ *     has returned -- also after lasr_step_submit / lasr_push_submit have returned.  *ticket identifies the push: the buffer
+ *     must stay untouched until lasr_push_consumed(ctx, ticket) returns 1 (0 = not yet; an event query, no blocking).
+ *     Every host push gets a ticket (ticket may be NULL); device pushes report -1.
  * lasr_step_stream: for every listed slot whose window is full, computes the log-mel frames of
  * the window's middle (TransformTime + StreamPostprocess + StackDownsample, transforms.py:
  * 306-342,436-441), buffers them (Buffer), and for slots whose buffer reached n_buffer runs
  * encoder + greedy decode with carried state (models.py:506-575).  Blocks until the tokens of
  * this step are on the host.  n_ran (optional) = number of slots the model ran for. */
+#define LASR_PUSH_PINNED_NOCOPY 1
+int lasr_push_pcm_ex(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket);
+int lasr_push_consumed(lasr_ctx* c, long long ticket);
 int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm);
 int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran);
 
@@ -145,6 +153,10 @@ int lasr_step_window(lasr_ctx* c, const int* slots, int n, const float* pcm, int
  * Every other state-changing call returns LASR_ESTATE while a submitted step is uncollected.
  * Results are identical to lasr_step_stream (same kernels, same order per stream).  Greedy only. */
 int lasr_step_submit(lasr_ctx* c, const int* slots, int n);
+/* lasr_push_pcm_ex + lasr_step_submit for the same slot list in ONE call (same results): when the chunk completes a model
+ * step the front-end launch takes the newest chunk from `pcm` and appends it to the PCM ring itself -- one launch less on
+ * the critical stream per model step.  At the in-flight limit it returns LASR_ESTATE and NOTHING is pushed. */
+int lasr_push_submit(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket);
 int lasr_step_wait(lasr_ctx* c, int* n_ran);
 int lasr_step_pending(lasr_ctx* c);   /* submitted model steps not yet collected (0..lasr_max_inflight()) */
 int lasr_max_inflight(const lasr_ctx* c);
@@ -254,6 +266,8 @@ int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us);
  * on the stream the cells run on.  lasr_cell_prof_read drains the pairs: microseconds and cell launches
  * accumulated since profiling was switched on (average launch duration = us_total / launches, next to whatever
  * else shares the GPU -- the number a rocprofv3 kernel trace of the same run shows). */
+/* on: 0 off; 1 HIP-event pairs + in-kernel clocks; 2 in-kernel clocks only (lasr_cell_prof_kernel) -- an event record
+ * between two kernels costs the stream a bubble of a few microseconds, twice per model step in mode 1. */
 int lasr_cell_prof(lasr_ctx* c, int on);
 /* Stream timeline of the pipelined protocol (diagnostics): while on, timestamped marks are recorded on the main
  * stream (tag 1 push, 3 first cell, 4 cells done, 5 model step enqueued) and on the decode stream (10 group reached,

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LASR_LIB") or os.path.join(_HERE, "csrc", "liblasr_hip.so")   # LASR_LIB: A/B builds
 
 LASR_OK, LASR_EINVAL, LASR_ENOMEM, LASR_EHIP, LASR_ESTATE, LASR_EFULL = 0, -1, -2, -3, -4, -5
+LASR_PUSH_PINNED_NOCOPY = 1
 
 
 class ModelDesc(C.Structure):
@@ -43,6 +44,9 @@ SYMBOLS = [
     ("lasr_stream_reset", C.c_int, [_P, C.c_int, C.c_int]),
     ("lasr_stream_close", C.c_int, [_P, C.c_int]),
     ("lasr_push_pcm", C.c_int, [_P, _P, C.c_int, _P]),
+    ("lasr_push_pcm_ex", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_longlong)]),
+    ("lasr_push_consumed", C.c_int, [_P, C.c_longlong]),
+    ("lasr_push_submit", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_longlong)]),
     ("lasr_step_stream", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     ("lasr_step_window", C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     ("lasr_step_submit", C.c_int, [_P, _P, C.c_int]),

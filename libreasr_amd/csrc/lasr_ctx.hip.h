@@ -93,6 +93,7 @@ struct lasr_ctx {
     // the main stream while ONE greedy loop keeps running on stream_dec across chunk boundaries: a row
     // that finished chunk k moves on to chunk k+1's frames while a bursty row is still on chunk k.
     hipStream_t stream_dec = nullptr;
+    hipStream_t stream_main_own = nullptr;   // LASR_MAIN_CUS experiment: CU-masked stream used instead of the caller's
     static constexpr int NFLY = 16; // steps in flight (ring of encoder-done events)
     static constexpr int RING = 64; // pe ring, frames per row
     static constexpr int TOKRING = 512, ENDSLOTS = 32;
@@ -170,14 +171,23 @@ struct lasr_ctx {
     float* pend = nullptr;          // [M][n_buffer*n_stack][n_mels]
     float* stage_pcm = nullptr; size_t stage_pcm_floats = 0;
     float* win_rs = nullptr; size_t win_rs_floats = 0;       // resampled client windows (lasr_step_window)
-    // streaming pushes from host memory: ring of device staging rows + one event per entry, so a push
-    // never has to drain the stream (the copy of chunk k+1 overlaps the kernels of chunk k)
+    // streaming pushes from host memory: ring of pinned staging entries (read by the ring-append / front-end kernel over PCIe)
+    // + one event per host push ("its source has been read": staging entry free, ticket consumed)
     static constexpr int NSTAGE = 64;     // > 2 pushes x 15 model steps in flight: a push never waits for its ring entry
-    float* push_stage = nullptr; hipEvent_t push_ev[NSTAGE] = {}; bool push_used[NSTAGE] = {}; int push_next = 0;
-    float* push_stage_host_dev = nullptr; bool push_zero_copy = true;   // device view of the pinned ring; LASR_PUSH_DMA=1: DMA + event instead
-    float* push_stage_host = nullptr;     // pinned mirror of the ring: caller's (pageable) buffer -> memcpy -> async DMA
-    hipStream_t stream_copy = nullptr;    // the DMA of chunk k+1 runs under the kernels of chunk k; the push kernel waits for it
-    hipEvent_t push_copied[NSTAGE] = {};
+    hipEvent_t push_ev[NSTAGE] = {}; bool push_used[NSTAGE] = {};
+    long long push_serial = 0;            // tickets handed out so far
+    float* push_stage_host = nullptr;     // pinned [NSTAGE][M][chunk]
+    float* push_stage_host_dev = nullptr; // its device view
+    struct CopyPool {                     // helper threads of the staging copy (lazy; LASR_PUSH_THREADS, default 2)
+        bool init = false;
+        std::vector<std::thread> th;
+        std::mutex m; std::condition_variable cv;
+        std::atomic<long long> gen{0}; std::atomic<bool> stop{false};
+        std::atomic<int> next{0}, done{0};
+        const char* src = nullptr; char* dst = nullptr; size_t bytes = 0, part_bytes = 0; int parts = 0;
+    } pool;
+    std::vector<int> h_ring_pos;          // host mirror of ring_pos (every append goes through the host: +1 per pushed chunk)
+    int fe_mode = 1;                      // fused front-end: 1 = k_fe_mel (+ ring append) -> k_stack_ln, 0 = k_frontend; LASR_FE_MODE
     float* lm_buf = nullptr; size_t lm_floats = 0;       // offline log-mel
     float* feat_stage = nullptr; size_t feat_stage_floats = 0;
 
@@ -203,6 +213,7 @@ struct lasr_ctx {
     // every model step, on the stream the cells are launched on; harvested lazily (ring of pairs)
     static constexpr int NCELLEV = 64;
     bool cell_prof = false;
+    bool cell_prof_events = true;   // lasr_cell_prof(c, 2): in-kernel clocks only, no HIP events on the stream
     hipEvent_t cp_ev[NCELLEV][2] = {};
     bool cp_ok = false;
     int cp_head = 0, cp_n = 0;      // ring: cp_n pairs outstanding, oldest at (cp_head - cp_n) mod NCELLEV
@@ -211,8 +222,8 @@ struct lasr_ctx {
     long long cp_launches = 0;
     // ... and the kernels' own durations: every cell launch gets a slot {min entry, max exit} of the device's constant
     // wall clock over its workgroups (what a kernel trace calls the kernel's duration: no launch gaps, no event overhead)
-    static constexpr int NCELLSLOT = 1 << 15;
-    unsigned long long* cp_slots = nullptr;   // device [NCELLSLOT][2]
+    static constexpr int NCELLSLOT = 1 << 12;
+    unsigned long long* cp_slots = nullptr;   // device [2][NCELLSLOT][PROF_W]: per launch and workgroup, entry clocks then exit clocks
     long long cp_slot_next = 0;
     std::vector<unsigned char> cp_slot_cells;  // cells computed by the launch of slot i (layer-wavefront launches: up to 8)
     int enc_wave = 0;               // encoder pass as a layer wavefront (cells of an anti-diagonal share a launch): default on for bf16; LASR_ENC_WAVE

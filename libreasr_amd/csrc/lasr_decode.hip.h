@@ -67,7 +67,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
     const int mt_total = c->Tcap * c->MT;
     const int par0 = c->enc_par;
     int cp_slot = -1;
-    if (c->cell_prof && c->cp_ok) {
+    if (c->cell_prof && c->cp_ok && c->cell_prof_events) {
         if (c->cp_n >= lasr_ctx::NCELLEV) cell_prof_harvest(c, false);
         cp_slot = c->cp_head;
         c->cp_head = (c->cp_head + 1) % lasr_ctx::NCELLEV;
@@ -75,6 +75,10 @@ void run_encoder(lasr_ctx* c, int T_max) {
         (void)hipEventRecord(c->cp_ev[cp_slot][0], c->stream);
     }
     tr_mark(c, 3, c->stream);
+    {   // experiment: extra latency on the main stream, once per model step
+        static const int dly = getenv("LASR_DELAY_MAIN_US") ? atoi(getenv("LASR_DELAY_MAIN_US")) : 0;
+        if (dly > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream, (unsigned long long)dly * 100ull);
+    }
     // layer wavefront: the cells (l, t) with l + t = d depend only on diagonal d - 1, so a diagonal is ONE launch
     // (k_gemm_multi, up to NPMAX cells): L + T - 1 launches instead of L * T, and the per-launch fixed costs of a cell
     // overlap its neighbours' K loops.  Cell (l, t) reads h parity par0 ^ (t & 1); all layers end on par0 ^ (T & 1).
@@ -154,8 +158,7 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
             const int it = first + q;
             c->dbg_gate = (it == 0);
             launch_logits(c, c->logits, c->la * M, true);
-            hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, max_iters,
-                               c->T_row_dec, s, it, (float*)nullptr, (int*)nullptr, c->la, M);
+            launch_select<false>(c->stream, M, c->logits, V, c->d.blank, max_iters, c->T_row_dec, s, it, nullptr, nullptr, c->la, M);
             launch_predictor(c);
             launch_ppj(c);
             launch_lm(c);

@@ -9,7 +9,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -69,9 +74,12 @@ void lasr_destroy(lasr_ctx* c) {
     if (c->tr_base) (void)hipEventDestroy(c->tr_base);
     if (c->trellis_host) (void)hipHostFree(c->trellis_host);
     if (c->push_stage_host) (void)hipHostFree(c->push_stage_host);
-    if (c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
-    for (auto& e : c->push_copied)
-        if (e) (void)hipEventDestroy(e);
+    if (!c->pool.th.empty()) {
+        c->pool.stop.store(true);
+        { std::lock_guard<std::mutex> lk(c->pool.m); }
+        c->pool.cv.notify_all();
+        for (auto& t : c->pool.th) t.join();
+    }
     for (auto& e : c->push_ev)
         if (e) (void)hipEventDestroy(e);
     for (void* p : c->host_allocs) (void)hipHostFree(p);
@@ -86,6 +94,7 @@ void lasr_destroy(lasr_ctx* c) {
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
     if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
+    if (c->stream_main_own) { (void)hipStreamSynchronize(c->stream_main_own); (void)hipStreamDestroy(c->stream_main_own); }
     delete c;
 }
 
@@ -264,6 +273,30 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         HIPCHK(c, hipMemset(c->T_row_ring[q], 0, sizeof(int) * M));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_enc[q], hipEventDisableTiming));
     }
+    // CU partition between the two streams of the pipelined protocol (experiment knobs; hipExtStreamCreateWithCUMask).  Mask
+    // bit i is CU (i / 8) of XCD (i % 8) (KFD interleaves the mask over the XCCs first, then the shader engines), so a
+    // contiguous bit range is spread evenly over the 8 XCDs.  LASR_DEC_CUS = n: the decode stream runs on mask bits [off, off + n)
+    // (LASR_DEC_CU_OFF, default 0); LASR_MAIN_CUS = m: the engine runs the main-stream work on its OWN stream restricted to bits
+    // [256 - m, 256) instead of the caller's stream (experiment only: the caller's stream order is not honoured).
+    auto cu_mask_stream = [&](hipStream_t* st, int first, int n) -> int {
+        int ncu = 0;
+        HIPCHK(c, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = first; i < first + n && i < ncu; ++i)
+            if (i >= 0) mask[i >> 5] |= 1u << (i & 31);
+        HIPCHK(c, hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
+        return LASR_OK;
+    };
+    if (getenv("LASR_MAIN_CUS") && atoi(getenv("LASR_MAIN_CUS")) > 0) {
+        int ncu = 0;
+        HIPCHK(c, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
+        const int m = std::min(ncu, atoi(getenv("LASR_MAIN_CUS")));
+        RC(cu_mask_stream(&c->stream_main_own, ncu - m, m));
+        c->stream = c->stream_main_own;
+    }
+    if (getenv("LASR_DEC_CUS") && atoi(getenv("LASR_DEC_CUS")) > 0) {
+        RC(cu_mask_stream(&c->stream_dec, getenv("LASR_DEC_CU_OFF") ? atoi(getenv("LASR_DEC_CU_OFF")) : 0, atoi(getenv("LASR_DEC_CUS"))));
+    } else
     if (getenv("LASR_DEC_STREAM_PRIO")) {      // experiment: the latency-critical decode chain on a high-priority HIP stream
         int lo = 0, hi = 0;
         HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -304,6 +337,8 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
     // (the reference front-end: 10 frames of 128 mels per stacked frame; other shapes take the per-chunk kernels)
     c->fe_fused = M <= 512 && d.n_buffer <= 4 && d.n_stack == 10 && d.n_mels <= 128 && d.feat == 1280 && !getenv("LASR_FE_LEGACY");
+    if (getenv("LASR_FE_MODE")) c->fe_mode = atoi(getenv("LASR_FE_MODE")) ? 1 : 0;
+    c->h_ring_pos.assign(M, 0);
     c->ring_chunks = c->fe_fused ? d.n_window + d.n_buffer - 1 : d.n_window;
     c->pend_serial.assign((size_t)M * d.n_buffer, 0); c->pend_mat.assign((size_t)M * d.n_buffer, 0);
     RC(dalloc(c, &c->win, (size_t)M * c->ring_chunks * d.chunk)); HIPCHK(c, hipMemset(c->win, 0, (size_t)M * c->ring_chunks * d.chunk * 4));
@@ -483,81 +518,161 @@ static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
     return LASR_OK;
 }
 
-int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) {
-    if (!c) return LASR_EINVAL;
-    RC(check_slots(c, slots, n, true));
-    if (n == 0) return LASR_OK;
-    if (!pcm) return fail(c, LASR_EINVAL, "pcm is null");
-    HIPCHK(c, hipSetDevice(c->device));
-    if (!c->pending.empty()) RC(cont_pump(c, c->kick_n));      // steps in flight: keep the decode loop fed
-    const int CH = c->d.chunk;
-    const float* src = pcm;
-    // three kinds of caller memory: device (read by the ring-append kernel in stream order), PINNED host (the same: the kernel
-    // reads it over PCIe in stream order, like hipMemcpyAsync would -- the buffer must stay untouched until the stream gets
-    // there), pageable host (copied into the engine's pinned ring before the call returns)
-    const void* pinned = is_device_ptr(pcm) ? nullptr : pinned_host_dev_ptr(pcm);
-    const bool from_host = !is_device_ptr(pcm) && !pinned;
-    if (pinned) src = (const float*)pinned;
-    int stage_i = -1;
-    if (from_host) {
-        if (!c->push_stage) {
-            RC(dalloc(c, &c->push_stage, (size_t)lasr_ctx::NSTAGE * c->M * CH));
-            HIPCHK(c, hipHostMalloc((void**)&c->push_stage_host, sizeof(float) * (size_t)lasr_ctx::NSTAGE * c->M * CH));
-            {
-                void* dp = nullptr;
-                HIPCHK(c, hipHostGetDevicePointer(&dp, c->push_stage_host, 0));
-                c->push_stage_host_dev = (float*)dp;
-                c->push_zero_copy = !(getenv("LASR_PUSH_DMA") && atoi(getenv("LASR_PUSH_DMA")) != 0);
+// ---- client chunks -> PCM ring.  Three kinds of caller memory:
+//   device           read by the ring-append (or front-end) kernel in stream order, like any stream-ordered copy;
+//   host (default)   pageable OR pinned: copied into the engine's own pinned staging ring before the call returns (the caller's
+//                    buffer is free on return); the kernel reads the staging entry over PCIe -- no DMA call, no copy stream;
+//   pinned, no copy  LASR_PUSH_PINNED_NOCOPY: the kernel reads the CALLER's pinned buffer over PCIe after the call has returned;
+//                    the buffer must stay untouched until lasr_push_consumed(ticket) says so.
+struct PushSrc { const float* src = nullptr; int ev_i = -1; long long ticket = -1; };
+
+// threaded copy into the staging ring: 328 KB per push at 64 streams is 40 us of one core when the source is cold (pageable
+// client buffers), which made the single host thread the limit of the PCIe-inclusive rate.  The calling thread takes parts as
+// well, so a helper that wakes up late costs nothing.
+static void pool_worker(lasr_ctx::CopyPool* P) {
+    long long seen = 0;
+    for (;;) {
+        {   // wait for a new job: spin briefly (pushes come every ~100 us in steady state), then sleep
+            int spins = 0;
+            while (P->gen.load(std::memory_order_acquire) == seen && !P->stop.load(std::memory_order_acquire)) {
+                if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+                std::unique_lock<std::mutex> lk(P->m);
+                P->cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return P->gen.load() != seen || P->stop.load(); });
             }
-            for (auto& e : c->push_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            for (auto& e : c->push_copied) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            HIPCHK(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
         }
-        stage_i = c->push_next;
-        c->push_next = (stage_i + 1) % lasr_ctx::NSTAGE;
-        if (c->push_used[stage_i]) HIPCHK(c, hipEventSynchronize(c->push_ev[stage_i]));   // its last reader (16 pushes ago) is done
-        float* dst = c->push_stage + (size_t)stage_i * c->M * CH;
-        float* pin = c->push_stage_host + (size_t)stage_i * c->M * CH;
-        if (c->push_zero_copy) {
-            // zero-copy: the ring-append kernel reads the pinned ring entry over PCIe itself (328 KB at 64 streams: a few
-            // microseconds on the stream) -- no DMA call, no copy stream, no cross-stream event (three driver calls and a
-            // cross-queue dependency per push less; the single host thread is what limits the PCIe-inclusive rate)
-            memcpy(pin, pcm, sizeof(float) * (size_t)n * CH);
-            src = c->push_stage_host_dev + (size_t)stage_i * c->M * CH;
-        } else {
-        memcpy(pin, pcm, sizeof(float) * (size_t)n * CH);      // the caller's buffer is free on return, whatever its kind
-        HIPCHK(c, hipMemcpyAsync(dst, pin, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream_copy));   // truly asynchronous
-        HIPCHK(c, hipEventRecord(c->push_copied[stage_i], c->stream_copy));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->push_copied[stage_i], 0));
-        src = dst;
+        if (P->stop.load(std::memory_order_acquire)) return;
+        seen = P->gen.load(std::memory_order_acquire);
+        for (;;) {
+            const int i = P->next.fetch_add(1, std::memory_order_acq_rel);
+            if (i >= P->parts) break;
+            const size_t lo = (size_t)i * P->part_bytes, hi = std::min(P->bytes, lo + P->part_bytes);
+            memcpy(P->dst + lo, P->src + lo, hi - lo);
+            P->done.fetch_add(1, std::memory_order_acq_rel);
         }
     }
-    tr_mark(c, 1, c->stream);
-    if (c->fe_fused) RC(materialize_pending(c, slots, n));      // irregular clients only: see there
+}
+static void staged_copy(lasr_ctx* c, void* dst, const void* src, size_t bytes) {
+    lasr_ctx::CopyPool& P = c->pool;
+    if (!P.init) {
+        P.init = true;
+        int nth = 2;
+        if (getenv("LASR_PUSH_THREADS")) nth = std::max(0, std::min(8, atoi(getenv("LASR_PUSH_THREADS"))));
+        for (int i = 0; i < nth; ++i) P.th.emplace_back(pool_worker, &P);
+    }
+    if (P.th.empty() || bytes < (size_t)(96 << 10)) { memcpy(dst, src, bytes); return; }
+    P.src = (const char*)src; P.dst = (char*)dst; P.bytes = bytes;
+    P.part_bytes = ((bytes / (4 * (P.th.size() + 1))) + 4095) & ~(size_t)4095;
+    P.parts = (int)((bytes + P.part_bytes - 1) / P.part_bytes);
+    P.next.store(0, std::memory_order_release); P.done.store(0, std::memory_order_release);
+    P.gen.fetch_add(1, std::memory_order_acq_rel);
+    P.cv.notify_all();
+    for (;;) {
+        const int i = P.next.fetch_add(1, std::memory_order_acq_rel);
+        if (i >= P.parts) break;
+        const size_t lo = (size_t)i * P.part_bytes, hi = std::min(bytes, lo + P.part_bytes);
+        memcpy(P.dst + lo, P.src + lo, hi - lo);
+        P.done.fetch_add(1, std::memory_order_acq_rel);
+    }
+    while (P.done.load(std::memory_order_acquire) < P.parts) __builtin_ia32_pause();
+}
+
+static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, PushSrc& ps) {
+    const int CH = c->d.chunk;
+    ps.src = pcm;
+    if (is_device_ptr(pcm)) {
+        if (flags & LASR_PUSH_PINNED_NOCOPY) return fail(c, LASR_EINVAL, "LASR_PUSH_PINNED_NOCOPY needs pinned HOST memory");
+        return LASR_OK;
+    }
+    if (!c->push_ev[0])
+        for (auto& e : c->push_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // one event per host push: "the kernel that reads this push's source has finished" (staging entry free / ticket consumed)
+    ps.ticket = c->push_serial++;
+    ps.ev_i = (int)(ps.ticket % lasr_ctx::NSTAGE);
+    if (c->push_used[ps.ev_i]) HIPCHK(c, hipEventSynchronize(c->push_ev[ps.ev_i]));       // 64 pushes ago: long done
+    if (flags & LASR_PUSH_PINNED_NOCOPY) {
+        const void* pinned = pinned_host_dev_ptr(pcm);
+        if (!pinned) return fail(c, LASR_EINVAL, "LASR_PUSH_PINNED_NOCOPY: the buffer is not pinned (device-mapped) host memory");
+        ps.src = (const float*)pinned;
+        return LASR_OK;
+    }
+    if (!c->push_stage_host) {
+        HIPCHK(c, hipHostMalloc((void**)&c->push_stage_host, sizeof(float) * (size_t)lasr_ctx::NSTAGE * c->M * CH));
+        void* dp = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer(&dp, c->push_stage_host, 0));
+        c->push_stage_host_dev = (float*)dp;
+    }
+    staged_copy(c, c->push_stage_host + (size_t)ps.ev_i * c->M * CH, pcm, sizeof(float) * (size_t)n * CH);
+    ps.src = c->push_stage_host_dev + (size_t)ps.ev_i * c->M * CH;
+    return LASR_OK;
+}
+// the plain ring append (one launch)
+static int push_append_launch(lasr_ctx* c, const int* slots, int n, const PushSrc& ps) {
+    const int CH = c->d.chunk;
     if (c->M <= 512) {      // slot -> staging-row map by value: no command-block copy for a push
         PushIdx pi;
         for (int r = 0; r < 512; ++r) pi.idx[r] = -1;
         for (int i = 0; i < n; ++i) pi.idx[slots[i]] = (short)i;
-        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, (const int*)nullptr, pi, c->win, c->ring_pos, CH, c->ring_chunks);
+        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, ps.src, (const int*)nullptr, pi, c->win, c->ring_pos, CH, c->ring_chunks);
     } else {
         RC(cmd_begin(c));
         for (int r = 0; r < c->M; ++r) c->hc.src_idx[r] = -1;
         for (int i = 0; i < n; ++i) c->hc.src_idx[slots[i]] = i;
         RC(cmd_commit(c));
         PushIdx pi;
-        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, src, (const int*)c->dc.src_idx, pi, c->win, c->ring_pos, CH, c->ring_chunks);
-    }
-    for (int i = 0; i < n; ++i) c->n_chunks[slots[i]]++;
-    if (from_host) {
-        HIPCHK(c, hipEventRecord(c->push_ev[stage_i], c->stream));
-        c->push_used[stage_i] = true;
+        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, ps.src, (const int*)c->dc.src_idx, pi, c->win, c->ring_pos, CH, c->ring_chunks);
     }
     return LASR_OK;
+}
+// after the launch that reads ps.src: the host mirrors and the "source consumed" event
+static int push_finish(lasr_ctx* c, const int* slots, int n, const PushSrc& ps, long long* ticket, bool counted = false) {
+    for (int i = 0; i < n; ++i) {
+        if (!counted) c->n_chunks[slots[i]]++;
+        c->h_ring_pos[slots[i]] = (c->h_ring_pos[slots[i]] + 1) % c->ring_chunks;
+    }
+    if (ps.ev_i >= 0) {
+        HIPCHK(c, hipEventRecord(c->push_ev[ps.ev_i], c->stream));
+        c->push_used[ps.ev_i] = true;
+    }
+    if (ticket) *ticket = ps.ticket;
+    return LASR_OK;
+}
+
+int lasr_push_pcm_ex(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket) {
+    if (!c) return LASR_EINVAL;
+    if (ticket) *ticket = -1;
+    RC(check_slots(c, slots, n, true));
+    if (n == 0) return LASR_OK;
+    if (!pcm) return fail(c, LASR_EINVAL, "pcm is null");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->pending.empty()) RC(cont_pump(c, c->kick_n));      // steps in flight: keep the decode loop fed
+    PushSrc ps;
+    RC(push_prepare(c, slots, n, pcm, flags, ps));
+    tr_mark(c, 1, c->stream);
+    if (c->fe_fused) RC(materialize_pending(c, slots, n));      // irregular clients only: see there
+    RC(push_append_launch(c, slots, n, ps));
+    return push_finish(c, slots, n, ps, ticket);
+}
+int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm) { return lasr_push_pcm_ex(c, slots, n, pcm, 0, nullptr); }
+
+// 1: the source of the push that returned `ticket` has been read (a LASR_PUSH_PINNED_NOCOPY buffer may be reused); 0: not yet
+int lasr_push_consumed(lasr_ctx* c, long long ticket) {
+    if (!c) return LASR_EINVAL;
+    if (ticket < 0 || ticket >= c->push_serial) return fail(c, LASR_EINVAL, "unknown push ticket %lld", ticket);
+    if (c->push_serial - ticket > lasr_ctx::NSTAGE) return 1;        // its event slot has been waited for and reused since
+    HIPCHK(c, hipSetDevice(c->device));
+    const hipError_t e = hipEventQuery(c->push_ev[ticket % lasr_ctx::NSTAGE]);
+    if (e == hipSuccess) return 1;
+    (void)hipGetLastError();
+    if (e == hipErrorNotReady) return 0;
+    return fail(c, LASR_EHIP, "hipEventQuery failed: %s", hipGetErrorString(e));
 }
 
 // front-end of one client chunk for the listed slots and, for the slots whose frame buffer filled up,
 // LayerNorm + encoder + encoder half of the joint -- all enqueued on c->stream, nothing synchronises
-static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::vector<int>& model_rows, int& Tm) {
+// fused (lasr_push_submit): the listed slots' newest chunk is still in the caller's buffer `fused->src` (row i of it belongs to
+// slots[i]); the front-end launch appends it to the PCM ring itself.  *fused_done tells the caller whether that happened.
+static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::vector<int>& model_rows, int& Tm,
+                                    const PushSrc* fused = nullptr, bool* fused_done = nullptr) {
     const lasr_model_desc& d = c->d;
     // window geometry (api-server.py:95-102 + TransformTime + StreamPostprocess)
     const long long N = (long long)d.n_window * d.chunk;
@@ -603,10 +718,39 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
                 f.age_v[j][s] = c->pend_mat[q] ? 255 : (unsigned char)age;
             }
         }
+        if (c->fe_mode == 1) {
+            // log-mel halves (+ the ring append of the newest chunk when fused) on 2 x n_buffer x rows workgroups, then stack + LayerNorm
+            FeMelArgs m{};
+            m.window = c->window; m.tw512 = c->tw512; m.tw1024 = c->tw1024; m.fb_start = c->fb_start; m.fb_off = c->fb_off; m.fb_w = c->fb_w;
+            m.n_mels = d.n_mels; m.hop = d.hop; m.fb_nnz = c->fb_nnz; m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win;
+            m.pcm = c->win; m.ring_pos = c->ring_pos; m.chunk = d.chunk; m.n_window = d.n_window; m.ring_chunks = c->ring_chunks; m.frame0 = a0;
+            m.pend = c->pend; m.pend_frames = d.n_buffer * d.n_stack;
+            m.trow_out = c->dc.T_row; m.enc_frames = f.enc_frames; m.enc_base = f.enc_base;
+            m.src = fused ? fused->src : nullptr;
+            for (int r = 0; r < 512; ++r) { m.idx[r] = -1; m.tp_pk[r] = 0; m.age_pk[r] = 0; }
+            for (int r = 0; r < c->M; ++r) m.tp_pk[r] = (unsigned char)(c->h_ring_pos[r] << 4);
+            if (fused)
+                for (int i = 0; i < n; ++i) m.idx[slots[i]] = (short)i;
+            for (int s : model_rows) {
+                m.tp_pk[s] |= (unsigned char)d.n_buffer;
+                unsigned pk = 0;
+                for (int j = 0; j < d.n_buffer; ++j) pk |= (unsigned)(f.age_v[j][s] == 255 ? 15 : f.age_v[j][s]) << (4 * j);
+                m.age_pk[s] = (unsigned short)pk;
+            }
+            hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * d.n_buffer, c->M), dim3(320), 0, c->stream, m);
+            if (fused_done) *fused_done = fused != nullptr;
+            RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring));    // the continuous loop reads its own frame counters
+            StackLnArgs a{};
+            a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
+            a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
+            a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.bf = c->bf; a.Tmax = Tm;
+            LAUNCH_STACK_LN( dim3((Tm + 3) / 4, c->M), dim3(256), 0, c->stream, a);
+        } else {
         const dim3 grid(d.n_buffer, c->M);
         hipLaunchKernelGGL((k_frontend<10, 20>), grid, dim3(640), 0, c->stream, f);
         // (after the launch that stores T_row: the synchronous protocol copies it to a fixed buffer on the stream)
         RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring));    // the continuous loop reads its own frame counters
+        }
         rec(c, 1);
         run_encoder(c, Tm);
         rec(c, 2);
@@ -699,9 +843,45 @@ static int cont_pump(lasr_ctx* c, int G);
 // encoder, so decoding resumes without the host).
 // Tokens are attributed to the step whose frames produced them: per-step results are identical to
 // lasr_step_stream.
+static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fused, bool* fused_done);
 int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     if (!c) return LASR_EINVAL;
     RC(check_slots(c, slots, n, true));
+    return submit_impl(c, slots, n, nullptr, nullptr);
+}
+
+// lasr_push_pcm_ex + lasr_step_submit in one call: when the chunk completes a model step, the front-end launch reads the newest
+// chunk straight from the source buffer and appends it to the PCM ring itself (one launch less per model step).
+int lasr_push_submit(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket) {
+    if (!c) return LASR_EINVAL;
+    if (ticket) *ticket = -1;
+    RC(check_slots(c, slots, n, true));
+    if (n == 0) return LASR_OK;
+    if (!pcm) return fail(c, LASR_EINVAL, "pcm is null");
+    if (c->W > 1) return fail(c, LASR_ESTATE, "lasr_push_submit is greedy-only; use lasr_push_pcm + lasr_step_stream with beam > 1");
+    if ((int)c->pending.size() + 1 > lasr_max_inflight(c))
+        return fail(c, LASR_ESTATE, "%d steps already in flight (limit %d): call lasr_step_wait (nothing was pushed)", (int)c->pending.size(), lasr_max_inflight(c));
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->pending.empty()) RC(cont_pump(c, c->kick_n));
+    PushSrc ps;
+    RC(push_prepare(c, slots, n, pcm, flags, ps));
+    tr_mark(c, 1, c->stream);
+    if (c->fe_fused) RC(materialize_pending(c, slots, n));
+    const bool can_fuse = c->fe_fused && c->fe_mode == 1;
+    if (!can_fuse) RC(push_append_launch(c, slots, n, ps));
+    for (int i = 0; i < n; ++i) c->n_chunks[slots[i]]++;
+    bool fused_done = false;
+    int rc = submit_impl(c, slots, n, can_fuse ? &ps : nullptr, &fused_done);
+    if (rc) {       // (argument errors were caught above: what can fail here is the runtime)
+        if (can_fuse && !fused_done) (void)push_append_launch(c, slots, n, ps);
+        (void)push_finish(c, slots, n, ps, ticket, true);
+        return rc;
+    }
+    if (can_fuse && !fused_done) RC(push_append_launch(c, slots, n, ps));      // no model step from this chunk: plain append
+    return push_finish(c, slots, n, ps, ticket, true);
+}
+
+static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fused, bool* fused_done) {
     if (c->W > 1) return fail(c, LASR_ESTATE, "lasr_step_submit is greedy-only; use lasr_step_stream with beam > 1");
     {   // in-flight limit: the event / T_row rings (NFLY) and the per-row rings the decode loop runs through --
         // encoder frames not yet decoded (pe ring), tokens not yet collected (token ring), step boundary marks
@@ -721,7 +901,7 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     int Tm = 0;
     const bool prof = c->profiling;
     c->profiling = false;
-    int rc = enqueue_frontend_encoder(c, slots, n, model_rows, Tm);
+    int rc = enqueue_frontend_encoder(c, slots, n, model_rows, Tm, fused, fused_done);
     c->profiling = prof;
     c->pe = pe_keep;
     if (rc) return rc;
@@ -827,11 +1007,12 @@ static int cont_launch_group(lasr_ctx* c, int G) {
         for (int q = 0; q < G; ++q) {
             s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
             launch_logits(c, c->logits, c->la * M, true);
-            hipLaunchKernelGGL((k_select<false>), dim3(M), dim3(256), 0, c->stream, c->logits, V, c->d.blank, c->d.max_iters_stream,
-                               c->c_avail, s, 0, (float*)nullptr, (int*)nullptr, c->la, M);
+            launch_select<false>(c->stream, M, c->logits, V, c->d.blank, c->d.max_iters_stream, c->c_avail, s, 0, nullptr, nullptr, c->la, M);
             launch_predictor(c);
             launch_ppj(c);
             launch_lm(c);
+            static const int dly = getenv("LASR_DELAY_DEC_US") ? atoi(getenv("LASR_DELAY_DEC_US")) : 0;    // experiment: see k_delay
+            if (dly > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream, (unsigned long long)dly * 100ull);
         }
     };
     if (c->use_graphs && !c->dbg) {
@@ -1238,8 +1419,7 @@ int lasr_joint(lasr_ctx* c, const float* h_pred, const float* h_enc, int B, floa
     launch_logits(c, logits, B, false);
     if (logp_max && argmax) {
         DecState s = c->ds;
-        hipLaunchKernelGGL((k_select<true>), dim3(B), dim3(256), 0, c->stream, (const float*)logits, V, c->d.blank, 1,
-                           (const int*)nullptr, s, 0, logp_max, argmax, 1, c->M);
+        launch_select<true>(c->stream, B, logits, V, c->d.blank, 1, nullptr, s, 0, logp_max, argmax, 1, c->M);
     }
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
@@ -1588,22 +1768,25 @@ int lasr_debug_timing(lasr_ctx* c, unsigned long long* out /*[5*4096*8]*/) {
 int lasr_cell_prof(lasr_ctx* c, int on) {
     if (!c) return LASR_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    if (on && !c->cp_ok) {
+    // on = 1: HIP-event pairs + in-kernel clocks; on = 2: in-kernel clocks only (an event record between two kernels
+    // costs the stream a bubble of several microseconds: twice per model step in mode 1)
+    c->cell_prof_events = on == 1;
+    if (on == 1 && !c->cp_ok) {
         for (auto& p : c->cp_ev)
             for (auto& e : p) HIPCHK(c, hipEventCreate(&e));
         c->cp_ok = true;
     }
     if (on) { cell_prof_harvest(c, true); c->cp_us = 0.0; c->cp_launches = 0; }
     if (on) {
+        const size_t half = (size_t)PROF_W * lasr_ctx::NCELLSLOT;
         if (!c->cp_slots) {
-            RC(dalloc(c, &c->cp_slots, (size_t)2 * lasr_ctx::NCELLSLOT));
+            RC(dalloc(c, &c->cp_slots, 2 * half));
             int khz = 0;
             if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) c->cp_clock_mhz = khz / 1e3;
             else (void)hipGetLastError();
         }
-        std::vector<unsigned long long> init((size_t)2 * lasr_ctx::NCELLSLOT);
-        for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0ull; }
-        HIPCHK(c, hipMemcpy(c->cp_slots, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemset(c->cp_slots, 0xff, half * sizeof(unsigned long long)));            // entry clocks: ~0 = not written
+        HIPCHK(c, hipMemset(c->cp_slots + half, 0, half * sizeof(unsigned long long)));         // exit clocks
         c->cp_slot_next = 0;
         c->cp_slot_cells.assign(lasr_ctx::NCELLSLOT, 0);
     }
@@ -1619,11 +1802,18 @@ int lasr_cell_prof_kernel(lasr_ctx* c, double* us_total, long long* launches, lo
     if (cells) *cells = 0;
     if (!c->cp_slots || c->cp_slot_next == 0) return LASR_OK;
     HIPCHK(c, hipDeviceSynchronize());
-    std::vector<unsigned long long> h((size_t)2 * c->cp_slot_next);
-    HIPCHK(c, hipMemcpy(h.data(), c->cp_slots, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const size_t half = (size_t)PROF_W * lasr_ctx::NCELLSLOT, used = (size_t)PROF_W * c->cp_slot_next;
+    std::vector<unsigned long long> he(used), hx(used);
+    HIPCHK(c, hipMemcpy(he.data(), c->cp_slots, used * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hx.data(), c->cp_slots + half, used * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (long long i = 0; i < c->cp_slot_next; ++i) {
-        if (h[2 * i] == ~0ull || h[2 * i + 1] < h[2 * i]) continue;
-        *us_total += (double)(h[2 * i + 1] - h[2 * i]) / c->cp_clock_mhz;
+        unsigned long long lo = ~0ull, hi = 0ull;
+        for (int w = 0; w < PROF_W; ++w) {
+            lo = std::min(lo, he[(size_t)i * PROF_W + w]);
+            hi = std::max(hi, hx[(size_t)i * PROF_W + w]);
+        }
+        if (lo == ~0ull || hi < lo) continue;
+        *us_total += (double)(hi - lo) / c->cp_clock_mhz;
         *launches += 1;
         if (cells) *cells += c->cp_slot_cells[i];
     }

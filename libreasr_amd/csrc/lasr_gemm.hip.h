@@ -81,6 +81,7 @@ __device__ __forceinline__ void act_st(int bf, void* p, size_t i, float v) {
     if (bf) OpsBF16::st(p, i, v); else OpsF32::st(p, i, v);
 }
 
+constexpr int PROF_W = 1024;     // per-launch slots of the in-job kernel timer (workgroup id modulo PROF_W)
 struct GemmArgs {
     const void* A[2];       // phase operand: fragment-major (row-major when AROW), element type of Ops
     int a_mt_total[2];      // m-tiles in A's fragment layout (lda in elements when AROW)
@@ -93,7 +94,8 @@ struct GemmArgs {
     const int* parent;      // beam search (AROW, W > 1): phase-1 rows are read from the row's parent hypothesis
     int beam_w;             //   slot: row r -> (r / W) * W + parent[r]; nullptr / 0: identity (greedy)
     unsigned long long* dbg; // optional per-workgroup phase timestamps [blocks][16] (LASR_DBG_TIMING)
-    unsigned long long* prof; // optional [2]: min entry / max exit wall_clock64() over the workgroups = the kernel's own duration
+    unsigned long long* prof; // optional: per-workgroup entry (prof[wg % PROF_W]) and exit (prof_x[wg % PROF_W]) wall_clock64(), plain stores --
+    unsigned long long* prof_x; //   max exit - min entry over the workgroups = the kernel's own duration (atomics on one word cost the job 7 %)
     int prio;                // wave priority for the whole kernel (s_setprio 0..3); experiments: LASR_DEC_PRIO / LASR_CELL_PRIO
 };
 
@@ -268,7 +270,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
     else if (g.prio == 1) __builtin_amdgcn_s_setprio(1);
     unsigned long long* dbg = g.dbg ? g.dbg + ((size_t)mg * gridDim.x + jb) * 16 : nullptr;
     if (dbg && tid == 0) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[5] = wall_clock64(); }
-    if (g.prof && tid == 0) atomicMin(&g.prof[0], (unsigned long long)wall_clock64());
+    const int prof_wg = (int)(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % PROF_W);
+    if (g.prof && tid == 0) g.prof[prof_wg] = (unsigned long long)wall_clock64();
 
     // (0) this wave's first weight fragment does not depend on flags / compaction: put it in flight
     //     before anything else (first-touch latency of the weight stream is the long pole)
@@ -414,7 +417,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
     if (dbg && tid == 0) dbg[3] = __builtin_amdgcn_s_memtime();
     Epi::template run<MT>(ea, RedView<NW, ROWS, LD>{red}, tid, jb, mg, n_act, row_map, pre, NW * 64);
     if (dbg && tid == 0) { dbg[4] = __builtin_amdgcn_s_memtime(); dbg[6] = wall_clock64(); }
-    if (g.prof && tid == 0) atomicMax(&g.prof[1], (unsigned long long)wall_clock64());
+    if (g.prof && tid == 0) g.prof_x[prof_wg] = (unsigned long long)wall_clock64();
 }
 
 template <class Ops, class Epi, int MT, int NW, bool AROW, int D>

@@ -216,6 +216,13 @@ __device__ __forceinline__ float block_sum_256(float x, float* sh4, int lane, in
     return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
+// experiments (LASR_DELAY_MAIN_US / LASR_DELAY_DEC_US): one wave holds its stream for `ticks` of the 100 MHz wall clock without
+// touching memory -- the marginal cost of a microsecond on either stream of the pipelined protocol
+__global__ void k_delay(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // frames of newly encoded steps become visible to the decode loop (continuous mode)
 __global__ void k_advance(int* __restrict__ counter, const int* __restrict__ add, int M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,11 +255,26 @@ __global__ void k_step_begin(DecState s, int M, int n_iter_slots, int reset_metr
 // next: the row consumes the whole run of blanks and, if it comes, the first token after it, in one
 // iteration.  The decisions, their order and every metric are those of the one-frame-per-iteration
 // loop; only the number of launches per frame changes.  (With an LM attached la = 1.)
-template <bool PLAIN>
+// LAT: compile-time bound of `la` (1, 2 or 4).  The logits of ALL lookahead frames are loaded up front (their addresses depend
+// on nothing this kernel loads) and their statistics are reduced together: one load round trip and two block reductions per
+// launch whatever la is; the decisions are then replayed in order from the per-frame (argmax, log p) by every thread (no
+// barrier in the state machine).  Same decisions, same order, same arithmetic per frame as the one-frame loop.
+template <bool PLAIN, int LAT>
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits, int V, int blank, int max_iters,
                                                 const int* __restrict__ T_row, DecState s, int iter_slot_in,
                                                 float* __restrict__ out_logp, int* __restrict__ out_arg, int la, int M) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int KEEP = 16;                        // logits kept in registers per thread and frame (V <= 4096)
+    float zv[LAT][KEEP];
+#pragma unroll
+    for (int k = 0; k < LAT; ++k) {
+        const float* z = logits + (size_t)((k < la ? k : 0) * M + r) * V;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) {
+            const int j = tid + 256 * q;
+            zv[k][q] = j < V ? z[j] : -INFINITY;
+        }
+    }
     const int iter_no = (!PLAIN && s.cont) ? (int)(*(const unsigned*)s.iter_ctr & 0x3fffffffu) : iter_slot_in;   // same value in every workgroup of the launch
     const int iter_slot = (!PLAIN && s.cont) ? (iter_no & 63) : iter_slot_in;
     if (!PLAIN && s.cont && r == 0 && tid == 0) {                                           // recycle the flag rings
@@ -270,8 +292,8 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
             *s.iter_ctr = iter_no + 1;
         }
     };
-    // state of the row: loaded up front so the latency overlaps the logits reads
-    int t = 0, Tr = 1, it0 = 0, n0 = 0, si0 = 0, no0 = 0;
+    // state of the row (in flight together with the logits)
+    int t = 0, Tr = 1, it_cur = 0, n0 = 0, si0 = 0, no0 = 0;
     double lp0 = 0.0;
     if (!PLAIN) {
         t = s.t_idx[r]; Tr = T_row[r];
@@ -286,85 +308,95 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
             }
             return;
         }
-        if (tid == 0) {
-            it0 = s.iters[r]; n0 = s.step_ntok[r]; si0 = s.sum_iters[r]; no0 = s.n_ones[r]; lp0 = s.logp_sum[r];
-        }
+        it_cur = s.iters[r];                                      // every thread replays the state machine
+        if (tid == 0) { n0 = s.step_ntok[r]; si0 = s.sum_iters[r]; no0 = s.n_ones[r]; lp0 = s.logp_sum[r]; }
     }
-    constexpr int KEEP = 16;                        // logits kept in registers per thread (V <= 4096)
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    __shared__ float ss[4];
-    int emitted = 0;
-    for (int k = 0;; ++k) {
-        const float* z = logits + (size_t)(k * M + r) * V;
-        float zv[KEEP];
-        float best = -INFINITY;
-        int arg = 0x7fffffff;
+    const int nla = PLAIN ? 1 : min(min(la, LAT), Tr - t);       // frames this launch may decide (uniform over the workgroup)
+    __shared__ float sv[LAT][4];
+    __shared__ int si[LAT][4];
+    __shared__ float ss[LAT][4];
+    float best[LAT], logp[LAT], sum0 = 0.f;
+    int arg[LAT];
+    // ---- argmax of every frame (ascending j per thread: first max wins), all frames through ONE barrier
 #pragma unroll
-        for (int q = 0; q < KEEP; ++q) {
-            const int j = tid + 256 * q;
-            zv[q] = j < V ? z[j] : -INFINITY;
-            if (zv[q] > best) { best = zv[q]; arg = j; }   // ascending j per thread: first max wins
-        }
+    for (int k = 0; k < LAT; ++k) {
+        best[k] = -INFINITY; arg[k] = 0x7fffffff; logp[k] = 0.f;
+        if (k >= nla) continue;
+        const float* z = logits + (size_t)(k * M + r) * V;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q)
+            if (zv[k][q] > best[k]) { best[k] = zv[k][q]; arg[k] = tid + 256 * q; }
         for (int j = tid + 256 * KEEP; j < V; j += 256) {
             const float x = z[j];
-            if (x > best) { best = x; arg = j; }
+            if (x > best[k]) { best[k] = x; arg[k] = j; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o);
-            const int oa = __shfl_xor(arg, o);
-            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+            const float ob = __shfl_xor(best[k], o);
+            const int oa = __shfl_xor(arg[k], o);
+            if (ob > best[k] || (ob == best[k] && oa < arg[k])) { best[k] = ob; arg[k] = oa; }
         }
-        if (lane == 0) { sv[w] = best; si[w] = arg; }
-        __syncthreads();
-        best = sv[0]; arg = si[0];
+        if (lane == 0) { sv[k][w] = best[k]; si[k][w] = arg[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LAT; ++k) {
+        if (k >= nla) continue;
+        best[k] = sv[k][0]; arg[k] = si[k][0];
 #pragma unroll
         for (int q = 1; q < 4; ++q)
-            if (sv[q] > best || (sv[q] == best && si[q] < arg)) { best = sv[q]; arg = si[q]; }
+            if (sv[k][q] > best[k] || (sv[k][q] == best[k] && si[k][q] < arg[k])) { best[k] = sv[k][q]; arg[k] = si[k][q]; }
+        const float* z = logits + (size_t)(k * M + r) * V;
         float sum = 0.f;
 #pragma unroll
-        for (int q = 0; q < KEEP; ++q) sum += expf(zv[q] - best);      // exp(-inf) = 0 for the padding
-        for (int j = tid + 256 * KEEP; j < V; j += 256) sum += expf(z[j] - best);
+        for (int q = 0; q < KEEP; ++q) sum += expf(zv[k][q] - best[k]);      // exp(-inf) = 0 for the padding
+        for (int j = tid + 256 * KEEP; j < V; j += 256) sum += expf(z[j] - best[k]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        if (lane == 0) ss[w] = sum;
-        __syncthreads();
-        sum = ss[0] + ss[1] + ss[2] + ss[3];
-        const float logp = -logf(sum);       // log_softmax at the argmax = z_max - logsumexp
-        if (PLAIN) {
-            if (tid == 0) { out_logp[r] = logp; out_arg[r] = arg; }
-            return;
-        }
-        const bool nonblank = arg != blank;      // decided by the joint alone (models.py:424-431)
-        if (s.lmz && nonblank && s.lm_valid[r]) {
+        if (lane == 0) ss[k][w] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LAT; ++k) {
+        if (k >= nla) continue;
+        const float sum = ss[k][0] + ss[k][1] + ss[k][2] + ss[k][3];
+        if (k == 0) sum0 = sum;
+        logp[k] = -logf(sum);                // log_softmax at the argmax = z_max - logsumexp
+    }
+    if (PLAIN) {
+        if (tid == 0) { out_logp[r] = logp[0]; out_arg[r] = arg[0]; }
+        return;
+    }
+    int tok0 = arg[0];                       // the token frame 0 emits if its decision is non-blank
+    if constexpr (LAT == 1) {
+        if (s.lmz && arg[0] != blank && s.lm_valid[r]) {
             // LMFuser.fuse (lm.py:59-79), only for a non-blank decision (models.py:427-431; uniform over
             // the workgroup): standardise the joint log-softmax (utils.py:162-164: subtract the mean,
             // divide by the unbiased std + 1e-5), entry 0 = MIN_VAL, re-pick argmax(alpha*lm + theta*joint).
             // V <= 4096 (checked at lasr_attach_lm): every value of the row is in zv[].
             __shared__ float sh4[4];
-            const float lse = logf(sum);
+            const float lse = logf(sum0);
             float part = 0.f;
 #pragma unroll
             for (int q = 0; q < KEEP; ++q) {
                 const int j = tid + 256 * q;
-                zv[q] = j < V ? (zv[q] - best) - lse : 0.f;        // log-softmax; padding contributes nothing
-                part += zv[q];
+                zv[0][q] = j < V ? (zv[0][q] - best[0]) - lse : 0.f;        // log-softmax; padding contributes nothing
+                part += zv[0][q];
             }
             const float mean = block_sum_256(part, sh4, lane, w) / (float)V;
             part = 0.f;
 #pragma unroll
             for (int q = 0; q < KEEP; ++q) {
                 const int j = tid + 256 * q;
-                zv[q] = j < V ? zv[q] - mean : 0.f;                // t.add_(-t.mean())
-                part += zv[q];
+                zv[0][q] = j < V ? zv[0][q] - mean : 0.f;                // t.add_(-t.mean())
+                part += zv[0][q];
             }
             const float mean2 = block_sum_256(part, sh4, lane, w) / (float)V;   // torch.std subtracts its own mean again
             part = 0.f;
 #pragma unroll
             for (int q = 0; q < KEEP; ++q) {
                 const int j = tid + 256 * q;
-                const float d = j < V ? zv[q] - mean2 : 0.f;
+                const float d = j < V ? zv[0][q] - mean2 : 0.f;
                 part += d * d;
             }
             const float sd = sqrtf(block_sum_256(part, sh4, lane, w) / (float)(V - 1));
@@ -376,7 +408,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
             for (int q = 0; q < KEEP; ++q) {
                 const int j = tid + 256 * q;
                 if (j >= V) continue;
-                const float jo = j == 0 ? s.lm_min : zv[q] / den;
+                const float jo = j == 0 ? s.lm_min : zv[0][q] / den;
                 const float f = __fadd_rn(__fmul_rn(s.lm_alpha, lz[j]), __fmul_rn(s.lm_theta, jo));   // no FMA contraction
                 if (f > fb) { fb = f; fa = j; }
             }
@@ -387,48 +419,44 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
                 if (ob > fb || (ob == fb && oa < fa)) { fb = ob; fa = oa; }
             }
             __syncthreads();
-            if (lane == 0) { sv[w] = fb; si[w] = fa; }
+            if (lane == 0) { sv[0][w] = fb; si[0][w] = fa; }
             __syncthreads();
-            fb = sv[0]; fa = si[0];
+            fb = sv[0][0]; fa = si[0][0];
 #pragma unroll
             for (int q = 1; q < 4; ++q)
-                if (sv[q] > fb || (sv[q] == fb && si[q] < fa)) { fb = sv[q]; fa = si[q]; }
-            arg = fa;                        // the emitted token; log p stays the unfused one (models.py:422)
+                if (sv[0][q] > fb || (sv[0][q] == fb && si[0][q] < fa)) { fb = sv[0][q]; fa = si[0][q]; }
+            tok0 = fa;                       // the emitted token; log p stays the unfused one (models.py:422)
         }
-        // ---- the decision (every thread tracks t and the loop control; thread 0 owns the rest of the state)
+    }
+    // ---- the decisions, in frame order (models.py:405-443, 530-571): a row consumes its run of blank frames and, if it
+    // comes, the first token after it.  Every thread tracks t and the per-frame evaluation count; thread 0 owns the rest.
+    int emitted = 0;
+#pragma unroll
+    for (int k = 0; k < LAT; ++k) {
+        if (k >= nla || emitted) continue;
+        const bool nonblank = arg[k] != blank;      // decided by the joint alone (models.py:424-431)
+        int it = it_cur + 1;
+        if (tid == 0) { lp0 += (double)logp[k]; si0 += 1; }
         bool frame_done = true;
-        int it = 0;
-        if (tid == 0) {
-            lp0 += (double)logp;
-            it = it0 + 1;
-            si0 += 1;
-        }
         if (nonblank) {
             emitted = 1;
             if (tid == 0) {
-                if (s.cont) s.step_tok[(size_t)r * s.tok_cap + (n0 % s.tok_cap)] = arg;
-                else if (n0 < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n0] = arg;
+                const int tok = k == 0 ? tok0 : arg[k];
+                if (s.cont) s.step_tok[(size_t)r * s.tok_cap + (n0 % s.tok_cap)] = tok;
+                else if (n0 < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n0] = tok;
                 n0 += 1;
-                s.token[r] = arg;
+                s.token[r] = tok;
             }
-            // the per-frame evaluation count lives in thread 0: broadcast "symbol cap reached"
-            __syncthreads();
-            if (tid == 0) sv[0] = (it >= max_iters) ? 1.f : 0.f;
-            __syncthreads();
-            frame_done = sv[0] != 0.f;
+            frame_done = it >= max_iters;           // per-frame symbol cap
         }
         if (frame_done) {
-            if (tid == 0) {
-                if (it == 1) no0 += 1;
-                it = 0;
-            }
+            if (tid == 0 && it == 1) no0 += 1;
+            it = 0;
             t += 1;
             if (tid == 0 && s.cont && t % s.step_T == 0)      // the row just finished one of its model steps
                 s.ntok_end[(size_t)r * s.end_slots + ((t / s.step_T - 1) % s.end_slots)] = n0;
         }
-        if (tid == 0) it0 = it;
-        if (emitted || k + 1 >= la || t >= Tr) break;
-        __syncthreads();                     // sv / si / ss are reused by the next frame's reductions
+        it_cur = it;
     }
     if (tid != 0) return;
     s.emit[r] = emitted;
@@ -437,13 +465,21 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     s.n_ones[r] = no0;
     s.step_ntok[r] = n0;
     s.t_idx[r] = t;
-    s.iters[r] = it0;
+    s.iters[r] = it_cur;
     if (s.cont && s.host_flag) {
         s.host_cur[r] = t;
         if (s.host_ntot) s.host_ntot[r] = n0;
     }
     if (t < Tr) atomicAdd(&s.unfinished[iter_slot], 1);     // continuous mode: rows that still have encoded frames to decode
     publish();
+}
+// launch with the compile-time lookahead bound that covers `la`
+template <bool PLAIN>
+inline void launch_select(hipStream_t st, int rows, const float* logits, int V, int blank, int max_iters, const int* T_row,
+                          const DecState& s, int iter_slot, float* out_logp, int* out_arg, int la, int M) {
+    if (la <= 1) hipLaunchKernelGGL((k_select<PLAIN, 1>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, 1, M);
+    else if (la == 2) hipLaunchKernelGGL((k_select<PLAIN, 2>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, la, M);
+    else hipLaunchKernelGGL((k_select<PLAIN, 4>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, la, M);
 }
 
 // LMFuser.advance (lm.py:49-53) for the rows that just emitted a token: log_softmax of the LM's output
@@ -977,8 +1013,16 @@ __device__ __forceinline__ void mel_log(const float* P, const MelTables& t, int 
     for (int i = 0, m = j; m < n_mels; ++i, m += 64) {
         const int mm = (paired && i == 1) ? 127 - j : m;
         const int s0 = t.fbs[mm], o0 = t.fbo[mm], cnt = t.fbo[mm + 1] - o0;
+        // taps are summed in bin order (one fma chain, the order of the per-chunk kernels); the LDS reads of four taps are issued
+        // together so that the chain waits for one LDS round trip per four taps instead of one per tap
         float acc = 0.f;
-        for (int q = 0; q < cnt; ++q) acc += P[s0 + q] * t.fbw[o0 + q];
+        int q = 0;
+        for (; q + 4 <= cnt; q += 4) {
+            const float p0 = P[s0 + q], p1 = P[s0 + q + 1], p2 = P[s0 + q + 2], p3 = P[s0 + q + 3];
+            const float w0 = t.fbw[o0 + q], w1 = t.fbw[o0 + q + 1], w2 = t.fbw[o0 + q + 2], w3 = t.fbw[o0 + q + 3];
+            acc += p0 * w0; acc += p1 * w1; acc += p2 * w2; acc += p3 * w3;
+        }
+        for (; q < cnt; ++q) acc += P[s0 + q] * t.fbw[o0 + q];
         out[mm] = logf(acc + 1e-6f);
     }
 }
@@ -1167,6 +1211,93 @@ __global__ __launch_bounds__(64 * NSTACK) void k_frontend(const FrontArgs a) {
         const float y = (x[q] - mu) * rstd * a.ln_w[f] + a.ln_b[f];
         act_st(a.bf, a.x0, act_off(a.bf, tp * a.MT * 16 + row, f, a.mt_total), y);
     }
+}
+
+// Streaming front-end of one model step, log-mel half (<= 512 rows): workgroup (2 t' + half, row) computes five of the ten
+// log-mel frames of stacked frame t' (one wave per frame) into the row's pending-frame buffer; k_stack_ln then stacks +
+// LayerNorms from there.  n_buffer x 2 x rows workgroups of 5 waves: 256 for the reference shape at 64 streams, one per CU
+// (k_frontend: 128 workgroups of 10 waves, half the CUs idle).  The ring append of the NEWEST client chunk is part of this
+// launch (lasr_push_submit): rows with idx >= 0 take the chunk from the caller's buffer `src` -- every wave that needs samples of
+// the slot being written reads them from `src`, workgroup (0, row) copies the chunk into the ring and publishes the new ring
+// position -- so a model step costs one ring-append launch less.  Same arithmetic per frame as k_logmel / k_frontend.
+struct FeMelArgs {
+    const float* window; const float2* tw512; const float2* tw1024;
+    const int* fb_start; const int* fb_off; const float* fb_w;
+    int n_mels, hop, fb_nnz, win_off, win_len;
+    float* pcm;              // [M][ring_chunks][chunk]
+    int* ring_pos;           // [M] next write slot (device copy, kept in step for k_push_pcm)
+    int chunk, n_window, ring_chunks, frame0;
+    float* pend;             // [M][n_buffer * n_stack][n_mels]
+    int pend_frames;
+    int* trow_out;           // [M]: the row's frame count of this step, for the kernels behind this one
+    int* enc_frames;         // pipelined protocol (else nullptr): see FrontArgs
+    int* enc_base;
+    const float* src;        // fused ring append (else nullptr): [n][chunk], row r takes chunk idx[r]
+    short idx[512];          // -1: the row is not pushed by this launch
+    unsigned char tp_pk[512];    // frames of this step (low nibble) | ring position BEFORE this launch's append (high nibble)
+    unsigned short age_pk[512];  // 4 bits per t': chunks pushed since the window of stacked frame t' was current; 15: already in pend
+};
+template <int NSTACK>
+__global__ __launch_bounds__(32 * NSTACK) void k_fe_mel(const FeMelArgs a) {
+    constexpr int NWV = NSTACK / 2;                      // waves per workgroup = frames per half
+    __shared__ float2 sz[NWV][512 + 8];
+    __shared__ float sp[NWV][520];
+    __shared__ float s_fbw[1536];
+    __shared__ int s_fbs[128], s_fbo[129];
+    __shared__ float2 s_tw512[512], s_tw1024[513];
+    const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
+    const int tp = blockIdx.x >> 1, half = blockIdx.x & 1, row = blockIdx.y;
+    const int Tr = a.tp_pk[row] & 15, pos = a.tp_pk[row] >> 4;
+    const int si = a.src ? (int)a.idx[row] : -1;
+    const int NR = a.ring_chunks;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            a.trow_out[row] = Tr;
+            if (a.enc_frames) { const int e = a.enc_frames[row]; a.enc_base[row] = e; a.enc_frames[row] = e + Tr; }
+            if (si >= 0) a.ring_pos[row] = (pos + 1) % NR;
+        }
+        if (si >= 0) {                                   // the ring append of this row's newest chunk
+            float* d = a.pcm + ((size_t)row * NR + pos) * a.chunk;
+            const float* s = a.src + (size_t)si * a.chunk;
+            if ((a.chunk & 3) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+                for (int i = threadIdx.x; i < a.chunk / 4; i += blockDim.x) ((float4*)d)[i] = ((const float4*)s)[i];
+            } else {
+                for (int i = threadIdx.x; i < a.chunk; i += blockDim.x) d[i] = s[i];
+            }
+        }
+    }
+    if (tp >= Tr) return;                                // uniform over the workgroup
+    const int age = (a.age_pk[row] >> (4 * tp)) & 15;
+    if (age == 15) return;                               // uniform: these frames were computed early, they are in pend
+    const MelTables tab{s_fbw, s_fbs, s_fbo, s_tw512, s_tw1024};
+    stage_mel_tables(tab, a.tw512, a.tw1024, a.fb_w, a.fb_start, a.fb_off, a.fb_nnz, a.n_mels);
+    const int f = half * NWV + w;                        // log-mel frame of the stacked frame
+    const int pos_after = si >= 0 ? (pos + 1) % NR : pos;
+    const int head = (pos_after - age - a.n_window + 2 * NR) % NR;
+    const float* ring = a.pcm + (size_t)row * NR * a.chunk;
+    const float* fresh = si >= 0 ? a.src + (size_t)si * a.chunk : nullptr;
+    const int N = a.n_window * a.chunk;
+    const int base = (a.frame0 + f) * a.hop - 512;
+    auto sample = [&](int n) -> float {
+        if (n < a.win_off || n >= a.win_off + a.win_len) return 0.f;
+        const float wv = a.window[n];
+        int q = base + n;
+        if (q < 0) q = -q;                               // reflect (torch.stft center=True, pad_mode="reflect")
+        if (q >= N) q = 2 * (N - 1) - q;
+        const int ck = q / a.chunk, wi = q - ck * a.chunk;
+        int slot = head + ck;
+        if (slot >= NR) slot -= NR;
+        const float x = (fresh && slot == pos) ? fresh[wi] : ring[(size_t)slot * a.chunk + wi];
+        return x * wv;
+    };
+    cf v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int n = j + 64 * m;
+        v[m] = cf{sample(2 * n), sample(2 * n + 1)};
+    }
+    fft1024_power(v, sz[w], sp[w], s_tw512, s_tw1024, j);
+    mel_log(sp[w], tab, a.n_mels, j, a.pend + ((size_t)row * a.pend_frames + (size_t)tp * NSTACK + f) * a.n_mels);
 }
 
 // Resample (transforms.py:135-144: torchaudio 0.6.0 transforms.Resample = kaldi LinearResample, un-vendored):

@@ -39,7 +39,9 @@ void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_tot
     g.M = c->M; g.dbg = c->dbg;
     if (c->cell_prof && c->cp_slots && c->cp_slot_next < lasr_ctx::NCELLSLOT) {
         c->cp_slot_cells[c->cp_slot_next] = 1;
-        g.prof = c->cp_slots + 2 * (c->cp_slot_next++);
+        g.prof = c->cp_slots + (size_t)PROF_W * c->cp_slot_next;
+        g.prof_x = g.prof + (size_t)PROF_W * lasr_ctx::NCELLSLOT;
+        c->cp_slot_next++;
     }
     using E = EpiLSTM<Ops, false, false, 8>;
     typename E::Args ea{};
@@ -69,7 +71,7 @@ void launch_enc_wave_t(lasr_ctx* c, const EncCellRef* cells, int n, int par0, in
     unsigned long long* prof = nullptr;
     if (c->cell_prof && c->cp_slots && c->cp_slot_next < lasr_ctx::NCELLSLOT) {
         c->cp_slot_cells[c->cp_slot_next] = (unsigned char)n;
-        prof = c->cp_slots + 2 * (c->cp_slot_next++);
+        prof = c->cp_slots + (size_t)PROF_W * (c->cp_slot_next++);
     }
     for (int i = 0; i < n; ++i) {
         const int l = cells[i].l, t = cells[i].t, par = par0 ^ (t & 1);
@@ -78,7 +80,7 @@ void launch_enc_wave_t(lasr_ctx* c, const EncCellRef* cells, int n, int par0, in
         GemmArgs& g = m.g[i];
         g.A[0] = xsrc; g.a_mt_total[0] = mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / Ops::KCH; g.W[0] = L.WxC;
         g.A[1] = c->enc_h[par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhC;
-        g.M = c->M; g.prof = prof; g.prio = c->cell_prio;
+        g.M = c->M; g.prof = prof; g.prof_x = prof ? prof + (size_t)PROF_W * lasr_ctx::NCELLSLOT : nullptr; g.prio = c->cell_prio;
         typename E::Args& ea = m.ea[i];
         ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t; ea.tile_mask = c->tile_masks.empty() ? ~0ull : c->tile_masks[t];
         ea.c = c->enc_c[l]; ea.h_in = c->enc_h[par][l]; ea.h_out = c->enc_h[par ^ 1][l];

@@ -121,16 +121,44 @@ class Engine:
         self._chk(self.lib.lasr_stream_close(self.ctx, int(slot)))
 
     # ------------------------------------------------------------------ streaming
-    def push(self, slots, pcm):
-        """pcm: [n, chunk] float32 torch (cuda or cpu) tensor or numpy array."""
-        a, p, n = self._slots(slots)
+    def _pcm(self, pcm, n):
         if isinstance(pcm, torch.Tensor):
             pcm = pcm.contiguous()
             assert pcm.dtype == torch.float32 and pcm.numel() == n * self.desc.chunk
         else:
             pcm = np.ascontiguousarray(pcm, dtype=np.float32)
             assert pcm.size == n * self.desc.chunk
-        self._chk(self.lib.lasr_push_pcm(self.ctx, p, n, _ptr(pcm)))
+        return pcm
+
+    def push(self, slots, pcm, pinned_nocopy=False):
+        """pcm: [n, chunk] float32 torch (cuda or cpu) tensor or numpy array.  Host memory (pageable or pinned) is copied before
+        the call returns; device memory is read in stream order.  pinned_nocopy=True (the tensor must be pinned host memory):
+        nothing is copied, the GPU reads the buffer later -- keep it untouched until push_consumed(ticket) is True.
+        Returns the push ticket (-1 for device memory)."""
+        a, p, n = self._slots(slots)
+        pcm = self._pcm(pcm, n)
+        t = C.c_longlong(-1)
+        self._chk(self.lib.lasr_push_pcm_ex(self.ctx, p, n, _ptr(pcm), N.LASR_PUSH_PINNED_NOCOPY if pinned_nocopy else 0, C.byref(t)))
+        return t.value
+
+    def push_submit(self, slots, pcm, pinned_nocopy=False):
+        """push(slots, pcm) + submit(slots) in one call (lasr_push_submit): the front-end launch of a model step takes the newest
+        chunk from `pcm` itself.  Same memory rules and results as push + submit.  Returns the push ticket."""
+        a, p, n = self._slots(slots)
+        pcm = self._pcm(pcm, n)
+        t = C.c_longlong(-1)
+        self._chk(self.lib.lasr_push_submit(self.ctx, p, n, _ptr(pcm), N.LASR_PUSH_PINNED_NOCOPY if pinned_nocopy else 0, C.byref(t)))
+        return t.value
+
+    def push_consumed(self, ticket):
+        """True once the source buffer of the push that returned `ticket` has been read by the GPU."""
+        rc = self.lib.lasr_push_consumed(self.ctx, int(ticket))
+        if rc < 0:
+            self._chk(rc)
+        return rc == 1
+
+    def max_inflight(self):
+        return int(self.lib.lasr_max_inflight(self.ctx))
 
     def step(self, slots):
         a, p, n = self._slots(slots)
@@ -299,7 +327,7 @@ class Engine:
 
     def cell_prof(self, on=True):
         """In-job HIP-event timing of the encoder-cell launches (see lasr_cell_prof)."""
-        self._chk(self.lib.lasr_cell_prof(self.ctx, 1 if on else 0))
+        self._chk(self.lib.lasr_cell_prof(self.ctx, int(on)))      # True / 1: events + in-kernel clocks; 2: clocks only
 
     def cell_prof_kernel(self):
         """-> (microseconds, launches, cells): the cell kernels' own durations since cell_prof(True) (in-kernel wall clock)

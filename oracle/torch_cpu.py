@@ -171,7 +171,11 @@ class _TorchStream:
         m = self.m
         x = torch.as_tensor(np.asarray(chunk))[None]
         encoder_out, self.enc_state = m.encoder(x, state=self.enc_state)
-        h_t_enc = encoder_out[0]
+        return self.decode_frames(encoder_out[0])
+
+    @torch.no_grad()
+    def decode_frames(self, h_t_enc):                # h_t_enc [T, H]: the greedy loop of models.py:526-575 on encoded frames
+        m = self.m
         y_seq = []
         for i in range(h_t_enc.size(-2)):
             h_enc = h_t_enc[..., i, :]
@@ -255,5 +259,48 @@ def time_stream_path(sd, cfg, pcm_rows, n_chunks, chunk=1280, threads=2):
                     dec.step(o)
             toks.append(dec.y)
         return time.perf_counter() - t0, toks
+    finally:
+        torch.set_num_threads(prev)
+
+
+def time_stream_path_batched(sd, cfg, pcm_rows, n_chunks, chunk=1280, threads=None):
+    """SURVEY 8d (ii) "best-effort CPU": the same operators with the ENCODER (and the front-end) batched over all
+    streams -- nn.LSTM on [B, 2, F] with carried state [1, B, H] per layer -- on `threads` cores; the greedy loop stays per
+    stream, batch 1, as in the reference (models.py:526-575).  Streams advance in lockstep (every stream pushes chunk k).
+    Returns (seconds, tokens per stream); the tokens equal time_stream_path's (tests/test_oracle.py)."""
+    import time
+    prev = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    try:
+        m = TorchTransducer(sd, cfg)
+        B = len(pcm_rows)
+        fe = TorchFrontend()
+        decs = [m.stream_decoder() for _ in range(B)]
+        pcm = torch.as_tensor(np.stack([np.asarray(r[:n_chunks * chunk], dtype=np.float32) for r in pcm_rows]))
+        frames, saved, enc_state = [], [], None
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for k in range(n_chunks):
+                frames.append(pcm[:, k * chunk:(k + 1) * chunk])
+                if len(frames) != fe.n_window:
+                    continue
+                aud = torch.cat(frames, dim=1)                       # [B, 3 * chunk]
+                del frames[0]
+                S = torch.stft(aud, fe.n_fft, fe.hop, fe.win, fe.window, center=True, pad_mode="reflect",
+                               normalized=False, onesided=True, return_complex=True)
+                mel = torch.matmul(S.abs().pow(2.0).transpose(1, 2), fe.fb)          # [B, T, n_mels]
+                spec = torch.log(mel + 1e-6)
+                a = spec.size(1) // 3 + 1
+                spec = spec[:, a:a + fe.n_stack]                     # [B, n_stack, n_mels]
+                saved.append(spec.permute(0, 2, 1).reshape(B, 1, -1))                # mel-major, frame-minor (transforms.py:436-441)
+                if len(saved) != fe.n_buffer:
+                    continue
+                x = torch.cat(saved, dim=1)                          # [B, n_buffer, F]
+                saved = []
+                enc_out, enc_state = m.encoder(x, state=enc_state)
+                for b in range(B):
+                    decs[b].decode_frames(enc_out[b])
+        return time.perf_counter() - t0, [d.y for d in decs]
     finally:
         torch.set_num_threads(prev)

@@ -229,3 +229,17 @@ def test_torch_cpu_reference_path_matches_reference(golden_dir, name, n_sec, n_s
                 counts.append(len(dec.step(o)))
         assert dec.y == list(g[f"st_tokens_{s}"])
         assert counts == list(g[f"st_counts_{s}"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_lstm"])
+def test_torch_cpu_batched_encoder_leg_equals_the_batch_1_path(name):
+    """bench.py's cpu_baseline.best_effort leg (encoder + front-end batched over the streams, every host
+    core) must decode exactly what the reference-faithful batch-1 path decodes."""
+    from oracle import torch_cpu as TC
+    cfg = synth.model_cfg(name)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    rows = [synth.synth_pcm(1, 36 * 1280, seed=1234 + s)[0] for s in range(5)]
+    _, one = TC.time_stream_path(sd, cfg, rows, 36)
+    _, bat = TC.time_stream_path_batched(sd, cfg, rows, 36, threads=4)
+    assert bat == one
+    assert sum(len(t) for t in one) > 0
