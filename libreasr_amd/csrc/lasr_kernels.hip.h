@@ -1284,7 +1284,8 @@ __global__ __launch_bounds__(32 * NSTACK) void k_fe_mel(const FeMelArgs a) {
         int q = base + n;
         if (q < 0) q = -q;                               // reflect (torch.stft center=True, pad_mode="reflect")
         if (q >= N) q = 2 * (N - 1) - q;
-        const int ck = q / a.chunk, wi = q - ck * a.chunk;
+        int ck = 0, wi = q;                              // q < n_window * chunk: a compare chain instead of an integer division
+        while (wi >= a.chunk) { wi -= a.chunk; ++ck; }
         int slot = head + ck;
         if (slot >= NR) slot -= NR;
         const float x = (fresh && slot == pos) ? fresh[wi] : ring[(size_t)slot * a.chunk + wi];
@@ -1395,6 +1396,79 @@ __global__ __launch_bounds__(256) void k_stack_ln(const StackLnArgs a) {
         const float y = (x[q] - mu) * rstd * a.ln_w[f] + a.ln_b[f];
         // element (t', row, f): m-tile index tp*MT + row/16 inside a layout of mt_total m-tiles
         act_st(a.bf, a.x0, act_off(a.bf, tp * a.MT * 16 + row, f, a.mt_total), y);
+    }
+}
+
+// Stack + LayerNorm of the streaming front-end for one m-tile (16 rows) and one stacked frame per workgroup: wave w takes row
+// 16 mt + w.  The 10 log-mel frames of a row are read with coalesced 256-byte loads and transposed through LDS into the stacked
+// order (feat[m * 10 + k] = mel[k][m]); the statistics are summed in k_stack_ln's order (lane j: f = j + 64 q, then the xor tree),
+// so the result is bit-identical to it; the tile's output is then written as whole 1 KiB fragments (k_stack_ln scatters 4-byte
+// stores over them: 12 us in the job for 128 (row, frame) pairs, most of it store traffic and four dependent round trips).
+struct LnTileArgs {
+    const float* pend;       // [M][pend_frames][128]
+    int pend_frames;
+    const int* T_row;        // [M]
+    const float* ln_w; const float* ln_b;
+    void* x0;
+    int MT, mt_total, bf;
+};
+__global__ __launch_bounds__(1024) void k_ln_tile(const LnTileArgs a) {
+    constexpr int F = 1280, NS = 10, NM = 128, LD = F + 4;
+    extern __shared__ float xs[];                    // [16][LD]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int mt = blockIdx.x, tp = blockIdx.y, r = 16 * mt + w;
+    const bool act = tp < a.T_row[r];
+    float* xr = xs + w * LD;
+    float lw[20], lb[20];
+#pragma unroll
+    for (int q = 0; q < 20; ++q) { lw[q] = a.ln_w[lane + 64 * q]; lb[q] = a.ln_b[lane + 64 * q]; }
+    if (act) {
+        const float* p = a.pend + ((size_t)r * a.pend_frames + (size_t)tp * NS) * NM;
+        float v0[NS], v1[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { v0[k] = p[k * NM + lane]; v1[k] = p[k * NM + lane + 64]; }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { xr[lane * NS + k] = v0[k]; xr[(lane + 64) * NS + k] = v1[k]; }
+        wave_sync_lds();
+        float x[20];
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 20; ++q) { x[q] = xr[lane + 64 * q]; sum += x[q]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mu = sum / (float)F;
+        float var = 0.f;
+#pragma unroll
+        for (int q = 0; q < 20; ++q) { const float d = x[q] - mu; var += d * d; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+        const float rstd = 1.0f / sqrtf(var / (float)F + 1e-5f);
+        wave_sync_lds();
+#pragma unroll
+        for (int q = 0; q < 20; ++q) xr[lane + 64 * q] = (x[q] - mu) * rstd * lw[q] + lb[q];
+    }
+    __syncthreads();
+    // the tile's fragments: chunk c of K, lane = g * 16 + i holds row i, k = KCH c + EPL g + e
+    const size_t frag0 = (size_t)tp * a.MT + mt;
+    if (!a.bf) {
+        for (int idx = threadIdx.x; idx < (F / 16) * 64; idx += 1024) {
+            const int c = idx >> 6, l = idx & 63, g = l >> 4, i = l & 15;
+            if (tp >= a.T_row[16 * mt + i]) continue;
+            const float* src = xs + i * LD + 16 * c + 4 * g;
+            ((float4*)a.x0)[((size_t)c * a.mt_total + frag0) * 64 + l] = float4{src[0], src[1], src[2], src[3]};
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < (F / 32) * 64; idx += 1024) {
+            const int c = idx >> 6, l = idx & 63, g = l >> 4, i = l & 15;
+            if (tp >= a.T_row[16 * mt + i]) continue;
+            const float* src = xs + i * LD + 32 * c + 8 * g;
+            uint4 o;
+            o.x = (unsigned)f32_to_bf16(src[0]) | ((unsigned)f32_to_bf16(src[1]) << 16);
+            o.y = (unsigned)f32_to_bf16(src[2]) | ((unsigned)f32_to_bf16(src[3]) << 16);
+            o.z = (unsigned)f32_to_bf16(src[4]) | ((unsigned)f32_to_bf16(src[5]) << 16);
+            o.w = (unsigned)f32_to_bf16(src[6]) | ((unsigned)f32_to_bf16(src[7]) << 16);
+            ((uint4*)a.x0)[((size_t)c * a.mt_total + frag0) * 64 + l] = o;
+        }
     }
 }
 

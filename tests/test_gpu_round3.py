@@ -62,7 +62,7 @@ def test_config1_64_rows_depth_12_push_submit_against_the_reference_path():
         while eng.pending():
             collect()
         assert deepest == depth
-        _, ref = TC.time_stream_path_batched(sd, cfg, list(pcm), n, threads=os.cpu_count() or 8)
+        _, ref = TC.time_stream_path_batched(sd, cfg, list(pcm), n, threads=8)
         n_tok = sum(len(r) for r in ref)
         bad = [i for i in range(B) if got[i] != ref[i]]
         assert not bad, f"streams {bad} differ from the reference path"

@@ -53,8 +53,9 @@ def test_grpc_server_batched_streams_and_unary():
         cfg = synth.model_cfg("tiny")
         m = O.OracleTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
         lang = IdLanguage()
-        n = 5
-        pcm = synth.synth_pcm(n, 16000 * 3, seed=1234)
+        n = 6
+        pcm = list(synth.synth_pcm(n - 1, 16000 * 3, seed=1234))
+        pcm.append(synth.synth_pcm(1, 16000 * 7, seed=77)[0])          # 7 s: runs past the 4 s reset threshold (api-server.py:44-50)
         got = [None] * n
         barrier = threading.Barrier(n)
 
@@ -75,6 +76,7 @@ def test_grpc_server_batched_streams_and_unary():
         for i in range(n):
             assert got[i] == expected_stream_transcripts(m, pcm[i], lang), f"stream {i}"
         assert max(sched.batches) > 1, "concurrent streams were never stepped as one batch"
+        assert sum(len(g) for g in got) > 10
         with grpc.insecure_channel(f"127.0.0.1:{port}") as ch:
             stub = apg.ASRStub(ch)
             text = stub.Transcribe(ap.Audio(data=pcm[0].tobytes(), sr=16000)).data
@@ -119,3 +121,87 @@ def test_grpc_server_batched_streams_and_unary():
     finally:
         server.stop(0)
         sched.shutdown()
+
+
+def test_scheduler_64_streams_on_the_pipelined_protocol_with_served_rates():
+    """the scheduler runs lasr_push_submit / lasr_step_wait with model steps in flight.  64 streams of
+    configs[1], every token against the reference's torch-CPU path; the served rate of (a) 64 producer threads, one per stream
+    (the gRPC servicer's shape: GIL-bound) and (b) the trunk interface (one producer, one queue entry per batch) is recorded."""
+    import json
+    import os
+    import time
+    import __graft_entry__ as graft
+    graft.build()
+    from libreasr_amd import server as srv
+    from libreasr_amd.lib.inference import load_stuff
+    from oracle import torch_cpu as TC
+
+    conf, language, model, _, _ = load_stuff("en", config_path="/nonexistent.yaml", synthetic="cfg2", max_streams=64)
+    eng = model.engine
+    cfg = synth.model_cfg("cfg2")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    B, n = 64, 64
+    pcm = np.stack([synth.synth_pcm(1, n * 1280, seed=1234 + s)[0] for s in range(B)])
+    _, ref = TC.time_stream_path_batched(sd, cfg, list(pcm), n, threads=8)
+    assert sum(len(r) for r in ref) > 500
+    rates = {}
+    sched = srv.Scheduler(eng, depth=12)
+    sched.start()
+    try:
+        # (a) one producer thread per stream (what 64 TranscribeStream RPCs do), results read per stream
+        streams = [sched.open() for _ in range(B)]
+        got = [[] for _ in range(B)]
+        start = threading.Barrier(B + 1)
+
+        def producer(i):
+            start.wait()
+            for k in range(n):
+                sched.push_nowait(streams[i], pcm[i, k * 1280:(k + 1) * 1280])
+            sched.push_eof(streams[i])
+            while True:
+                r = streams[i].outq.get()
+                if r is srv.EOF:
+                    break
+                assert not isinstance(r, Exception), r
+                if r is not None:
+                    got[i] += r
+
+        ths = [threading.Thread(target=producer, args=(i,)) for i in range(B)]
+        [t.start() for t in ths]
+        start.wait()
+        t0 = time.perf_counter()
+        [t.join(timeout=300) for t in ths]
+        dt = time.perf_counter() - t0
+        rates["threads_per_stream"] = B * n * 0.08 / dt
+        bad = [i for i in range(B) if got[i] != ref[i]]
+        assert not bad, f"per-stream form: streams {bad} differ"
+        assert sched.max_inflight_seen > 1, "model steps were never in flight together"
+        for st in streams:
+            sched.close(st)
+        # (b) trunk interface: one producer, one entry per batch of 64 chunks
+        streams = [sched.open() for _ in range(B)]
+        got = {st.slot: [] for st in streams}
+        chunks = np.ascontiguousarray(pcm.reshape(B, n, 1280).transpose(1, 0, 2))
+        t0 = time.perf_counter()
+        for k in range(n):
+            sched.push_batch(streams, chunks[k])
+        n_steps = (n - 2) // 2
+        for _ in range(n_steps):
+            item = sched.batch_outq.get(timeout=120)
+            assert not isinstance(item, Exception), item
+            for st, t in zip(*item):
+                got[st.slot] += t
+        dt = time.perf_counter() - t0
+        rates["trunk_push_batch"] = B * n * 0.08 / dt
+        bad = [i for i, st in enumerate(streams) if got[st.slot] != ref[i]]
+        assert not bad, f"trunk form: streams {bad} differ"
+        rates["max_steps_in_flight"] = sched.max_inflight_seen
+        print("served audio-s/s:", json.dumps(rates))
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/served_rate.json", "w") as f:
+            json.dump({"streams": B, "chunks_per_stream": n, "model": "configs[1] (cfg2, f32, greedy)", "pcm": "pageable host arrays",
+                       "audio_sec_per_sec": rates}, f)
+        assert rates["trunk_push_batch"] > 10000
+    finally:
+        sched.shutdown()
+        eng.close()
