@@ -1495,15 +1495,18 @@ int lasr_step_window(lasr_ctx* c, const int* slots, int n, const float* pcm, int
     const int a0 = T / 3 + 1;                               // StreamPostprocess (transforms.py:335-342)
     if (T - a0 < d.n_stack) return fail(c, LASR_EINVAL, "window of %lld samples at 16 kHz yields %d < n_stack frames after the cut", Nw, T - a0);
     if (Nw <= d.n_fft / 2) return fail(c, LASR_EINVAL, "window shorter than the reflect padding");
+    for (int i = 0; i < n; ++i) {           // validate every slot BEFORE any state changes: an error leaves nothing half-done
+        const int s = slots[i];
+        for (int j = 0; j < c->n_pend[s]; ++j)
+            if (c->fe_fused && !c->pend_mat[(size_t)s * d.n_buffer + j])
+                return fail(c, LASR_ESTATE, "slot %d has frames pending from lasr_push_pcm steps: do not mix the two streaming forms", s);
+    }
     RC(cmd_begin(c));
     std::vector<int> model_rows;
     MelArgs m{};
     fill_mel_args(c, m);
     for (int i = 0; i < n; ++i) {
         const int s = slots[i];
-        for (int j = 0; j < c->n_pend[s]; ++j)
-            if (c->fe_fused && !c->pend_mat[(size_t)s * d.n_buffer + j])
-                return fail(c, LASR_ESTATE, "slot %d has frames pending from lasr_push_pcm steps: do not mix the two streaming forms", s);
         m.dst_row_v[i] = (short)s;
         m.sel_v[i] = (short)(c->n_pend[s] * d.n_stack);
         c->pend_mat[(size_t)s * d.n_buffer + c->n_pend[s]] = 1;

@@ -64,7 +64,16 @@ def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_st
         except Exception:
             print("[LM] Failed to load.")
     if lm_sd is not None and beam == 1:
-        eng.attach_lm(lm_sd, int8=lm_int8)      # lm_int8: as load_lm serves it (maybe_quantize, lm.py:97); False: fp32 / bf16 LM
+        # lm_int8: as load_lm serves it (maybe_quantize, lm.py:97); False: fp32 / bf16 LM.  maybe_quantize swallows a failed
+        # quantisation and serves the fp32 LM (utils.py:197-210): an LM shape the int8 path does not take does the same here
+        from .._native import LASR_EINVAL, LasrError
+        try:
+            eng.attach_lm(lm_sd, int8=lm_int8)
+        except LasrError as e:
+            if not (lm_int8 and e.code == LASR_EINVAL):
+                raise
+            print(f"[quantization] failed ({e}); serving the unquantised LM")
+            eng.attach_lm(lm_sd, int8=False)
         print("[LM] loaded.")
     # tokenizer: the configured file (testing.yaml:153-154, per-language override :320-321), else where the model archive
     # puts it (model_utils.py:31-47: <lang>/tokenizer.yttm-model under ./tmp)

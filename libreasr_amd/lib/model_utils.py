@@ -36,10 +36,65 @@ def extract_tars(paths_archive=None, path_dest=_PATH_DEST):
     return out
 
 
+class _Opaque(list):
+    """Stand-in for every class a checkpoint names that is not a tensor building block: fastai's `learn.save(with_opt=True)`
+    (libreasr/lib/patches.py:93) pickles the optimizer state next to the weights, and `Optimizer.state_dict()` holds
+    `fastcore.foundation.L` objects (fastcore is not a dependency here, and arbitrary classes must not be imported from an
+    archive found in the working directory anyway).  Only sd["model"] is read; whatever lands in a stand-in is dropped."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+
+    def __setstate__(self, state):
+        pass
+
+    def __setitem__(self, k, v):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Opaque()
+
+
+def _restricted_pickle():
+    """A pickle module whose Unpickler resolves ONLY what tensors are made of; any other global becomes _Opaque."""
+    import collections
+    import pickle
+    import types
+
+    allowed_torch = {"_rebuild_tensor_v2", "_rebuild_tensor", "_rebuild_parameter", "_rebuild_parameter_with_state",
+                     "_rebuild_qtensor", "Size", "device", "dtype"}
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == "collections" and name == "OrderedDict":
+                return collections.OrderedDict
+            if module in ("torch._utils", "torch") and name in allowed_torch:
+                return getattr(torch._utils if module == "torch._utils" else torch, name)
+            if module == "torch" and (name.endswith("Storage") or name in ("float32", "float16", "bfloat16", "float64", "int64", "int32", "int8", "uint8", "bool")):
+                return getattr(torch, name)
+            if module == "torch.serialization" and name == "_get_layout":
+                return torch.serialization._get_layout
+            return _Opaque
+
+    mod = types.ModuleType("libreasr_amd_restricted_pickle")
+    mod.Unpickler = Unpickler
+    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
+    mod.__name__ = "pickle"            # torch.load special-cases the module's name in one code path
+    for k in ("HIGHEST_PROTOCOL", "DEFAULT_PROTOCOL", "PickleError", "UnpicklingError", "dumps", "loads", "dump", "Pickler"):
+        setattr(mod, k, getattr(pickle, k))
+    return mod
+
+
 def _safe_load(path):
-    """Checkpoints come out of an archive found in the working directory: tensors-only unpickling.  The fastai
-    wrapper's "opt" entry is plain containers + tensors and loads under weights_only as well."""
-    return torch.load(str(path), map_location="cpu", weights_only=True)
+    """Checkpoints come out of an archive found in the working directory.  First tensors-only unpickling (torch's
+    weights_only); a fastai `model.pth` written with the optimizer state names classes that loader rejects
+    (fastcore.foundation.L): it is then read with an Unpickler that builds tensors and plain containers only and turns
+    every other class into an inert stand-in -- nothing from the file is imported or executed."""
+    import pickle
+    try:
+        return torch.load(str(path), map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError:
+        return torch.load(str(path), map_location="cpu", weights_only=False, pickle_module=_restricted_pickle())
 
 
 def load_model_state_dict(path):
@@ -47,6 +102,9 @@ def load_model_state_dict(path):
     sd = _safe_load(path)
     if isinstance(sd, dict) and "model" in sd and not any(str(k).startswith("encoder.") for k in sd):
         sd = sd["model"]
+    if not isinstance(sd, dict) or not any(torch.is_tensor(v) for v in sd.values()):
+        raise ValueError(f"{path}: no state_dict found (expected tensors under the reference's key names, or a fastai "
+                         "{'model': state_dict, 'opt': ...} wrapper)")
     return {k: v for k, v in sd.items() if torch.is_tensor(v)}
 
 

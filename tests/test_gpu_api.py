@@ -147,3 +147,23 @@ def test_model_archive_to_engine_end_to_end(tmp_path, monkeypatch, golden_dir):
         assert last == list(g["st_tokens_0"])
     finally:
         asr.engine.close()
+
+
+def test_load_stuff_serves_the_fp32_lm_when_the_int8_form_does_not_take_it():
+    """maybe_quantize swallows a failed quantisation and serves the unquantised LM (utils.py:197-210).  An LM wider
+    than the int8 path's exact-accumulation bound (hidden > 1024) must therefore attach as fp32, not raise."""
+    import __graft_entry__ as graft
+    graft.build()
+    from libreasr_amd.lib.inference import load_stuff
+    wide = dict(vocab=64, embed=32, hidden=1040, layers=1, emb_scale=4.0)
+    conf, lang, model, x_tfm, x_tfm_stream = load_stuff("en", config_path="/nonexistent.yaml", synthetic="tiny", max_streams=16,
+                                                        synthetic_lm=wide, lm_int8=True)
+    try:
+        assert model.engine.lm_cfg is not None and model.engine.lm_cfg["hidden"] == 1040
+        pcm = synth.synth_pcm(1, 16000 * 2, seed=4)[0]
+        slot = model.engine.open()
+        model.engine.transcribe_pcm([slot], [pcm])
+        toks, _, _ = model.engine.fetch(slot)
+        assert isinstance(toks, list)
+    finally:
+        model.engine.close()

@@ -210,3 +210,50 @@ def test_yttm_model_reader_decodes_like_the_reference_call(tmp_path):
     assert lang.denumericalize(lang.numericalize("ab cc ab")) == "ab cc ab"
     with pytest.raises(ValueError):
         yttm.BPE(model=__file__.replace("test_host.py", "conftest.py"))
+
+
+class _FakeFastcoreL(list):                      # pickled under the name fastai's optimizer state uses: fastcore.foundation.L
+    def __reduce__(self):
+        return (_FakeFastcoreL, (list(self),))
+
+
+class _Evil:
+    def __reduce__(self):
+        import os
+        return (os.system, ("echo pwned > lasr_pwned_marker",))
+
+
+def test_fastai_checkpoint_with_optimizer_state_loads_and_nothing_from_it_runs(tmp_path, monkeypatch):
+    """the reference saves with_opt=True (libreasr/lib/patches.py:93) and fastai's Optimizer.state_dict() holds
+    fastcore.foundation.L objects, which torch.load(weights_only=True) rejects.  The loader must still return the weights,
+    without importing fastcore and without executing anything the file names."""
+    import sys
+    import types
+    import torch
+    from libreasr_amd import synth
+    from libreasr_amd.lib import model_utils as mu
+    cfg = synth.model_cfg("tiny")
+    sd = {k: torch.as_tensor(v) for k, v in synth.synth_state_dict(cfg, seed=0).items()}
+    fc, fcf = types.ModuleType("fastcore"), types.ModuleType("fastcore.foundation")
+    fcf.L = _FakeFastcoreL
+    keep = (_FakeFastcoreL.__module__, _FakeFastcoreL.__qualname__, _FakeFastcoreL.__name__)
+    sys.modules["fastcore"], sys.modules["fastcore.foundation"] = fc, fcf
+    _FakeFastcoreL.__module__, _FakeFastcoreL.__qualname__, _FakeFastcoreL.__name__ = "fastcore.foundation", "L", "L"
+    p = tmp_path / "model.pth"
+    try:
+        torch.save({"model": sd, "opt": {"hypers": _FakeFastcoreL([{"lr": 1e-3, "mom": 0.9}]),
+                                         "state": [{"grad_avg": torch.zeros(3)}]}}, p)
+    finally:
+        _FakeFastcoreL.__module__, _FakeFastcoreL.__qualname__, _FakeFastcoreL.__name__ = keep
+        del sys.modules["fastcore"], sys.modules["fastcore.foundation"]
+    got = mu.load_model_state_dict(p)
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    # a hostile "opt" entry is not executed
+    monkeypatch.chdir(tmp_path)
+    torch.save({"model": sd, "opt": _Evil()}, p)
+    got = mu.load_model_state_dict(p)
+    assert set(got) == set(sd) and not (tmp_path / "lasr_pwned_marker").exists()
+    # not a checkpoint at all: a clear error
+    torch.save({"opt": 1}, p)
+    with pytest.raises(ValueError):
+        mu.load_model_state_dict(p)
