@@ -180,6 +180,8 @@ struct lasr_ctx {
     long long push_serial = 0;            // tickets handed out so far
     float* push_stage_host = nullptr;     // pinned [NSTAGE][M][chunk]
     float* push_stage_host_dev = nullptr; // its device view
+    float* push_stage_dev = nullptr;      // device [NSTAGE][M][chunk]: target of the per-push DMA
+    hipStream_t stream_copy = nullptr; hipEvent_t push_copied[NSTAGE] = {}; bool push_dma[NSTAGE] = {};
     struct CopyPool {                     // helper threads of the staging copy (lazy; LASR_PUSH_THREADS, default 2)
         bool init = false;
         std::vector<std::thread> th;

@@ -74,6 +74,9 @@ void lasr_destroy(lasr_ctx* c) {
     if (c->tr_base) (void)hipEventDestroy(c->tr_base);
     if (c->trellis_host) (void)hipHostFree(c->trellis_host);
     if (c->push_stage_host) (void)hipHostFree(c->push_stage_host);
+    if (c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
+    for (auto& e : c->push_copied)
+        if (e) (void)hipEventDestroy(e);
     if (!c->pool.th.empty()) {
         c->pool.stop.store(true);
         { std::lock_guard<std::mutex> lk(c->pool.m); }
@@ -526,7 +529,7 @@ static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
 //                    buffer is free on return); the kernel reads the staging entry over PCIe -- no DMA call, no copy stream;
 //   pinned, no copy  LASR_PUSH_PINNED_NOCOPY: the kernel reads the CALLER's pinned buffer over PCIe after the call has returned;
 //                    the buffer must stay untouched until lasr_push_consumed(ticket) says so.
-struct PushSrc { const float* src = nullptr; int ev_i = -1; long long ticket = -1; };
+struct PushSrc { const float* src = nullptr; int ev_i = -1; long long ticket = -1; bool dma = false; };
 
 // threaded copy into the staging ring: 328 KB per push at 64 streams is 40 us of one core when the source is cold (pageable
 // client buffers), which made the single host thread the limit of the PCIe-inclusive rate.  The calling thread takes parts as
@@ -591,21 +594,43 @@ static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, 
     ps.ticket = c->push_serial++;
     ps.ev_i = (int)(ps.ticket % lasr_ctx::NSTAGE);
     if (c->push_used[ps.ev_i]) HIPCHK(c, hipEventSynchronize(c->push_ev[ps.ev_i]));       // 64 pushes ago: long done
+    // How the bytes cross PCIe: a DMA (hipMemcpyAsync on a copy-only stream) into a device staging entry, issued NOW -- the ctx
+    // stream is usually a model step behind the host, so the copy is long done when the front-end / ring-append kernel gets
+    // there, and that kernel reads HBM.  (LASR_PUSH_ZEROCOPY=1: the kernel reads the pinned memory itself, 16 bytes per lane
+    // over PCIe: ~20 us of the critical stream per 328 KB chunk batch, measured 43 k against 51 k audio-s/s resident.)
+    static const bool zero_copy = getenv("LASR_PUSH_ZEROCOPY") && atoi(getenv("LASR_PUSH_ZEROCOPY")) != 0;
+    const float* host_src = nullptr;
     if (flags & LASR_PUSH_PINNED_NOCOPY) {
         const void* pinned = pinned_host_dev_ptr(pcm);
         if (!pinned) return fail(c, LASR_EINVAL, "LASR_PUSH_PINNED_NOCOPY: the buffer is not pinned (device-mapped) host memory");
         ps.src = (const float*)pinned;
-        return LASR_OK;
+        host_src = pcm;
+    } else {
+        if (!c->push_stage_host) {
+            HIPCHK(c, hipHostMalloc((void**)&c->push_stage_host, sizeof(float) * (size_t)lasr_ctx::NSTAGE * c->M * CH));
+            void* dp = nullptr;
+            HIPCHK(c, hipHostGetDevicePointer(&dp, c->push_stage_host, 0));
+            c->push_stage_host_dev = (float*)dp;
+        }
+        static const bool dbg_nocopy = getenv("LASR_DBG_NOSTAGECOPY") != nullptr;     // experiment: GPU-side cost of the staged path alone
+        if (!dbg_nocopy) staged_copy(c, c->push_stage_host + (size_t)ps.ev_i * c->M * CH, pcm, sizeof(float) * (size_t)n * CH);
+        ps.src = c->push_stage_host_dev + (size_t)ps.ev_i * c->M * CH;
+        host_src = c->push_stage_host + (size_t)ps.ev_i * c->M * CH;
     }
-    if (!c->push_stage_host) {
-        HIPCHK(c, hipHostMalloc((void**)&c->push_stage_host, sizeof(float) * (size_t)lasr_ctx::NSTAGE * c->M * CH));
-        void* dp = nullptr;
-        HIPCHK(c, hipHostGetDevicePointer(&dp, c->push_stage_host, 0));
-        c->push_stage_host_dev = (float*)dp;
+    if (!zero_copy) {
+        if (!c->push_stage_dev) {
+            RC(dalloc(c, &c->push_stage_dev, (size_t)lasr_ctx::NSTAGE * c->M * CH));
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+            for (auto& e : c->push_copied) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        // (the device entry was last read by the kernel of push serial - NSTAGE: waited for above through push_ev)
+        float* dst = c->push_stage_dev + (size_t)ps.ev_i * c->M * CH;
+        HIPCHK(c, hipMemcpyAsync(dst, host_src, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream_copy));
+        HIPCHK(c, hipEventRecord(c->push_copied[ps.ev_i], c->stream_copy));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->push_copied[ps.ev_i], 0));
+        ps.src = dst;
+        ps.dma = true;
     }
-    static const bool dbg_nocopy = getenv("LASR_DBG_NOSTAGECOPY") != nullptr;     // experiment: GPU-side cost of the staged path alone
-    if (!dbg_nocopy) staged_copy(c, c->push_stage_host + (size_t)ps.ev_i * c->M * CH, pcm, sizeof(float) * (size_t)n * CH);
-    ps.src = c->push_stage_host_dev + (size_t)ps.ev_i * c->M * CH;
     return LASR_OK;
 }
 // the plain ring append (one launch)
@@ -636,6 +661,7 @@ static int push_finish(lasr_ctx* c, const int* slots, int n, const PushSrc& ps, 
     if (ps.ev_i >= 0) {
         HIPCHK(c, hipEventRecord(c->push_ev[ps.ev_i], c->stream));
         c->push_used[ps.ev_i] = true;
+        c->push_dma[ps.ev_i] = ps.dma;
     }
     if (ticket) *ticket = ps.ticket;
     return LASR_OK;
@@ -664,7 +690,9 @@ int lasr_push_consumed(lasr_ctx* c, long long ticket) {
     if (ticket < 0 || ticket >= c->push_serial) return fail(c, LASR_EINVAL, "unknown push ticket %lld", ticket);
     if (c->push_serial - ticket > lasr_ctx::NSTAGE) return 1;        // its event slot has been waited for and reused since
     HIPCHK(c, hipSetDevice(c->device));
-    const hipError_t e = hipEventQuery(c->push_ev[ticket % lasr_ctx::NSTAGE]);
+    // (DMA path: the source has been read once the copy is done; zero-copy path: once the reading kernel is)
+    hipEvent_t ev = c->push_dma[ticket % lasr_ctx::NSTAGE] ? c->push_copied[ticket % lasr_ctx::NSTAGE] : c->push_ev[ticket % lasr_ctx::NSTAGE];
+    const hipError_t e = hipEventQuery(ev);
     if (e == hipSuccess) return 1;
     (void)hipGetLastError();
     if (e == hipErrorNotReady) return 0;

@@ -20,12 +20,12 @@ from oracle import rnnt_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-EPS_LOGIT = 0.25      # greedy: top-1 minus top-2 logit below which a bf16 decision counts as a tie (logit scale ~10)
-EPS_SCORE = 0.25      # beam: gap between hypothesis scores (sums of log p) at the selection boundary
+EPS_LOGIT = 0.08      # greedy: top-1 minus top-2 logit below which a bf16 decision counts as a tie (logit scale ~10)
+EPS_SCORE = 0.08      # beam: gap between hypothesis scores (sums of log p) at the selection boundary
 # floors = what was observed on the MI355X (profiles/r03/parity_counts.json) minus one
-FLOOR_BF16_GREEDY = 40      # of 64 streams exact
-FLOOR_CFG2_BEAM4 = 8        # of 16
-FLOOR_CFG5_BEAM8 = 8        # of 16
+FLOOR_BF16_GREEDY = 63      # of 64 streams exact (observed 64)
+FLOOR_CFG2_BEAM4 = 14       # of 16 (observed 15, one margin-tie at 0.011)
+FLOOR_CFG5_BEAM8 = 15       # of 16 (observed 16)
 
 
 def make(name, **kw):
