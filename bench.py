@@ -231,8 +231,7 @@ def main():
     ap.add_argument("--cpu-chunks", type=int, default=150)
     ap.add_argument("--cpu-be-chunks", type=int, default=60,
                     help="chunks per stream of the best-effort CPU leg (all host cores, encoder batched over the streams)")
-    ap.add_argument("--beam", type=int, default=1,
-                    help="beam width (1 = greedy, the headline config); > 1 runs the synchronous protocol")
+    ap.add_argument("--beam", type=int, default=1, help="beam width (1 = greedy, the headline config)")
     ap.add_argument("--depth", type=int, default=12,
                     help="pipelined mode: model steps in flight before the oldest is collected (1..15)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -299,7 +298,7 @@ def main():
     slots = [eng.open() for _ in range(B)]
     assert slots == list(range(B))
 
-    pipelined = not args.no_pipeline and args.beam == 1
+    pipelined = not args.no_pipeline            # beam > 1: the selection loop runs across chunk boundaries as well (round 3)
     FETCH_CAP = 64 if args.beam == 1 else 8192      # beam: every fetch hands out the whole current best hypothesis
     push_t = {}                                   # chunk index -> host time of its push (latency bookkeeping)
     order = []                                    # model chunks submitted and not yet collected

@@ -67,10 +67,10 @@ typedef struct {
     int32_t beam;        /* 1 = greedy (the only decode the reference has); 2..8 = beam  */
                          /* search width W (spec: oracle _beam_frame):     */
                          /* W hypothesis slots per stream, streams x W <= 1024 rows.     */
-                         /* Synchronous entry points only (not lasr_step_submit); then   */
-                         /* lasr_fetch returns the WHOLE current best hypothesis after   */
-                         /* every model step (it may change retroactively), neg_logp =   */
-                         /* -its score, align = 0.                                       */
+                         /* lasr_fetch then returns the WHOLE current best hypothesis    */
+                         /* after every model step (it may change retroactively),        */
+                         /* neg_logp = -its score, align = 0.  Both protocols (the        */
+                         /* pipelined one: <= 512 stream slots); no LM inside the beam.   */
 } lasr_model_desc;
 
 /* Fills `d` with the reference defaults listed above (4x1024 encoder, 2xNBRC predictor). */
@@ -151,7 +151,9 @@ int lasr_step_window(lasr_ctx* c, const int* slots, int n, const float* pcm, int
  * behind while the others run ahead on the frames of later steps.  At the limit lasr_step_submit returns LASR_ESTATE and changes nothing (the pushed chunk stays
  * pushed: call lasr_step_wait, then submit again).
  * Every other state-changing call returns LASR_ESTATE while a submitted step is uncollected.
- * Results are identical to lasr_step_stream (same kernels, same order per stream).  Greedy only. */
+ * Results are identical to lasr_step_stream (same kernels, same order per stream).  With beam > 1 the selection loop runs
+ * across chunk boundaries too (every stream on its own frame cursor); lasr_fetch after lasr_step_wait hands out the best
+ * hypothesis as of that model step. */
 int lasr_step_submit(lasr_ctx* c, const int* slots, int n);
 /* lasr_push_pcm_ex + lasr_step_submit for the same slot list in ONE call (same results): when the chunk completes a model
  * step the front-end launch takes the newest chunk from `pcm` and appends it to the PCM ring itself -- one launch less on

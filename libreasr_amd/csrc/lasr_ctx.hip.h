@@ -67,7 +67,20 @@ struct lasr_ctx {
     std::vector<void*> pred_y1;
     float* pp1 = nullptr;
     double* b_score = nullptr; int *b_alive = nullptr, *b_inB = nullptr, *b_parent = nullptr, *b_trellis = nullptr;
-    std::vector<std::vector<std::vector<int32_t>>> hyp;   // host: token history of every hypothesis slot [M][W]
+    // host: token history of every hypothesis slot as a shared-prefix tree per stream (a round re-parents W slots: copying W
+    // token vectors per round grows with the length of the stream; a node per emitted token does not)
+    struct BeamHost { std::vector<int> par, tok; std::vector<int> cur; };
+    std::vector<BeamHost> bh;
+    // continuous beam loop (lasr_step_submit / lasr_step_wait with beam > 1): pinned rings written by k_beam_select
+    static constexpr int TRING = 128;
+    int *b_tre_host = nullptr, *b_tre_dev = nullptr;         // [TRING][Md] records of a round
+    int *b_fdone_host = nullptr, *b_fdone_dev = nullptr;     // [TRING][M]  frame finished in that round
+    double *b_endsc_host = nullptr, *b_endsc_dev = nullptr;  // [M][ENDSLOTS][W] slot scores at the end of a model step
+    int *b_endal_host = nullptr, *b_endal_dev = nullptr;     // [M][ENDSLOTS]    alive mask
+    long long b_rounds_replayed = 0;
+    std::vector<long long> b_frames_done;                    // per stream: frames the host has seen finished
+    struct BeamResult { std::vector<int32_t> tokens; double score; };
+    std::vector<std::deque<BeamResult>> b_results;           // per stream: finished model steps not yet collected
     std::vector<std::vector<int32_t>> committed;          // host: best hypothesis at the last predictor reset(s)
     std::vector<double> committed_score;
     std::vector<std::vector<int32_t>> best_full;          // host: committed + current best hypothesis

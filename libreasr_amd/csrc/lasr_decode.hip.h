@@ -117,6 +117,35 @@ void run_encoder(lasr_ctx* c, int T_max) {
     launch_linear<false, 3>(c, J / 16, T_max * c->MT, g, H, ea);
 }
 
+// ---- host side of the beam: hypotheses as a shared-prefix tree per stream
+void bh_reset(lasr_ctx::BeamHost& B, int W) { B.par.clear(); B.tok.clear(); B.cur.assign(W, -1); }
+void bh_tokens(const lasr_ctx::BeamHost& B, int node, std::vector<int32_t>& out) {      // appends root -> leaf
+    const size_t at = out.size();
+    for (int n = node; n >= 0; n = B.par[n]) out.push_back(B.tok[n]);
+    std::reverse(out.begin() + at, out.end());
+}
+// one selection round of a stream: e[j] = (parent slot << 16) | (token + 1 if extended else 0); -2 dead slot
+void bh_apply(lasr_ctx::BeamHost& B, const int* e, int W) {
+    int nh[8];
+    for (int j = 0; j < W; ++j) {
+        if (e[j] < 0) { nh[j] = -1; continue; }
+        const int p = B.cur[e[j] >> 16], tok = e[j] & 0xffff;
+        if (tok) { B.par.push_back(p); B.tok.push_back(tok - 1); nh[j] = (int)B.par.size() - 1; }
+        else nh[j] = p;
+    }
+    for (int j = 0; j < W; ++j) B.cur[j] = nh[j];
+    if (B.par.size() > (size_t)1 << 18) {           // compaction: keep the live hypotheses only
+        std::vector<std::vector<int32_t>> live(W);
+        for (int j = 0; j < W; ++j) bh_tokens(B, B.cur[j], live[j]);
+        B.par.clear(); B.tok.clear();
+        for (int j = 0; j < W; ++j) {
+            int n = -1;
+            for (int32_t t : live[j]) { B.par.push_back(n); B.tok.push_back(t); n = (int)B.par.size() - 1; }
+            B.cur[j] = n;
+        }
+    }
+}
+
 // Greedy decode of the current step (T_row_dev, pe ready).  Blocks until done; fills host queues.
 int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::vector<int>& rows);
 
@@ -274,19 +303,12 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
     HIPCHK(c, hipMemcpyAsync(sc, c->b_score, sizeof(double) * Md, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(alive, c->b_alive, sizeof(int) * Md, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<std::vector<int32_t>> nh(W);
     for (int r : rows) {
-        auto& H = c->hyp[r];
+        auto& H = c->bh[r];
         for (int it = 0; it < iter; ++it) {
             const int* e = tre + (size_t)it * Md + (size_t)r * W;
             if (e[0] == -1) continue;                          // stream idle in this round
-            for (int j = 0; j < W; ++j) {
-                if (e[j] < 0) { nh[j].clear(); continue; }     // dead slot
-                nh[j] = H[e[j] >> 16];
-                const int tok = e[j] & 0xffff;
-                if (tok) nh[j].push_back(tok - 1);
-            }
-            for (int j = 0; j < W; ++j) H[j].swap(nh[j]);
+            bh_apply(H, e, W);
         }
         int best = -1;
         for (int j = 0; j < W; ++j)
@@ -294,7 +316,7 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
         auto& q = c->best_full[r];
         q = c->committed[r];                                   // what earlier predictor resets froze
         double score = c->committed_score[r];
-        if (best >= 0) { q.insert(q.end(), H[best].begin(), H[best].end()); score += sc[(size_t)r * W + best]; }
+        if (best >= 0) { bh_tokens(H, H.cur[best], q); score += sc[(size_t)r * W + best]; }
         c->queue[r] = q;                                       // beam mode: lasr_fetch hands out the whole best hypothesis
         c->neg_logp[r] = -score;
         c->align[r] = 0.0;                                     // alignment_score is a greedy-loop metric
@@ -305,10 +327,9 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
 // host side of a predictor reset in beam mode: the best hypothesis so far is frozen, the beam restarts
 void beam_host_reset(lasr_ctx* c, int slot, bool forget) {
     if (c->W <= 1) return;
-    auto& H = c->hyp[slot];
     if (forget) { c->committed[slot].clear(); c->committed_score[slot] = 0.0; c->best_full[slot].clear(); }
     else { c->committed[slot] = c->best_full[slot]; c->committed_score[slot] = -c->neg_logp[slot]; }
-    for (auto& h : H) h.clear();
+    bh_reset(c->bh[slot], c->W);
 }
 
 void rec(lasr_ctx* c, int i) {

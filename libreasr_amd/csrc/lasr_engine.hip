@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -260,8 +261,27 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         RC(dalloc(c, &c->b_score, Md)); RC(dalloc(c, &c->b_alive, Md)); RC(dalloc(c, &c->b_inB, Md)); RC(dalloc(c, &c->b_parent, Md));
         HIPCHK(c, hipMemset(c->b_score, 0, sizeof(double) * Md)); HIPCHK(c, hipMemset(c->b_alive, 0, sizeof(int) * Md));
         HIPCHK(c, hipMemset(c->b_inB, 0, sizeof(int) * Md)); HIPCHK(c, hipMemset(c->b_parent, 0, sizeof(int) * Md));
-        c->hyp.assign(M, std::vector<std::vector<int32_t>>(c->W));
+        c->bh.assign(M, lasr_ctx::BeamHost{});
+        for (auto& b : c->bh) bh_reset(b, c->W);
         c->committed.assign(M, {}); c->committed_score.assign(M, 0.0); c->best_full.assign(M, {});
+        c->b_frames_done.assign(M, 0); c->b_results.assign(M, {});
+        {   // continuous beam loop: the rounds' records, frame marks and step-end scores in pinned host memory (zero-copy stores)
+            const size_t n_tre = (size_t)lasr_ctx::TRING * Md, n_fd = (size_t)lasr_ctx::TRING * M;
+            const size_t n_es = (size_t)M * lasr_ctx::ENDSLOTS * c->W, n_ea = (size_t)M * lasr_ctx::ENDSLOTS;
+            char* blk = nullptr;
+            const size_t bytes = sizeof(double) * n_es + sizeof(int) * (n_tre + n_fd + n_ea) + 64;
+            HIPCHK(c, hipHostMalloc((void**)&blk, bytes));
+            c->host_allocs.push_back(blk);
+            memset(blk, 0, bytes);
+            void* dp = nullptr;
+            HIPCHK(c, hipHostGetDevicePointer(&dp, blk, 0));
+            char* dblk = (char*)dp;
+            c->b_endsc_host = (double*)blk; c->b_endsc_dev = (double*)dblk;
+            size_t off = sizeof(double) * n_es;
+            c->b_tre_host = (int*)(blk + off); c->b_tre_dev = (int*)(dblk + off); off += sizeof(int) * n_tre;
+            c->b_fdone_host = (int*)(blk + off); c->b_fdone_dev = (int*)(dblk + off); off += sizeof(int) * n_fd;
+            c->b_endal_host = (int*)(blk + off); c->b_endal_dev = (int*)(dblk + off);
+        }
     }
     RC(dalloc(c, (char**)&c->ja, Mj * J * c->esz)); HIPCHK(c, hipMemset(c->ja, 0, Mj * J * c->esz));
     RC(dalloc(c, (char**)&c->cvt_a, (size_t)M * H * c->esz)); RC(dalloc(c, (char**)&c->cvt_b, (size_t)M * H * c->esz));
@@ -908,7 +928,6 @@ int lasr_push_submit(lasr_ctx* c, const int* slots, int n, const float* pcm, int
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
     if (!pcm) return fail(c, LASR_EINVAL, "pcm is null");
-    if (c->W > 1) return fail(c, LASR_ESTATE, "lasr_push_submit is greedy-only; use lasr_push_pcm + lasr_step_stream with beam > 1");
     if ((int)c->pending.size() + 1 > lasr_max_inflight(c))
         return fail(c, LASR_ESTATE, "%d steps already in flight (limit %d): call lasr_step_wait (nothing was pushed)", (int)c->pending.size(), lasr_max_inflight(c));
     HIPCHK(c, hipSetDevice(c->device));
@@ -932,7 +951,7 @@ int lasr_push_submit(lasr_ctx* c, const int* slots, int n, const float* pcm, int
 }
 
 static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fused, bool* fused_done) {
-    if (c->W > 1) return fail(c, LASR_ESTATE, "lasr_step_submit is greedy-only; use lasr_step_stream with beam > 1");
+    if (c->W > 1 && c->M > 512) return fail(c, LASR_ESTATE, "the pipelined protocol with beam > 1 takes up to 512 stream slots");
     {   // in-flight limit: the event / T_row rings (NFLY) and the per-row rings the decode loop runs through --
         // encoder frames not yet decoded (pe ring), tokens not yet collected (token ring), step boundary marks
         const int inflight = (int)c->pending.size() + 1, Tm = c->d.n_buffer;
@@ -1037,6 +1056,12 @@ static int cont_launch_group(lasr_ctx* c, int G) {
         q.admitted = true;
         admitted_any = true;
     }
+    if (admitted_any && c->W > 1) {     // beam: every hypothesis slot of the streams that have a frame to decode
+        AvailV av;
+        for (int r = 0; r < 512; ++r) av.v[r] = r < M ? c->h_avail[r] : 0;
+        hipLaunchKernelGGL(k_ja_admit_beam, dim3(grid1((size_t)c->Md * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)cur_pp(c),
+                           (const int*)c->c_cur, av, c->c_avail, c->ja, J, c->Md, c->W, M, c->MTj, c->pe_ring_R, c->bf);
+    } else
     if (admitted_any) {  // rows that were idle need their joint activation for the new frames
         if (by_value) {
             AvailV av;
@@ -1053,8 +1078,28 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     c->dbg_gate = false;
     // the G iterations are launch-invariant (the flag-ring slot comes from a device counter, the last k_select
     // publishes the cursors and the "rows with frames left" word): replayed as one hipGraph per (G, ping-pong parities)
+    BeamState bs{};
+    if (c->W > 1) {
+        bs.W = c->W; bs.V = V; bs.blank = c->d.blank; bs.max_iters = c->d.max_iters_stream; bs.Md = c->Md;
+        bs.t_idx = c->c_cur; bs.iters = c->c_iters; bs.T_row = c->c_avail;
+        bs.score = c->b_score; bs.alive = c->b_alive; bs.inB = c->b_inB; bs.token = c->ds.token; bs.emit = c->ds.emit;
+        bs.parent = c->b_parent; bs.trellis = c->b_tre_dev; bs.unfinished = c->c_behind; bs.dbg = nullptr;
+        bs.cont = 1; bs.tring = lasr_ctx::TRING; bs.frame_done = c->b_fdone_dev; bs.iter_ctr = c->c_iter; bs.done_blocks = c->c_done;
+        bs.host_cur = c->c_hcur_dev; bs.step_T = c->d.n_buffer; bs.end_slots = lasr_ctx::ENDSLOTS;
+        bs.end_score = c->b_endsc_dev; bs.end_alive = c->b_endal_dev;
+    }
     auto enqueue = [&]() {
         for (int q = 0; q < G; ++q) {
+            if (c->W > 1) {                 // one selection round: logits of every hypothesis slot -> ordered top-W -> predictor / joint
+                bs.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
+                launch_logits(c, c->logits, c->Md, true);
+                if (c->W <= 2) hipLaunchKernelGGL((k_beam_select<2>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, bs, 0);
+                else if (c->W <= 4) hipLaunchKernelGGL((k_beam_select<4>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, bs, 0);
+                else hipLaunchKernelGGL((k_beam_select<8>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, bs, 0);
+                launch_predictor(c, true);
+                launch_ppj(c, true);
+                continue;
+            }
             s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
             launch_logits(c, c->logits, c->la * M, true);
             launch_select<false>(c->stream, M, c->logits, V, c->d.blank, c->d.max_iters_stream, c->c_avail, s, 0, nullptr, nullptr, c->la, M);
@@ -1095,6 +1140,38 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     return LASR_OK;
 }
 
+// continuous beam loop: replay the rounds of the groups that have completed into the streams' hypothesis trees; a stream that
+// finished a model step in a round gets that step's result (best alive slot by the scores the kernel stored for the step)
+static void beam_replay(lasr_ctx* c) {
+    const int W = c->W, Md = c->Md, M = c->M, Tm = c->d.n_buffer;
+    for (long long it = c->b_rounds_replayed; it < c->cont_iters; ++it) {
+        const int slot = (int)(it % lasr_ctx::TRING);
+        const int* tre = c->b_tre_host + (size_t)slot * Md;
+        const int* fd = c->b_fdone_host + (size_t)slot * M;
+        for (int q = 0; q < c->d.max_streams; ++q) {
+            const int* e = tre + (size_t)q * W;
+            if (e[0] == -1) continue;                          // stream idle in this round
+            auto& H = c->bh[q];
+            bh_apply(H, e, W);
+            if (!fd[q]) continue;
+            const long long frames = ++c->b_frames_done[q];
+            if (frames % Tm) continue;
+            const int es = (int)((frames / Tm - 1) % lasr_ctx::ENDSLOTS);
+            const double* sc = c->b_endsc_host + ((size_t)q * lasr_ctx::ENDSLOTS + es) * W;
+            const int am = c->b_endal_host[(size_t)q * lasr_ctx::ENDSLOTS + es];
+            int best = -1;
+            for (int j = 0; j < W; ++j)
+                if (((am >> j) & 1) && (best < 0 || sc[j] > sc[best])) best = j;
+            lasr_ctx::BeamResult r;
+            r.tokens = c->committed[q];
+            r.score = c->committed_score[q];
+            if (best >= 0) { bh_tokens(H, H.cur[best], r.tokens); r.score += sc[best]; }
+            c->b_results[q].push_back(std::move(r));
+        }
+    }
+    c->b_rounds_replayed = c->cont_iters;
+}
+
 // non-blocking: if the in-flight group has finished, consume its flag and snapshot the rows' frame cursors
 // (nothing writes them again until the next group is launched)
 static void cont_poll(lasr_ctx* c) {
@@ -1105,6 +1182,7 @@ static void cont_poll(lasr_ctx* c) {
     c->work_left = v;
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     memcpy(c->h_cur_seen.data(), c->cont_host + 16, sizeof(int) * c->M);
+    if (c->W > 1) beam_replay(c);
     if (c->tr_on) {     // iterations this group needed = most decisions (frames + tokens) any row made in it; rows that moved
         const int* nt = c->cont_host + 16 + c->M;
         int need = 0, rows = 0;
@@ -1155,6 +1233,15 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran) {
     // in pinned memory (written by the kernels of the groups that completed before the cursors were published)
     lasr_ctx::PendingStep& P = c->pending.front();
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (c->W > 1) {      // beam: the whole best hypothesis as of this model step (lasr_fetch semantics of beam > 1)
+        for (int r : P.rows) {
+            if (c->b_results[r].empty()) return fail(c, LASR_EHIP, "beam: no result for slot %d although its step is decoded", r);
+            lasr_ctx::BeamResult& br = c->b_results[r].front();
+            c->queue[r] = br.tokens; c->best_full[r] = br.tokens;
+            c->neg_logp[r] = -br.score; c->align[r] = 0.0;
+            c->b_results[r].pop_front();
+        }
+    } else
     for (int r : P.rows) {
         const int j = P.target[r] / P.Tm - 1;
         const long long end = h_end[(size_t)r * lasr_ctx::ENDSLOTS + (j % lasr_ctx::ENDSLOTS)];

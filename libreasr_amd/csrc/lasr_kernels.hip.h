@@ -642,6 +642,21 @@ struct BeamState {
     int* trellis;      // [n_iter_slots][Md]  (parent << 16) | (token + 1 if extended else 0); -1 stream idle, -2 dead slot
     int* unfinished;   // [n_iter_slots]
     unsigned long long* dbg;   // LASR_DBG_TIMING: phase timestamps of workgroup 0 (wall_clock64, 10 ns ticks)
+    // continuous mode (lasr_step_submit / lasr_step_wait with beam > 1): the selection loop keeps running across chunk boundaries,
+    // every stream on its own frame cursor (rounds per model step = those the stream needs, not the maximum over the batch).
+    //   t_idx = global frame cursor, T_row = frames available; the round's records go to slot (round % tring) of the pinned
+    //   trellis ring, with a per-stream "frame finished in this round" word beside them; when a stream finishes a model step
+    //   (cursor % step_T == 0) its slot scores / alive flags are stored for the host under the step's index.
+    int cont;
+    int tring;           // rounds in the trellis ring
+    int* frame_done;     // [tring][M] pinned: 1 iff the stream finished its frame in that round
+    int* iter_ctr;       // device round counter (launch-invariant groups: hipGraph replay)
+    int* done_blocks;    // [64]
+    int* host_flag;      // last round of a group: "streams with frames left" goes here (pinned), else nullptr
+    int* host_cur;       // [M] pinned: frame cursors, stored with the flag
+    int step_T, end_slots;
+    double* end_score;   // [M][end_slots][W] pinned
+    int* end_alive;      // [M][end_slots] pinned (bit j = slot j alive)
 };
 
 // WT: compile-time bound of W (2, 4, 8).  One workgroup of 1024 threads per stream: its W x V logits
@@ -664,12 +679,34 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
             zv[b][k] = v < V ? z[v] : -INFINITY;
         }
     }
-    int* tre = s.trellis + (size_t)iter_slot * s.Md + r0;
+    const int iter_no = s.cont ? (int)(*(const unsigned*)s.iter_ctr & 0x3fffffffu) : iter_slot;     // same value in every workgroup
+    const int uslot = s.cont ? (iter_no & 63) : iter_slot;                                          // slot of the flag rings
+    int* tre = s.trellis + (size_t)(s.cont ? iter_no % s.tring : iter_slot) * s.Md + r0;
+    if (s.cont && q == 0 && tid == 0) {                                                             // recycle the flag rings
+        s.unfinished[(uslot + 32) & 63] = 0;
+        s.done_blocks[(uslot + 32) & 63] = 0;
+    }
+    auto publish = [&]() {           // thread 0 of every workgroup, after its last store of this launch (continuous mode)
+        if (!s.cont) return;
+        if (s.host_flag) __threadfence_system();     // this stream's records (pinned memory) before the count
+        if (atomicAdd(&s.done_blocks[uslot], 1) == (int)gridDim.x - 1) {      // last workgroup of the launch
+            if (s.host_flag) {
+                const int v = atomicAdd(&s.unfinished[uslot], 0);
+                __hip_atomic_store(s.host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            *s.iter_ctr = iter_no + 1;
+        }
+    };
     const bool dbg = s.dbg && q == 0 && tid == 0;
     if (dbg) s.dbg[0] = wall_clock64();
     const int t = s.t_idx[q], Tr = s.T_row[q];
     if (t >= Tr) {                                   // stream has nothing to decode: identity round
         if (tid < W) { s.emit[r0 + tid] = 0; s.parent[r0 + tid] = tid; tre[tid] = -1; }
+        if (tid == 0 && s.cont) {
+            s.frame_done[(size_t)(iter_no % s.tring) * gridDim.x + q] = 0;
+            if (s.host_flag) s.host_cur[q] = t;
+            publish();
+        }
         return;
     }
     __shared__ double sc[WT];
@@ -837,8 +874,37 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
     if (all_b) { tn = t + 1; rn = 0; }
     for (int j = 0; j < W; ++j) s.inB[r0 + j] = all_b ? 0 : (sel_sc[j] > -INFINITY ? nib[j] : 0);
     s.t_idx[q] = tn; s.iters[q] = rn;
-    if (tn < Tr) atomicAdd(&s.unfinished[iter_slot], 1);
+    if (s.cont) {
+        s.frame_done[(size_t)(iter_no % s.tring) * gridDim.x + q] = all_b ? 1 : 0;
+        if (all_b && tn % s.step_T == 0) {           // the stream just finished one of its model steps: scores for the host
+            const int es = (tn / s.step_T - 1) % s.end_slots;
+            int am = 0;
+            for (int j = 0; j < W; ++j) {
+                s.end_score[((size_t)q * s.end_slots + es) * W + j] = sel_sc[j];
+                if (sel_sc[j] > -INFINITY) am |= 1 << j;
+            }
+            s.end_alive[(size_t)q * s.end_slots + es] = am;
+        }
+        if (s.host_flag) s.host_cur[q] = tn;
+    }
+    if (tn < Tr) atomicAdd(&s.unfinished[uslot], 1);
     if (dbg) s.dbg[4] = wall_clock64();
+    publish();
+}
+
+// continuous beam loop, admission of newly encoded steps (<= 512 streams): frames-available counts by value (as k_ja_admit) and
+// the joint activation of every hypothesis slot of the streams that have a frame to decode (rows = stream * W + slot)
+__global__ void k_ja_admit_beam(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
+                                const AvailV av, int* __restrict__ avail_out, void* __restrict__ ja, int J, int Md, int W, int M_enc,
+                                int MT, int ring, int bf) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Md * J) return;
+    const int r = idx / J, j = idx - r * J, q = r / W;
+    const int Tav = av.v[q];
+    if (j == 0 && r == q * W) avail_out[q] = Tav;
+    const int t = t_idx[q];
+    if (t >= Tav) return;
+    act_st(bf, ja, act_off(bf, r, j, MT), tanhf(pe[((size_t)(t % ring) * M_enc + q) * J + j] + pp[(size_t)r * J + j]));
 }
 
 // start of a beam decode step: per-stream cursors and the iteration flags

@@ -48,7 +48,7 @@ class Engine:
             raise ValueError("dtype must be 'f32' or 'bf16'")
         d.dtype = 1 if dtype == "bf16" else 0      # bf16: weights + GEMM-input activations, f32 accumulate
         self.dtype = dtype
-        d.beam = int(beam)                         # 1 = greedy; 2..8 = beam search (synchronous entry points)
+        d.beam = int(beam)                         # 1 = greedy; 2..8 = beam search (both protocols)
         self.beam = int(beam)
         for k, v in fe.items():
             setattr(d, k, int(v))

@@ -55,6 +55,7 @@ class _Stream:
         self.steps = 0                      # model steps since the last reset (api-server.py:117,133)
         self.text_of = None                 # tokens -> text of the chunk (reset policy: "the chunk produced no text")
         self.eof = False
+        self.y_prev = []                    # beam search: the best hypothesis as of the previous model step
 
 
 class Scheduler(threading.Thread):
@@ -75,7 +76,8 @@ class Scheduler(threading.Thread):
         self.streams, self.ctl, self.stop_flag = {}, collections.deque(), False
         self.batches = []                   # sizes of the streaming batches (observability / tests)
         self.max_inflight_seen = 0
-        self.depth = max(1, min(int(depth), engine.max_inflight())) if engine.beam == 1 else 0
+        self.depth = max(1, min(int(depth), engine.max_inflight()))
+        self.beam = engine.beam
         self.inflight = collections.deque() # per submitted model step: the streams whose model ran, in slot-list order
         self.batchq, self.batch_outq = collections.deque(), queue.Queue()     # trunk interface (push_batch)
         self.downsample = downsample or engine.desc.stride
@@ -181,7 +183,13 @@ class Scheduler(threading.Thread):
         st.steps += 1
         cell.append(tokens)
         if st.text_of is not None and isinstance(tokens, list):
-            if st.text_of(tokens) == "" and should_reset(st.steps, self.downsample, self.n_buffer):
+            new = tokens
+            if self.beam > 1:               # the engine hands out the whole best hypothesis: this chunk's part follows the common prefix
+                n = 0
+                while n < min(len(st.y_prev), len(tokens)) and st.y_prev[n] == tokens[n]:
+                    n += 1
+                st.y_prev, new = list(tokens), tokens[n:]
+            if st.text_of(new) == "" and should_reset(st.steps, self.downsample, self.n_buffer):
                 self._reset(st)             # (the stream has nothing in flight: see _may_run_ahead)
         self._flush(st)
 
@@ -193,12 +201,18 @@ class Scheduler(threading.Thread):
         """Tokens of the oldest model step in flight -> its streams."""
         rows = self.inflight.popleft()
         self.eng.wait()
-        toks = self.eng.fetch_many([s.slot for s, _ in rows], cap=256)
+        toks = self.eng.fetch_many([s.slot for s, _ in rows], cap=256 if self.beam == 1 else 8192)
         if rows and rows[0][1] is None:      # a push_batch step: one item for the whole step
             for (s, _), t in zip(rows, toks):
                 s.inflight -= 1
                 s.steps += 1
-                if s.text_of is not None and s.text_of(t) == "" and should_reset(s.steps, self.downsample, self.n_buffer):
+                new = t
+                if self.beam > 1:
+                    n = 0
+                    while n < min(len(s.y_prev), len(t)) and s.y_prev[n] == t[n]:
+                        n += 1
+                    s.y_prev, new = list(t), t[n:]
+                if s.text_of is not None and s.text_of(new) == "" and should_reset(s.steps, self.downsample, self.n_buffer):
                     self._reset(s)
             self.batch_outq.put(([s for s, _ in rows], toks))
             return
@@ -299,30 +313,19 @@ class Scheduler(threading.Thread):
                             if s.n_pend == d.n_buffer:
                                 s.n_pend, r = 0, True
                         ran.append(r)
-                    if self.depth:
-                        before = self.eng.pending()
-                        self.eng.push_submit(slots, np.stack([p for _, _, p in fast]))
-                        rows = [(s, cell) for (s, cell, _), r in zip(fast, ran) if r]
-                        assert (self.eng.pending() > before) == bool(rows)
-                        for (s, cell, _), r in zip(fast, ran):
-                            if not r:
-                                cell.append(None)
-                                self._flush(s)
-                        if rows:
-                            for s, _ in rows:
-                                s.inflight += 1
-                            self.inflight.append(rows)
-                            self.max_inflight_seen = max(self.max_inflight_seen, len(self.inflight))
-                    else:                                       # beam search: synchronous protocol
-                        self.eng.push(slots, np.stack([p for _, _, p in fast]))
-                        self.eng.step(slots)
-                        toks = self.eng.fetch_many(slots, cap=8192)
-                        for (s, cell, _), r, t in zip(fast, ran, toks):
-                            if r:
-                                self._deliver(s, cell, t)
-                            else:
-                                cell.append(None)
-                                self._flush(s)
+                    before = self.eng.pending()
+                    self.eng.push_submit(slots, np.stack([p for _, _, p in fast]))
+                    rows = [(s, cell) for (s, cell, _), r in zip(fast, ran) if r]
+                    assert (self.eng.pending() > before) == bool(rows)
+                    for (s, cell, _), r in zip(fast, ran):
+                        if not r:
+                            cell.append(None)
+                            self._flush(s)
+                    if rows:
+                        for s, _ in rows:
+                            s.inflight += 1
+                        self.inflight.append(rows)
+                        self.max_inflight_seen = max(self.max_inflight_seen, len(self.inflight))
             except Exception as e:
                 for s, cell, _ in fast:
                     if not cell:
@@ -403,7 +406,7 @@ class ASRServicer(apg.ASRServicer):
         return ap.Transcript(data=self.lang.denumericalize(tokens))
 
     def TranscribeStream(self, request_iterator, context):                 # api-server.py:82-134
-        st = self._guard(context, lambda: self.sched.open(text_of=None if self.beam > 1 else self.lang.denumericalize))
+        st = self._guard(context, lambda: self.sched.open(text_of=self.lang.denumericalize))
 
         def reader():                       # frames are queued as they arrive; results come back in frame order on st.outq
             try:
@@ -449,9 +452,7 @@ class ASRServicer(apg.ASRServicer):
                         continue
                     last_diff = diff
                     yield ap.Transcript(data=diff)
-                elif self.beam > 1 and should_reset(steps, self.downsample, self.n_buffer):
-                    self.sched.reset(st)    # (greedy: the scheduler applies the same rule between two model steps of the stream)
-                    steps = 0
+                # (the reset rule of api-server.py:131-134 is applied by the scheduler, between two model steps of the stream)
         finally:
             self.sched.close(st)
 

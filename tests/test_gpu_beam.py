@@ -114,14 +114,93 @@ def test_beam_bf16_cfg2_runs_and_tracks_emulation():
         eng.close_slot(s)
 
 
-def test_beam_rejects_pipeline_and_bad_width():
-    from libreasr_amd import _native as N
+@pytest.mark.parametrize("name,W", [("tiny", 2), ("tiny", 4), ("tiny_lstm", 4), ("tiny", 8)])
+def test_beam_on_the_pipelined_protocol_equals_the_oracle_per_model_step(name, W):
+    """Round 3: beam search on lasr_push_submit / lasr_step_wait -- the selection loop runs across chunk boundaries, every stream
+    on its own frame cursor.  After EVERY model step the best hypothesis must be the oracle's (StreamBeamDecoder), for streams
+    that join at different chunks, with several steps in flight; then a predictor reset freezes the best hypothesis."""
+    eng, m, cfg = engine(name, W)
+    n = 3
+    pcm = synth.synth_pcm(n, 16000 * 3, seed=31)
+    chunks = [synth.stream_chunks(pcm[i], 1280, lead=1, tail=6) for i in range(n)]
+    slots = [eng.open() for _ in range(n)]
+    fes = [O.StreamFrontend() for _ in range(n)]
+    decs = [O.StreamBeamDecoder(m, W) for _ in range(n)]
+    ref_hist = [[] for _ in range(n)]               # oracle: best hypothesis after every model step
+    got_hist = [[] for _ in range(n)]
+    order = []                                      # per submitted model step: the streams that ran
+    start = [0, 1, 3]
+
+    def collect():
+        rows = order.pop(0)
+        assert eng.wait() == len(rows)
+        for i in rows:
+            t, neg_logp, _ = eng.fetch(slots[i])
+            got_hist[i].append((t, -neg_logp))
+
+    for k in range(len(chunks[0]) + max(start)):
+        act = [i for i in range(n) if 0 <= k - start[i] < len(chunks[i])]
+        if not act:
+            continue
+        before = eng.pending()
+        eng.push_submit([slots[i] for i in act], np.stack([chunks[i][k - start[i]] for i in act]))
+        ran = []
+        for i in act:
+            o = fes[i].push(chunks[i][k - start[i]])
+            if o is not None:
+                y, sc = decs[i].step(o)
+                ref_hist[i].append((list(y), sc))
+                ran.append(i)
+        assert (eng.pending() > before) == bool(ran)
+        if ran:
+            order.append(ran)
+        if eng.pending() >= 4:
+            collect()
+    while eng.pending():
+        collect()
+    n_tok = 0
+    for i in range(n):
+        assert len(got_hist[i]) == len(ref_hist[i]) > 5
+        for j, ((t, sc), (y, rsc)) in enumerate(zip(got_hist[i], ref_hist[i])):
+            assert t == y, (i, j, t, y)
+            assert abs(sc - rsc) < 1e-3 * max(1.0, abs(rsc)), (i, j, sc, rsc)
+        n_tok += len(ref_hist[i][-1][0])
+    assert n_tok > 3
+    # the synchronous protocol continues a stream the pipelined one started (same device state, same host trees): the
+    # hypothesis after every further step must be what an all-synchronous and an all-pipelined run of the same chunks give
+    extra = synth.stream_chunks(pcm[1], 1280, lead=0, tail=2)[:6]
+    mixed = []
+    for ch in extra:
+        eng.push([slots[0]], ch[None])
+        if eng.step([slots[0]]):
+            mixed.append(eng.fetch(slots[0])[0])
+    assert len(mixed) >= 2
+    whole = chunks[0] + extra
+    for proto in ("sync", "pipelined"):
+        sl = eng.open()
+        hist = []
+        for ch in whole:
+            if proto == "sync":
+                eng.push([sl], ch[None])
+                if eng.step([sl]):
+                    hist.append(eng.fetch(sl)[0])
+            else:
+                eng.push_submit([sl], ch[None])
+                if eng.pending() >= 3 and eng.wait():
+                    hist.append(eng.fetch(sl)[0])
+        while eng.pending():
+            if eng.wait():
+                hist.append(eng.fetch(sl)[0])
+        assert hist[-len(mixed):] == mixed, proto
+        assert hist[:len(got_hist[0])] == [t for t, _ in got_hist[0]], proto
+        eng.close_slot(sl)
+    for sl in slots:
+        eng.close_slot(sl)
+
+
+def test_beam_rejects_bad_width():
     from libreasr_amd.engine import Engine
-    eng, _, cfg = engine("tiny", 2)
-    s = eng.open()
-    with pytest.raises(N.LasrError):
-        eng.submit([s])
-    eng.close_slot(s)
+    cfg = synth.model_cfg("tiny")
     sd = synth.synth_state_dict(cfg, seed=0)
     with pytest.raises(ValueError):
         Engine(sd, cfg, max_streams=8, beam=9)
