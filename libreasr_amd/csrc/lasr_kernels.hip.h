@@ -223,6 +223,67 @@ __global__ void k_delay(unsigned long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// ---- wave-wide reductions on DPP row operations + v_readlane instead of ds_bpermute butterflies (a __shfl_xor step is an LDS
+// crossbar round trip of ~90 cycles per dword; k_beam_select spent 17 of its 20 us in such steps).  Lane pairing: quad_perm for
+// xor 1 / xor 2, row_half_mirror / row_mirror for the 8- and 16-lane steps (after the quad steps all lanes of a quad hold the same
+// value, so mirroring pairs the same operands as xor 4 / xor 8), then the four row results combined as (r0 + r1) + (r2 + r3):
+// the same association as the xor butterfly -- sums are bit-identical to it.  Every lane returns the wave's result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float readlane_f32(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+__device__ __forceinline__ float wave_sum_f32(float x) {
+    x += dpp_f32<0xB1>(x); x += dpp_f32<0x4E>(x); x += dpp_f32<0x141>(x); x += dpp_f32<0x140>(x);
+    return (readlane_f32(x, 0) + readlane_f32(x, 16)) + (readlane_f32(x, 32) + readlane_f32(x, 48));
+}
+__device__ __forceinline__ float wave_max_f32(float x) {
+    x = fmaxf(x, dpp_f32<0xB1>(x)); x = fmaxf(x, dpp_f32<0x4E>(x)); x = fmaxf(x, dpp_f32<0x141>(x)); x = fmaxf(x, dpp_f32<0x140>(x));
+    return fmaxf(fmaxf(readlane_f32(x, 0), readlane_f32(x, 16)), fmaxf(readlane_f32(x, 32), readlane_f32(x, 48)));
+}
+// argmax under the total order (value descending, ord ascending)
+template <int CTRL>
+__device__ __forceinline__ void dpp_argmax_step(double& best, int& ord) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(best), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(best), CTRL, 0xf, 0xf, false);
+    const int oo = __builtin_amdgcn_update_dpp(0, ord, CTRL, 0xf, 0xf, false);
+    const double ob = __hiloint2double(hi, lo);
+    if (ob > best || (ob == best && oo < ord)) { best = ob; ord = oo; }
+}
+__device__ __forceinline__ void wave_argmax_f64(double& best, int& ord) {
+    dpp_argmax_step<0xB1>(best, ord); dpp_argmax_step<0x4E>(best, ord); dpp_argmax_step<0x141>(best, ord); dpp_argmax_step<0x140>(best, ord);
+    const int lo = __double2loint(best), hi = __double2hiint(best);
+    double b = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    int o = __builtin_amdgcn_readlane(ord, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const double ob = __hiloint2double(__builtin_amdgcn_readlane(hi, r), __builtin_amdgcn_readlane(lo, r));
+        const int oo = __builtin_amdgcn_readlane(ord, r);
+        if (ob > b || (ob == b && oo < o)) { b = ob; o = oo; }
+    }
+    best = b; ord = o;
+}
+
+// argmax of (float value, int index): larger value first, smaller index among equals
+template <int CTRL>
+__device__ __forceinline__ void dpp_argmax32_step(float& best, int& arg) {
+    const float ob = dpp_f32<CTRL>(best);
+    const int oa = __builtin_amdgcn_update_dpp(0, arg, CTRL, 0xf, 0xf, false);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+}
+__device__ __forceinline__ void wave_argmax_f32(float& best, int& arg) {
+    dpp_argmax32_step<0xB1>(best, arg); dpp_argmax32_step<0x4E>(best, arg); dpp_argmax32_step<0x141>(best, arg); dpp_argmax32_step<0x140>(best, arg);
+    float b = readlane_f32(best, 0);
+    int a = __builtin_amdgcn_readlane(arg, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float ob = readlane_f32(best, r);
+        const int oa = __builtin_amdgcn_readlane(arg, r);
+        if (ob > b || (ob == b && oa < a)) { b = ob; a = oa; }
+    }
+    best = b; arg = a;
+}
+
 // frames of newly encoded steps become visible to the decode loop (continuous mode)
 __global__ void k_advance(int* __restrict__ counter, const int* __restrict__ add, int M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -330,12 +391,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
             const float x = z[j];
             if (x > best[k]) { best[k] = x; arg[k] = j; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best[k], o);
-            const int oa = __shfl_xor(arg[k], o);
-            if (ob > best[k] || (ob == best[k] && oa < arg[k])) { best[k] = ob; arg[k] = oa; }
-        }
+        wave_argmax_f32(best[k], arg[k]);
         if (lane == 0) { sv[k][w] = best[k]; si[k][w] = arg[k]; }
     }
     __syncthreads();
@@ -351,8 +407,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
 #pragma unroll
         for (int q = 0; q < KEEP; ++q) sum += expf(zv[k][q] - best[k]);      // exp(-inf) = 0 for the padding
         for (int j = tid + 256 * KEEP; j < V; j += 256) sum += expf(z[j] - best[k]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = wave_sum_f32(sum);                     // same association as the xor butterfly: bit-identical
         if (lane == 0) ss[k][w] = sum;
     }
     __syncthreads();
@@ -738,8 +793,7 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
         float x = -INFINITY;
 #pragma unroll
         for (int k = 0; k < KEEP; ++k) x = fmaxf(x, zv[b][k]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+        x = wave_max_f32(x);
         if (lane == 0) redf[w][b] = x;
     }
     __syncthreads();
@@ -748,8 +802,7 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
 #pragma unroll
         for (int b = 0; b < WT; ++b) {
             float x = lane < NWV ? redf[lane][b] : -INFINITY;
-#pragma unroll
-            for (int o = NWV / 2; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+            x = wave_max_f32(x);
             if (lane == 0) bc[0][b] = x;
         }
     }
@@ -763,8 +816,7 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
 #pragma unroll
             for (int k = 0; k < KEEP; ++k) sum += expf(zv[b][k] - m[b]);      // exp(-inf) = 0 for the padding
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = wave_sum_f32(sum);                     // (same association as the xor butterfly: bit-identical)
         if (lane == 0) redf[w][b] = sum;
     }
     __syncthreads();
@@ -783,66 +835,101 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
 #pragma unroll
     for (int b = 0; b < WT; ++b) lg[b] = bc[1][b];
     if (dbg) s.dbg[2] = wall_clock64();
-    // ---- W ordered argmax passes.  Pass j only admits candidates strictly after winner j-1 in the total order
-    // (score desc, ord asc).  Every thread caches its local best: it stays valid until it wins, so after the
-    // first pass only the winning thread rescans its candidates; the cross-wave step is done by wave 0 alone.
-    double last_sc = INFINITY;
-    int last_ord = -1;
-    double lbest = -INFINITY;
-    int lord = 0x7fffffff;
-    bool stale = true;
-    for (int j = 0; j < W; ++j) {
-        if (stale) {
-            lbest = -INFINITY; lord = 0x7fffffff;
-            auto offer = [&](double val, int ord) {
-                const bool after = val < last_sc || (val == last_sc && ord > last_ord);
-                const bool better = val > lbest || (val == lbest && ord < lord);
-                if ((val > -INFINITY) && after && better) { lbest = val; lord = ord; }
+    // ---- the ordered top-W of all candidates, in two wave-level stages (no block-wide reduction per winner):
+    //   (1) every wave finds the ordered top-W of ITS candidates: pass j admits only candidates strictly after the wave's winner
+    //       j-1 in the total order (score desc, ord asc), so no "taken" set is needed; every lane caches its local best, which
+    //       stays valid until it wins -- only the winning lane rescans;
+    //   (2) wave 0 selects the ordered top-W among the NWV x W wave winners the same way.
+    // The global top-W is contained in the union of the waves' top-W, and both stages use the same total order, so the result
+    // is the one a single ordered scan gives.
+    __shared__ double cand_sc[NWV][WT];
+    __shared__ int cand_ord[NWV][WT];
+    {
+        // Per lane and row the (up to) KEEP extension candidates are sorted once (log p descending, token ascending: the total
+        // order restricted to a row, where the score is monotonic in log p); the lane's best remaining candidate is then the best
+        // of its rows' heads -- W values to compare per pass instead of W x KEEP -- and a lane that wins pops that row's head.
+        static_assert(KEEP == 4, "4-element sorting network");
+        int kp[WT];                                  // original k of the sorted positions, 2 bits each, head in the low bits
+#pragma unroll
+        for (int b = 0; b < WT; ++b) {
+            kp[b] = 0 | (1 << 2) | (2 << 4) | (3 << 6);
+            if (!al[b]) {
+#pragma unroll
+                for (int k = 0; k < KEEP; ++k) zv[b][k] = -INFINITY;
+                continue;
+            }
+            if (ib[b]) {                             // carried unchanged: ONE candidate (thread 0), score sc[b] (+ 0), ord b (V + 1)
+                zv[b][0] = tid == 0 ? 0.f : -INFINITY;
+#pragma unroll
+                for (int k = 1; k < KEEP; ++k) zv[b][k] = -INFINITY;
+                continue;
+            }
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) zv[b][k] = (zv[b][k] - m[b]) - lg[b];      // log p (padding stays -inf)
+            int k0 = 0, k1 = 1, k2 = 2, k3 = 3;
+            auto cx = [&](float& a, int& ka, float& c, int& kc) {                       // a before c unless c is strictly better
+                if (c > a || (c == a && kc < ka)) { const float t = a; a = c; c = t; const int tk = ka; ka = kc; kc = tk; }
             };
+            cx(zv[b][0], k0, zv[b][1], k1); cx(zv[b][2], k2, zv[b][3], k3);
+            cx(zv[b][0], k0, zv[b][2], k2); cx(zv[b][1], k1, zv[b][3], k3);
+            cx(zv[b][1], k1, zv[b][2], k2);
+            kp[b] = k0 | (k1 << 2) | (k2 << 4) | (k3 << 6);
+        }
+        for (int j = 0; j < W; ++j) {
+            double best = -INFINITY;
+            int bord = 0x7fffffff;
 #pragma unroll
             for (int b = 0; b < WT; ++b) {
-                if (!al[b]) continue;
-                if (ib[b]) {
-                    if (tid == 0) offer(sc[b], b * (V + 1));
-                    continue;
-                }
-                const double sb = sc[b];
-#pragma unroll
-                for (int k = 0; k < KEEP; ++k) offer(sb + (double)((zv[b][k] - m[b]) - lg[b]), b * (V + 1) + 1 + tid + NT * k);
+                const float h = zv[b][0];
+                if (!(h > -INFINITY)) continue;
+                const double val = sc[b] + (double)h;
+                const int ord = b * (V + 1) + (ib[b] ? 0 : 1 + tid + NT * (kp[b] & 3));
+                if (val > best || (val == best && ord < bord)) { best = val; bord = ord; }
             }
-            stale = false;
-        }
-        double best = lbest;
-        int bord = lord;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ob = __shfl_xor(best, o);
-            const int oo = __shfl_xor(bord, o);
-            if (ob > best || (ob == best && oo < bord)) { best = ob; bord = oo; }
-        }
-        if (lane == 0) { redd[w] = best; redi[w] = bord; }
-        __syncthreads();
-        if (w == 0) {                                // 16 wave results -> one, by wave 0
-            best = lane < NWV ? redd[lane] : -INFINITY;
-            bord = lane < NWV ? redi[lane] : 0x7fffffff;
-#pragma unroll
-            for (int o = NWV / 2; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o);
-                const int oo = __shfl_xor(bord, o);
-                if (ob > best || (ob == best && oo < bord)) { best = ob; bord = oo; }
+            const int mine = bord;
+            wave_argmax_f64(best, bord);
+            if (lane == 0) { cand_sc[w][j] = best; cand_ord[w][j] = bord; }
+            if (!(best > -INFINITY)) {               // this wave's candidates are exhausted (wave-uniform)
+                if (lane == 0)
+                    for (int k = j + 1; k < W; ++k) { cand_sc[w][k] = -INFINITY; cand_ord[w][k] = 0x7fffffff; }
+                break;
             }
+            if (mine == bord) {                      // this lane's candidate won: pop the head of its row
+                const int bw = bord / (V + 1);
+#pragma unroll
+                for (int b = 0; b < WT; ++b)
+                    if (b == bw) { zv[b][0] = zv[b][1]; zv[b][1] = zv[b][2]; zv[b][2] = zv[b][3]; zv[b][3] = -INFINITY; kp[b] >>= 2; }
+            }
+        }
+    }
+    __syncthreads();
+    if (dbg) s.dbg[9] = wall_clock64();
+    if (w == 0) {
+        // NWV x W <= 128 wave winners: two per lane
+        double c0 = -INFINITY, c1 = -INFINITY;
+        int o0 = 0x7fffffff, o1 = 0x7fffffff;
+        if (lane < NWV * W) { c0 = cand_sc[lane / W][lane % W]; o0 = cand_ord[lane / W][lane % W]; }
+        if (lane + 64 < NWV * W) { c1 = cand_sc[(lane + 64) / W][(lane + 64) % W]; o1 = cand_ord[(lane + 64) / W][(lane + 64) % W]; }
+        double last_sc = INFINITY;
+        int last_ord = -1;
+        for (int j = 0; j < W; ++j) {
+            double best = -INFINITY;
+            int bord = 0x7fffffff;
+            auto offer = [&](double val, int ord) {
+                const bool after = val < last_sc || (val == last_sc && ord > last_ord);
+                const bool better = val > best || (val == best && ord < bord);
+                if ((val > -INFINITY) && after && better) { best = val; bord = ord; }
+            };
+            offer(c0, o0); offer(c1, o1);
+            wave_argmax_f64(best, bord);
             if (lane == 0) { sel_sc[j] = best; sel_ord[j] = bord; }
+            if (!(best > -INFINITY)) {               // candidates exhausted: the remaining slots are dead
+                if (lane == 0)
+                    for (int k = j + 1; k < W; ++k) { sel_sc[k] = -INFINITY; sel_ord[k] = 0x7fffffff; }
+                break;
+            }
+            last_sc = best; last_ord = bord;
         }
-        __syncthreads();
-        best = sel_sc[j]; bord = sel_ord[j];
-        if (dbg && j == 0) s.dbg[9] = wall_clock64();
-        if (!(best > -INFINITY)) {                   // candidates exhausted: the remaining slots are dead
-            if (tid == 0)
-                for (int k = j + 1; k < W; ++k) { sel_sc[k] = -INFINITY; sel_ord[k] = 0x7fffffff; }
-            break;
-        }
-        if (bord == lord) stale = true;              // this thread's candidate won: find its next one
-        last_sc = best; last_ord = bord;
     }
     __syncthreads();
     if (tid != 0) return;

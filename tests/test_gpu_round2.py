@@ -202,7 +202,7 @@ def test_config2_bf16_greedy_streaming_exact_up_to_ties():
         eng.close()
 
 
-def _beam_stream_case(name, W, B, n_chunks, check_rows, floor):
+def _beam_stream_case(name, W, B, n_chunks, check_rows, floor, protocol="sync"):
     eng, sd, cfg = make(name, max_streams=B, dtype="bf16", beam=W)
     try:
         mb = O.OracleTransducer(sd, cfg, operand="bf16")
@@ -210,13 +210,25 @@ def _beam_stream_case(name, W, B, n_chunks, check_rows, floor):
         slots = [eng.open() for _ in range(B)]
         hist = [[] for _ in range(B)]                     # best hypothesis after every model step
         score = [0.0] * B
+
+        def take():
+            for i in check_rows:
+                t, nl, _ = eng.fetch(slots[i])
+                hist[i].append(t if t else (hist[i][-1] if hist[i] else []))
+                score[i] = -nl
+
         for k in range(n_chunks):
-            eng.push(slots, pcm[:, k * 1280:(k + 1) * 1280])
-            if eng.step(slots):
-                for i in check_rows:
-                    t, nl, _ = eng.fetch(slots[i])
-                    hist[i].append(t if t else (hist[i][-1] if hist[i] else []))
-                    score[i] = -nl
+            if protocol == "sync":
+                eng.push(slots, pcm[:, k * 1280:(k + 1) * 1280])
+                if eng.step(slots):
+                    take()
+            else:                                         # the selection loop across chunk boundaries, 6 model steps in flight
+                eng.push_submit(slots, pcm[:, k * 1280:(k + 1) * 1280])
+                if eng.pending() >= 6 and eng.wait():
+                    take()
+        while eng.pending():
+            if eng.wait():
+                take()
         equal = tie = 0
         tie_margins = []
         for i in check_rows:
@@ -239,7 +251,7 @@ def _beam_stream_case(name, W, B, n_chunks, check_rows, floor):
                 assert abs(score[i] - dec.best()[1]) < 0.1 * max(1.0, abs(score[i]))     # still a neighbouring hypothesis
         print(f"{name} bf16 beam {W}, {len(check_rows)} of {B} streams x {n_chunks} chunks vs the emulation: {equal} equal at "
               f"every model step, {tie} diverged at a margin-tie (< {EPS_SCORE})")
-        record_parity(f"{name}_bf16_beam{W}_streaming", checked=len(check_rows), exact=equal, tie=tie, chunks=n_chunks, streams=B,
+        record_parity(f"{name}_bf16_beam{W}_streaming_{protocol}", checked=len(check_rows), exact=equal, tie=tie, chunks=n_chunks, streams=B,
                       eps=EPS_SCORE, max_margin_at_a_disagreement=max(tie_margins) if tie_margins else None,
                       margins_at_disagreements=sorted(tie_margins))
         assert equal >= floor, (equal, tie_margins)
@@ -248,14 +260,16 @@ def _beam_stream_case(name, W, B, n_chunks, check_rows, floor):
         eng.close()
 
 
-def test_config2_bf16_beam4_streaming():
+@pytest.mark.parametrize("protocol", ["sync", "pipelined"])
+def test_config2_bf16_beam4_streaming(protocol):
     """BASELINE configs[2]: cfg2, bf16, beam 4, 80 ms streaming chunks, 64 streams; 16 rows x 24 chunks checked."""
-    _beam_stream_case("cfg2", 4, 64, 24, list(range(0, 64, 4)), FLOOR_CFG2_BEAM4)
+    _beam_stream_case("cfg2", 4, 64, 24, list(range(0, 64, 4)), FLOOR_CFG2_BEAM4, protocol)
 
 
-def test_config4_cfg5_bf16_beam8_128_streams():
+@pytest.mark.parametrize("protocol", ["sync", "pipelined"])
+def test_config4_cfg5_bf16_beam8_128_streams(protocol):
     """BASELINE configs[4] per-GPU shape: 8x1536 encoder, 2xLSTM predictor, bf16, beam 8, 128 streams; 16 rows x 24 chunks."""
-    _beam_stream_case("cfg5", 8, 128, 24, list(range(0, 128, 8)), FLOOR_CFG5_BEAM8)
+    _beam_stream_case("cfg5", 8, 128, 24, list(range(0, 128, 8)), FLOOR_CFG5_BEAM8, protocol)
 
 
 def test_fused_frontend_irregular_pushes_equal_the_per_chunk_kernels():
