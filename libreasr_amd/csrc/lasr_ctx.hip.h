@@ -56,7 +56,6 @@ struct lasr_ctx {
     // recurrent state (row == slot)
     std::vector<void*> enc_h[2], pred_h[2], pred_y;      // element-typed (A operands)
     std::vector<float*> enc_c, pred_c;
-    int cell_lds_pad = 0, cell_lds_pad_multi = 0;   // extra dynamic LDS of the encoder-cell launches (LASR_CELL_LDS_PAD): see launch_gemm
     int cell_nw = 0;                // waves per encoder-cell workgroup (0: 4 for f32, 8 for bf16); LASR_CELL_NW
     int dec_prio = 1, cell_prio = 0;   // s_setprio of the decode-stream GEMMs / of everything else (experiments)
     int logits_mt = 2;              // m-tiles per workgroup of the logits GEMM (1 | 2 | 4); LASR_LOGITS_MT
@@ -107,7 +106,6 @@ struct lasr_ctx {
     // the main stream while ONE greedy loop keeps running on stream_dec across chunk boundaries: a row
     // that finished chunk k moves on to chunk k+1's frames while a bursty row is still on chunk k.
     hipStream_t stream_dec = nullptr;
-    hipStream_t stream_fe_dbg = nullptr;     // LASR_DBG_FE_SIDE timing experiment
     hipStream_t stream_main_own = nullptr;   // LASR_MAIN_CUS experiment: CU-masked stream used instead of the caller's
     static constexpr int NFLY = 16; // steps in flight (ring of encoder-done events)
     static constexpr int RING = 64; // pe ring, frames per row

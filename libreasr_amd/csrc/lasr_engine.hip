@@ -128,8 +128,6 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     {
         if (getenv("LASR_NO_GRAPH")) c->use_graphs = false;
         if (getenv("LASR_CELL_NW")) c->cell_nw = atoi(getenv("LASR_CELL_NW")) == 4 ? 4 : 8;
-        if (getenv("LASR_CELL_LDS_PAD")) c->cell_lds_pad = c->cell_lds_pad_multi = std::max(0, std::min(140 << 10, atoi(getenv("LASR_CELL_LDS_PAD"))));
-        if (getenv("LASR_CELL_LDS_PAD_MULTI")) c->cell_lds_pad_multi = std::max(0, std::min(140 << 10, atoi(getenv("LASR_CELL_LDS_PAD_MULTI"))));
         // encoder pass as a layer wavefront: bf16 cells are load-paced with idle MFMA time, two of them per CU overlap (streaming
         // +4 %, offline +14 %); f32 cells are MFMA-paced, two per CU only contend (-4 %)
         c->enc_wave = c->bf ? 1 : 0;
@@ -632,8 +630,7 @@ static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, 
             HIPCHK(c, hipHostGetDevicePointer(&dp, c->push_stage_host, 0));
             c->push_stage_host_dev = (float*)dp;
         }
-        static const bool dbg_nocopy = getenv("LASR_DBG_NOSTAGECOPY") != nullptr;     // experiment: GPU-side cost of the staged path alone
-        if (!dbg_nocopy) staged_copy(c, c->push_stage_host + (size_t)ps.ev_i * c->M * CH, pcm, sizeof(float) * (size_t)n * CH);
+        staged_copy(c, c->push_stage_host + (size_t)ps.ev_i * c->M * CH, pcm, sizeof(float) * (size_t)n * CH);
         ps.src = c->push_stage_host_dev + (size_t)ps.ev_i * c->M * CH;
         host_src = c->push_stage_host + (size_t)ps.ev_i * c->M * CH;
     }
@@ -660,8 +657,7 @@ static int push_append_launch(lasr_ctx* c, const int* slots, int n, const PushSr
         PushIdx pi;
         for (int r = 0; r < 512; ++r) pi.idx[r] = -1;
         for (int i = 0; i < n; ++i) pi.idx[slots[i]] = (short)i;
-        static const bool dbg_side = getenv("LASR_DBG_FE_SIDE") != nullptr;      // timing experiment, see enqueue_frontend_encoder
-        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, (dbg_side && c->stream_fe_dbg) ? c->stream_fe_dbg : c->stream, ps.src, (const int*)nullptr, pi, c->win, c->ring_pos, CH, c->ring_chunks);
+        hipLaunchKernelGGL(k_push_pcm, dim3(c->M), dim3(256), 0, c->stream, ps.src, (const int*)nullptr, pi, c->win, c->ring_pos, CH, c->ring_chunks);
     } else {
         RC(cmd_begin(c));
         for (int r = 0; r < c->M; ++r) c->hc.src_idx[r] = -1;
@@ -789,14 +785,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
                 for (int j = 0; j < d.n_buffer; ++j) pk |= (unsigned)(f.age_v[j][s] == 255 ? 15 : f.age_v[j][s]) << (4 * j);
                 m.age_pk[s] = (unsigned short)pk;
             }
-            // LASR_DBG_FE_SIDE: timing experiment ONLY (no ordering against the cells: results are not valid) -- what would the job
-            // gain if the front-end ran beside the previous step's cells instead of in front of this step's
-            static const bool dbg_side = getenv("LASR_DBG_FE_SIDE") != nullptr;
             hipStream_t fe_st = c->stream;
-            if (dbg_side) {
-                if (!c->stream_fe_dbg) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_fe_dbg, hipStreamNonBlocking));
-                fe_st = c->stream_fe_dbg;
-            }
             hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * d.n_buffer, c->M), dim3(320), 0, fe_st, m);
             if (fused_done) *fused_done = fused != nullptr;
             RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring));    // the continuous loop reads its own frame counters

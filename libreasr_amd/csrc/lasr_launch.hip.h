@@ -6,14 +6,11 @@
 namespace {
 
 // ---------------------------------------------------------------------------- launch helpers
-// lds_pad: extra (unused) dynamic LDS bytes.  The encoder cell asks for more than half a CU's LDS so that the workgroup dispatcher
-// can never put two of its 256 workgroups on one CU while the decode stream's workgroups are around (an MFMA-paced workgroup
-// that shares its CU's matrix pipes takes twice as long, and the launch lasts as long as its slowest workgroup).
 template <class Ops, class Epi, int MT, bool AROW, int D = 3, int NWV = NW>
-void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g0, const typename Epi::Args& ea, int lds_pad = 0) {
+void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g0, const typename Epi::Args& ea) {
     GemmArgs g = g0;
     g.prio = (c->stream == c->stream_dec && c->stream_dec) ? c->dec_prio : c->cell_prio;
-    hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NWV, AROW, D>), dim3(n_groups, m_groups), dim3(NWV * 64), lds_pad, c->stream, g, ea);
+    hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NWV, AROW, D>), dim3(n_groups, m_groups), dim3(NWV * 64), 0, c->stream, g, ea);
 }
 
 int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
@@ -55,13 +52,8 @@ void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_tot
     // K split over 4 waves for f32 operands (12.8 us against 17.2 us with 8: fewer requests in flight, half the
     // LDS reduction), 8 waves for bf16 (5.4 us against 6.6 us); LASR_CELL_NW overrides
     const int nw = c->cell_nw ? c->cell_nw : (Ops::BF ? 8 : 4);
-    if (c->cell_lds_pad > 0) {       // more than 64 KB of LDS per workgroup has to be allowed per kernel
-        static bool set4 = false, set8 = false;
-        if (nw == 4 && !set4) { (void)hipFuncSetAttribute((const void*)k_gemm<Ops, E, 2, 4, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->cell_lds_pad); set4 = true; }
-        if (nw != 4 && !set8) { (void)hipFuncSetAttribute((const void*)k_gemm<Ops, E, 2, NW, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->cell_lds_pad); set8 = true; }
-    }
-    if (nw == 4) launch_gemm<Ops, E, 2, false, 3, 4>(c, H / 8, c->M / 32, g, ea, c->cell_lds_pad);
-    else launch_gemm<Ops, E, 2, false>(c, H / 8, c->M / 32, g, ea, c->cell_lds_pad);
+    if (nw == 4) launch_gemm<Ops, E, 2, false, 3, 4>(c, H / 8, c->M / 32, g, ea);
+    else launch_gemm<Ops, E, 2, false>(c, H / 8, c->M / 32, g, ea);
 }
 void launch_enc_cell(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
     if (c->bf) launch_enc_cell_t<OpsBF16>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
@@ -97,13 +89,8 @@ void launch_enc_wave_t(lasr_ctx* c, const EncCellRef* cells, int n, int par0, in
     }
     const int nw = c->cell_nw ? c->cell_nw : (Ops::BF ? 8 : 4);
     const dim3 grid(H / 8, c->M / 32, n);
-    if (c->cell_lds_pad_multi > 0) {
-        static bool set4 = false, set8 = false;
-        if (nw == 4 && !set4) { (void)hipFuncSetAttribute((const void*)k_gemm_multi<Ops, E, 2, 4, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->cell_lds_pad_multi); set4 = true; }
-        if (nw != 4 && !set8) { (void)hipFuncSetAttribute((const void*)k_gemm_multi<Ops, E, 2, NW, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->cell_lds_pad_multi); set8 = true; }
-    }
-    if (nw == 4) hipLaunchKernelGGL((k_gemm_multi<Ops, E, 2, 4, false, 3>), grid, dim3(256), c->cell_lds_pad_multi, c->stream, m);
-    else hipLaunchKernelGGL((k_gemm_multi<Ops, E, 2, NW, false, 3>), grid, dim3(NW * 64), c->cell_lds_pad_multi, c->stream, m);
+    if (nw == 4) hipLaunchKernelGGL((k_gemm_multi<Ops, E, 2, 4, false, 3>), grid, dim3(256), 0, c->stream, m);
+    else hipLaunchKernelGGL((k_gemm_multi<Ops, E, 2, NW, false, 3>), grid, dim3(NW * 64), 0, c->stream, m);
 }
 void launch_enc_wave(lasr_ctx* c, const EncCellRef* cells, int n, int par0, int mt_total) {
     if (c->bf) launch_enc_wave_t<OpsBF16>(c, cells, n, par0, mt_total);
