@@ -1,0 +1,230 @@
+"""CPU tests of the gRPC scheduler's logic (libreasr_amd/server.py) against a FAKE engine: result order per stream, the
+servicer's reset rule applied between two model steps of a stream (api-server.py:44-50,131-134), steps in flight, the trunk
+interface, end-of-stream, and shutdown (callers must get an error, not hang).  The engine calls themselves are covered
+on the GPU (tests/test_gpu_server.py)."""
+import collections
+import threading
+import time
+import types
+
+import numpy as np
+import pytest
+
+from libreasr_amd import server as srv
+
+
+class FakeEngine:
+    """Front-end bookkeeping of the real engine (3-chunk window, 2-frame Buffer) with 'tokens' that are a pure function of the
+    stream's model-step history since its last reset, so any mis-ordering or misplaced reset shows in the output."""
+
+    def __init__(self, max_streams=8, beam=1, inflight=15, silent=()):
+        self.desc = types.SimpleNamespace(sample_rate=16000, chunk=4, n_window=3, n_buffer=2, stride=8)
+        self.beam, self._max, self._inflight = beam, max_streams, inflight
+        self.open_, self.n_chunks, self.n_pend, self.acc = set(), {}, {}, {}
+        self.since_reset = {}
+        self.steps, self.queue = collections.deque(), {}
+        self.resets = []                    # (slot, model steps the slot had run when it was reset)
+        self.total_steps = {}
+        self.silent = set(silent)           # slots whose steps produce no tokens
+        self.max_pending = 0
+        self.lock_owner = None
+
+    def _own(self):                         # a lasr_ctx is single-caller: every call must come from ONE thread
+        me = threading.get_ident()
+        assert self.lock_owner in (None, me), "engine called from two threads"
+        self.lock_owner = me
+
+    def max_inflight(self):
+        return self._inflight
+
+    def open(self):
+        self._own()
+        s = min(set(range(self._max)) - self.open_)
+        self.open_.add(s)
+        self.n_chunks[s] = self.n_pend[s] = self.since_reset[s] = self.total_steps[s] = 0
+        self.acc[s] = 0.0
+        self.queue[s] = []
+        return s
+
+    def close_slot(self, s):
+        self._own()
+        assert not any(s in rows for rows in self.steps), "close with a step in flight"
+        self.open_.discard(s)
+
+    def reset(self, s, what):
+        self._own()
+        assert not any(s in rows for rows in self.steps), "reset with a step in flight"
+        self.resets.append((s, self.total_steps[s]))
+        self.since_reset[s] = 0
+
+    def push_submit(self, slots, pcm):
+        self._own()
+        assert len(self.steps) < self._inflight
+        rows = []
+        for s, ch in zip(slots, np.asarray(pcm)):
+            self.n_chunks[s] += 1
+            self.acc[s] += float(ch.sum())
+            if self.n_chunks[s] >= self.desc.n_window:
+                self.n_pend[s] += 1
+                if self.n_pend[s] == self.desc.n_buffer:
+                    self.n_pend[s] = 0
+                    rows.append(s)
+        if rows:
+            out = {}
+            for s in rows:
+                self.total_steps[s] += 1
+                self.since_reset[s] += 1
+                out[s] = [] if s in self.silent else [int(self.acc[s]) % 97, self.since_reset[s]]
+            self.steps.append(out)
+            self.max_pending = max(self.max_pending, len(self.steps))
+
+    def pending(self):
+        return len(self.steps)
+
+    def wait(self):
+        self._own()
+        out = self.steps.popleft()
+        for s, t in out.items():
+            self.queue[s] = t
+        return len(out)
+
+    def fetch_many(self, slots, cap=256):
+        self._own()
+        r = [self.queue[s] for s in slots]
+        for s in slots:
+            self.queue[s] = []
+        return r
+
+
+def run_stream(sched, st, chunks, out):
+    for c in chunks:
+        sched.push_nowait(st, c)
+    sched.push_eof(st)
+    while True:
+        r = st.outq.get(timeout=20)
+        if r is srv.EOF:
+            return
+        out.append(r)
+
+
+def expected(chunks, slot_silent=False, text_rule=True, thresh_steps=25):
+    """What the reference servicer's loop would see for one stream of the fake engine (incl. its reset rule)."""
+    out, n, pend, acc, since = [], 0, 0, 0.0, 0
+    steps = 0
+    for c in chunks:
+        n += 1
+        acc += float(c.sum())
+        ran = False
+        if n >= 3:
+            pend += 1
+            if pend == 2:
+                pend, ran = 0, True
+        if not ran:
+            out.append(None)
+            continue
+        since += 1
+        steps += 1
+        toks = [] if slot_silent else [int(acc) % 97, since]
+        out.append(toks)
+        if text_rule and not toks and srv.should_reset(steps, 8, 2):
+            since, steps = 0, 0
+    return out
+
+
+def test_results_in_order_steps_in_flight_and_eof():
+    eng = FakeEngine()
+    sched = srv.Scheduler(eng, depth=4)
+    sched.start()
+    try:
+        rng = np.random.default_rng(0)
+        data = [[rng.integers(0, 9, 4).astype(np.float32) for _ in range(41 + 3 * i)] for i in range(5)]
+        sts = [sched.open(text_of=lambda t: "x" if t else "") for _ in range(5)]
+        outs = [[] for _ in range(5)]
+        ths = [threading.Thread(target=run_stream, args=(sched, sts[i], data[i], outs[i])) for i in range(5)]
+        [t.start() for t in ths]
+        [t.join(timeout=30) for t in ths]
+        for i in range(5):
+            assert outs[i] == expected(data[i]), i
+        assert eng.max_pending > 1, "model steps were never in flight together"
+        assert max(sched.batches) > 1
+        for st in sts:
+            sched.close(st)
+    finally:
+        sched.shutdown()
+
+
+def test_reset_rule_is_applied_between_two_steps_of_the_stream_not_later():
+    """A silent stream crosses the 4 s threshold (25 model steps of 160 ms): the reset must land right after the 25th step
+    although the producer has queued every chunk up front and other streams keep the pipeline full."""
+    eng = FakeEngine(silent={0})
+    sched = srv.Scheduler(eng, depth=8)
+    sched.start()
+    try:
+        rng = np.random.default_rng(1)
+        data = [[rng.integers(0, 9, 4).astype(np.float32) for _ in range(140)] for _ in range(3)]
+        sts = [sched.open(text_of=lambda t: "x" if t else "") for _ in range(3)]
+        assert sts[0].slot == 0
+        outs = [[] for _ in range(3)]
+        ths = [threading.Thread(target=run_stream, args=(sched, sts[i], data[i], outs[i])) for i in range(3)]
+        [t.start() for t in ths]
+        [t.join(timeout=30) for t in ths]
+        assert outs[0] == expected(data[0], slot_silent=True)
+        assert [r for r in eng.resets if r[0] == 0] == [(0, 25), (0, 50)]           # 69 model steps: resets after the 25th and 50th
+        assert outs[1] == expected(data[1]) and outs[2] == expected(data[2])
+        assert not [r for r in eng.resets if r[0] != 0]
+    finally:
+        sched.shutdown()
+
+
+def test_trunk_interface_and_blocking_push():
+    eng = FakeEngine(max_streams=16)
+    sched = srv.Scheduler(eng, depth=6)
+    sched.start()
+    try:
+        rng = np.random.default_rng(2)
+        B, n = 12, 30
+        chunks = rng.integers(0, 9, (n, B, 4)).astype(np.float32)
+        sts = [sched.open() for _ in range(B)]
+        for k in range(n):
+            sched.push_batch(sts, chunks[k])
+        got = {st.slot: [] for st in sts}
+        for _ in range((n - 2) // 2):
+            rows, toks = sched.batch_outq.get(timeout=20)
+            for st, t in zip(rows, toks):
+                got[st.slot].append(t)
+        for i, st in enumerate(sts):
+            exp = [t for t in expected([chunks[k, i] for k in range(n)], text_rule=False) if t is not None]
+            assert got[st.slot] == exp
+        # the blocking form returns each chunk's own result
+        st = sched.open()
+        res = [sched.push(st, chunks[k, 0]) for k in range(9)]
+        assert res == expected([chunks[k, 0] for k in range(9)], text_rule=False)
+    finally:
+        sched.shutdown()
+
+
+def test_shutdown_unblocks_everyone():
+    eng = FakeEngine()
+    sched = srv.Scheduler(eng, depth=2)
+    sched.start()
+    st = sched.open()
+    got = []
+
+    def blocked():
+        try:
+            got.append(st.outq.get(timeout=20))
+        except Exception as e:              # pragma: no cover
+            got.append(e)
+
+    t = threading.Thread(target=blocked)
+    t.start()
+    time.sleep(0.05)
+    sched.shutdown()
+    t.join(timeout=10)
+    assert got and isinstance(got[0], RuntimeError)
+    sched.join(timeout=10)
+    assert not sched.is_alive()
+    with pytest.raises(RuntimeError):
+        sched.open()
+    with pytest.raises(RuntimeError):
+        sched.push_nowait(st, np.zeros(4, np.float32))
