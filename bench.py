@@ -237,11 +237,13 @@ def main():
                          "(a selection round is ~10x a greedy iteration: 6 steps keep the p50 push->tokens latency under 5 ms)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
-    ap.add_argument("--prof-steps", type=int, default=0,
-                    help="steps of an extra PROFILED region behind the timed one (only used with --cell-prof-in-timed 0)")
-    ap.add_argument("--cell-prof-in-timed", type=int, default=1,
-                    help="timers of the dominant kernel inside the timed region: 1 = HIP-event pair per model step on the cells' stream + "
-                         "per-workgroup clock stores in the cell kernels (measured: no effect on `value`), 2 = clocks only, 0 = none")
+    ap.add_argument("--prof-steps", type=int, default=8,
+                    help="steps of the extra PROFILED region behind the timed one (in-kernel clocks of the cell launches; the cells then "
+                         "run as plain launches, not as the main-stream graph); used unless --cell-prof-in-timed is 1 or 2")
+    ap.add_argument("--cell-prof-in-timed", type=int, default=3,
+                    help="timers of the dominant kernel inside the timed region: 3 = one HIP-event pair per model step around the cell "
+                         "sequence on the cells' stream (the cells stay one hipGraph replay per model step); 1 = events + per-workgroup "
+                         "clock stores in the cell kernels (plain launches), 2 = clocks only, 0 = none")
     ap.add_argument("--check-rows", type=int, default=8,
                     help="self-check: rows replayed through the synchronous protocol after the timed region (0 = off)")
     ap.add_argument("--split-push", action="store_true",
@@ -417,10 +419,12 @@ def main():
         if not pipelined:
             enc_ms.append(st["encoder_ms"]); dec_ms.append(st["decode_ms"]); fe_ms.append(st["frontend_ms"])
 
-    # The dominant kernel is timed INSIDE the timed region: one HIP-event pair per model step around the cell sequence (on the
-    # cells' stream) and, in the cell kernels, one plain store of the device wall clock per workgroup at entry and exit.  Both
-    # are free at the resolution of this bench (round 2's timers used two atomics on one word per workgroup: they cost the
-    # job 10 % and inflated the cell's own duration by 2 us; profiles/r03/r03b_timer_cost.txt).
+    # The dominant kernel is timed INSIDE the timed region with one HIP-event pair per model step around the cell sequence, on the
+    # cells' stream (`launch_us_events`; the cells themselves run as one hipGraph replay per model step).  The kernels' own
+    # durations (`launch_us`: max exit - min entry of the device wall clock over a launch's workgroups, one plain store per
+    # workgroup at entry and exit) need a per-launch slot pointer, i.e. plain launches: they come from a short region of the same
+    # job right behind the timed one.  (Round 2's timers used two atomics on one word per workgroup: they cost the job 10 % and
+    # inflated the cell's own duration by 2 us; profiles/r03/r03_experiments.txt A.)
     if args.trace:
         eng.trace(True)
     elif args.cell_prof_in_timed:
@@ -436,18 +440,23 @@ def main():
         eng.trace(False)
     k_next = P + W + K
     prof_value = None
-    if args.cell_prof_in_timed and not args.trace:
-        Kp = K
-        prof_elapsed = elapsed
-    else:
-        Kp = max(0, min(args.steps, args.prof_steps)) * CPS
-        if Kp and not args.trace:
-            eng.cell_prof(True)                   # HIP-event pair around every model step's cell sequence + in-kernel clocks
-            prof_elapsed, _ = timed_region(k_next, Kp, None, host=args.host_pcm, barrier=False)
-            k_next += Kp
-            prof_value = Kp * B * CHUNK / SR / prof_elapsed
-    cell_us_total, cell_launches = eng.cell_prof_read() if (Kp and not args.trace and args.cell_prof_in_timed != 2) else (0.0, 0)
-    cell_kernel_us_total, cell_kernel_launches, cell_kernel_cells = eng.cell_prof_kernel() if (Kp and not args.trace) else (0.0, 0, 0)
+    cell_us_total, cell_launches = (0.0, 0)
+    cell_kernel_us_total, cell_kernel_launches, cell_kernel_cells = (0.0, 0, 0)
+    Kp = 0
+    if not args.trace:
+        if args.cell_prof_in_timed in (1, 3):
+            cell_us_total, cell_launches = eng.cell_prof_read()          # HIP-event pairs of the timed region
+        if args.cell_prof_in_timed in (1, 2):
+            Kp = K
+            cell_kernel_us_total, cell_kernel_launches, cell_kernel_cells = eng.cell_prof_kernel()
+        else:
+            Kp = max(0, min(args.steps, args.prof_steps)) * CPS
+            if Kp:                                # the kernels' own durations: a short region of the same job with the in-kernel clocks on
+                eng.cell_prof(2)
+                prof_elapsed, _ = timed_region(k_next, Kp, None, host=args.host_pcm, barrier=False)
+                k_next += Kp
+                prof_value = Kp * B * CHUNK / SR / prof_elapsed
+                cell_kernel_us_total, cell_kernel_launches, cell_kernel_cells = eng.cell_prof_kernel()
     eng.cell_prof(False)
     eng.set_profiling(False)
 
@@ -536,9 +545,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(cell_us, 3), "launches_timed": int(cell_kernel_launches or cell_launches),
-                         "measured_in": ("the timed region itself (--cell-prof-in-timed)" if args.cell_prof_in_timed else
-                                         f"a separate profiled region of {Kp // CPS} steps right behind the timed one (same streams, same "
-                                         "pipeline, cell timers on): the timed region itself carries no event records or in-kernel timers"),
+                         "measured_in": ("launch_us and launch_us_events: the timed region itself" if args.cell_prof_in_timed in (1, 2) else
+                                         f"launch_us_events: the timed region (one HIP-event pair per model step around the cell graph); "
+                                         f"launch_us: {Kp // CPS} further steps of the same job right behind it, cells as plain launches "
+                                         "with in-kernel clocks"),
                          "value_profiled": round(prof_value, 1) if prof_value else None,
                          "timing": "in-job (next to the decode stream), every cell launch of the timed region: kernel duration = max exit - "
                                    "min entry of the device wall clock over the launch's workgroups (the quantity rocprofv3 --kernel-trace "

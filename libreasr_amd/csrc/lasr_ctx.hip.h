@@ -134,6 +134,12 @@ struct lasr_ctx {
     // predictor parity at group start, frames)
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
     bool use_graphs = true;
+    // main stream: the cell sequence of a pipelined model step as one graph per (active m-tiles, parity); default on for bf16
+    // operands only (LASR_MAIN_GRAPH overrides)
+    bool main_graph = false;
+    hipStream_t stream_cap = nullptr;
+    std::map<std::vector<unsigned long long>, hipGraphExec_t> mgraphs;
+    int* T_row_main = nullptr;      // [M] fixed home of the step's per-row frame counts on the main stream (pipelined protocol)
 
     // LM shallow fusion (lasr_attach_lm): Embedding -> LSTM stack -> Linear -> log_softmax, stepped once
     // per emitted token for the rows that emitted (same compacted cell kernels as the predictor)

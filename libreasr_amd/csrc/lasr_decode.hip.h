@@ -82,29 +82,67 @@ void run_encoder(lasr_ctx* c, int T_max) {
     // layer wavefront: the cells (l, t) with l + t = d depend only on diagonal d - 1, so a diagonal is ONE launch
     // (k_gemm_multi, up to NPMAX cells): L + T - 1 launches instead of L * T, and the per-launch fixed costs of a cell
     // overlap its neighbours' K loops.  Cell (l, t) reads h parity par0 ^ (t & 1); all layers end on par0 ^ (T & 1).
-    if (c->enc_wave && L > 1 && T_max > 1) {
-        EncCellRef cells[NPMAX];
-        for (int d = 0; d < L + T_max - 1; ++d) {
-            int n = 0;
-            for (int l = std::min(d, L - 1); l >= 0 && d - l < T_max; --l) {
-                cells[n++] = EncCellRef{l, d - l};
-                if (n == NPMAX) { launch_enc_wave(c, cells, n, par0, mt_total); n = 0; }
+    // Otherwise layer-major order: every layer starts from parity par0 and toggles T_max times (enc_h[par][l] is
+    // indexed by the parity at launch time, so all layers end on par0 ^ (T_max & 1)).
+    auto enqueue_cells = [&]() {
+        if (c->enc_wave && L > 1 && T_max > 1) {
+            EncCellRef cells[NPMAX];
+            for (int d = 0; d < L + T_max - 1; ++d) {
+                int n = 0;
+                for (int l = std::min(d, L - 1); l >= 0 && d - l < T_max; --l) {
+                    cells[n++] = EncCellRef{l, d - l};
+                    if (n == NPMAX) { launch_enc_wave(c, cells, n, par0, mt_total); n = 0; }
+                }
+                if (n) launch_enc_wave(c, cells, n, par0, mt_total);
             }
-            if (n) launch_enc_wave(c, cells, n, par0, mt_total);
+        } else {
+            for (int l = 0; l < L; ++l) {
+                c->enc_par = par0;
+                const void* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
+                void* ydst = c->ybuf[l & 1];
+                for (int t = 0; t < T_max; ++t) {
+                    launch_enc_cell(c, l, t, xsrc, mt_total, ydst, mt_total);
+                    c->enc_par ^= 1;
+                }
+            }
         }
         c->enc_par = par0 ^ (T_max & 1);
-    } else
-    // layer-major order: every layer starts from parity par0 and toggles T_max times (enc_h[par][l] is
-    // indexed by the parity at launch time, so all layers end on par0 ^ (T_max & 1))
-    for (int l = 0; l < L; ++l) {
-        c->enc_par = par0;
-        const void* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
-        void* ydst = c->ybuf[l & 1];
-        for (int t = 0; t < T_max; ++t) {
-            launch_enc_cell(c, l, t, xsrc, mt_total, ydst, mt_total);
-            c->enc_par ^= 1;
+    };
+    // Pipelined protocol: the cell sequence of a model step (launches whose arguments only depend on which m-tiles are active
+    // and on the ping-pong parity) is replayed as ONE hipGraph on the caller's stream: 8 (bf16 wavefront: 5) launches -> 1 per
+    // model step on the host.  The graph is recorded by capturing on an internal stream (the caller's may be the legacy NULL
+    // stream, which cannot capture) and launched on the caller's.  Not with the in-kernel timers (a per-launch slot pointer) or
+    // the debug stamps.
+    bool replayed = false;
+    if (c->main_graph && c->use_graphs && c->pe == c->pe_ring && !(c->cell_prof && c->cp_slots) && !c->dbg && T_max <= 8) {
+        std::vector<unsigned long long> key{(unsigned long long)T_max, (unsigned long long)par0, (unsigned long long)(uintptr_t)c->T_row_dev,
+                                            (unsigned long long)(uintptr_t)c->x0, (unsigned long long)mt_total, (unsigned long long)c->enc_wave};
+        for (int t = 0; t < T_max; ++t) key.push_back(c->tile_masks.empty() ? ~0ull : c->tile_masks[t]);
+        auto it = c->mgraphs.find(key);
+        bool ok = true;
+        if (it == c->mgraphs.end()) {
+            if (!c->stream_cap && hipStreamCreateWithFlags(&c->stream_cap, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+            hipGraph_t gr = nullptr;
+            hipGraphExec_t ex = nullptr;
+            hipStream_t keep = c->stream;
+            if (ok && hipStreamBeginCapture(c->stream_cap, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                c->stream = c->stream_cap;
+                enqueue_cells();
+                c->stream = keep;
+                c->enc_par = par0;
+                if (hipStreamEndCapture(c->stream_cap, &gr) != hipSuccess || !gr) ok = false;
+                if (ok && hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) != hipSuccess) ok = false;
+                if (gr) (void)hipGraphDestroy(gr);
+            } else ok = false;
+            if (!ok) { (void)hipGetLastError(); c->main_graph = false; }      // (fall back to plain launches for good)
+            else it = c->mgraphs.emplace(key, ex).first;
+        }
+        if (ok && hipGraphLaunch(it->second, c->stream) == hipSuccess) {
+            c->enc_par = par0 ^ (T_max & 1);
+            replayed = true;
         }
     }
+    if (!replayed) enqueue_cells();
     if (cp_slot >= 0) { (void)hipEventRecord(c->cp_ev[cp_slot][1], c->stream); c->cp_n++; }
     tr_mark(c, 4, c->stream);
     // encoder half of the joint for all frames: pe[t][r] = W1e * enc[t][r]

@@ -97,6 +97,8 @@ void lasr_destroy(lasr_ctx* c) {
             for (auto& e : p) (void)hipEventDestroy(e);
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : c->mgraphs) (void)hipGraphExecDestroy(kv.second);
+    if (c->stream_cap) (void)hipStreamDestroy(c->stream_cap);
     if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
     if (c->stream_main_own) { (void)hipStreamSynchronize(c->stream_main_own); (void)hipStreamDestroy(c->stream_main_own); }
     delete c;
@@ -290,6 +292,12 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     HIPCHK(c, hipMemset(c->zero_rows, 0, sizeof(int) * M));
     RC(dalloc(c, &c->T_row_fix, M));
     HIPCHK(c, hipMemset(c->T_row_fix, 0, sizeof(int) * M));
+    RC(dalloc(c, &c->T_row_main, M));
+    HIPCHK(c, hipMemset(c->T_row_main, 0, sizeof(int) * M));
+    // measured (profiles/r03/r03_experiments.txt I): host time per model step 66 -> 45 us, but the replay starts its first cell ~6 us
+    // later than a plain launch does: f32 -2 % (52.8 against 54.0 k audio-s/s), bf16 +0.5 %  =>  on for bf16, off for f32
+    c->main_graph = c->bf != 0;
+    if (getenv("LASR_MAIN_GRAPH")) c->main_graph = atoi(getenv("LASR_MAIN_GRAPH")) != 0;
     c->T_row_dev = c->zero_rows;
     for (int q = 0; q < lasr_ctx::NFLY; ++q) {
         RC(dalloc(c, &c->T_row_ring[q], M));
@@ -773,7 +781,8 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             m.n_mels = d.n_mels; m.hop = d.hop; m.fb_nnz = c->fb_nnz; m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win;
             m.pcm = c->win; m.ring_pos = c->ring_pos; m.chunk = d.chunk; m.n_window = d.n_window; m.ring_chunks = c->ring_chunks; m.frame0 = a0;
             m.pend = c->pend; m.pend_frames = d.n_buffer * d.n_stack;
-            m.trow_out = c->dc.T_row; m.enc_frames = f.enc_frames; m.enc_base = f.enc_base;
+            int* trow_home = (c->pe == c->pe_ring) ? c->T_row_main : nullptr;      // pipelined: one fixed buffer (see commit_T_rows)
+            m.trow_out = trow_home ? trow_home : c->dc.T_row; m.enc_frames = f.enc_frames; m.enc_base = f.enc_base;
             m.src = fused ? fused->src : nullptr;
             for (int r = 0; r < 512; ++r) { m.idx[r] = -1; m.tp_pk[r] = 0; m.age_pk[r] = 0; }
             for (int r = 0; r < c->M; ++r) m.tp_pk[r] = (unsigned char)(c->h_ring_pos[r] << 4);
@@ -788,7 +797,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             hipStream_t fe_st = c->stream;
             hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * d.n_buffer, c->M), dim3(320), 0, fe_st, m);
             if (fused_done) *fused_done = fused != nullptr;
-            RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring));    // the continuous loop reads its own frame counters
+            RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring, trow_home));    // the continuous loop reads its own frame counters
             StackLnArgs a{};
             a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
             a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
@@ -1899,14 +1908,15 @@ int lasr_cell_prof(lasr_ctx* c, int on) {
     HIPCHK(c, hipSetDevice(c->device));
     // on = 1: HIP-event pairs + in-kernel clocks; on = 2: in-kernel clocks only (an event record between two kernels
     // costs the stream a bubble of several microseconds: twice per model step in mode 1)
-    c->cell_prof_events = on == 1;
-    if (on == 1 && !c->cp_ok) {
+    c->cell_prof_events = on == 1 || on == 3;
+    if ((on == 1 || on == 3) && !c->cp_ok) {
         for (auto& p : c->cp_ev)
             for (auto& e : p) HIPCHK(c, hipEventCreate(&e));
         c->cp_ok = true;
     }
     if (on) { cell_prof_harvest(c, true); c->cp_us = 0.0; c->cp_launches = 0; }
-    if (on) {
+    if (on == 3) { dfree(c, c->cp_slots); c->cp_slots = nullptr; c->cp_slot_next = 0; }      // events only: the cells stay graph-replayable
+    if (on && on != 3) {
         const size_t half = (size_t)PROF_W * lasr_ctx::NCELLSLOT;
         if (!c->cp_slots) {
             RC(dalloc(c, &c->cp_slots, 2 * half));

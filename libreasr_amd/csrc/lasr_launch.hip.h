@@ -338,8 +338,10 @@ int cmd_commit(lasr_ctx* c) {
 
 // device copy of the step's T_row (from the committed command block) + host-side per-step masks of
 // the m-tiles that contain an active row (passed by value to the encoder cell kernels)
-int commit_T_rows(lasr_ctx* c, int T_max, bool fixed_copy = true) {
-    c->T_row_dev = c->dc.T_row;             // the command ring (NCMD blocks) outlives every step in flight
+int commit_T_rows(lasr_ctx* c, int T_max, bool fixed_copy = true, int* fixed_home = nullptr) {
+    // (fixed_home: the front-end launch wrote the counts there itself -- the pipelined protocol keeps ONE buffer on the main
+    //  stream, so the cell launches of every step have the same arguments and can be replayed as a graph)
+    c->T_row_dev = fixed_home ? fixed_home : c->dc.T_row;             // the command ring (NCMD blocks) outlives every step in flight
     // decode kernels of the synchronous protocols read a FIXED buffer (cached graphs replay baked-in pointers)
     if (fixed_copy) {
         HIPCHK(c, hipMemcpyAsync(c->T_row_fix, c->T_row_dev, sizeof(int) * c->M, hipMemcpyDeviceToDevice, c->stream));
@@ -363,6 +365,8 @@ int ensure_T(lasr_ctx* c, int T) {
     c->graphs.clear();
     for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
     c->cgraphs.clear();
+    for (auto& kv : c->mgraphs) (void)hipGraphExecDestroy(kv.second);
+    c->mgraphs.clear();
     const int M = c->M, H = c->d.hidden, F = c->d.feat, J = c->d.joint;
     int cap = std::max(T, std::max(2 * c->Tcap, c->d.n_buffer));
     dfree(c, c->x0); dfree(c, c->ybuf[0]); dfree(c, c->ybuf[1]); dfree(c, c->pe_sync);
