@@ -233,8 +233,8 @@ def main():
                     help="chunks per stream of the best-effort CPU leg (all host cores, encoder batched over the streams)")
     ap.add_argument("--beam", type=int, default=1, help="beam width (1 = greedy, the headline config)")
     ap.add_argument("--depth", type=int, default=None,
-                    help="pipelined mode: model steps in flight before the oldest is collected (1..15); default 12 greedy, 6 beam "
-                         "(a selection round is ~10x a greedy iteration: 6 steps keep the p50 push->tokens latency under 5 ms)")
+                    help="pipelined mode: model steps in flight before the oldest is collected (1..15); default 12 greedy, beam 6 (<= 64 "
+                         "streams) / 3 (more): what keeps the p50 push->tokens latency under 5 ms")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
     ap.add_argument("--prof-steps", type=int, default=8,
@@ -253,8 +253,8 @@ def main():
                     help="CPU-only: exercise sharding + aggregation over gloo (no GPU work)")
     args = ap.parse_args()
 
-    if args.depth is None:
-        args.depth = 12 if args.beam == 1 else 6
+    if args.depth is None:       # beam: a model step of selection rounds is long; the depth that keeps p50 push->tokens under 5 ms
+        args.depth = 12 if args.beam == 1 else (6 if args.streams <= 64 else 3)
     rank, world, local = dist_env()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))

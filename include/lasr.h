@@ -239,8 +239,10 @@ int lasr_resample(lasr_ctx* c, const float* pcm, int B, int64_t N_in, int sr_in,
  * non-blank decision the token is re-picked as argmax(alpha * standardize(LM log-probs) + theta *
  * standardize(joint log-softmax)) with entry 0 forced to min_val on both sides; the LM is stepped on every
  * emitted token.  The blank / non-blank decision and the accumulated log p are those of the joint alone.
- * fp32 (or the ctx's bf16 operand mode); the reference additionally int8-quantises the LM dynamically
- * (lm.py:97) -- not reproduced.  Greedy only (beam = 1).  lasr_stream_reset bit 4 resets the LM state
+ * fp32 (or the ctx's bf16 operand mode); the int8-served form of the reference (lm.py:97) is lasr_attach_lm_int8 (greedy only).
+ * With beam > 1 (no reference: spec = oracle _beam_frame with an LM) every hypothesis slot carries its own LM state; a hypothesis
+ * offers its blank extension and its BEST non-blank extension per round, and the token a selected non-blank extension emits is the
+ * fuser's re-pick -- beam = 1 is then exactly the reference's greedy loop with fusion.  lasr_stream_reset bit 4 resets the LM state
  * (reset_lm, models.py:491-492); lasr_transcribe_* start every utterance with a fresh LM state.
  * Weight blob (float32): embed.weight [V,E]; per layer l: rnn.weight_ih_l{l} [4H,I], rnn.weight_hh_l{l}
  * [4H,H], rnn.bias_ih_l{l} [4H], rnn.bias_hh_l{l} [4H] (torch gate order i,f,g,o); linear.weight [V,H]

@@ -118,6 +118,7 @@ struct lasr_ctx {
     int* c_hcur_dev = nullptr;      // device view of the pinned per-row frame cursors (cont_host + 16)
     int *c_ntok_end = nullptr, *c_tok_ring = nullptr, *c_behind = nullptr, *c_enc_frames = nullptr, *c_enc_base = nullptr;
     int *c_done = nullptr, *c_flag_dev = nullptr;   // workgroups finished per iteration; device view of cont_host[0]
+    int* c_done2 = nullptr;                         // second arrival ring (k_beam_fuse publishes the round when an LM is attached)
     int* c_iter = nullptr;                          // device-side iteration counter of the continuous loop
     std::map<std::tuple<int, int, int>, hipGraphExec_t> cgraphs;   // (iterations, predictor parity, LM parity) -> group
     int* cont_host = nullptr;       // pinned: [0] flag, [16..16+M) per-row frame cursors, then (after NFLY*M ints) ntok_end + token ring
@@ -155,6 +156,8 @@ struct lasr_ctx {
         int par = 0;
         float *raw = nullptr, *lmz = nullptr;          // [M][V] output-layer logits / standardised log-probs
         int* valid = nullptr;
+        // beam search (rows = hypothesis slots, Md of them): c, y, lmz and valid ping-pong like h (a slot may continue any parent)
+        std::vector<void*> y1; std::vector<float*> cst1; float* lmz1 = nullptr; int* valid1 = nullptr;
         // int8-served form (lasr_attach_lm_int8): integer-valued bf16 weights (row-major tiles of 16 outputs, K padded to 32),
         // per-tensor weight scales, separate biases; fp32 state (h[0][l] == h[1][l] row-major [M][H], cst[l] as [H][M])
         bool q8 = false;

@@ -27,8 +27,11 @@ int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3, bool plain_rows = fals
     hipLaunchKernelGGL(k_reset_rows, dim3(grid1((size_t)c->M * c->d.hidden)), dim3(256), 0, c->stream, a);
     if (c->lm.on && (mask & 2)) {      // LM state lives on the decode side, like the predictor's
         LmResetArgs la{};
-        la.what = c->dc.what; la.M = c->M; la.H = c->lm.H; la.L = c->lm.L; la.bf = c->lm.q8 ? 0 : c->bf; la.lm_valid = c->lm.valid;
-        for (int l = 0; l < c->lm.L; ++l) { la.h[l] = c->lm.h[c->lm.par][l]; la.c[l] = c->lm.cst[l]; }
+        const bool lb = c->W > 1 && !plain_rows;         // beam: W slots per stream, current parity of every ping-pong buffer
+        la.what = c->dc.what; la.M = c->M; la.H = c->lm.H; la.L = c->lm.L; la.bf = c->lm.q8 ? 0 : c->bf;
+        la.W = lb ? c->W : 1; la.Md = lb ? c->Md : c->M;
+        la.lm_valid = (lb && c->lm.par) ? c->lm.valid1 : c->lm.valid;
+        for (int l = 0; l < c->lm.L; ++l) { la.h[l] = c->lm.h[c->lm.par][l]; la.c[l] = (lb && c->lm.par) ? c->lm.cst1[l] : c->lm.cst[l]; }
         hipLaunchKernelGGL(k_lm_reset, dim3(grid1((size_t)c->M * c->lm.H)), dim3(256), 0, c->stream, la);
     }
     if (any_pred) {
@@ -315,11 +318,10 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
         const int n = std::min(group, total_cap - iter);
         for (int q = 0; q < n; ++q) {
             launch_logits(c, c->logits, Md, true);
-            if (W <= 2) hipLaunchKernelGGL((k_beam_select<2>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter + q);
-            else if (W <= 4) hipLaunchKernelGGL((k_beam_select<4>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter + q);
-            else hipLaunchKernelGGL((k_beam_select<8>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter + q);
+            launch_beam_select(c, b, iter + q);
             launch_predictor(c, true);
             launch_ppj(c, true);
+            launch_lm(c, true);
         }
         iter += n;
         __atomic_store_n(&res[0], -1, __ATOMIC_RELEASE);

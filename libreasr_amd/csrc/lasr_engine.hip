@@ -346,6 +346,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         HIPCHK(c, hipMemset(p, 0, sizeof(int) * M));
     HIPCHK(c, hipMemset(c->c_behind, 0, sizeof(int) * 64));
     RC(dalloc(c, &c->c_done, 64)); HIPCHK(c, hipMemset(c->c_done, 0, sizeof(int) * 64));
+    RC(dalloc(c, &c->c_done2, 64)); HIPCHK(c, hipMemset(c->c_done2, 0, sizeof(int) * 64));
     RC(dalloc(c, &c->c_iter, 4)); HIPCHK(c, hipMemset(c->c_iter, 0, sizeof(int) * 4));
     HIPCHK(c, hipHostMalloc((void**)&c->cont_host, sizeof(int) * (16 + (size_t)M * (lasr_ctx::NFLY + lasr_ctx::ENDSLOTS + lasr_ctx::TOKRING))));
     memset(c->cont_host, 0, sizeof(int) * (16 + (size_t)M * (lasr_ctx::NFLY + lasr_ctx::ENDSLOTS + lasr_ctx::TOKRING)));
@@ -1091,11 +1092,10 @@ static int cont_launch_group(lasr_ctx* c, int G) {
             if (c->W > 1) {                 // one selection round: logits of every hypothesis slot -> ordered top-W -> predictor / joint
                 bs.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
                 launch_logits(c, c->logits, c->Md, true);
-                if (c->W <= 2) hipLaunchKernelGGL((k_beam_select<2>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, bs, 0);
-                else if (c->W <= 4) hipLaunchKernelGGL((k_beam_select<4>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, bs, 0);
-                else hipLaunchKernelGGL((k_beam_select<8>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, bs, 0);
+                launch_beam_select(c, bs, 0);
                 launch_predictor(c, true);
                 launch_ppj(c, true);
+                launch_lm(c, true);
                 continue;
             }
             s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
@@ -1725,7 +1725,6 @@ size_t lasr_lm_weight_count(const lasr_lm_desc* d) {
 int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, size_t n_weights) {
     if (!c) return LASR_EINVAL;
     if (c->lm.on) return fail(c, LASR_ESTATE, "an LM is already attached");
-    if (c->W > 1) return fail(c, LASR_ESTATE, "LM shallow fusion is implemented for greedy decoding (beam = 1)");
     if (!d || !weights || n_weights != lasr_lm_weight_count(d) || n_weights == 0)
         return fail(c, LASR_EINVAL, "LM weight blob has %zu floats, expected %zu", n_weights, d ? lasr_lm_weight_count(d) : (size_t)0);
     if (d->vocab != c->d.vocab) return fail(c, LASR_EINVAL, "LM vocabulary %d != model vocabulary %d", d->vocab, c->d.vocab);
@@ -1735,7 +1734,8 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     lasr_ctx::LM& m = c->lm;
-    const int V = d->vocab, E = d->embed, H = d->hidden, L = d->layers, M = c->M;
+    const int V = d->vocab, E = d->embed, H = d->hidden, L = d->layers;
+    const int M = c->Md;                               // LM rows: streams, or hypothesis slots with beam > 1 (Md = M x W)
     m.E = E; m.H = H; m.L = L; m.alpha = d->alpha; m.theta = d->theta; m.min_val = d->min_val;
     Reader rd{weights, n_weights};
     const float* embed = rd.take((size_t)V * E);
@@ -1777,6 +1777,15 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
     }
     RC(dalloc(c, &m.raw, (size_t)M * V)); RC(dalloc(c, &m.lmz, (size_t)M * V)); RC(dalloc(c, &m.valid, M));
     HIPCHK(c, hipMemset(m.lmz, 0, sizeof(float) * (size_t)M * V)); HIPCHK(c, hipMemset(m.valid, 0, sizeof(int) * M));
+    if (c->W > 1) {                                    // second parity of everything a re-parented slot inherits
+        m.y1.assign(L, nullptr); m.cst1.assign(L, nullptr);
+        for (int l = 0; l < L; ++l) {
+            RC(dalloc(c, (char**)&m.y1[l], (size_t)M * H * c->esz)); HIPCHK(c, hipMemset(m.y1[l], 0, (size_t)M * H * c->esz));
+            RC(dalloc(c, &m.cst1[l], (size_t)M * H)); HIPCHK(c, hipMemset(m.cst1[l], 0, sizeof(float) * (size_t)M * H));
+        }
+        RC(dalloc(c, &m.lmz1, (size_t)M * V)); RC(dalloc(c, &m.valid1, M));
+        HIPCHK(c, hipMemset(m.lmz1, 0, sizeof(float) * (size_t)M * V)); HIPCHK(c, hipMemset(m.valid1, 0, sizeof(int) * M));
+    }
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);   // decode groups change shape
     c->graphs.clear();
     for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);

@@ -539,11 +539,24 @@ inline void launch_select(hipStream_t st, int rows, const float* logits, int V, 
 
 // LMFuser.advance (lm.py:49-53) for the rows that just emitted a token: log_softmax of the LM's output
 // layer, standardise (utils.py:162-164), entry 0 = MIN_VAL.  One workgroup per row, V <= 4096.
+// Beam search (W > 1): rows are hypothesis slots; a slot that was not extended takes the LM output of its PARENT slot from
+// the other parity (lmz_in / valid_in), like the predictor state.
 __global__ __launch_bounds__(256) void k_lm_post(const float* __restrict__ raw, const int* __restrict__ emit,
-                                                 float* __restrict__ lmz, int* __restrict__ lm_valid, int V, float min_val) {
+                                                 float* __restrict__ lmz, int* __restrict__ lm_valid, int V, float min_val,
+                                                 const int* __restrict__ parent, int W, const float* __restrict__ lmz_in,
+                                                 const int* __restrict__ valid_in) {
     constexpr int KEEP = 16;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (!emit[r]) return;
+    if (!emit[r]) {
+        if (W > 1) {
+            const int pr = (r / W) * W + parent[r];
+            const float* src = lmz_in + (size_t)pr * V;
+            float* dst = lmz + (size_t)r * V;
+            for (int j = tid; j < V; j += 256) dst[j] = src[j];
+            if (tid == 0) lm_valid[r] = valid_in[pr];
+        }
+        return;
+    }
     __shared__ float sh4[4];
     const float* z = raw + (size_t)r * V;
     float zv[KEEP];
@@ -600,8 +613,9 @@ __global__ __launch_bounds__(256) void k_lm_post(const float* __restrict__ raw, 
 struct LmResetArgs {
     const int* what;
     int M, H, L, bf;
-    void* h[8];          // current parity, row-major [M][H]
-    float* c[8];         // [H][M]
+    int W, Md;           // beam search: W hypothesis slots per stream (rows r W .. r W + W - 1 of Md)
+    void* h[8];          // current parity, row-major [Md][H]
+    float* c[8];         // [H][Md]
     int* lm_valid;
 };
 __global__ void k_lm_reset(const LmResetArgs a) {
@@ -609,10 +623,13 @@ __global__ void k_lm_reset(const LmResetArgs a) {
     if (idx >= a.M * a.H) return;
     const int r = idx / a.H, u = idx - r * a.H;
     if (!(a.what[r] & 4)) return;
-    if (u == 0) a.lm_valid[r] = 0;
-    for (int l = 0; l < a.L; ++l) {
-        act_st(a.bf, a.h[l], (size_t)r * a.H + u, 0.f);
-        a.c[l][(size_t)u * a.M + r] = 0.f;
+    for (int b = 0; b < a.W; ++b) {
+        const int rp = r * a.W + b;
+        if (u == 0) a.lm_valid[rp] = 0;
+        for (int l = 0; l < a.L; ++l) {
+            act_st(a.bf, a.h[l], (size_t)rp * a.H + u, 0.f);
+            a.c[l][(size_t)u * a.Md + rp] = 0.f;
+        }
     }
 }
 
@@ -712,6 +729,11 @@ struct BeamState {
     int step_T, end_slots;
     double* end_score;   // [M][end_slots][W] pinned
     int* end_alive;      // [M][end_slots] pinned (bit j = slot j alive)
+    // LM shallow fusion inside the beam (spec: oracle _beam_frame with an LM): a hypothesis offers its blank extension and its
+    // BEST non-blank extension only; the emitted token of a selected non-blank extension is re-picked by k_beam_fuse, which then
+    // also owns the host publication of the round (lm_on: k_beam_select does not publish to the host)
+    int lm_on;
+    int* done2;          // [64] second arrival counter (k_beam_fuse)
 };
 
 // WT: compile-time bound of W (2, 4, 8).  One workgroup of 1024 threads per stream: its W x V logits
@@ -743,9 +765,9 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
     }
     auto publish = [&]() {           // thread 0 of every workgroup, after its last store of this launch (continuous mode)
         if (!s.cont) return;
-        if (s.host_flag) __threadfence_system();     // this stream's records (pinned memory) before the count
+        if (s.host_flag && !s.lm_on) __threadfence_system();     // this stream's records (pinned memory) before the count
         if (atomicAdd(&s.done_blocks[uslot], 1) == (int)gridDim.x - 1) {      // last workgroup of the launch
-            if (s.host_flag) {
+            if (s.host_flag && !s.lm_on) {
                 const int v = atomicAdd(&s.unfinished[uslot], 0);
                 __hip_atomic_store(s.host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -834,6 +856,39 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < WT; ++b) lg[b] = bc[1][b];
+    int nb_arg[WT];
+#pragma unroll
+    for (int b = 0; b < WT; ++b) nb_arg[b] = -1;
+    if (s.lm_on) {                                   // per row: argmax of z over the non-blank tokens (first maximum)
+        __shared__ float nbv[NWV][WT];
+        __shared__ int nba[NWV][WT];
+        __shared__ int nbr[WT];
+#pragma unroll
+        for (int b = 0; b < WT; ++b) {
+            float x = -INFINITY;
+            int a = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const int v = tid + NT * k;
+                if (v != s.blank && v < V && zv[b][k] > x) { x = zv[b][k]; a = v; }
+            }
+            wave_argmax_f32(x, a);
+            if (lane == 0) { nbv[w][b] = x; nba[w][b] = a; }
+        }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int b = 0; b < WT; ++b) {
+                float x = lane < NWV ? nbv[lane][b] : -INFINITY;
+                int a = lane < NWV ? nba[lane][b] : 0x7fffffff;
+                wave_argmax_f32(x, a);
+                if (lane == 0) nbr[b] = a;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < WT; ++b) nb_arg[b] = nbr[b];
+    }
     if (dbg) s.dbg[2] = wall_clock64();
     // ---- the ordered top-W of all candidates, in two wave-level stages (no block-wide reduction per winner):
     //   (1) every wave finds the ordered top-W of ITS candidates: pass j admits only candidates strictly after the wave's winner
@@ -866,6 +921,13 @@ __global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ 
             }
 #pragma unroll
             for (int k = 0; k < KEEP; ++k) zv[b][k] = (zv[b][k] - m[b]) - lg[b];      // log p (padding stays -inf)
+            if (s.lm_on) {                           // LM fusion: only the blank and the row's best non-blank token are candidates
+#pragma unroll
+                for (int k = 0; k < KEEP; ++k) {
+                    const int v = tid + NT * k;
+                    if (v != s.blank && v != nb_arg[b]) zv[b][k] = -INFINITY;
+                }
+            }
             int k0 = 0, k1 = 1, k2 = 2, k3 = 3;
             auto cx = [&](float& a, int& ka, float& c, int& kc) {                       // a before c unless c is strictly better
                 if (c > a || (c == a && kc < ka)) { const float t = a; a = c; c = t; const int tk = ka; ka = kc; kc = tk; }
@@ -1000,6 +1062,102 @@ __global__ void k_beam_begin(BeamState s, int M, int n_iter_slots) {
     if (i < M) { s.t_idx[i] = 0; s.iters[i] = 0; }
     if (i < s.Md) { s.emit[i] = 0; s.parent[i] = i % s.W; s.inB[i] = 0; }
     if (i < n_iter_slots) s.unfinished[i] = 0;
+}
+
+// LM shallow fusion inside the beam (spec: oracle _beam_frame with an LM attached): the token of every slot that was extended
+// by its parent's best non-blank token in this round is re-picked as LMFuser.fuse does (lm.py:59-79) from the PARENT's joint
+// log-softmax and LM output; the round's record is patched accordingly.  One workgroup per hypothesis slot.  In continuous mode
+// this launch, not k_beam_select, publishes the round to the host (the records are final only now).
+__global__ __launch_bounds__(256) void k_beam_fuse(const float* __restrict__ logits, BeamState s, int iter_slot,
+                                                   const float* __restrict__ lmz, const int* __restrict__ lm_valid, float alpha,
+                                                   float theta, float lm_min) {
+    constexpr int KEEP = 16;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int W = s.W, V = s.V, q = r / W;
+    const int iter_no = s.cont ? (int)((*(const unsigned*)s.iter_ctr - 1u) & 0x3fffffffu) : iter_slot;   // k_beam_select has moved on by one
+    const int uslot = s.cont ? (iter_no & 63) : iter_slot;
+    if (s.cont && r == 0 && tid == 0) s.done2[(uslot + 32) & 63] = 0;
+    const int par = s.parent[r], prow = q * W + par;
+    if (s.emit[r] && lm_valid[prow]) {               // uniform over the workgroup
+        __shared__ float sh4[4];
+        __shared__ float sv[4];
+        __shared__ int si[4];
+        const float* z = logits + (size_t)prow * V;
+        float zv[KEEP];
+        float best = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int j = tid + 256 * k;
+            zv[k] = j < V ? z[j] : -INFINITY;
+            best = fmaxf(best, zv[k]);
+        }
+        best = wave_max_f32(best);
+        if (lane == 0) sh4[w] = best;
+        __syncthreads();
+        best = fmaxf(fmaxf(sh4[0], sh4[1]), fmaxf(sh4[2], sh4[3]));
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) part += expf(zv[k] - best);
+        part = wave_sum_f32(part);
+        __syncthreads();
+        if (lane == 0) sh4[w] = part;
+        __syncthreads();
+        const float lse = logf(sh4[0] + sh4[1] + sh4[2] + sh4[3]);     // (same sums as k_select's: the joint log-softmax the greedy fuser sees)
+        part = 0.f;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int j = tid + 256 * k;
+            zv[k] = j < V ? (zv[k] - best) - lse : 0.f;
+            part += zv[k];
+        }
+        const float mean = block_sum_256(part, sh4, lane, w) / (float)V;
+        part = 0.f;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int j = tid + 256 * k;
+            zv[k] = j < V ? zv[k] - mean : 0.f;                      // t.add_(-t.mean())
+            part += zv[k];
+        }
+        const float mean2 = block_sum_256(part, sh4, lane, w) / (float)V;   // torch.std subtracts its own mean again
+        part = 0.f;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int j = tid + 256 * k;
+            const float d = j < V ? zv[k] - mean2 : 0.f;
+            part += d * d;
+        }
+        const float den = sqrtf(block_sum_256(part, sh4, lane, w) / (float)(V - 1)) + 1e-5f;
+        const float* lz = lmz + (size_t)prow * V;
+        float fb = -INFINITY;
+        int fa = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int j = tid + 256 * k;
+            if (j >= V) continue;
+            const float jo = j == 0 ? lm_min : zv[k] / den;
+            const float f = __fadd_rn(__fmul_rn(alpha, lz[j]), __fmul_rn(theta, jo));   // no FMA contraction
+            if (f > fb) { fb = f; fa = j; }
+        }
+        wave_argmax_f32(fb, fa);
+        __syncthreads();
+        if (lane == 0) { sv[w] = fb; si[w] = fa; }
+        __syncthreads();
+        fb = sv[0]; fa = si[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (sv[k] > fb || (sv[k] == fb && si[k] < fa)) { fb = sv[k]; fa = si[k]; }
+        if (tid == 0) {
+            s.token[r] = fa;
+            s.trellis[(size_t)(s.cont ? iter_no % s.tring : iter_slot) * s.Md + r] = (par << 16) | (fa + 1);
+        }
+    }
+    if (tid == 0 && s.cont) {
+        if (s.host_flag) __threadfence_system();
+        if (atomicAdd(&s.done2[uslot], 1) == (int)gridDim.x - 1 && s.host_flag) {
+            const int v = atomicAdd(&s.unfinished[uslot], 0);
+            __hip_atomic_store(s.host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -199,34 +199,45 @@ void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, c
 // LMFuser.advance (lm.py:49-53) for the rows with emit != 0: LM step on the token just emitted, then
 // log_softmax + standardise + [0] = MIN_VAL into lmz (read by the next k_select of that row)
 template <class Ops>
-void launch_lm_t(lasr_ctx* c) {
+void launch_lm_t(lasr_ctx* c, bool beam) {
     lasr_ctx::LM& m = c->lm;
-    const int H = m.H, M = c->M, V = c->d.vocab, p = m.par;
+    const int H = m.H, V = c->d.vocab, p = m.par;
+    const int R = beam ? c->Md : c->M;                   // LM rows: streams, or hypothesis slots (beam: parity p -> p ^ 1, parent-indirected)
     for (int l = 0; l < m.L; ++l) {
         const Cell& L = m.cells[l];
         GemmArgs g{};
-        if (l > 0) { g.A[0] = m.y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA; }
+        void* y_out = (beam && !p) ? m.y1[l] : m.y[l];
+        const void* y_in = (beam && p) ? m.y1[l] : m.y[l];
+        if (l > 0) { g.A[0] = (beam && !p) ? m.y1[l - 1] : m.y[l - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / Ops::KCH; g.W[0] = L.WxA; }
         g.A[1] = m.h[p][l]; g.a_mt_total[1] = H; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhA;
-        g.compact = c->ds.emit; g.M = M;
+        if (beam) { g.parent = c->b_parent; g.beam_w = c->W; }
+        g.compact = c->ds.emit; g.M = R;
         typename EpiLSTM<Ops, true, true, 4>::Args ea{};
         ea.bias = L.bias; ea.tab = L.tab; ea.token = c->ds.token; ea.flag = c->ds.emit; ea.t = 0;
-        ea.c = m.cst[l]; ea.h_in = m.h[p][l]; ea.h_out = m.h[p ^ 1][l]; ea.y = m.y[l];
-        ea.bn_s = m.ones; ea.bn_t = m.zeros; ea.H = H; ea.M = M; ea.MT = c->MT;
+        ea.c = (beam && !p) ? m.cst1[l] : m.cst[l]; ea.h_in = m.h[p][l]; ea.h_out = m.h[p ^ 1][l]; ea.y = y_out;
+        ea.bn_s = m.ones; ea.bn_t = m.zeros; ea.H = H; ea.M = R; ea.MT = R / 16;
+        if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.c_in = p ? m.cst1[l] : m.cst[l]; ea.y_in = y_in; }
         if (l == 0) {
-            launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, M / (16 * MTA), g, ea);
+            launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, R / (16 * MTA), g, ea);
         } else {
             typename EpiLSTM<Ops, true, false, 4>::Args eb{};
             memcpy(&eb, &ea, sizeof(eb));
-            launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, M / (16 * MTA), g, eb);
+            launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, R / (16 * MTA), g, eb);
         }
     }
-    m.par ^= 1;
     GemmArgs g{};
-    g.A[0] = m.y[m.L - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.W[0] = m.Wout; g.a_rows = M;
+    g.A[0] = (beam && !p) ? m.y1[m.L - 1] : m.y[m.L - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.W[0] = m.Wout; g.a_rows = R;
     EpiLinear::Args ea{};
-    ea.bias = m.bout; ea.out = m.raw; ea.ldo = V; ea.n_rows = M; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
-    launch_linear<true, -1>(c, V / 16, M / 16, g, H, ea);
-    hipLaunchKernelGGL(k_lm_post, dim3(M), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val);
+    ea.bias = m.bout; ea.out = m.raw; ea.ldo = V; ea.n_rows = R; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = R;
+    launch_linear<true, -1>(c, V / 16, R / 16, g, H, ea);
+    if (beam)
+        hipLaunchKernelGGL(k_lm_post, dim3(R), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, p ? m.lmz : m.lmz1,
+                           p ? m.valid : m.valid1, V, m.min_val, (const int*)c->b_parent, c->W, (const float*)(p ? m.lmz1 : m.lmz),
+                           (const int*)(p ? m.valid1 : m.valid));
+    else
+        hipLaunchKernelGGL(k_lm_post, dim3(R), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val,
+                           (const int*)nullptr, 1, (const float*)m.lmz, (const int*)m.valid);
+    m.par ^= 1;
 }
 // int8-served LM step (see k_lm_quant): per layer  quantise -> GEMV -> dequantise  for the x side (layers > 0) and the h side,
 // element-wise cell for the rows that emitted; then the output layer the same way and k_lm_post.  The GEMVs run for all M
@@ -252,13 +263,28 @@ void launch_lm_q8(lasr_ctx* c) {
     }
     m.par ^= 1;
     lm_q_gemv(c, (const float*)m.h[0][m.L - 1], H, H, m.Kp_h, m.qWout, m.s_out, m.bout, m.raw, V, M, m.qa, m.sx);
-    hipLaunchKernelGGL(k_lm_post, dim3(M), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val);
+    hipLaunchKernelGGL(k_lm_post, dim3(M), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val,
+                       (const int*)nullptr, 1, (const float*)m.lmz, (const int*)m.valid);
 }
-void launch_lm(lasr_ctx* c) {
+void launch_lm(lasr_ctx* c, bool beam = false) {
     if (!c->lm.on) return;
     if (c->lm.q8) { launch_lm_q8(c); return; }
-    if (c->bf) launch_lm_t<OpsBF16>(c);
-    else launch_lm_t<OpsF32>(c);
+    if (c->bf) launch_lm_t<OpsBF16>(c, beam);
+    else launch_lm_t<OpsF32>(c, beam);
+}
+// current-parity LM output of the hypothesis slots (beam): parity 0 = lmz / valid, parity 1 = lmz1 / valid1
+const float* cur_lmz(lasr_ctx* c) { return (c->W > 1 && c->lm.par) ? c->lm.lmz1 : c->lm.lmz; }
+const int* cur_lm_valid(lasr_ctx* c) { return (c->W > 1 && c->lm.par) ? c->lm.valid1 : c->lm.valid; }
+// the selection kernel of one beam round (+ the LM re-pick of the extended slots' tokens)
+void launch_beam_select(lasr_ctx* c, BeamState& b, int iter_slot) {
+    const int M = c->M;
+    b.lm_on = c->lm.on ? 1 : 0; b.done2 = c->c_done2;
+    if (c->W <= 2) hipLaunchKernelGGL((k_beam_select<2>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter_slot);
+    else if (c->W <= 4) hipLaunchKernelGGL((k_beam_select<4>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter_slot);
+    else hipLaunchKernelGGL((k_beam_select<8>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter_slot);
+    if (c->lm.on)
+        hipLaunchKernelGGL(k_beam_fuse, dim3(c->Md), dim3(256), 0, c->stream, (const float*)c->logits, b, iter_slot, cur_lmz(c), cur_lm_valid(c),
+                           c->lm.alpha, c->lm.theta, c->lm.min_val);
 }
 
 // plain linear over element-typed A (fragment-major, or row-major when AROW); f32 row-major output

@@ -63,7 +63,9 @@ def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_st
             lm_sd = _load_lm_sd(f"./tmp/{lang}/lm.pth")
         except Exception:
             print("[LM] Failed to load.")
-    if lm_sd is not None and beam == 1:
+    if lm_sd is not None:
+        if beam > 1:
+            lm_int8 = False                 # the beam takes the fp32 / bf16 LM (per-hypothesis LM state); int8 form: greedy only
         # lm_int8: as load_lm serves it (maybe_quantize, lm.py:97); False: fp32 / bf16 LM.  maybe_quantize swallows a failed
         # quantisation and serves the fp32 LM (utils.py:197-210): an LM shape the int8 path does not take does the same here
         from .._native import LASR_EINVAL, LasrError

@@ -496,40 +496,65 @@ class OracleTransducer:
         source slot asc, then "already in B" first, then v asc).  Blank extensions join B, non-blank
         ones are expanded again (predictor stepped) unless the round cap is reached -- exactly the
         greedy loop of models.py:405-443 when W == 1.  Scores are float64 sums of float32 log-probs
-        (every decision incl. blanks, as log_p at models.py:420-422); no length norm, no merging."""
+        (every decision incl. blanks, as log_p at models.py:420-422); no length norm, no merging.
+
+        With an LM attached (self.lm; builder-authored like the beam itself -- the reference fuses only in its greedy loop,
+        lm.py:56-83 / models.py:427-431, where the LM never changes WHETHER a token is emitted or its log p, only WHICH token):
+        a hypothesis offers TWO candidates per round, its blank extension and its best non-blank extension (score + log p of the
+        joint's best non-blank token, first maximum); when the latter is selected the emitted token is the fuser's re-pick
+        (LMFuser.fuse on that hypothesis' joint log-softmax and LM state) and the hypothesis' LM advances on it.  W = 1 is then
+        exactly the reference's greedy loop with shallow fusion."""
         A = [dict(h, inB=False) for h in hyps]
         for rnd in range(1, max_iters + 1):
             cands = []
             for b, h in enumerate(A):
                 if h["inB"]:
-                    cands.append((-h["score"], b, 0, -1, h))
+                    cands.append((-h["score"], b, 0, -1, h, None))
                     continue
                 lp, _ = self.joint_logp(h["h_pred"], enc_t[None])
                 lp = lp[0]
-                # only the W best tokens of a hyp can make the global top W
-                top = np.argsort(-lp, kind="stable")[:W]
+                if self.lm is not None:
+                    nb = lp.copy()
+                    nb[self.blank] = -np.inf
+                    top = [self.blank, int(nb.argmax())]
+                else:
+                    # only the W best tokens of a hyp can make the global top W
+                    top = np.argsort(-lp, kind="stable")[:W]
                 for v in top:
-                    cands.append((-(h["score"] + float(lp[v])), b, 1, int(v), h))
+                    cands.append((-(h["score"] + float(lp[v])), b, 1, int(v), h, lp))
             cands.sort(key=lambda c: c[:4])
             if margins is not None and len(cands) > W:      # score gap at the selection boundary (W-th vs next candidate)
                 margins.append(cands[W][0] - cands[W - 1][0])
             new = []
-            for negs, b, kind, v, h in cands[:W]:
+            for negs, b, kind, v, h, lp in cands[:W]:
                 if kind == 0:
                     new.append(h)
                 elif v == self.blank:
                     new.append(dict(h, score=-negs, inB=True))
                 else:
+                    fz = h.get("fuser")
+                    if fz is not None:
+                        v = fz.fuse(lp, v)                   # lm.py:59-79: the emitted token; the score keeps the joint's log p
+                        nf = LMFuser(self.lm)
+                        nf.lm_logits, nf.lm_state = fz.lm_logits, fz.lm_state
+                        nf.advance(v)                        # lm.py:49-53
                     hp, ps = self.predictor([v], h["pstate"])
-                    new.append(dict(score=-negs, y=h["y"] + [v], h_pred=hp, pstate=ps, inB=(rnd == max_iters)))
+                    nh = dict(score=-negs, y=h["y"] + [v], h_pred=hp, pstate=ps, inB=(rnd == max_iters))
+                    if fz is not None:
+                        nh["fuser"] = nf
+                    new.append(nh)
             A = new
             if all(h["inB"] for h in A):
                 break
-        return [{k: h[k] for k in ("score", "y", "h_pred", "pstate")} for h in A]
+        keys = ("score", "y", "h_pred", "pstate") + (("fuser",) if self.lm is not None else ())
+        return [{k: h[k] for k in keys} for h in A]
 
     def beam_init(self):
         h_pred, pstate = self.predictor([self.bos])
-        return [dict(score=0.0, y=[], h_pred=h_pred, pstate=pstate)]
+        h = dict(score=0.0, y=[], h_pred=h_pred, pstate=pstate)
+        if self.lm is not None:
+            h["fuser"] = LMFuser(self.lm)
+        return [h]
 
     def decode_beam(self, feats, W, max_iters=3):
         """Offline beam search over one utterance: returns (best tokens, best score, all hyps)."""

@@ -206,3 +206,71 @@ def test_beam_rejects_bad_width():
         Engine(sd, cfg, max_streams=8, beam=9)
     with pytest.raises(ValueError):
         Engine(sd, cfg, max_streams=512, beam=4)      # 512 x 4 decoder rows > 1024
+
+
+@pytest.mark.parametrize("name,lm_name,W", [("tiny", "tiny_lm", 2), ("tiny", "tiny_lm", 4), ("tiny_lstm", "tiny_lm_untied", 4)])
+def test_beam_with_lm_fusion_matches_the_oracle_on_every_protocol(name, lm_name, W):
+    """Round 3: LM shallow fusion inside the beam (spec: oracle _beam_frame with an LM -- a hypothesis offers its blank and its best
+    non-blank extension; the emitted token is the fuser's re-pick, lm.py:59-79; W = 1 is the reference's greedy + LM, checked on the
+    CPU in tests/test_oracle.py).  Offline, synchronous streaming and pipelined streaming against the oracle."""
+    import __graft_entry__ as graft
+    from libreasr_amd.engine import Engine
+    graft.build()
+    cfg = synth.model_cfg(name)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    lm_sd = synth.synth_lm_state_dict(lm_name)
+    eng = Engine(sd, cfg, max_streams=8, beam=W)
+    eng.attach_lm(lm_sd, int8=False)
+    try:
+        m = O.OracleTransducer(sd, cfg)
+        m.lm = O.OracleLM(lm_sd)
+        m0 = O.OracleTransducer(sd, cfg)                       # the same beam without an LM: the fusion must matter somewhere
+        n = 3
+        pcm = synth.synth_pcm(n, 16000 * 3, seed=1234)
+        slots = [eng.open() for _ in range(n)]
+        eng.transcribe_pcm(slots, [pcm[i] for i in range(n)])
+        differs = 0
+        for i, sl in enumerate(slots):
+            toks, neg_logp, _ = eng.fetch(sl)
+            f = O.features_offline(pcm[i])
+            y, score, _ = m.decode_beam(f, W)
+            assert toks == y, (i, toks, y)
+            assert abs(-neg_logp - score) < 2e-3 * max(1.0, abs(score))
+            differs += y != m0.decode_beam(f, W)[0]
+        for proto in ("sync", "pipelined"):
+            for sl in slots:
+                eng.reset(sl, 15)
+            fes = [O.StreamFrontend() for _ in range(n)]
+            decs = [O.StreamBeamDecoder(m, W) for _ in range(n)]
+            plain = [O.StreamBeamDecoder(m0, W) for _ in range(n)]
+            ref = [[] for _ in range(n)]
+            got = [[] for _ in range(n)]
+            chunks = [synth.stream_chunks(pcm[i], 1280, lead=1, tail=6) for i in range(n)]
+            for k in range(len(chunks[0])):
+                batch = np.stack([chunks[i][k] for i in range(n)])
+                for i in range(n):
+                    o = fes[i].push(chunks[i][k])
+                    if o is not None:
+                        ref[i].append(list(decs[i].step(o)[0]))
+                        plain[i].step(o)
+                if proto == "sync":
+                    eng.push(slots, batch)
+                    if eng.step(slots):
+                        for i in range(n):
+                            got[i].append(eng.fetch(slots[i])[0])
+                else:
+                    eng.push_submit(slots, batch)
+                    if eng.pending() >= 4 and eng.wait():
+                        for i in range(n):
+                            got[i].append(eng.fetch(slots[i])[0])
+            while eng.pending():
+                if eng.wait():
+                    for i in range(n):
+                        got[i].append(eng.fetch(slots[i])[0])
+            for i in range(n):
+                assert got[i] == ref[i], (proto, i)
+                differs += decs[i].best()[0] != plain[i].best()[0]
+        if lm_name == "tiny_lm":                            # (a peaked LM: it must have changed a hypothesis somewhere)
+            assert differs > 0, "the LM never changed a hypothesis: the test does not exercise the fusion"
+    finally:
+        eng.close()

@@ -152,7 +152,8 @@ def test_lm_attach_errors():
     eng.close()
     eng = Engine(sd, cfg, max_streams=4, beam=2)
     with pytest.raises(N.LasrError):
-        eng.attach_lm(synth.synth_lm_state_dict("tiny_lm"))   # greedy only
+        eng.attach_lm(synth.synth_lm_state_dict("tiny_lm"), int8=True)   # the int8-served form is greedy only
+    eng.attach_lm(synth.synth_lm_state_dict("tiny_lm"), int8=False)      # the beam takes the fp32 / bf16 LM (round 3)
     eng.close()
 
 

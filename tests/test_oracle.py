@@ -243,3 +243,29 @@ def test_torch_cpu_batched_encoder_leg_equals_the_batch_1_path(name):
     _, bat = TC.time_stream_path_batched(sd, cfg, rows, 36, threads=4)
     assert bat == one
     assert sum(len(t) for t in one) > 0
+
+
+@pytest.mark.parametrize("name,lm_name", [("tiny", "tiny_lm"), ("tiny_lstm", "tiny_lm_untied")])
+def test_beam_width_1_with_lm_is_the_greedy_loop_with_shallow_fusion(name, lm_name):
+    """The builder-authored spec of LM fusion inside the beam (oracle _beam_frame) reduces, at W = 1, to the reference's greedy loop
+    with shallow fusion (models.py:405-443 + lm.py:43-83), which the oracle pins to the reference's own goldens
+    (test_lm_shallow_fusion_matches_reference): tokens and scores, offline and streaming."""
+    cfg = synth.model_cfg(name)
+    m = O.OracleTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
+    m.lm = O.OracleLM(synth.synth_lm_state_dict(lm_name))
+    pcm = synth.synth_pcm(3, 16000 * 3, seed=1234)
+    n_tok = 0
+    for i in range(3):
+        f = O.features_offline(pcm[i])
+        g = m.decode_greedy(f)
+        y, score, _ = m.decode_beam(f, 1)
+        assert y == g[0] and abs(-g[1] - score) < 1e-4
+        fe, d1, dg = O.StreamFrontend(), O.StreamBeamDecoder(m, 1), m.stream_decoder()
+        for ch in synth.stream_chunks(pcm[i], 1280, lead=1, tail=4):
+            o = fe.push(ch)
+            if o is not None:
+                d1.step(o)
+                dg.step(o)
+        assert d1.best()[0] == dg.y
+        n_tok += len(dg.y)
+    assert n_tok > 10
