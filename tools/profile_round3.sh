@@ -13,7 +13,7 @@ $B --dtype bf16 --beam 4 --steps 10 --warmup 3 > $O/bench_bf16_beam4.json 2>/dev
 $B --dtype bf16 --beam 4 --steps 10 --warmup 3 --depth 12 > $O/bench_bf16_beam4_depth12.json 2>/dev/null
 $B --dtype bf16 --beam 4 --steps 10 --warmup 3 --no-pipeline > $O/bench_bf16_beam4_sync.json 2>/dev/null
 $B --model cfg5 --dtype bf16 --streams 128 --depth 6 > $O/bench_cfg5_bf16.json 2>/dev/null
-$B --model cfg5 --dtype bf16 --streams 128 --beam 8 --steps 8 --warmup 2 > $O/bench_cfg5_bf16_beam8.json 2>/dev/null
+$B --model cfg5 --dtype bf16 --streams 128 --beam 8 --steps 8 --warmup 2 --depth 6 > $O/bench_cfg5_bf16_beam8.json 2>/dev/null
 $B --model cfg5 --dtype bf16 --streams 128 --beam 8 --steps 8 --warmup 2 --depth 3 > $O/bench_cfg5_bf16_beam8_depth3.json 2>/dev/null
 $B --model cfg5 --dtype bf16 --streams 128 --beam 8 --steps 8 --warmup 2 --no-pipeline > $O/bench_cfg5_bf16_beam8_sync.json 2>/dev/null
 $B --no-pipeline > $O/bench_f32_sync.json 2>/dev/null
@@ -39,3 +39,16 @@ PY
 done
 cat $O/timeline_f32.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+# PMC passes on the isolated cell (one counter group per pass; gpurun refuses --pmc together with the hip / hsa trace domains)
+if [ -n "$LASR_PROFILE_PMC" ]; then
+  cd /tmp
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+    n=$(echo $grp | tr ' ' '_' | cut -c1-40)
+    LASR_BENCH_LAYERS=1 timeout 200 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc_f32_$n -o pmc -- python3 $R/tools/cellbench.py cfg2 30 > /dev/null 2>&1
+    LASR_DTYPE=bf16 LASR_BENCH_LAYERS=1 timeout 200 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc_bf16_$n -o pmc -- python3 $R/tools/cellbench.py cfg2 30 > /dev/null 2>&1
+  done
+  cd $R
+  for f in $O/pmc_*/pmc_results.db; do echo "== $f"; python3 tools/rocpd_pmc.py $f --filter EpiLSTM; done > $O/cell_pmc.txt 2>&1
+  rm -rf $O/pmc_*
+  cat $O/cell_pmc.txt
+fi
