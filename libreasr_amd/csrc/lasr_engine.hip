@@ -1038,6 +1038,7 @@ static int cont_launch_group(lasr_ctx* c, int G) {
     s.host_ntot = c->tr_on ? c->c_hcur_dev + M : nullptr;
     s.ntok_end = c->c_ntok_end; s.step_T = c->d.n_buffer; s.end_slots = lasr_ctx::ENDSLOTS; s.done_blocks = c->c_done;
     s.iter_ctr = c->c_iter;
+    s.dbg = c->dbg ? c->dbg + ((size_t)4 * 4096 + 4095) * 16 : nullptr;
     int* flag = c->cont_host;
     // admit encoded steps in order.  While rows still have frames to decode only steps whose encoder has finished are
     // admitted (the loop must not stall behind an encoder); when nothing is left the first one is admitted unconditionally:

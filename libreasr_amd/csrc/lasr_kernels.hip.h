@@ -204,6 +204,7 @@ struct DecState {
     const float* lmz;  // [M][V] (nullptr: no LM attached)
     const int* lm_valid; // [M] the LM has advanced at least once since the last LM reset
     float lm_alpha, lm_theta, lm_min;
+    unsigned long long* dbg;   // LASR_DBG_TIMING: phase stamps of k_select's workgroup 0 (wall clock, 10 ns ticks)
 };
 
 // block-wide sum over 256 threads (4 waves); every thread gets the result
@@ -325,6 +326,8 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
                                                 const int* __restrict__ T_row, DecState s, int iter_slot_in,
                                                 float* __restrict__ out_logp, int* __restrict__ out_arg, int la, int M) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool dbgt = !PLAIN && s.dbg && r == 0 && tid == 0;
+    const unsigned long long t_entry = dbgt ? wall_clock64() : 0ull;
     constexpr int KEEP = 16;                        // logits kept in registers per thread and frame (V <= 4096)
     float zv[LAT][KEEP];
 #pragma unroll
@@ -372,6 +375,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         it_cur = s.iters[r];                                      // every thread replays the state machine
         if (tid == 0) { n0 = s.step_ntok[r]; si0 = s.sum_iters[r]; no0 = s.n_ones[r]; lp0 = s.logp_sum[r]; }
     }
+    if (dbgt) { s.dbg[0] = t_entry; s.dbg[1] = wall_clock64(); }  // state loaded (stamps of a launch in which row 0 decodes)
     const int nla = PLAIN ? 1 : min(min(la, LAT), Tr - t);       // frames this launch may decide (uniform over the workgroup)
     __shared__ float sv[LAT][4];
     __shared__ int si[LAT][4];
@@ -422,6 +426,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         if (tid == 0) { out_logp[r] = logp[0]; out_arg[r] = arg[0]; }
         return;
     }
+    if (dbgt) s.dbg[2] = wall_clock64();                          // statistics of all frames done
     int tok0 = arg[0];                       // the token frame 0 emits if its decision is non-blank
     if constexpr (LAT == 1) {
         if (s.lmz && arg[0] != blank && s.lm_valid[r]) {
@@ -514,6 +519,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         it_cur = it;
     }
     if (tid != 0) return;
+    if (dbgt) s.dbg[3] = wall_clock64();                          // decisions replayed
     s.emit[r] = emitted;
     s.logp_sum[r] = lp0;
     s.sum_iters[r] = si0;
@@ -526,7 +532,9 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         if (s.host_ntot) s.host_ntot[r] = n0;
     }
     if (t < Tr) atomicAdd(&s.unfinished[iter_slot], 1);     // continuous mode: rows that still have encoded frames to decode
+    if (dbgt) s.dbg[4] = wall_clock64();                          // state stored
     publish();
+    if (dbgt) s.dbg[5] = wall_clock64();
 }
 // launch with the compile-time lookahead bound that covers `la`
 template <bool PLAIN>
