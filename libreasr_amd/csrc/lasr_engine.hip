@@ -595,7 +595,8 @@ static void staged_copy(lasr_ctx* c, void* dst, const void* src, size_t bytes) {
     P.src = (const char*)src; P.dst = (char*)dst; P.bytes = bytes;
     P.part_bytes = ((bytes / (4 * (P.th.size() + 1))) + 4095) & ~(size_t)4095;
     P.parts = (int)((bytes + P.part_bytes - 1) / P.part_bytes);
-    P.next.store(0, std::memory_order_release); P.done.store(0, std::memory_order_release);
+    P.done.store(0, std::memory_order_release);          // (before `next`: a helper still leaving the previous job may take a part at once)
+    P.next.store(0, std::memory_order_release);
     P.gen.fetch_add(1, std::memory_order_acq_rel);
     P.cv.notify_all();
     for (;;) {
