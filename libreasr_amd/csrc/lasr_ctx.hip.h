@@ -205,10 +205,11 @@ struct lasr_ctx {
     struct CopyPool {                     // helper threads of the staging copy (lazy; LASR_PUSH_THREADS, default 2)
         bool init = false;
         std::vector<std::thread> th;
-        std::mutex m; std::condition_variable cv;
-        std::atomic<long long> gen{0}; std::atomic<bool> stop{false};
-        std::atomic<int> next{0}, done{0};
-        const char* src = nullptr; char* dst = nullptr; size_t bytes = 0, part_bytes = 0; int parts = 0;
+        std::mutex m; std::condition_variable cv;                 // the job below is read and claimed under m
+        const char* src = nullptr; char* dst = nullptr; size_t bytes = 0, part_bytes = 0;
+        int parts = 0, next = 0, done = 0; long long gen = 0;
+        std::atomic<long long> gen_hint{0}, done_hint{0};         // spin targets: a new job exists / job g is complete
+        std::atomic<bool> stop{false};
     } pool;
     std::vector<int> h_ring_pos;          // host mirror of ring_pos (every append goes through the host: +1 per pushed chunk)
     int fe_mode = 1;                      // fused front-end: 1 = k_fe_mel (+ ring append) -> k_stack_ln, 0 = k_frontend; LASR_FE_MODE

@@ -79,8 +79,7 @@ void lasr_destroy(lasr_ctx* c) {
     for (auto& e : c->push_copied)
         if (e) (void)hipEventDestroy(e);
     if (!c->pool.th.empty()) {
-        c->pool.stop.store(true);
-        { std::lock_guard<std::mutex> lk(c->pool.m); }
+        { std::lock_guard<std::mutex> lk(c->pool.m); c->pool.stop.store(true); }
         c->pool.cv.notify_all();
         for (auto& t : c->pool.th) t.join();
     }
@@ -564,22 +563,24 @@ struct PushSrc { const float* src = nullptr; int ev_i = -1; long long ticket = -
 static void pool_worker(lasr_ctx::CopyPool* P) {
     long long seen = 0;
     for (;;) {
-        {   // wait for a new job: spin briefly (pushes come every ~100 us in steady state), then sleep
-            int spins = 0;
-            while (P->gen.load(std::memory_order_acquire) == seen && !P->stop.load(std::memory_order_acquire)) {
-                if (++spins < 20000) { __builtin_ia32_pause(); continue; }
-                std::unique_lock<std::mutex> lk(P->m);
-                P->cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return P->gen.load() != seen || P->stop.load(); });
-            }
+        // wait for a new job: spin briefly on the hint (pushes come every ~100 us in steady state), then sleep
+        for (int spins = 0; P->gen_hint.load(std::memory_order_acquire) == seen && !P->stop.load(std::memory_order_acquire); ++spins) {
+            if (spins < 20000) { __builtin_ia32_pause(); continue; }
+            std::unique_lock<std::mutex> lk(P->m);
+            P->cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return P->gen != seen || P->stop.load(); });
+            break;
         }
         if (P->stop.load(std::memory_order_acquire)) return;
-        seen = P->gen.load(std::memory_order_acquire);
-        for (;;) {
-            const int i = P->next.fetch_add(1, std::memory_order_acq_rel);
-            if (i >= P->parts) break;
+        std::unique_lock<std::mutex> lk(P->m);               // parts are claimed under the lock: the job's fields cannot change under a helper
+        seen = P->gen;
+        while (P->next < P->parts) {
+            const int i = P->next++;
             const size_t lo = (size_t)i * P->part_bytes, hi = std::min(P->bytes, lo + P->part_bytes);
-            memcpy(P->dst + lo, P->src + lo, hi - lo);
-            P->done.fetch_add(1, std::memory_order_acq_rel);
+            const char* s = P->src; char* d = P->dst;
+            lk.unlock();
+            memcpy(d + lo, s + lo, hi - lo);
+            lk.lock();
+            if (++P->done == P->parts) P->done_hint.store(P->gen, std::memory_order_release);
         }
     }
 }
@@ -592,21 +593,24 @@ static void staged_copy(lasr_ctx* c, void* dst, const void* src, size_t bytes) {
         for (int i = 0; i < nth; ++i) P.th.emplace_back(pool_worker, &P);
     }
     if (P.th.empty() || bytes < (size_t)(96 << 10)) { memcpy(dst, src, bytes); return; }
+    std::unique_lock<std::mutex> lk(P.m);                    // (the previous job is complete: done == parts, nobody is copying)
     P.src = (const char*)src; P.dst = (char*)dst; P.bytes = bytes;
     P.part_bytes = ((bytes / (4 * (P.th.size() + 1))) + 4095) & ~(size_t)4095;
     P.parts = (int)((bytes + P.part_bytes - 1) / P.part_bytes);
-    P.done.store(0, std::memory_order_release);          // (before `next`: a helper still leaving the previous job may take a part at once)
-    P.next.store(0, std::memory_order_release);
-    P.gen.fetch_add(1, std::memory_order_acq_rel);
+    P.next = 0; P.done = 0;
+    const long long g = ++P.gen;
+    P.gen_hint.store(g, std::memory_order_release);
     P.cv.notify_all();
-    for (;;) {
-        const int i = P.next.fetch_add(1, std::memory_order_acq_rel);
-        if (i >= P.parts) break;
+    while (P.next < P.parts) {                               // the calling thread takes parts as well
+        const int i = P.next++;
         const size_t lo = (size_t)i * P.part_bytes, hi = std::min(bytes, lo + P.part_bytes);
-        memcpy(P.dst + lo, P.src + lo, hi - lo);
-        P.done.fetch_add(1, std::memory_order_acq_rel);
+        lk.unlock();
+        memcpy((char*)dst + lo, (const char*)src + lo, hi - lo);
+        lk.lock();
+        if (++P.done == P.parts) P.done_hint.store(g, std::memory_order_release);
     }
-    while (P.done.load(std::memory_order_acquire) < P.parts) __builtin_ia32_pause();
+    lk.unlock();
+    while (P.done_hint.load(std::memory_order_acquire) != g) __builtin_ia32_pause();      // parts still being copied by helpers
 }
 
 static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, PushSrc& ps) {
