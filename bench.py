@@ -420,7 +420,7 @@ def main():
             enc_ms.append(st["encoder_ms"]); dec_ms.append(st["decode_ms"]); fe_ms.append(st["frontend_ms"])
 
     # The dominant kernel is timed INSIDE the timed region with one HIP-event pair per model step around the cell sequence, on the
-    # cells' stream (`launch_us_events`; the cells themselves run as one hipGraph replay per model step).  The kernels' own
+    # cells' stream (`launch_us_events`; with bf16 operands the cell sequence is one hipGraph replay per model step).  The kernels' own
     # durations (`launch_us`: max exit - min entry of the device wall clock over a launch's workgroups, one plain store per
     # workgroup at entry and exit) need a per-launch slot pointer, i.e. plain launches: they come from a short region of the same
     # job right behind the timed one.  (Round 2's timers used two atomics on one word per workgroup: they cost the job 10 % and
