@@ -140,8 +140,14 @@ def test_results_in_order_steps_in_flight_and_eof():
         data = [[rng.integers(0, 9, 4).astype(np.float32) for _ in range(41 + 3 * i)] for i in range(5)]
         sts = [sched.open(text_of=lambda t: "x" if t else "") for _ in range(5)]
         outs = [[] for _ in range(5)]
+        gate = threading.Event()              # hold the scheduler thread while the producers fill their queues: the ticks behind it
+        holder = threading.Thread(target=lambda: sched._call(lambda: gate.wait(10)))       # then see several streams ready at once
+        holder.start()
         ths = [threading.Thread(target=run_stream, args=(sched, sts[i], data[i], outs[i])) for i in range(5)]
         [t.start() for t in ths]
+        time.sleep(0.2)
+        gate.set()
+        holder.join(timeout=10)
         [t.join(timeout=30) for t in ths]
         for i in range(5):
             assert outs[i] == expected(data[i]), i
