@@ -221,7 +221,12 @@ class Engine:
         cnt = np.zeros(n, dtype=np.int32)
         self._chk(self.lib.lasr_fetch_many(self.ctx, p, n, buf.ctypes.data_as(C.c_void_p), cap,
                                            cnt.ctypes.data_as(C.c_void_p)))
-        return [buf[i, :cnt[i]].tolist() for i in range(n)]
+        cl = cnt.tolist()
+        mx = max(cl) if n else 0
+        if mx == 0:
+            return [[] for _ in range(n)]
+        rows = buf[:, :mx].tolist()          # (one conversion of the occupied columns instead of a slice + tolist per slot)
+        return [r[:c] for r, c in zip(rows, cl)]
 
     # ------------------------------------------------------------------ offline
     def transcribe_pcm(self, slots, pcm_list):

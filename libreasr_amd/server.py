@@ -43,19 +43,36 @@ EOF = object()          # end-of-stream marker on a stream's result queue
 
 
 class _Stream:
+    __slots__ = ("slot", "inq", "outq", "n_pend", "generic", "frames", "results", "text_of", "eof", "y_prev", "trunk", "col", "closed")
+
     def __init__(self, slot):
-        self.slot, self.inq, self.outq = slot, collections.deque(), queue.Queue()
-        self.n_chunks, self.n_pend = 0, 0
+        self.slot, self.inq, self.outq = slot, collections.deque(), queue.SimpleQueue()
         self.generic = None                 # decided by the first frame: False = 16 kHz / 80 ms fused path, True = window form
-        self.frames = []                    # generic form: the last (up to) 3 client frames (api-server.py:85-99)
+        self.frames, self.n_pend = [], 0    # generic form: the last (up to) 3 client frames (api-server.py:85-99), windows in the Buffer
         # results leave in chunk order: one entry per accepted chunk, [value] once known (None = no model call for the chunk,
         # list = new token ids, Exception); a chunk whose model step is still in flight holds the queue behind it
         self.results = collections.deque()
-        self.inflight = 0                   # model steps submitted and not collected
-        self.steps = 0                      # model steps since the last reset (api-server.py:117,133)
         self.text_of = None                 # tokens -> text of the chunk (reset policy: "the chunk produced no text")
         self.eof = False
         self.y_prev = []                    # beam search: the best hypothesis as of the previous model step
+        self.trunk, self.col = None, -1     # fed through push_batch: its trunk and its column there (results go to batch_outq)
+        self.closed = False                 # frames that arrive after close (a reader thread still running) are dropped
+
+
+class _Trunk:
+    """Streams fed together through push_batch: the frames stay in the caller's [n, chunk] arrays, every stream has a cursor."""
+    __slots__ = ("streams", "slots", "live", "batches", "base", "pushed", "lut")
+
+    def __init__(self, streams, n_slots):
+        self.streams = list(streams)
+        self.slots = np.array([s.slot for s in streams], np.int64)
+        self.live = self.slots.copy()       # slots of the streams that are still open
+        self.lut = np.full(n_slots, -1, np.int64)              # slot -> column of the batches
+        self.lut[self.slots] = np.arange(len(self.slots))
+        self.batches, self.base, self.pushed = collections.deque(), 0, 0   # batches[k] has serial base + k
+
+
+_FAR = 1 << 60
 
 
 class Scheduler(threading.Thread):
@@ -67,25 +84,61 @@ class Scheduler(threading.Thread):
 
     The reset policy of the servicer (api-server.py:44-50,131-134: after >= 4000 ms since the last reset, the first model step
     without text resets encoder / predictor / LM) is applied HERE, between two model steps of the stream as the reference does:
-    a stream that has reached the threshold is not run ahead (its next chunk waits until the step in flight has been judged).
-    Beam search (beam > 1) and generic client frames take the synchronous entry points."""
+    a stream that has reached the threshold is not run ahead -- the chunk that would start its next model step waits until the
+    step in flight has been judged (chunks that only fill the window / the Buffer go through: a reset does not touch those).
+    The other streams keep going; a model step costs the GPU the same for 1 row or 64, so the tick keeps the streams in phase:
+    when the streams whose chunk completes a model step are not the majority of a tick they wait for the next one (one loop
+    iteration), where the others have caught up.
+    Generic client frames (other rates / lengths) take the synchronous entry point.
 
-    def __init__(self, engine, depth=12, downsample=None, n_buffer=None):
+    The per-stream bookkeeping (frames queued, frames to the next model step, steps in flight, steps since the last reset) lives
+    in arrays indexed by slot: a tick classifies all streams with a dozen vector operations whatever their number."""
+
+    def __init__(self, engine, depth=12, downsample=None, n_buffer=None, held_depth=4):
         super().__init__(daemon=True, name="lasr-scheduler")
         self.eng, self.cv = engine, threading.Condition()
         self.streams, self.ctl, self.stop_flag = {}, collections.deque(), False
         self.batches = []                   # sizes of the streaming batches (observability / tests)
+        self.step_rows = []                 # rows per submitted model step (observability / tests)
         self.max_inflight_seen = 0
         self.depth = max(1, min(int(depth), engine.max_inflight()))
+        # while a stream is held at the reset threshold its verdict is `steps in flight` model steps away and the steps submitted
+        # meanwhile run without it: fewer steps in flight then (faster-than-real-time replays with the reset rule: rows per model
+        # step 45 of 64 at 4 against 27 at 12 in a saturated simulation; a real-time stream is never run ahead at all)
+        self.held_depth = max(1, min(int(held_depth), self.depth))
+        self.any_held = False
         self.beam = engine.beam
-        self.inflight = collections.deque() # per submitted model step: the streams whose model ran, in slot-list order
-        self.batchq, self.batch_outq = collections.deque(), queue.Queue()     # trunk interface (push_batch)
+        self.inflight = collections.deque() # per submitted model step: (slots of its streams, {slot: result cell} | None)
+        self.batch_outq = queue.SimpleQueue()   # trunk interface (push_batch): one item per collected model step
         self.downsample = downsample or engine.desc.stride
         self.n_buffer = n_buffer or engine.desc.n_buffer
+        k = 1                               # should_reset is monotone in the step count: the first count at which it holds
+        while not should_reset(k, self.downsample, self.n_buffer) and k < (1 << 20):
+            k += 1
+        self.reset_steps = k
+        N = int(getattr(engine, "max_streams", 0) or getattr(engine.desc, "max_streams", 0) or 1024)
+        z = lambda v=0: np.full(N, v, np.int64)
+        self.qn = z()                       # frames waiting (written under cv by the producers)
+        self.eofp = np.zeros(N, bool)       # an EOF marker waits behind the frames
+        self.n_wait = 0                     # frames + EOF markers waiting, all streams
+        self.fast = np.zeros(N, bool)       # fused path decided (16 kHz / 80 ms frames)
+        self.phase = z()                    # frames up to and including the one that completes the next model step (1: the next frame does)
+        self.infl = z()                     # model steps submitted and not collected
+        self.stp = z()                      # model steps since the last reset (api-server.py:117,133)
+        self.rat = z(_FAR)                  # steps since the last reset from which the reset rule can fire (_FAR: no text function)
+        self.cur = z()                      # trunk streams: serial of the next batch to take
+        self.is_trunk = np.zeros(N, bool)
+        self.trunks = []
+        # counters that let a tick skip whole groups of vector operations
+        self.n_slow = 0                     # open streams whose form is undecided or generic
+        self.n_ruled = 0                    # open streams with a text function (the reset rule applies)
+        self.n_eof = 0                      # EOF markers waiting
+        self.n_blocked = 0                  # frames waiting in streams that the last tick found held at the reset threshold
+        self._rows = np.zeros((N, engine.desc.chunk), np.float32)          # per-stream form: the frames of a tick, row by row
 
     # ---- called from RPC threads -----------------------------------------------------------
     def _call(self, fn):
-        done = queue.Queue()
+        done = queue.SimpleQueue()
         with self.cv:
             if self.stop_flag:
                 raise RuntimeError("scheduler shut down")
@@ -103,7 +156,7 @@ class Scheduler(threading.Thread):
         self._call(lambda: self._close(st))
 
     def reset(self, st):
-        self._call(lambda: self._reset(st))
+        self._call(lambda: self._reset(st.slot))
 
     def transcribe(self, pcm, sr=16000):
         return self._call(lambda: self._offline(pcm, sr))
@@ -113,7 +166,13 @@ class Scheduler(threading.Thread):
         with self.cv:
             if self.stop_flag:
                 raise RuntimeError("scheduler shut down")
+            if st.closed:
+                return
+            if st.trunk is not None:
+                raise ValueError("this stream is fed through push_batch")
             st.inq.append((chunk, int(sr) or 16000))
+            self.qn[st.slot] += 1
+            self.n_wait += 1
             self.cv.notify()
 
     def push(self, st, chunk, sr=16000):
@@ -122,20 +181,47 @@ class Scheduler(threading.Thread):
         return st.outq.get()
 
     def push_batch(self, streams, chunks):
-        """Trunk interface (one producer feeding many streams, e.g. a bridge that demultiplexes one connection): ONE queue entry
-        for a whole batch -- chunks [n, chunk] float32 at the model rate, chunks[i] belongs to streams[i].  Every collected model
-        step arrives as ONE item (streams_that_ran, token_lists) on self.batch_outq.  Same engine calls, same reset rule as the
-        per-stream form, O(1) queue traffic per batch instead of O(streams); a stream uses either this form or push / push_nowait."""
+        """Trunk interface (one producer feeding many streams, e.g. a bridge that demultiplexes one connection): ONE call for a
+        whole batch -- chunks [n, chunk] float32 at the model rate, chunks[i] belongs to streams[i]; the first call fixes the
+        trunk's stream list, every later call passes the same list.  The array is not copied here: hand over a fresh one per
+        call.  Every collected model step arrives as ONE item (streams_that_ran, token_lists) on self.batch_outq: a stream's
+        steps arrive in order, but one item need not hold every stream of the trunk (a stream at the reset threshold waits for
+        its previous step, see the class docstring).  Same engine calls, same reset rule as the per-stream form; a stream uses
+        either this form or push / push_nowait."""
         with self.cv:
             if self.stop_flag:
                 raise RuntimeError("scheduler shut down")
-            self.batchq.append((list(streams), chunks))
+            T = streams[0].trunk
+            if T is None:
+                if any(s.trunk is not None or s.inq or s.generic is not None for s in streams):
+                    raise ValueError("push_batch: a trunk is made of fresh streams")
+                T = _Trunk(streams, len(self.qn))
+                for i, s in enumerate(streams):
+                    s.trunk, s.col, s.generic = T, i, False
+                sl = T.slots
+                self.n_slow -= int(np.count_nonzero(~self.fast[sl]))
+                self.is_trunk[sl] = True
+                self.fast[sl] = True
+                self.cur[sl] = 0
+                self.trunks.append(T)
+            elif len(streams) != len(T.streams) or streams[-1] is not T.streams[-1]:
+                raise ValueError("push_batch: the stream list of a trunk is fixed by its first call")
+            if chunks.shape[0] != len(T.streams) or chunks.shape[1] != self.eng.desc.chunk:
+                raise ValueError(f"push_batch: chunks must be [{len(T.streams)}, {self.eng.desc.chunk}]")
+            T.batches.append(chunks)
+            T.pushed += 1
+            self.qn[T.live] += 1
+            self.n_wait += len(T.live)
             self.cv.notify()
 
     def push_eof(self, st):
         """After the last frame: EOF is put on st.outq behind the result of the last frame."""
         with self.cv:
-            st.inq.append(EOF)
+            if st.closed or self.eofp[st.slot]:
+                return
+            self.eofp[st.slot] = True
+            self.n_wait += 1
+            self.n_eof += 1
             self.cv.notify()
 
     def shutdown(self):
@@ -147,18 +233,39 @@ class Scheduler(threading.Thread):
     def _open(self, text_of=None):
         st = _Stream(self.eng.open())
         st.text_of = text_of
+        i, d = st.slot, self.eng.desc
         with self.cv:
-            self.streams[st.slot] = st
+            self.streams[i] = st
+            self.qn[i], self.eofp[i], self.fast[i], self.is_trunk[i] = 0, False, False, False
+            self.n_slow += 1
+            self.n_ruled += text_of is not None
+        self.infl[i], self.stp[i], self.cur[i] = 0, 0, 0
+        self.rat[i] = self.reset_steps if text_of is not None else _FAR
+        self.phase[i] = d.n_window + d.n_buffer - 1      # window full at frame n_window, then every n_buffer-th frame completes a step
         return st
 
     def _close(self, st):
+        i = st.slot
         with self.cv:
-            self.streams.pop(st.slot, None)
-        self.eng.close_slot(st.slot)
+            self.streams.pop(i, None)
+            self.n_wait -= int(self.qn[i]) + int(self.eofp[i])
+            self.n_eof -= int(self.eofp[i])
+            self.n_slow -= not self.fast[i]
+            self.n_ruled -= st.text_of is not None
+            self.qn[i], self.eofp[i], self.fast[i] = 0, False, False
+            st.inq.clear()
+            st.closed = True
+            if st.trunk is not None:
+                T = st.trunk
+                T.live = T.live[T.live != i]
+                self.is_trunk[i] = False
+                if not len(T.live):
+                    self.trunks.remove(T)
+        self.eng.close_slot(i)
 
-    def _reset(self, st):
-        self.eng.reset(st.slot, 1 | 2 | 4)                                 # models.py:494-497
-        st.steps = 0
+    def _reset(self, i):
+        self.eng.reset(i, 1 | 2 | 4)                                       # models.py:494-497
+        self.stp[i] = 0
 
     def _offline(self, pcm, sr=16000):
         slot = self.eng.open()
@@ -178,47 +285,51 @@ class Scheduler(threading.Thread):
             st.outq.put(EOF)
             st.eof = False
 
-    def _deliver(self, st, cell, tokens):
-        """A model step of `st` has been decoded: its tokens, and the servicer's reset rule (api-server.py:131-134)."""
-        st.steps += 1
-        cell.append(tokens)
-        if st.text_of is not None and isinstance(tokens, list):
-            new = tokens
-            if self.beam > 1:               # the engine hands out the whole best hypothesis: this chunk's part follows the common prefix
-                n = 0
-                while n < min(len(st.y_prev), len(tokens)) and st.y_prev[n] == tokens[n]:
-                    n += 1
-                st.y_prev, new = list(tokens), tokens[n:]
-            if st.text_of(new) == "" and should_reset(st.steps, self.downsample, self.n_buffer):
-                self._reset(st)             # (the stream has nothing in flight: see _may_run_ahead)
-        self._flush(st)
-
-    def _may_run_ahead(self, st):
-        # once the reset threshold is within reach of the steps in flight, every further step must see the decision of the one before
-        return st.inflight == 0 or st.text_of is None or not should_reset(st.steps + st.inflight + 1, self.downsample, self.n_buffer)
+    def _judge(self, st, tokens):
+        """A model step of `st` (already counted in stp) has been decoded: the servicer's reset rule (api-server.py:131-134)."""
+        new = tokens
+        if self.beam > 1:                   # the engine hands out the whole best hypothesis: this chunk's part follows the common prefix
+            n = 0
+            while n < min(len(st.y_prev), len(tokens)) and st.y_prev[n] == tokens[n]:
+                n += 1
+            st.y_prev, new = list(tokens), tokens[n:]
+        if self.stp[st.slot] >= self.rat[st.slot] and (not new or st.text_of(new) == ""):
+            self._reset(st.slot)            # (the stream has nothing in flight: see _take)
 
     def _collect(self):
         """Tokens of the oldest model step in flight -> its streams."""
-        rows = self.inflight.popleft()
-        self.eng.wait()
-        toks = self.eng.fetch_many([s.slot for s, _ in rows], cap=256 if self.beam == 1 else 8192)
-        if rows and rows[0][1] is None:      # a push_batch step: one item for the whole step
-            for (s, _), t in zip(rows, toks):
-                s.inflight -= 1
-                s.steps += 1
-                new = t
-                if self.beam > 1:
-                    n = 0
-                    while n < min(len(s.y_prev), len(t)) and s.y_prev[n] == t[n]:
-                        n += 1
-                    s.y_prev, new = list(t), t[n:]
-                if s.text_of is not None and s.text_of(new) == "" and should_reset(s.steps, self.downsample, self.n_buffer):
-                    self._reset(s)
-            self.batch_outq.put(([s for s, _ in rows], toks))
+        sl, cells = self.inflight.popleft()
+        ran = self.eng.wait()
+        if ran != len(sl):                   # the host mirror of the window / Buffer bookkeeping and the engine disagree
+            raise RuntimeError(f"scheduler: expected a model step of {len(sl)} streams, the engine ran {ran}")
+        toks = self.eng.fetch_many(sl, cap=256 if self.beam == 1 else 8192)
+        self.infl[sl] -= 1
+        self.stp[sl] += 1
+        streams = self.streams
+        rows = [streams[i] for i in sl.tolist()]
+        if self.beam > 1:                    # (the hypothesis of the previous step is needed for every later judgement)
+            for s, t in zip(rows, toks):
+                if s.text_of is not None:
+                    self._judge(s, t)
+        elif self.n_ruled:
+            hot = np.flatnonzero(self.stp[sl] >= self.rat[sl])
+            for k in hot.tolist():           # only the streams within reach of the reset rule
+                self._judge(rows[k], toks[k])
+        self.n_blocked = 0                   # (a judged step may have released a held stream: the next tick finds out)
+        if cells is None:                    # a step of trunk streams only
+            self.batch_outq.put((rows, toks))
             return
-        for (s, cell), t in zip(rows, toks):
-            s.inflight -= 1
-            self._deliver(s, cell, t)
+        t_streams, t_toks = [], []
+        for s, t in zip(rows, toks):
+            cell = cells.get(s.slot)
+            if cell is None:
+                t_streams.append(s)
+                t_toks.append(t)
+            else:
+                cell.append(t)
+                self._flush(s)
+        if t_streams:
+            self.batch_outq.put((t_streams, t_toks))
 
     def _drain(self):
         while self.inflight:
@@ -234,152 +345,254 @@ class Scheduler(threading.Thread):
                 for fn, done in self.ctl:
                     done.put(err)
                 self.ctl.clear()
+                trunk_waits = bool(self.inflight) or any(self.qn[T.live].any() for T in self.trunks)
                 for st in self.streams.values():
                     st.inq.clear()
                     st.outq.put(err)
+                self.qn[:] = 0
+                self.eofp[:] = False
+                self.n_wait = self.n_eof = 0
+                if trunk_waits:
+                    self.batch_outq.put(err)                   # a trunk consumer waiting for the steps it has queued
+
+    def _take(self):
+        """(cv held) One frame of every stream that can go now.  Returns (slots whose frame only fills the window / Buffer, slots
+        whose frame completes a model step, [(stream, frame)] of the generic form); the frames of the fused path are taken by
+        _gather."""
+        d = self.eng.desc
+        qn, fast = self.qn, self.fast
+        has = qn > 0
+        gen = []
+        if self.n_slow:                      # first frame of a stream, or the generic form
+            for i in np.flatnonzero(has & ~fast).tolist():
+                s = self.streams[i]
+                if s.generic is None:        # the stream's first frame decides its form
+                    pcm, sr = s.inq[0]
+                    s.generic = not (sr == d.sample_rate and pcm.shape[0] == d.chunk)
+                    if not s.generic:
+                        fast[i] = True
+                        self.n_slow -= 1
+                        continue
+                gen.append((s, s.inq.popleft()))
+                qn[i] -= 1
+                self.n_wait -= 1
+                has[i] = qn[i] > 0
+        ready = has & fast
+        step_f = ready & (self.phase == 1)
+        if self.n_ruled:                     # at the reset threshold: the step in flight is judged before the next one starts
+            infl = self.infl
+            held = step_f & (infl > 0) & (self.stp + infl + 1 >= self.rat)
+            self.n_blocked = int(qn[held].sum()) + (int(np.count_nonzero(self.eofp & held)) if self.n_eof else 0)
+            self.any_held = self.n_blocked > 0
+            steps_m = step_f & ~held
+        else:
+            steps_m = step_f
+            self.any_held = False
+        fills_m = ready & ~step_f
+        n_st, n_fl = int(np.count_nonzero(steps_m)), int(np.count_nonzero(fills_m))
+        # a model step costs the GPU the same for one row or all of them: step frames that are not the majority of the tick wait
+        # for the next one, where the streams that only fill their window / Buffer now have their own step frame up
+        if n_fl and n_st <= n_fl:
+            n_st = 0
+        fills = np.flatnonzero(fills_m) if n_fl else _EMPTY
+        steps = np.flatnonzero(steps_m) if n_st else _EMPTY
+        if self.n_eof:
+            for i in np.flatnonzero(self.eofp & (qn == 0)).tolist():
+                self.eofp[i] = False
+                self.n_wait -= 1
+                self.n_eof -= 1
+                s = self.streams.get(i)
+                if s is not None:
+                    s.eof = True
+                    self._flush(s)
+        return fills, steps, gen
+
+    def _gather(self, take):
+        """(cv held) The frames of the fused-path slots `take` -> (slots in row order, [rows, chunk] matrix or list of rows,
+        {slot: cell} of the per-stream form)."""
+        d = self.eng.desc
+        CH = d.chunk
+        self.qn[take] -= 1
+        self.n_wait -= len(take)
+        mats, order, cells = [], [], None
+        n_trunk = 0
+        if self.trunks:
+            whole = len(self.trunks) == 1 and len(take) == len(self.trunks[0].live) and len(take) == len(self.streams)
+            for T in self.trunks:
+                sl = T.live                  # (whole: the tick took exactly the trunk's streams)
+                if not whole:
+                    sl = np.intersect1d(sl, take, assume_unique=True)
+                    if not len(sl):
+                        continue
+                n_trunk += len(sl)
+                cur = self.cur[sl]
+                c0 = int(cur[0])
+                if (cur == c0).all():        # the common case: every taken stream of the trunk reads the same batch
+                    arr = T.batches[c0 - T.base]
+                    mats.append(arr if len(sl) == arr.shape[0] else arr[T.lut[sl]])
+                    order.append(sl)
+                else:
+                    cols = T.lut[sl]
+                    for c in np.unique(cur).tolist():
+                        m = cur == c
+                        mats.append(T.batches[c - T.base][cols[m]])
+                        order.append(sl[m])
+                self.cur[sl] += 1
+                lo = int(self.cur[T.live].min())
+                while T.base < lo:           # batches every live stream has passed
+                    T.batches.popleft()
+                    T.base += 1
+        if n_trunk != len(take):
+            cells = {}
+            sl, k = [], 0
+            buf = self._rows                 # (push_submit copies host memory before it returns: one buffer serves every tick)
+            for i in take[~self.is_trunk[take]].tolist():
+                s = self.streams[i]
+                pcm, sr = s.inq.popleft()
+                cell = []
+                s.results.append(cell)
+                if sr != d.sample_rate or pcm.shape[0] > CH:
+                    cell.append(ValueError(f"stream opened with {CH}-sample {d.sample_rate} Hz frames: got {pcm.shape[0]} samples at {sr} Hz"))
+                    continue                 # (flushed by the caller, outside the lock)
+                if pcm.shape[0] < CH:                           # api-client.py:40-41 pads the last slice with zeros
+                    buf[k, :pcm.shape[0]] = pcm
+                    buf[k, pcm.shape[0]:] = 0.0
+                else:
+                    buf[k] = pcm
+                k += 1
+                cells[i] = cell
+                sl.append(i)
+            if k:
+                mats.append(buf[:k])
+                order.append(np.array(sl, np.int64))
+        if not mats:
+            return _EMPTY, None, cells
+        if len(mats) == 1:
+            return order[0], mats[0], cells
+        return np.concatenate(order), np.concatenate(mats), cells
+
+    def _work_waiting(self):
+        # frames are waiting in streams that can go (n_blocked: frames and EOF markers behind a stream held at the reset threshold,
+        # as of the last tick; an estimate on the safe side costs one empty tick)
+        return bool(self.ctl) or self.n_wait > self.n_blocked
 
     def _run(self):
         d = self.eng.desc
         while True:
             with self.cv:
-                while (not self.stop_flag and not self.ctl and not self.inflight and not self.batchq
-                       and not any(s.inq and (s.inq[0] is EOF or self._may_run_ahead(s)) for s in self.streams.values())):
+                while not (self.stop_flag or self.ctl or self.inflight or self.n_wait > 0):
                     self.cv.wait()
                 if self.stop_flag:
                     return
                 ctl = list(self.ctl)
                 self.ctl.clear()
-                batch = None
-                if self.batchq and all(self._may_run_ahead(s) for s in self.batchq[0][0]):
-                    batch = self.batchq.popleft()
-                ready, chunks = [], []
-                for s in self.streams.values():
-                    if not s.inq:
-                        continue
-                    if s.inq[0] is EOF:
-                        s.inq.popleft()
-                        s.eof = True
-                        self._flush(s)
-                        continue
-                    if self._may_run_ahead(s):
-                        ready.append(s)
-                        chunks.append(s.inq.popleft())
-            if ctl:
-                self._drain()                # state-changing calls need an idle engine
+                if not ctl:
+                    fills, steps, gen = self._take()
+                    take = fills if not len(steps) else steps if not len(fills) else np.concatenate((fills, steps))
+                    order, mat, cells = self._gather(take) if len(take) else (_EMPTY, None, None)
+            if ctl:                          # open / close / reset / offline calls: before any frame of this tick is taken
+                self._drain()                # (state-changing calls need an idle engine)
                 for fn, done in ctl:
                     try:
                         done.put(fn())
                     except Exception as e:   # surfaced in the calling RPC thread
                         done.put(e)
-            if batch is not None:
-                self._submit_batch(*batch)
-            if not ready:
-                if self.inflight and (batch is None or len(self.inflight) >= self.depth or not self._work_waiting()):
-                    self._collect()
                 continue
-            fast, generic = [], collections.OrderedDict()
-            for s, (pcm, sr) in zip(ready, chunks):
-                cell = []
-                s.results.append(cell)
-                if s.generic is None:
-                    s.generic = not (sr == d.sample_rate and pcm.shape[0] == d.chunk)
-                if not s.generic:
-                    if sr != d.sample_rate or pcm.shape[0] > d.chunk:
-                        cell.append(ValueError(f"stream opened with {d.chunk}-sample {d.sample_rate} Hz frames: got {pcm.shape[0]} samples at {sr} Hz"))
-                        self._flush(s)
-                        continue
-                    if pcm.shape[0] < d.chunk:                  # api-client.py:40-41 pads the last slice with zeros
-                        pcm = np.concatenate([pcm, np.zeros(d.chunk - pcm.shape[0], np.float32)])
-                    fast.append((s, cell, pcm))
-                else:                                           # api-server.py:85-99: window of the last 3 frames
-                    s.frames.append(pcm)
-                    if len(s.frames) != d.n_window:
-                        cell.append(None)
-                        self._flush(s)
-                        continue
-                    win = np.concatenate(s.frames)
-                    del s.frames[0]
-                    generic.setdefault((win.shape[0], sr), []).append((s, cell, win))
-            try:
-                if fast:
-                    slots = [s.slot for s, _, _ in fast]
-                    self.batches.append(len(fast))
-                    ran = []
-                    for s, cell, _ in fast:                     # host mirror of the engine's window / Buffer bookkeeping
-                        s.n_chunks += 1
-                        r = False
-                        if s.n_chunks >= d.n_window:            # window full -> one more frame in the Buffer
-                            s.n_pend += 1
-                            if s.n_pend == d.n_buffer:
-                                s.n_pend, r = 0, True
-                        ran.append(r)
-                    before = self.eng.pending()
-                    self.eng.push_submit(slots, np.stack([p for _, _, p in fast]))
-                    rows = [(s, cell) for (s, cell, _), r in zip(fast, ran) if r]
-                    assert (self.eng.pending() > before) == bool(rows)
-                    for (s, cell, _), r in zip(fast, ran):
-                        if not r:
-                            cell.append(None)
-                            self._flush(s)
-                    if rows:
-                        for s, _ in rows:
-                            s.inflight += 1
-                        self.inflight.append(rows)
-                        self.max_inflight_seen = max(self.max_inflight_seen, len(self.inflight))
-            except Exception as e:
-                for s, cell, _ in fast:
-                    if not cell:
-                        cell.append(e)
-                    self._flush(s)
-            if generic:
-                self._drain()                                   # lasr_step_window is a synchronous entry point
-            for (N, sr), group in generic.items():              # same window length and rate: one batched call
-                try:
-                    slots = [s.slot for s, _, _ in group]
-                    self.eng.step_window(slots, np.stack([w for _, _, w in group]), sr)
-                    toks = self.eng.fetch_many(slots, cap=8192 if self.eng.beam > 1 else 256)
-                    for (s, cell, _), t in zip(group, toks):
-                        s.n_pend += 1
-                        if s.n_pend == d.n_buffer:
-                            s.n_pend = 0
-                            self._deliver(s, cell, t)
-                        else:
-                            cell.append(None)
-                            self._flush(s)
-                except Exception as e:
-                    for s, cell, _ in group:
-                        if not cell:
-                            cell.append(e)
-                        self._flush(s)
+            if not len(take) and not gen:    # nothing can move (streams held at the reset threshold, or only markers handled):
+                if self.inflight:            # the way forward is the oldest step's verdict
+                    self._collect()
+                else:
+                    with self.cv:
+                        if not (self.stop_flag or self.ctl) and self.n_wait > 0:
+                            self.cv.wait(0.01)                  # (defensive: never spin on frames that cannot go)
+                continue
+            if len(take):
+                self._submit_fast(fills, steps, take, order, mat, cells)
+            if gen:
+                self._submit_generic(gen, d)
             # collect: at the depth limit, or as soon as no further chunk is waiting (latency of a lightly loaded server)
-            while self.inflight and (len(self.inflight) >= self.depth or not self._work_waiting()):
+            while self.inflight and (len(self.inflight) >= (self.held_depth if self.any_held else self.depth) or not self._work_waiting()):
                 self._collect()
 
-    def _submit_batch(self, streams, chunks):
-        d = self.eng.desc
+    def _fail(self, s, cell, e):
+        if not cell:
+            cell.append(e)
+        self._flush(s)
+
+    def _submit_fast(self, fills, steps, take, order, mat, cells):
+        """One frame of each taken stream -> ONE lasr_push_submit; `steps` (the streams whose frame completes a model step)
+        share the model step."""
+        nb = self.eng.desc.n_buffer
+        if cells is not None and len(order) != len(take):       # refused frames (wrong size / rate) left the batch
+            ok = np.zeros(len(self.qn), bool)
+            ok[order] = True
+            for i in take[~ok[take]].tolist():
+                self._flush(self.streams[i])
+            fills, steps = fills[ok[fills]], steps[ok[steps]]
+            if not len(order):
+                return
         try:
-            rows = []
-            for s in streams:                                   # host mirror of the engine's window / Buffer bookkeeping
-                s.n_chunks += 1
-                if s.n_chunks >= d.n_window:
+            self.batches.append(len(order))
+            self.eng.push_submit(order, mat)
+        except Exception as e:
+            if cells is None or len(cells) != len(order):
+                self.batch_outq.put(e)
+            for i, cell in (cells or {}).items():
+                self._fail(self.streams[i], cell, e)
+            return
+        self.phase[order] -= 1                                  # host mirror of the engine's window / Buffer bookkeeping
+        if cells is not None:
+            for i in fills.tolist():
+                cell = cells.pop(i, None)
+                if cell is not None:
+                    cell.append(None)                           # no model call for this frame
+                    self._flush(self.streams[i])
+        if len(steps):
+            self.phase[steps] = nb
+            self.infl[steps] += 1
+            self.step_rows.append(len(steps))
+            self.inflight.append((steps, cells if cells else None))
+            if len(self.inflight) > self.max_inflight_seen:
+                self.max_inflight_seen = len(self.inflight)
+
+    def _submit_generic(self, gen, d):
+        """api-server.py:85-99: window of the last 3 frames, resampled + transformed per call (lasr_step_window, synchronous)."""
+        groups = collections.OrderedDict()
+        for s, (pcm, sr) in gen:
+            cell = []
+            s.results.append(cell)
+            s.frames.append(pcm)
+            if len(s.frames) != d.n_window:
+                cell.append(None)
+                self._flush(s)
+                continue
+            win = np.concatenate(s.frames)
+            del s.frames[0]
+            groups.setdefault((win.shape[0], sr), []).append((s, cell, win))
+        if groups:
+            self._drain()
+        for (N, sr), group in groups.items():                   # same window length and rate: one batched call
+            try:
+                slots = [s.slot for s, _, _ in group]
+                self.eng.step_window(slots, np.stack([w for _, _, w in group]), sr)
+                toks = self.eng.fetch_many(slots, cap=8192 if self.eng.beam > 1 else 256)
+                for (s, cell, _), t in zip(group, toks):
                     s.n_pend += 1
                     if s.n_pend == d.n_buffer:
                         s.n_pend = 0
-                        s.inflight += 1
-                        rows.append((s, None))
-            self.batches.append(len(streams))
-            self.eng.push_submit([s.slot for s in streams], chunks)
-            if rows:
-                self.inflight.append(rows)
-                self.max_inflight_seen = max(self.max_inflight_seen, len(self.inflight))
-        except Exception as e:
-            self.batch_outq.put(e)
+                        self.stp[s.slot] += 1
+                        if s.text_of is not None:
+                            self._judge(s, t)
+                        cell.append(t)
+                    else:
+                        cell.append(None)
+                    self._flush(s)
+            except Exception as e:
+                for s, cell, _ in group:
+                    self._fail(s, cell, e)
 
-    def _work_waiting(self):
-        with self.cv:
-            if self.batchq and all(self._may_run_ahead(s) for s in self.batchq[0][0]):
-                return True
-            return bool(self.ctl) or any(s.inq and s.inq[0] is not EOF and self._may_run_ahead(s) for s in self.streams.values())
+
+_EMPTY = np.zeros(0, np.int64)
 
 
 class ASRServicer(apg.ASRServicer):

@@ -185,10 +185,11 @@ def test_scheduler_64_streams_on_the_pipelined_protocol_with_served_rates():
         t0 = time.perf_counter()
         for k in range(n):
             sched.push_batch(streams, chunks[k])
-        n_steps = (n - 2) // 2
-        for _ in range(n_steps):
+        n_steps, seen = (n - 2) // 2, 0
+        while seen < B * n_steps:                      # one item per collected model step: (streams that ran, their tokens)
             item = sched.batch_outq.get(timeout=120)
             assert not isinstance(item, Exception), item
+            seen += len(item[0])
             for st, t in zip(*item):
                 got[st.slot] += t
         dt = time.perf_counter() - t0

@@ -17,7 +17,7 @@ class FakeEngine:
     """Front-end bookkeeping of the real engine (3-chunk window, 2-frame Buffer) with 'tokens' that are a pure function of the
     stream's model-step history since its last reset, so any mis-ordering or misplaced reset shows in the output."""
 
-    def __init__(self, max_streams=8, beam=1, inflight=15, silent=()):
+    def __init__(self, max_streams=8, beam=1, inflight=15, silent=(), silent_after=None):
         self.desc = types.SimpleNamespace(sample_rate=16000, chunk=4, n_window=3, n_buffer=2, stride=8)
         self.beam, self._max, self._inflight = beam, max_streams, inflight
         self.open_, self.n_chunks, self.n_pend, self.acc = set(), {}, {}, {}
@@ -26,6 +26,8 @@ class FakeEngine:
         self.resets = []                    # (slot, model steps the slot had run when it was reset)
         self.total_steps = {}
         self.silent = set(silent)           # slots whose steps produce no tokens
+        self.silent_after = silent_after    # beam > 1: model steps since the last reset after which the hypothesis stops growing
+        self.hyp = {}                       # beam > 1: the whole best hypothesis since the last reset (what lasr_fetch hands out)
         self.max_pending = 0
         self.lock_owner = None
 
@@ -44,6 +46,7 @@ class FakeEngine:
         self.n_chunks[s] = self.n_pend[s] = self.since_reset[s] = self.total_steps[s] = 0
         self.acc[s] = 0.0
         self.queue[s] = []
+        self.hyp[s] = []
         return s
 
     def close_slot(self, s):
@@ -56,6 +59,7 @@ class FakeEngine:
         assert not any(s in rows for rows in self.steps), "reset with a step in flight"
         self.resets.append((s, self.total_steps[s]))
         self.since_reset[s] = 0
+        self.hyp[s] = []
 
     def push_submit(self, slots, pcm):
         self._own()
@@ -75,6 +79,10 @@ class FakeEngine:
                 self.total_steps[s] += 1
                 self.since_reset[s] += 1
                 out[s] = [] if s in self.silent else [int(self.acc[s]) % 97, self.since_reset[s]]
+                if self.beam > 1:           # the engine hands out the WHOLE hypothesis after every model step
+                    if self.silent_after is None or self.since_reset[s] <= self.silent_after:
+                        self.hyp[s] = self.hyp[s] + out[s]
+                    out[s] = list(self.hyp[s])
             self.steps.append(out)
             self.max_pending = max(self.max_pending, len(self.steps))
 
@@ -194,10 +202,11 @@ def test_trunk_interface_and_blocking_push():
         for k in range(n):
             sched.push_batch(sts, chunks[k])
         got = {st.slot: [] for st in sts}
-        for _ in range((n - 2) // 2):
+        while sum(len(g) for g in got.values()) < B * ((n - 2) // 2):      # one item per collected model step
             rows, toks = sched.batch_outq.get(timeout=20)
             for st, t in zip(rows, toks):
                 got[st.slot].append(t)
+        assert sched.step_rows == [B] * ((n - 2) // 2)          # nothing held anybody back: every step ran all the streams
         for i, st in enumerate(sts):
             exp = [t for t in expected([chunks[k, i] for k in range(n)], text_rule=False) if t is not None]
             assert got[st.slot] == exp
@@ -205,6 +214,106 @@ def test_trunk_interface_and_blocking_push():
         st = sched.open()
         res = [sched.push(st, chunks[k, 0]) for k in range(9)]
         assert res == expected([chunks[k, 0] for k in range(9)], text_rule=False)
+    finally:
+        sched.shutdown()
+
+
+def test_trunk_streams_at_the_reset_threshold_hold_only_themselves():
+    """Trunk form with the servicer's reset rule: silent streams reach the threshold after 25 model steps and are then taken one
+    step at a time (each step judged before the next starts) while the other streams keep the pipeline full.  Every stream's
+    results and the resets are exactly the per-stream sequence."""
+    eng = FakeEngine(max_streams=8, silent={1, 4})
+    sched = srv.Scheduler(eng, depth=6)
+    sched.start()
+    try:
+        rng = np.random.default_rng(5)
+        B, n = 6, 150
+        chunks = rng.integers(0, 9, (n, B, 4)).astype(np.float32)
+        sts = [sched.open(text_of=lambda t: "x" if t else "") for _ in range(B)]
+        for k in range(n):
+            sched.push_batch(sts, chunks[k])
+        got = {st.slot: [] for st in sts}
+        while sum(len(g) for g in got.values()) < B * ((n - 2) // 2):
+            item = sched.batch_outq.get(timeout=20)
+            assert not isinstance(item, Exception), item
+            for st, t in zip(*item):
+                got[st.slot].append(t)
+        for i, st in enumerate(sts):
+            exp = [t for t in expected([chunks[k, i] for k in range(n)], slot_silent=st.slot in eng.silent) if t is not None]
+            assert got[st.slot] == exp, i
+        assert sorted(eng.resets) == [(1, 25), (1, 50), (4, 25), (4, 50)]
+        assert eng.max_pending > 1
+    finally:
+        sched.shutdown()
+
+
+def test_streams_that_start_out_of_phase_end_up_sharing_their_model_steps():
+    """A model step costs the GPU the same for one row or all of them.  Half of the streams are one frame ahead of the others
+    (their model steps would fall on the other half's fill frames): the step frames of a minority wait one tick, after which
+    all streams complete their model steps in the same tick."""
+    eng = FakeEngine(max_streams=8)
+    sched = srv.Scheduler(eng, depth=4)
+    sched.start()
+    try:
+        rng = np.random.default_rng(6)
+        n = 61
+        data = [[rng.integers(0, 9, 4).astype(np.float32) for _ in range(n + (i % 2))] for i in range(8)]
+        sts = [sched.open() for _ in range(8)]
+        outs = [[] for _ in range(8)]
+        for i in range(1, 8, 2):                                # the odd streams have had one frame already
+            assert sched.push(sts[i], data[i][0]) is None
+            outs[i].append(None)
+        gate = threading.Event()
+        holder = threading.Thread(target=lambda: sched._call(lambda: gate.wait(10)))
+        holder.start()
+        ths = [threading.Thread(target=run_stream, args=(sched, sts[i], data[i][(i % 2):], outs[i])) for i in range(8)]
+        [t.start() for t in ths]
+        time.sleep(0.2)
+        gate.set()
+        holder.join(timeout=10)
+        [t.join(timeout=30) for t in ths]
+        for i in range(8):
+            assert outs[i] == expected(data[i], text_rule=False), i
+        assert sched.step_rows.count(8) >= len(sched.step_rows) - 2, sched.step_rows
+    finally:
+        sched.shutdown()
+
+
+def test_frames_after_close_are_dropped():
+    eng = FakeEngine()
+    sched = srv.Scheduler(eng, depth=2)
+    sched.start()
+    try:
+        st = sched.open()
+        sched.push_nowait(st, np.ones(4, np.float32))
+        sched.close(st)
+        sched.push_nowait(st, np.ones(4, np.float32))            # a reader thread that has not noticed yet
+        sched.push_eof(st)
+        st2 = sched.open()                                       # takes the slot over
+        assert st2.slot == st.slot
+        res = [sched.push(st2, np.full(4, k, np.float32)) for k in range(6)]
+        assert res == expected([np.full(4, k, np.float32) for k in range(6)], text_rule=False)
+    finally:
+        sched.shutdown()
+
+
+def test_beam_engine_reset_rule_looks_at_what_the_step_added_to_the_hypothesis():
+    """beam > 1: every fetch is the whole best hypothesis; "the chunk produced no text" (api-server.py:131-134) is judged on what
+    follows the common prefix with the previous step's hypothesis."""
+    eng = FakeEngine(beam=4, silent_after=10)
+    sched = srv.Scheduler(eng, depth=5)
+    sched.start()
+    try:
+        rng = np.random.default_rng(7)
+        data = [rng.integers(0, 9, 4).astype(np.float32) for _ in range(2 + 2 * 60)]
+        st = sched.open(text_of=lambda t: "x" if t else "")
+        out = []
+        run_stream(sched, st, data, out)
+        hyps = [o for o in out if o is not None]
+        assert len(hyps) == 60
+        # the hypothesis grows for 10 steps, then stands still: the 25th step since the last reset adds nothing -> reset; the same again
+        assert eng.resets == [(0, 25), (0, 50)]
+        assert len(hyps[9]) == 20 and hyps[24] == hyps[9] and len(hyps[25]) == 2 and hyps[49] == hyps[34] and len(hyps[34]) == 20
     finally:
         sched.shutdown()
 
