@@ -197,6 +197,49 @@ def test_scheduler_64_streams_on_the_pipelined_protocol_with_served_rates():
         bad = [i for i, st in enumerate(streams) if got[st.slot] != ref[i]]
         assert not bad, f"trunk form: streams {bad} differ"
         rates["max_steps_in_flight"] = sched.max_inflight_seen
+        for st in streams:
+            sched.close(st)
+        sched.shutdown()
+        sched.join(timeout=30)
+
+        # (c) the same trunk with the servicer's reset rule (api-server.py:44-50,131-134) on every stream, 128 chunks: streams
+        # that reach the 4 s threshold are taken one step at a time while the others run ahead.  The tokens must not depend on
+        # how far anybody ran ahead: depth 12 == depth 1 (every step judged before the next is submitted)
+        n2 = 128
+        pcm2 = np.stack([synth.synth_pcm(1, n2 * 1280, seed=4321 + s)[0] for s in range(B)])
+        chunks2 = np.ascontiguousarray(pcm2.reshape(B, n2, 1280).transpose(1, 0, 2))
+
+        def run_trunk(depth):
+            sc = srv.Scheduler(eng, depth=depth)
+            sc.start()
+            try:
+                sts = [sc.open(text_of=language.denumericalize) for _ in range(B)]
+                out = {st.slot: [] for st in sts}
+                t0 = time.perf_counter()
+                for k in range(n2):
+                    sc.push_batch(sts, chunks2[k])
+                seen = 0
+                while seen < B * ((n2 - 2) // 2):
+                    item = sc.batch_outq.get(timeout=120)
+                    assert not isinstance(item, Exception), item
+                    seen += len(item[0])
+                    for st, t in zip(*item):
+                        out[st.slot].append(t)
+                dt = time.perf_counter() - t0
+                for st in sts:
+                    sc.close(st)
+                return [out[st.slot] for st in sts], B * n2 * 0.08 / dt, float(np.mean(sc.step_rows))
+            finally:
+                sc.shutdown()
+                sc.join(timeout=30)
+
+        deep, rate_deep, rows_deep = run_trunk(12)
+        flat, rate_flat, rows_flat = run_trunk(1)
+        assert deep == flat, "tokens depend on the number of steps in flight"
+        assert rows_flat == B
+        rates["trunk_reset_rule"] = rate_deep
+        rates["trunk_reset_rule_rows_per_step"] = rows_deep
+        rates["trunk_reset_rule_depth1"] = rate_flat
         print("served audio-s/s:", json.dumps(rates))
         os.makedirs("gpurun_out", exist_ok=True)
         with open("gpurun_out/served_rate.json", "w") as f:
