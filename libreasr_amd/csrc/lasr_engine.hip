@@ -552,9 +552,10 @@ static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
 // ---- client chunks -> PCM ring.  Three kinds of caller memory:
 //   device           read by the ring-append (or front-end) kernel in stream order, like any stream-ordered copy;
 //   host (default)   pageable OR pinned: copied into the engine's own pinned staging ring before the call returns (the caller's
-//                    buffer is free on return); the kernel reads the staging entry over PCIe -- no DMA call, no copy stream;
-//   pinned, no copy  LASR_PUSH_PINNED_NOCOPY: the kernel reads the CALLER's pinned buffer over PCIe after the call has returned;
-//                    the buffer must stay untouched until lasr_push_consumed(ticket) says so.
+//                    buffer is free on return), DMA'd from there into a device staging entry on a copy-only stream; the kernel
+//                    reads HBM (LASR_PUSH_ZEROCOPY=1: the kernel reads the pinned staging entry over PCIe itself, no DMA);
+//   pinned, no copy  LASR_PUSH_PINNED_NOCOPY: the DMA (or, zero-copy, the kernel) reads the CALLER's pinned buffer after the call
+//                    has returned; the buffer must stay untouched until lasr_push_consumed(ticket) says so.
 struct PushSrc { const float* src = nullptr; int ev_i = -1; long long ticket = -1; bool dma = false; };
 
 // threaded copy into the staging ring: 328 KB per push at 64 streams is 40 us of one core when the source is cold (pageable

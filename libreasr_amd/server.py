@@ -94,7 +94,7 @@ class Scheduler(threading.Thread):
     The per-stream bookkeeping (frames queued, frames to the next model step, steps in flight, steps since the last reset) lives
     in arrays indexed by slot: a tick classifies all streams with a dozen vector operations whatever their number."""
 
-    def __init__(self, engine, depth=12, downsample=None, n_buffer=None, held_depth=4):
+    def __init__(self, engine, depth=12, downsample=None, n_buffer=None, held_depth=3):
         super().__init__(daemon=True, name="lasr-scheduler")
         self.eng, self.cv = engine, threading.Condition()
         self.streams, self.ctl, self.stop_flag = {}, collections.deque(), False
@@ -103,8 +103,9 @@ class Scheduler(threading.Thread):
         self.max_inflight_seen = 0
         self.depth = max(1, min(int(depth), engine.max_inflight()))
         # while a stream is held at the reset threshold its verdict is `steps in flight` model steps away and the steps submitted
-        # meanwhile run without it: fewer steps in flight then (faster-than-real-time replays with the reset rule: rows per model
-        # step 45 of 64 at 4 against 27 at 12 in a saturated simulation; a real-time stream is never run ahead at all)
+        # meanwhile run without it: fewer steps in flight then (faster-than-real-time replays with the reset rule, 64 streams of
+        # configs[1] on the GPU: 13.9 k audio-s/s at 12, 20.1 k at 6, 21.4 k at 3, 20.3 k at 1, tools/served_depth_sweep.py; a
+        # real-time stream is never run ahead at all)
         self.held_depth = max(1, min(int(held_depth), self.depth))
         self.any_held = False
         self.beam = engine.beam
