@@ -55,11 +55,15 @@ def dist_env():
 
 def dist_init(world, use_cuda):
     """One process per GPU; backend "nccl" is RCCL on ROCm, gloo for the CPU self-test."""
-    if world == 1:
+    # LASR_BENCH_FORCE_DIST=1: a world of ONE rank still goes through the process group (on a 1-GPU box this is the only way to
+    # run the job's RCCL calls -- init, barrier, all_reduce, all_gather on device tensors -- on real hardware)
+    if world == 1 and not os.environ.get("LASR_BENCH_FORCE_DIST"):
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     # LASR_BENCH_BACKEND=gloo: dry run of the multi-rank path where RCCL cannot be used (several ranks on ONE GPU)
     dist.init_process_group(backend=os.environ.get("LASR_BENCH_BACKEND", "nccl") if use_cuda else "gloo")
     return dist
@@ -272,6 +276,13 @@ def main():
             dist.destroy_process_group()
         return
 
+    # The contract is ONE JSON line on stdout.  RCCL / HIP runtime libraries print their warnings to stdout (RCCL's "NCCL WARN"
+    # lines do, also at process-group teardown): everything this process writes to fd 1 goes to stderr from here on, and rank 0
+    # writes the line to the real stdout as the last thing it does.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from libreasr_amd import synth
     from libreasr_amd.engine import Engine
@@ -474,6 +485,7 @@ def main():
         per_rank = [b.tolist() for b in bufs]
 
     rc_final = 0
+    line = ""
     if rank == 0:
         L, H = cfg["enc_layers"], cfg["hidden"]
         bf = args.dtype == "bf16"
@@ -652,7 +664,10 @@ def main():
                 out["cpu_baseline"]["best_effort"] = cpu_best_effort(cfg, sd, B, args.cpu_be_chunks)
             except Exception as e:
                 out["cpu_baseline"]["best_effort"] = {"error": str(e)[:200]}
-        print(json.dumps(out), flush=True)
+        if dist is not None:
+            out["dist"] = {"backend": dist.get_backend(), "world": world,
+                           "collectives": "barrier x4, all_reduce(MAX, SUM) of f64, all_gather of the per-rank figures"}
+        line = json.dumps(out)
         if out.get("tokens_equal") is False:
             print("bench.py: SELF-CHECK FAILED: " + json.dumps(out.get("self_check")), file=sys.stderr, flush=True)
             rc_final = 3
@@ -660,6 +675,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(real_stdout, (line + "\n").encode())
     if rc_final:
         raise SystemExit(rc_final)
 
