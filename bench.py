@@ -65,6 +65,9 @@ def dist_init(world, use_cuda):
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     # LASR_BENCH_BACKEND=gloo: dry run of the multi-rank path where RCCL cannot be used (several ranks on ONE GPU)
+    # (no device_id= here: binding the device at init makes the process group initialise RCCL eagerly, and the job then runs at
+    #  37 k instead of 50 k audio-s/s on the MI355X -- measured at world 1, profiles/r03/r03_experiments.txt M; torch.cuda.set_device
+    #  has already put this rank on its GPU, the lazily created communicator costs 1-2 %)
     dist.init_process_group(backend=os.environ.get("LASR_BENCH_BACKEND", "nccl") if use_cuda else "gloo")
     return dist
 
