@@ -121,6 +121,10 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         c->la = c->la_stream;
         if (getenv("LASR_KICK")) c->kick_n = std::max(1, atoi(getenv("LASR_KICK")));
         if (getenv("LASR_GROUP")) c->wait_n = std::max(1, atoi(getenv("LASR_GROUP")));
+        // beam: a model step takes ~5 selection rounds per frame; with short rounds (configs[2]: 77 us) the host round trip per
+        // group is worth amortising (4 rounds per group: 13.4-13.8 -> 14.3-14.5 k audio-s/s), with long ones (configs[4]: 1024
+        // hypothesis rows x 1536) the rounds launched past the need cost more (10.3 -> 10.0 k): profiles/r03/r03_experiments.txt O
+        else if (c->W > 1 && (size_t)Md * H <= (size_t)256 * 1024) c->wait_n = 4;
     }
     const size_t Mj = (size_t)c->MTj * 16;
     c->G_pred = d.pred_cell ? 4 : 3;

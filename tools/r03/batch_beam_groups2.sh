@@ -1,0 +1,16 @@
+#!/bin/bash
+run2() { env "$@" timeout 300 python bench.py --dtype bf16 --beam 4 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('cfg2b4', sys.argv[1:], d['value'], d['stage_ms_per_model_step']['decode_iters'], d['latency_ms']['p50_model_chunk'])" "$@"; }
+run4() { env "$@" timeout 300 python bench.py --model cfg5 --dtype bf16 --streams 128 --beam 8 --steps 8 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('cfg5b8', sys.argv[1:], d['value'], d['stage_ms_per_model_step']['decode_iters'], d['latency_ms']['p50_model_chunk'])" "$@"; }
+run2 LASR_GROUP=4
+run2 LASR_GROUP=6
+run2 LASR_GROUP=8
+run2 LASR_GROUP=12
+run2 LASR_GROUP=8 LASR_KICK=8
+run4 A=base
+run4 LASR_GROUP=4
+run4 LASR_GROUP=8
+run4 LASR_GROUP=8 LASR_KICK=6
