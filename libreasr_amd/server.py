@@ -130,6 +130,7 @@ class Scheduler(threading.Thread):
         self.cur = z()                      # trunk streams: serial of the next batch to take
         self.is_trunk = np.zeros(N, bool)
         self.trunks = []
+        self.error = None                   # the exception that ended the scheduler thread, if any
         # counters that let a tick skip whole groups of vector operations
         self.n_slow = 0                     # open streams whose form is undecided or generic
         self.n_ruled = 0                    # open streams with a text function (the reset rule applies)
@@ -142,7 +143,7 @@ class Scheduler(threading.Thread):
         done = queue.SimpleQueue()
         with self.cv:
             if self.stop_flag:
-                raise RuntimeError("scheduler shut down")
+                raise RuntimeError("scheduler shut down" if self.error is None else f"scheduler stopped by {type(self.error).__name__}: {self.error}")
             self.ctl.append((fn, done))
             self.cv.notify()
         res = done.get()
@@ -166,7 +167,7 @@ class Scheduler(threading.Thread):
         """Queue one client frame; its result (None / token list / Exception) appears on st.outq, in frame order."""
         with self.cv:
             if self.stop_flag:
-                raise RuntimeError("scheduler shut down")
+                raise RuntimeError("scheduler shut down" if self.error is None else f"scheduler stopped by {type(self.error).__name__}: {self.error}")
             if st.closed:
                 return
             if st.trunk is not None:
@@ -191,7 +192,7 @@ class Scheduler(threading.Thread):
         either this form or push / push_nowait."""
         with self.cv:
             if self.stop_flag:
-                raise RuntimeError("scheduler shut down")
+                raise RuntimeError("scheduler shut down" if self.error is None else f"scheduler stopped by {type(self.error).__name__}: {self.error}")
             T = streams[0].trunk
             if T is None:
                 if any(s.trunk is not None or s.inq or s.generic is not None for s in streams):
@@ -337,12 +338,17 @@ class Scheduler(threading.Thread):
             self._collect()
 
     def run(self):
+        cause = None
         try:
             self._run()
+        except BaseException as e:           # an engine error ends the scheduler: the waiters are told why
+            cause = e
+            raise
         finally:                             # whoever still waits for a result or a call gets an error, not a hang
             with self.cv:
                 self.stop_flag = True
-                err = RuntimeError("scheduler shut down")
+                err = RuntimeError("scheduler shut down" if cause is None else f"scheduler stopped by {type(cause).__name__}: {cause}")
+                self.error = cause
                 for fn, done in self.ctl:
                     done.put(err)
                 self.ctl.clear()

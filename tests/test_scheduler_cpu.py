@@ -318,6 +318,31 @@ def test_beam_engine_reset_rule_looks_at_what_the_step_added_to_the_hypothesis()
         sched.shutdown()
 
 
+@pytest.mark.filterwarnings("ignore::pytest.PytestUnhandledThreadExceptionWarning")      # (the thread re-raises: traceback in the log)
+def test_an_engine_error_ends_the_scheduler_and_reaches_every_waiter():
+    class Broken(FakeEngine):
+        def wait(self):
+            raise OSError("device lost")
+
+    eng = Broken()
+    sched = srv.Scheduler(eng, depth=2)
+    sched.start()
+    st = sched.open()
+    for k in range(6):
+        sched.push_nowait(st, np.full(4, k, np.float32))
+    got = []
+    while True:
+        r = st.outq.get(timeout=20)
+        got.append(r)
+        if isinstance(r, Exception):
+            break
+    assert isinstance(got[-1], RuntimeError) and "device lost" in str(got[-1])
+    sched.join(timeout=10)
+    assert not sched.is_alive() and isinstance(sched.error, OSError)
+    with pytest.raises(RuntimeError, match="device lost"):
+        sched.open()
+
+
 def test_shutdown_unblocks_everyone():
     eng = FakeEngine()
     sched = srv.Scheduler(eng, depth=2)
