@@ -249,3 +249,63 @@ def test_scheduler_64_streams_on_the_pipelined_protocol_with_served_rates():
     finally:
         sched.shutdown()
         eng.close()
+
+
+def test_scheduler_serves_a_beam_engine_like_the_engine_itself():
+    """beam > 1 through the scheduler (pipelined protocol, several streams at different phases): the hypothesis handed out after
+    every model step equals the one the same engine gives when driven directly, chunk by chunk, through the synchronous
+    protocol (the reset rule on whole hypotheses is covered against a fake engine in tests/test_scheduler_cpu.py)."""
+    import __graft_entry__ as graft
+    graft.build()
+    from libreasr_amd import server as srv
+    from libreasr_amd.engine import Engine
+
+    cfg = synth.model_cfg("tiny")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    eng = Engine(sd, cfg, max_streams=8, beam=4)
+    try:
+        n_streams, n = 4, 44
+        pcm = [synth.synth_pcm(1, (n + i) * 1280, seed=900 + i)[0] for i in range(n_streams)]
+        chunks = [[p[k * 1280:(k + 1) * 1280] for k in range(len(p) // 1280)] for p in pcm]
+        # directly: synchronous protocol, one stream after the other
+        ref = []
+        for i in range(n_streams):
+            s = eng.open()
+            hyps = []
+            for c in chunks[i]:
+                eng.push([s], c[None])
+                if eng.step([s]):
+                    hyps.append(eng.fetch(s)[0])
+            ref.append(hyps)
+            eng.close_slot(s)
+        assert sum(len(h) for h in ref) > 60 and any(len(h[-1]) > 0 for h in ref)
+        sched = srv.Scheduler(eng, depth=6)
+        sched.start()
+        try:
+            sts = [sched.open() for _ in range(n_streams)]
+            got = [[] for _ in range(n_streams)]
+
+            def run(i):
+                for c in chunks[i]:
+                    sched.push_nowait(sts[i], c)
+                sched.push_eof(sts[i])
+                while True:
+                    r = sts[i].outq.get(timeout=60)
+                    if r is srv.EOF:
+                        return
+                    assert not isinstance(r, Exception), r
+                    if r is not None:
+                        got[i].append(r)
+
+            ths = [threading.Thread(target=run, args=(i,)) for i in range(n_streams)]
+            [t.start() for t in ths]
+            [t.join(timeout=120) for t in ths]
+            for i in range(n_streams):
+                assert got[i] == ref[i], f"stream {i}"
+            assert sched.max_inflight_seen > 1
+            for st in sts:
+                sched.close(st)
+        finally:
+            sched.shutdown()
+    finally:
+        eng.close()
