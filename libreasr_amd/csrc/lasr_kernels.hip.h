@@ -744,13 +744,15 @@ struct BeamState {
     int* done2;          // [64] second arrival counter (k_beam_fuse)
 };
 
-// WT: compile-time bound of W (2, 4, 8).  One workgroup of 1024 threads per stream: its W x V logits
-// are read ONCE into registers (KEEP = 4 per thread and row: V <= 4096, issued before anything else);
+// WT: compile-time bound of W (2, 4, 8).  One workgroup of NT threads per stream: its W x V logits
+// are read ONCE into registers (KEEP = 4 per thread and row: V <= 4 NT, issued before anything else);
 // the statistics of all rows are reduced together and the W ordered argmax passes scan 4 W register
 // values per thread, so the kernel is a handful of block reductions deep.
-template <int WT>
-__global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ logits, BeamState s, int iter_slot) {
-    constexpr int KEEP = 4, NT = 1024, NWV = NT / 64;
+// NT: threads per workgroup = 512 for V <= 2048 (all KEEP register slots of a row hold real logits: half the waves, half the
+// wave winners to merge, the same instructions per thread), 1024 up to V = 4096.
+template <int WT, int NT>
+__global__ __launch_bounds__(NT) void k_beam_select(const float* __restrict__ logits, BeamState s, int iter_slot) {
+    constexpr int KEEP = 4, NWV = NT / 64;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int W = s.W, V = s.V, r0 = q * W;
     // ---- the stream's logits -> registers (in flight while the state below is fetched)

@@ -279,9 +279,18 @@ const int* cur_lm_valid(lasr_ctx* c) { return (c->W > 1 && c->lm.par) ? c->lm.va
 void launch_beam_select(lasr_ctx* c, BeamState& b, int iter_slot) {
     const int M = c->M;
     b.lm_on = c->lm.on ? 1 : 0; b.done2 = c->c_done2;
-    if (c->W <= 2) hipLaunchKernelGGL((k_beam_select<2>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter_slot);
-    else if (c->W <= 4) hipLaunchKernelGGL((k_beam_select<4>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter_slot);
-    else hipLaunchKernelGGL((k_beam_select<8>), dim3(M), dim3(1024), 0, c->stream, (const float*)c->logits, b, iter_slot);
+    static const int nt_env = getenv("LASR_BEAM_NT") ? atoi(getenv("LASR_BEAM_NT")) : 0;      // experiment: 512 | 1024
+    const bool small = nt_env ? nt_env == 512 && c->d.vocab <= 2048 : c->d.vocab <= 2048;
+    const float* lg = (const float*)c->logits;
+    if (small) {
+        if (c->W <= 2) hipLaunchKernelGGL((k_beam_select<2, 512>), dim3(M), dim3(512), 0, c->stream, lg, b, iter_slot);
+        else if (c->W <= 4) hipLaunchKernelGGL((k_beam_select<4, 512>), dim3(M), dim3(512), 0, c->stream, lg, b, iter_slot);
+        else hipLaunchKernelGGL((k_beam_select<8, 512>), dim3(M), dim3(512), 0, c->stream, lg, b, iter_slot);
+    } else {
+        if (c->W <= 2) hipLaunchKernelGGL((k_beam_select<2, 1024>), dim3(M), dim3(1024), 0, c->stream, lg, b, iter_slot);
+        else if (c->W <= 4) hipLaunchKernelGGL((k_beam_select<4, 1024>), dim3(M), dim3(1024), 0, c->stream, lg, b, iter_slot);
+        else hipLaunchKernelGGL((k_beam_select<8, 1024>), dim3(M), dim3(1024), 0, c->stream, lg, b, iter_slot);
+    }
     if (c->lm.on)
         hipLaunchKernelGGL(k_beam_fuse, dim3(c->Md), dim3(256), 0, c->stream, (const float*)c->logits, b, iter_slot, cur_lmz(c), cur_lm_valid(c),
                            c->lm.alpha, c->lm.theta, c->lm.min_val);
