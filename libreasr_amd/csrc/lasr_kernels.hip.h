@@ -321,14 +321,15 @@ __global__ void k_step_begin(DecState s, int M, int n_iter_slots, int reset_metr
 // on nothing this kernel loads) and their statistics are reduced together: one load round trip and two block reductions per
 // launch whatever la is; the decisions are then replayed in order from the per-frame (argmax, log p) by every thread (no
 // barrier in the state machine).  Same decisions, same order, same arithmetic per frame as the one-frame loop.
-template <bool PLAIN, int LAT>
+// KEEP: logits kept in registers per thread and frame (8 covers V <= 2048, 16 V <= 4096; the rest of a larger row is re-read).  A
+// slot past V holds -inf and contributes an exact zero, so the results do not depend on KEEP.
+template <bool PLAIN, int LAT, int KEEP>
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits, int V, int blank, int max_iters,
                                                 const int* __restrict__ T_row, DecState s, int iter_slot_in,
                                                 float* __restrict__ out_logp, int* __restrict__ out_arg, int la, int M) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool dbgt = !PLAIN && s.dbg && r == 0 && tid == 0;
     const unsigned long long t_entry = dbgt ? wall_clock64() : 0ull;
-    constexpr int KEEP = 16;                        // logits kept in registers per thread and frame (V <= 4096)
     float zv[LAT][KEEP];
 #pragma unroll
     for (int k = 0; k < LAT; ++k) {
@@ -540,9 +541,15 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
 template <bool PLAIN>
 inline void launch_select(hipStream_t st, int rows, const float* logits, int V, int blank, int max_iters, const int* T_row,
                           const DecState& s, int iter_slot, float* out_logp, int* out_arg, int la, int M) {
-    if (la <= 1) hipLaunchKernelGGL((k_select<PLAIN, 1>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, 1, M);
-    else if (la == 2) hipLaunchKernelGGL((k_select<PLAIN, 2>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, la, M);
-    else hipLaunchKernelGGL((k_select<PLAIN, 4>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, la, M);
+    if (V <= 2048 && !s.lmz) {      // (the LM re-pick keeps the whole row in registers: 16 slots)
+        if (la <= 1) hipLaunchKernelGGL((k_select<PLAIN, 1, 8>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, 1, M);
+        else if (la == 2) hipLaunchKernelGGL((k_select<PLAIN, 2, 8>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, la, M);
+        else hipLaunchKernelGGL((k_select<PLAIN, 4, 8>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, la, M);
+        return;
+    }
+    if (la <= 1) hipLaunchKernelGGL((k_select<PLAIN, 1, 16>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, 1, M);
+    else if (la == 2) hipLaunchKernelGGL((k_select<PLAIN, 2, 16>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, la, M);
+    else hipLaunchKernelGGL((k_select<PLAIN, 4, 16>), dim3(rows), dim3(256), 0, st, logits, V, blank, max_iters, T_row, s, iter_slot, out_logp, out_arg, la, M);
 }
 
 // LMFuser.advance (lm.py:49-53) for the rows that just emitted a token: log_softmax of the LM's output
