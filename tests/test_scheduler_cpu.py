@@ -343,6 +343,102 @@ def test_an_engine_error_ends_the_scheduler_and_reaches_every_waiter():
         sched.open()
 
 
+def test_random_stream_lifetimes_keep_the_bookkeeping_consistent():
+    """Streams of random length opened, fed (per-stream form, with and without the reset rule, some silent), reset and closed from
+    several client threads while others run: every stream's results are its own sequence, slots are reused, and the scheduler ends
+    with nothing waiting and nothing in flight."""
+    eng = FakeEngine(max_streams=6, silent={1, 4})
+    sched = srv.Scheduler(eng, depth=5)
+    sched.start()
+    errors = []
+
+    def client(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for _ in range(6):
+                ruled = bool(rng.integers(0, 2))
+                st = sched.open(text_of=(lambda t: "x" if t else "") if ruled else None)
+                n = int(rng.integers(1, 90))
+                data = [rng.integers(0, 9, 4).astype(np.float32) for _ in range(n)]
+                out = []
+                if rng.integers(0, 2):
+                    run_stream(sched, st, data, out)
+                else:                       # the blocking form, one frame at a time
+                    out = [sched.push(st, c) for c in data]
+                exp = expected(data, slot_silent=st.slot in eng.silent, text_rule=ruled)
+                if out != exp:
+                    errors.append((seed, st.slot, n, ruled))
+                if rng.integers(0, 3) == 0:
+                    sched.reset(st)
+                sched.close(st)
+        except Exception as e:              # pragma: no cover
+            errors.append((seed, repr(e)))
+
+    try:
+        ths = [threading.Thread(target=client, args=(100 + i,)) for i in range(5)]
+        [t.start() for t in ths]
+        [t.join(timeout=60) for t in ths]
+        assert not any(t.is_alive() for t in ths)
+        assert not errors, errors
+        assert sched.n_wait == 0 and not sched.inflight and not sched.streams
+        assert int(sched.qn.sum()) == 0 and not sched.eofp.any() and sched.n_eof == 0 and sched.n_slow == 0 and sched.n_ruled == 0
+        assert int(sched.infl.sum()) == 0
+    finally:
+        sched.shutdown()
+
+
+@pytest.mark.parametrize("ruled,close_at", [(False, None), (True, 17), (True, None)])
+def test_a_trunk_beside_per_stream_clients_with_a_member_closed_midway(ruled, close_at):
+    """A trunk of three streams fed by one producer, two per-stream clients beside it in the same scheduler, one trunk member
+    closed while batches keep coming: everybody still gets exactly their own sequence."""
+    eng = FakeEngine(max_streams=8, silent={2})
+    sched = srv.Scheduler(eng, depth=4)
+    sched.start()
+    errors = []
+    tf = (lambda t: "x" if t else "") if ruled else None
+    try:
+        rng0 = np.random.default_rng(3)
+        B, n = 3, 90
+        sts = [sched.open(text_of=tf) for _ in range(B)]
+        chunks = rng0.integers(0, 9, (n, B, 4)).astype(np.float32)
+
+        def trunk():
+            for k in range(n):
+                if close_at is not None and k == close_at:
+                    sched.close(sts[1])
+                sched.push_batch(sts, chunks[k])
+
+        def client(seed):
+            rng = np.random.default_rng(seed)
+            for _ in range(3):
+                st = sched.open(text_of=tf)
+                data = [rng.integers(0, 9, 4).astype(np.float32) for _ in range(int(rng.integers(1, 80)))]
+                out = []
+                run_stream(sched, st, data, out)
+                if out != expected(data, slot_silent=st.slot in eng.silent, text_rule=ruled):
+                    errors.append((seed, st.slot))
+                sched.close(st)
+
+        ths = [threading.Thread(target=trunk)] + [threading.Thread(target=client, args=(50 + i,)) for i in range(2)]
+        [t.start() for t in ths]
+        [t.join(timeout=60) for t in ths]
+        assert not any(t.is_alive() for t in ths) and not errors, errors
+        live = [i for i in range(B) if not (close_at is not None and i == 1)]
+        want = {sts[i].slot: [t for t in expected([chunks[k, i] for k in range(n)], slot_silent=sts[i].slot in eng.silent,
+                                                  text_rule=ruled) if t is not None] for i in live}
+        got = {sts[i].slot: [] for i in range(B)}
+        while any(len(got[sl]) < len(want[sl]) for sl in want):
+            item = sched.batch_outq.get(timeout=20)
+            assert not isinstance(item, Exception), item
+            for st, t in zip(*item):
+                got[st.slot].append(t)
+        for sl in want:
+            assert got[sl] == want[sl], sl
+        assert sched.n_wait == 0 and not sched.inflight
+    finally:
+        sched.shutdown()
+
+
 def test_shutdown_unblocks_everyone():
     eng = FakeEngine()
     sched = srv.Scheduler(eng, depth=2)
