@@ -2,7 +2,7 @@
 device path (PCM in, token ids / text out; features never leave the GPU).
 
     asr = LibreASR.load("en", synthetic="cfg2")
-    text = asr.transcribe(pcm)                       # 1-D float32 16 kHz, or path to a .flac
+    text = asr.transcribe(pcm)                       # 1-D float32 16 kHz, or path to a .flac / .wav (any rate: resampled on the GPU)
     for text_so_far in asr.stream(chunks): ...       # 80 ms float32 chunks (bytes / arrays / tensors)
 """
 import numpy as np
@@ -36,12 +36,27 @@ class LibreASR:
             return x.reshape(-1)
         return np.asarray(x, dtype=np.float32).reshape(-1)
 
+    def _utterance(self, x):
+        """One utterance at the model rate.  Files (.flac, .wav; first channel, as ChannelCut transforms.py:128-132) at another rate
+        go through the engine's resampler, the call the servicer makes for a unary request (Resample.encodes, transforms.py:135-144)."""
+        if not isinstance(x, str):
+            return self._pcm(x)
+        if x.lower().endswith((".wav", ".wave")):
+            from . import wav
+            pcm, sr, _ = wav.decode(x)
+        else:
+            from . import flac
+            pcm, sr, _ = flac.decode(x)
+        if sr != self.engine.desc.sample_rate:
+            pcm = self.engine.resample(torch.as_tensor(np.ascontiguousarray(pcm)[None]).to(self.engine.device), sr)[0]
+        return pcm
+
     def transcribe(self, audio, return_ids=False):
         """Whole utterance(s): fresh state, greedy, max_iters_offline (Transcribe RPC, api-server.py:64-80)."""
         batch = audio if isinstance(audio, (list, tuple)) else [audio]
         slots = [self.engine.open() for _ in batch]
         try:
-            self.engine.transcribe_pcm(slots, [self._pcm(a) for a in batch])
+            self.engine.transcribe_pcm(slots, [self._utterance(a) for a in batch])
             ids = [self.engine.fetch(s)[0] for s in slots]
         finally:
             for s in slots:

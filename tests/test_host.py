@@ -257,3 +257,67 @@ def test_fastai_checkpoint_with_optimizer_state_loads_and_nothing_from_it_runs(t
     torch.save({"opt": 1}, p)
     with pytest.raises(ValueError):
         mu.load_model_state_dict(p)
+
+
+def test_wav_reader_formats(tmp_path):
+    """libreasr_amd/wav.py: integer PCM 8 / 16 / 24 / 32 bit, float32 / float64, WAVE_FORMAT_EXTENSIBLE, odd chunk sizes, extra
+    chunks; first channel only, scaled as torchaudio.load does (2^(bits-1))."""
+    import struct
+    import wave
+    from libreasr_amd import wav
+
+    rng = np.random.default_rng(0)
+    n = 777
+
+    def riff(fmt_body, data, extra=b""):
+        body = b"WAVE" + extra + b"fmt " + struct.pack("<I", len(fmt_body)) + fmt_body + b"data" + struct.pack("<I", len(data)) + data
+        if len(data) & 1:
+            body += b"\0"
+        return b"RIFF" + struct.pack("<I", len(body)) + body
+
+    # 16-bit stereo written by the stdlib
+    x16 = rng.integers(-32768, 32767, (n, 2)).astype(np.int16)
+    p = str(tmp_path / "a.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(48000)
+        w.writeframes(x16.tobytes())
+    y, sr, bits = wav.decode(p)
+    assert (sr, bits) == (48000, 16) and np.array_equal(y, x16[:, 0].astype(np.float32) / 32768.0)
+    # 8-bit unsigned mono with an odd data size, and a LIST chunk in front of fmt
+    x8 = rng.integers(0, 255, n).astype(np.uint8)
+    p = str(tmp_path / "b.wav")
+    open(p, "wb").write(riff(struct.pack("<HHIIHH", 1, 1, 8000, 8000, 1, 8), x8.tobytes(), extra=b"LIST" + struct.pack("<I", 3) + b"abc\0"))
+    y, sr, bits = wav.decode(p)
+    assert (sr, bits) == (8000, 8) and np.array_equal(y, (x8.astype(np.float32) - 128.0) / 128.0)
+    # 24-bit mono
+    v24 = rng.integers(-(1 << 23), (1 << 23) - 1, n)
+    raw = b"".join(int(v).to_bytes(3, "little", signed=True) for v in v24)
+    p = str(tmp_path / "c.wav")
+    open(p, "wb").write(riff(struct.pack("<HHIIHH", 1, 1, 44100, 44100 * 3, 3, 24), raw))
+    y, sr, bits = wav.decode(p)
+    assert (sr, bits) == (44100, 24) and np.array_equal(y, (v24.astype(np.float64) / float(1 << 23)).astype(np.float32))
+    # 32-bit integer, 3 channels, WAVE_FORMAT_EXTENSIBLE
+    v32 = rng.integers(-(1 << 31), (1 << 31) - 1, (n, 3)).astype(np.int32)
+    ext = struct.pack("<HHIIHH", 0xFFFE, 3, 16000, 16000 * 12, 12, 32) + struct.pack("<HHI", 22, 32, 7) + struct.pack("<H", 1) + b"\0" * 14
+    p = str(tmp_path / "d.wav")
+    open(p, "wb").write(riff(ext, v32.tobytes()))
+    y, sr, bits = wav.decode(p)
+    assert (sr, bits) == (16000, 32) and np.array_equal(y, (v32[:, 0].astype(np.float64) / float(1 << 31)).astype(np.float32))
+    # float32 and float64
+    f = rng.standard_normal((n, 2)).astype(np.float32)
+    p = str(tmp_path / "e.wav")
+    open(p, "wb").write(riff(struct.pack("<HHIIHH", 3, 2, 16000, 16000 * 8, 8, 32), f.tobytes()))
+    y, sr, bits = wav.decode(p)
+    assert (sr, bits) == (16000, 32) and np.array_equal(y, f[:, 0])
+    p = str(tmp_path / "f.wav")
+    open(p, "wb").write(riff(struct.pack("<HHIIHH", 3, 1, 22050, 22050 * 8, 8, 64), f[:, 1].astype(np.float64).tobytes()))
+    y, sr, bits = wav.decode(p)
+    assert (sr, bits) == (22050, 64) and np.array_equal(y, f[:, 1])
+    # refusals
+    for bad in (b"RIFX" + b"\0" * 40, riff(struct.pack("<HHIIHH", 7, 1, 8000, 8000, 1, 8), b"\0" * 8), riff(struct.pack("<HHIIHH", 1, 2, 8000, 8000, 3, 16), b"\0" * 8)):
+        p = str(tmp_path / "bad.wav")
+        open(p, "wb").write(bad)
+        with pytest.raises(ValueError):
+            wav.decode(p)
