@@ -70,7 +70,8 @@ typedef struct {
                          /* lasr_fetch then returns the WHOLE current best hypothesis    */
                          /* after every model step (it may change retroactively),        */
                          /* neg_logp = -its score, align = 0.  Both protocols (the        */
-                         /* pipelined one: <= 512 stream slots); no LM inside the beam.   */
+                         /* pipelined one: <= 512 stream slots); an attached LM is fused  */
+                         /* inside the beam (see lasr_attach_lm).                         */
 } lasr_model_desc;
 
 /* Fills `d` with the reference defaults listed above (4x1024 encoder, 2xNBRC predictor). */
@@ -225,6 +226,22 @@ int lasr_sync(lasr_ctx* c);
  * K-loop end / reduce / exit, wall clock at entry / exit) of the last launch of each GEMM kind
  * (0 encoder cell, 1-2 predictor layers, 3 PPJ, 4 logits): out[5][4096][16] (slots 8..15: per-wave end of the K loop). */
 int lasr_debug_timing(lasr_ctx* c, unsigned long long* out);
+
+/* Debug / test read-out of the resident per-slot state (what the reference keeps in Python closures: the servicer's window,
+ * Buffer.saved, the encoder / predictor state of Transducer.transcribe_stream, models.py:466-500).  Synchronises both engine
+ * streams, then copies one [rows][cols] row-major float32 matrix to `out` (host, `cap` floats; *rows / *cols optional):
+ *   what 0: LayerNorm'ed stacked features of frame `index` of the last step   [M][feat]
+ *        1 / 2: encoder h / c of layer `index`                                [M][hidden]
+ *        3: encoder half of the joint (synchronous protocol), frame `index`   [M][joint]
+ *        4: predictor half of the joint                                        [M * beam][joint]
+ *        5: predictor h of layer `index`                                       [M * beam][hidden]
+ *        6: the PCM ring                                                       [M][(n_window + n_buffer - 1) * chunk]
+ *        7: pending log-mel frames (Buffer)                                    [M][n_buffer * n_stack * n_mels]
+ *        8: last encoder layer's BatchNorm'ed output, frame `index`            [M][hidden]
+ *        9: integers as floats [8][M]: device ring position, host mirror, chunks pushed, frames pending, frames of the
+ *           last step, frame cursor, last token, emitted flag
+ * M = max_streams rounded up to 64.  LASR_EFULL if cap is too small (*rows / *cols are set). */
+int lasr_debug_read(lasr_ctx* c, int what, int index, float* out, size_t cap, int* rows, int* cols);
 
 /* ---- Resampling for non-16 kHz clients.  Replaces Resample.encodes, transforms.py:135-144
  * (torchaudio 0.6.0 transforms.Resample == compliance.kaldi.resample_waveform, lowpass_filter_width 6: a

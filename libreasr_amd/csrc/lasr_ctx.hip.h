@@ -226,6 +226,8 @@ struct lasr_ctx {
 
     // host results
     int* res_host = nullptr;        // pinned: unfinished flag + ntok + tokens + metrics
+    int* res_dev = nullptr;         // its device view (k_publish stores the step's results there)
+    int* pub_arrivals = nullptr;    // device: workgroups of the running k_publish that have stored their part
     size_t res_bytes = 0;
 
     // host mirrors
@@ -299,6 +301,10 @@ int dalloc(lasr_ctx* c, T** p, size_t n) {
     if (e != hipSuccess) return fail(c, LASR_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
     c->dev_allocs.push_back(q);
     *p = (T*)q;
+    // LASR_POISON=1 (tests / soak): every device allocation starts as 0xff bytes (f32 / bf16 NaN, int -1) instead of whatever the
+    // previous owner of the memory left: a kernel that reads a buffer it should first have written shows up at once
+    static const int poison = getenv("LASR_POISON") ? atoi(getenv("LASR_POISON")) : 0;
+    if (poison && hipMemset(q, 0xff, n * sizeof(T)) != hipSuccess) return fail(c, LASR_EHIP, "poison fill failed");
     return LASR_OK;
 }
 void dfree(lasr_ctx* c, void* p) {

@@ -233,12 +233,26 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
             launch_ppj(c);
             launch_lm(c);
         }
-        // payload first, the "rows still decoding" word last: the host spins on that word
-        HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * ((size_t)M + (size_t)M * s.tok_cap), hipMemcpyDeviceToHost, c->stream));
-        if (offline) {
-            HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(n_ones, c->ds.n_ones, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(logp, c->ds.logp_sum, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+        // The host spins on the "rows still decoding" word in pinned memory.  Streaming: the step's tokens so far travel with it --
+        // k_publish stores them into the pinned block and releases the word last (system scope).  Offline (whole utterances,
+        // large token blocks): only the word comes back per group; the results are copied once at the end, behind a real
+        // synchronisation.  A word that arrives by hipMemcpyAsync carries nothing but itself: no ordering against any other
+        // copy is assumed anywhere (LASR_SYNC_MEMCPY=1 restores the round-3 "payload copy, then flag copy" for A/B runs).
+        static const bool legacy = getenv("LASR_SYNC_MEMCPY") && atoi(getenv("LASR_SYNC_MEMCPY")) != 0;
+        const int n_pay = M + M * s.tok_cap;
+        if (!offline && !legacy) {
+            const int nb = std::max(1, std::min(64, (n_pay + 1023) / 1024));
+            hipLaunchKernelGGL(k_publish, dim3(nb), dim3(256), 0, c->stream, (const int*)c->ds.step_ntok, c->res_dev + 4, n_pay,
+                               (const int*)(c->ds.unfinished + (first + n - 1)), c->res_dev, c->pub_arrivals);
+            return LASR_OK;
+        }
+        if (legacy) {
+            HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * (size_t)n_pay, hipMemcpyDeviceToHost, c->stream));
+            if (offline) {
+                HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(n_ones, c->ds.n_ones, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(logp, c->ds.logp_sum, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+            }
         }
         HIPCHK(c, hipMemcpyAsync(res, c->ds.unfinished + (first + n - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
         return LASR_OK;
@@ -246,6 +260,8 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
     while (iter < total_cap) {
         const int n = std::min(group, total_cap - iter);
         bool launched = false;
+        __atomic_store_n(&res[0], -1, __ATOMIC_RELEASE);      // sentinel, overwritten by the last copy of the group (stored BEFORE anything
+                                                              // of the group is enqueued: a fast group must not be overwritten by it)
         if (graphs && (n % 2) == 0) {
             const auto key = std::make_tuple(iter, n, buf_idx, c->pred_par + 2 * c->lm.par, T_max * 1024 + max_iters);
             auto it = c->graphs.find(key);
@@ -265,12 +281,13 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
             HIPCHK(c, hipGraphLaunch(it->second, c->stream));
             launched = true;
         }
-        __atomic_store_n(&res[0], -1, __ATOMIC_RELEASE);      // sentinel, overwritten by the last copy of the group
         if (!launched) RC(enqueue_group(iter, n));
         iter += n;
         // spin on the pinned word instead of hipStreamSynchronize (interrupt wake-up costs ~10-20 us per
-        // round trip, and there are 2-4 per step); fall back to a real sync if nothing arrives
-        {
+        // round trip, and there are 2-4 per step); fall back to a real sync if nothing arrives.  LASR_SPIN=0: always a real sync
+        static const bool spin = !(getenv("LASR_SPIN") && atoi(getenv("LASR_SPIN")) == 0);
+        if (!spin) HIPCHK(c, hipStreamSynchronize(c->stream));
+        else {
             unsigned long long spins = 0;
             while (__atomic_load_n((volatile int*)&res[0], __ATOMIC_ACQUIRE) == -1) {
                 __builtin_ia32_pause();
@@ -281,6 +298,14 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
         group = next_group;
     }
     c->stats.decode_iters = iter;
+    if (offline && !(getenv("LASR_SYNC_MEMCPY") && atoi(getenv("LASR_SYNC_MEMCPY")) != 0)) {
+        // offline results: one copy each, read only after the stream has been synchronised
+        HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * ((size_t)M + (size_t)M * s.tok_cap), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(n_ones, c->ds.n_ones, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(logp, c->ds.logp_sum, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     for (int r : rows) {
         const int n = std::min(ntok[r], s.tok_cap);
         for (int q = 0; q < n; ++q) c->queue[r].push_back(toks[(size_t)r * s.tok_cap + q]);

@@ -293,6 +293,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     RC(dalloc(c, &c->ds.emit, Md)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->zero_rows, M));
     HIPCHK(c, hipMemset(c->zero_rows, 0, sizeof(int) * M));
+    RC(dalloc(c, &c->pub_arrivals, 4)); HIPCHK(c, hipMemset(c->pub_arrivals, 0, sizeof(int) * 4));
     RC(dalloc(c, &c->T_row_fix, M));
     HIPCHK(c, hipMemset(c->T_row_fix, 0, sizeof(int) * M));
     RC(dalloc(c, &c->T_row_main, M));
@@ -2020,6 +2021,74 @@ int lasr_trace_read(lasr_ctx* c, double* us, int* tags, int cap, int* n) {
         us[i] = 1e3 * (double)ms;
         *n = i + 1;
     }
+    return LASR_OK;
+}
+
+// Debug / test read-out of the resident state (synchronises the ctx stream and the decode stream): [rows][K] row-major f32
+// into `out` (host).  what: 0 x0 (LayerNorm'ed features) of frame `index`; 1 enc_h / 2 enc_c of layer `index` (current
+// parity); 3 pe (joint encoder half, synchronous buffer) of frame `index`; 4 pp; 5 pred_h of layer `index` (current parity,
+// decoder rows); 6 PCM ring [M][ring_chunks * chunk]; 7 pending log-mel frames [M][n_buffer * n_stack * n_mels];
+// 8 last encoder layer's output of frame `index`; 9 integers as floats [8][M]: ring_pos, host ring mirror, n_chunks,
+// n_pend, T_row_fix, t_idx, token, emit.  *rows / *cols (optional) describe the matrix; cap = floats `out` holds.
+int lasr_debug_read(lasr_ctx* c, int what, int index, float* out, size_t cap, int* rows, int* cols) {
+    if (!c || !out) return LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream_dec) HIPCHK(c, hipStreamSynchronize(c->stream_dec));
+    const lasr_model_desc& d = c->d;
+    const int M = c->M, H = d.hidden, F = d.feat, J = d.joint;
+    int R = M, K = 0;
+    const int mt_total = c->Tcap * c->MT;
+    enum { FRAG, ROWMAJ_ELEM, ROWMAJ_F32, UNITMAJ, INTS } kind = ROWMAJ_F32;
+    const void* src = nullptr; int frag_mt_total = 0, frag_mt_off = 0;
+    switch (what) {
+        case 0: if (index < 0 || index >= c->Tcap) return fail(c, LASR_EINVAL, "frame out of range");
+                kind = FRAG; src = c->x0; K = F; frag_mt_total = mt_total; frag_mt_off = index * c->MT; break;
+        case 1: if (index < 0 || index >= d.enc_layers) return fail(c, LASR_EINVAL, "layer out of range");
+                kind = FRAG; src = c->enc_h[c->enc_par][index]; K = H; frag_mt_total = c->MT; frag_mt_off = 0; break;
+        case 2: if (index < 0 || index >= d.enc_layers) return fail(c, LASR_EINVAL, "layer out of range");
+                kind = UNITMAJ; src = c->enc_c[index]; K = H; break;
+        case 3: if (index < 0 || index >= c->Tcap) return fail(c, LASR_EINVAL, "frame out of range");
+                kind = ROWMAJ_F32; src = c->pe_sync + (size_t)index * M * J; K = J; break;
+        case 4: kind = ROWMAJ_F32; src = cur_pp(c); K = J; R = c->Md; break;
+        case 5: if (index < 0 || index >= d.pred_layers) return fail(c, LASR_EINVAL, "layer out of range");
+                kind = ROWMAJ_ELEM; src = c->pred_h[c->pred_par][index]; K = H; R = c->Md; break;
+        case 6: kind = ROWMAJ_F32; src = c->win; K = c->ring_chunks * d.chunk; break;
+        case 7: kind = ROWMAJ_F32; src = c->pend; K = d.n_buffer * d.n_stack * d.n_mels; break;
+        case 8: if (index < 0 || index >= c->Tcap) return fail(c, LASR_EINVAL, "frame out of range");
+                kind = FRAG; src = c->ybuf[(d.enc_layers - 1) & 1]; K = H; frag_mt_total = mt_total; frag_mt_off = index * c->MT; break;
+        case 9: kind = INTS; R = 8; K = M; break;
+        default: return fail(c, LASR_EINVAL, "unknown debug read %d", what);
+    }
+    if (rows) *rows = R;
+    if (cols) *cols = K;
+    if ((size_t)R * K > cap) return fail(c, LASR_EFULL, "debug read needs %zu floats", (size_t)R * K);
+    if (kind == INTS) {
+        std::vector<int> tmp(M);
+        auto put = [&](int row, const int* v) { for (int r = 0; r < M; ++r) out[(size_t)row * M + r] = (float)v[r]; };
+        HIPCHK(c, hipMemcpy(tmp.data(), c->ring_pos, sizeof(int) * M, hipMemcpyDeviceToHost)); put(0, tmp.data());
+        put(1, c->h_ring_pos.data()); put(2, c->n_chunks.data()); put(3, c->n_pend.data());
+        HIPCHK(c, hipMemcpy(tmp.data(), c->T_row_fix, sizeof(int) * M, hipMemcpyDeviceToHost)); put(4, tmp.data());
+        HIPCHK(c, hipMemcpy(tmp.data(), c->ds.t_idx, sizeof(int) * M, hipMemcpyDeviceToHost)); put(5, tmp.data());
+        HIPCHK(c, hipMemcpy(tmp.data(), c->ds.token, sizeof(int) * M, hipMemcpyDeviceToHost)); put(6, tmp.data());
+        HIPCHK(c, hipMemcpy(tmp.data(), c->ds.emit, sizeof(int) * M, hipMemcpyDeviceToHost)); put(7, tmp.data());
+        return LASR_OK;
+    }
+    if (kind == ROWMAJ_F32) {
+        HIPCHK(c, hipMemcpy(out, src, sizeof(float) * (size_t)R * K, hipMemcpyDeviceToHost));
+        return LASR_OK;
+    }
+    float* tmp = nullptr;
+    RC(dalloc(c, &tmp, (size_t)R * K));
+    if (kind == FRAG)
+        hipLaunchKernelGGL(k_from_frag, dim3(grid1((size_t)R * K)), dim3(256), 0, c->stream, src, frag_mt_total, frag_mt_off, tmp, K, R, K, c->bf);
+    else if (kind == ROWMAJ_ELEM)
+        hipLaunchKernelGGL(k_from_elem, dim3(grid1((size_t)R * K)), dim3(256), 0, c->stream, src, tmp, (size_t)R * K, c->bf);
+    else
+        hipLaunchKernelGGL(k_c_to_rows, dim3(grid1((size_t)R * K)), dim3(256), 0, c->stream, (const float*)src, M, tmp, R, K);
+    hipError_t e = hipMemcpy(out, tmp, sizeof(float) * (size_t)R * K, hipMemcpyDeviceToHost);
+    dfree(c, tmp);
+    if (e != hipSuccess) return fail(c, LASR_EHIP, "debug read copy failed: %s", hipGetErrorString(e));
     return LASR_OK;
 }
 

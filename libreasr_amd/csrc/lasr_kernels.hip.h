@@ -285,6 +285,24 @@ __device__ __forceinline__ void wave_argmax_f32(float& best, int& arg) {
     best = b; arg = a;
 }
 
+// Synchronous protocol, end of a group of decode iterations: the step's results so far (token counts + tokens) go to the
+// pinned result block by zero-copy stores and the "rows still decoding" word is published LAST, by a system-scope release
+// store of the last workgroup to arrive -- the host spins on that word.  (Two hipMemcpyAsync calls "payload, then flag" are
+// NOT such a protocol: HIP orders the copies on the stream, not their visibility to a host that has not synchronised; a
+// fresh flag over a stale payload was observed at a rate of 3e-3 per stream, tools/soak.py.)
+__global__ __launch_bounds__(256) void k_publish(const int* __restrict__ src, int* __restrict__ dst_host, int n,
+                                                 const int* __restrict__ flag_src, int* __restrict__ flag_host, int* __restrict__ arrivals) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst_host[i] = src[i];
+    __threadfence_system();                          // this thread's stores are visible system-wide ...
+    __syncthreads();                                 // ... and so are the whole workgroup's
+    if (threadIdx.x == 0) {
+        if (atomicAdd(arrivals, 1) == (int)gridDim.x - 1) {
+            atomicExch(arrivals, 0);                 // the next launch is stream-ordered behind this one
+            __hip_atomic_store(flag_host, *flag_src, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // frames of newly encoded steps become visible to the decode loop (continuous mode)
 __global__ void k_advance(int* __restrict__ counter, const int* __restrict__ add, int M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

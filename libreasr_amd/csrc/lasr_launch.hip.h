@@ -435,6 +435,12 @@ int ensure_T(lasr_ctx* c, int T) {
     if (c->res_host) (void)hipHostFree(c->res_host);
     c->res_bytes = sizeof(int) * (8 + 3 * (size_t)M) + sizeof(double) * M + sizeof(int) * (size_t)M * c->tok_cap_alloc + 64;
     HIPCHK(c, hipHostMalloc((void**)&c->res_host, c->res_bytes));
+    memset(c->res_host, 0, c->res_bytes);
+    {
+        void* dp = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer(&dp, c->res_host, 0));
+        c->res_dev = (int*)dp;
+    }
     c->Tcap = cap;
     return LASR_OK;
 }

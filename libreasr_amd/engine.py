@@ -330,6 +330,20 @@ class Engine:
     def sync(self):
         self._chk(self.lib.lasr_sync(self.ctx))
 
+    DEBUG_READS = dict(x0=0, enc_h=1, enc_c=2, pe=3, pp=4, pred_h=5, ring=6, pend=7, enc_out=8, ints=9)
+
+    def debug_read(self, what, index=0):
+        """Resident state as a [rows, cols] float32 array (lasr_debug_read; tests and the soak tool)."""
+        w = self.DEBUG_READS[what] if isinstance(what, str) else int(what)
+        r, k = C.c_int(0), C.c_int(0)
+        probe = np.empty(1, dtype=np.float32)
+        rc = self.lib.lasr_debug_read(self.ctx, w, int(index), probe.ctypes.data_as(C.c_void_p), 0, C.byref(r), C.byref(k))
+        if rc != N.LASR_EFULL:
+            self._chk(rc)
+        out = np.empty((r.value, k.value), dtype=np.float32)
+        self._chk(self.lib.lasr_debug_read(self.ctx, w, int(index), out.ctypes.data_as(C.c_void_p), out.size, C.byref(r), C.byref(k)))
+        return out
+
     def cell_prof(self, on=True):
         """In-job HIP-event timing of the encoder-cell launches (see lasr_cell_prof)."""
         self._chk(self.lib.lasr_cell_prof(self.ctx, int(on)))      # True / 1: events + in-kernel clocks; 2: clocks only
