@@ -68,8 +68,28 @@ def dist_init(world, use_cuda):
     # (no device_id= here: binding the device at init makes the process group initialise RCCL eagerly, and the job then runs at
     #  37 k instead of 50 k audio-s/s on the MI355X -- measured at world 1, profiles/r03/r03_experiments.txt M; torch.cuda.set_device
     #  has already put this rank on its GPU, the lazily created communicator costs 1-2 %)
-    dist.init_process_group(backend=os.environ.get("LASR_BENCH_BACKEND", "nccl") if use_cuda else "gloo")
+    backend = os.environ.get("LASR_BENCH_BACKEND", "nccl") if use_cuda else "gloo"
+    if use_cuda and backend == "nccl" and os.environ.get("LASR_BENCH_EAGER_RCCL"):      # A/B: the eager initialisation (see above)
+        import torch
+        dist.init_process_group(backend=backend, device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group(backend=backend)
     return dist
+
+
+_HOST_PG = [None]
+
+
+def host_barrier(dist):
+    """The barriers that bracket the timed region run on a gloo group beside the RCCL one: a barrier on the default (RCCL)
+    group would create the communicator -- channels, streams, proxy threads -- right in front of t0, and an eagerly created
+    communicator has been seen to put both engine streams on one hardware queue (profiles/r03/r03_experiments.txt M).  RCCL is
+    still what carries the job's collectives (the max / sum all_reduce and the all_gather of the per-rank figures), after t1."""
+    if dist is None:
+        return
+    if _HOST_PG[0] is None:
+        _HOST_PG[0] = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
+    dist.barrier(group=_HOST_PG[0])
 
 
 def shard_streams(total_streams, world, rank):
@@ -400,7 +420,7 @@ def main():
         """barrier + sync | n steps, every token on the host | sync + barrier.  Returns (elapsed, tokens)."""
         torch.cuda.synchronize(device)
         if dist is not None and barrier:
-            dist.barrier()
+            host_barrier(dist)
         tokens = 0
         t0 = time.perf_counter()
         for k in range(k0, k0 + n):
@@ -411,7 +431,7 @@ def main():
         tokens += drain(lat_out)
         torch.cuda.synchronize(device)
         if dist is not None and barrier:
-            dist.barrier()
+            host_barrier(dist)
         return time.perf_counter() - t0, tokens
 
     # CPython's cyclic GC would stop this (single) host thread for tens of ms in the middle of the timed
@@ -445,6 +465,9 @@ def main():
         eng.cell_prof(args.cell_prof_in_timed)
     for k in host_us:
         host_us[k] = 0.0 if k != "n_model_steps" else 0
+    if dist is not None:
+        host_barrier(dist)                        # (creates the gloo group outside the timed region)
+    overlap_before = eng.overlap_probe(10000) if pipelined else float("nan")      # 2 x 10 ms: do the engine's streams overlap?
     elapsed, tokens = timed_region(P + W, K, lat_model, host=args.host_pcm, stats=on_stats)
     host_timed = dict(host_us)
     recording[0] = False                          # the self-check compares everything up to the end of the timed region
@@ -478,8 +501,9 @@ def main():
     elapsed_max, audio_total = aggregate(dist, elapsed, audio_local, device)
     # per-rank figures on rank 0 (a straggler is visible in the driver's N-GPU line): value, elapsed, host time per model step
     nms = max(1, host_timed["n_model_steps"])
+    overlap_after = eng.overlap_probe(10000) if pipelined else float("nan")       # ... and after the job's RCCL collectives
     mine = [float(rank), audio_local / elapsed, elapsed, 1e6 * host_timed["push"] / nms, 1e6 * host_timed["submit"] / nms,
-            1e6 * host_timed["wait"] / nms, 1e6 * host_timed["fetch"] / nms]
+            1e6 * host_timed["wait"] / nms, 1e6 * host_timed["fetch"] / nms, overlap_before, overlap_after]
     per_rank = [mine]
     if dist is not None:
         t = torch.tensor(mine, dtype=torch.float64, device=device)
@@ -538,11 +562,16 @@ def main():
                        "streams_per_gpu": B, "chunk_ms": 80, "parallelism": f"dp{world} (independent streams, no collective)",
                        "pipeline": (f"submit/wait, {args.depth} model steps in flight: encoder of later chunks on the main stream, "
                                     "one continuous greedy loop on a second stream") if pipelined else "synchronous",
+                       "decode_groups": ("launched by the library's native pump thread (LASR_PUMP=0: by the API calls)"
+                                         if os.environ.get("LASR_PUMP", "1") != "0" else "launched by the API calls (LASR_PUMP=0)") if pipelined else None,
                        "priming_chunks": P},
             "per_gpu_value": round(audio_total / elapsed_max / world, 1),
             "per_rank": [{"rank": int(v[0]), "value": round(v[1], 1), "elapsed_s": round(v[2], 5),
                           "host_us_per_model_step": {"push": round(v[3], 1), "submit": round(v[4], 1), "wait_incl_spin": round(v[5], 1),
-                                                     "fetch": round(v[6], 1)}} for v in per_rank],
+                                                     "fetch": round(v[6], 1), "busy": round(v[3] + v[4] + v[6], 1)},
+                          # two 10 ms delay kernels, one per engine stream, wall time / 10 ms: ~1 = concurrent, ~2 = one hardware queue
+                          "overlap_probe": {"before_timed": round(v[7], 3), "after_collectives": round(v[8], 3)},
+                          "streams_overlap": bool(v[7] < 1.5) if v[7] == v[7] else None} for v in per_rank],
             "latency_ms": {"definition": "host time from lasr_push_pcm of a model chunk to its tokens on the host"
                                          + (" (pipelined: includes the queueing behind the steps in flight)" if pipelined else ""),
                            "p50_model_chunk": round(1e3 * float(np.median(lat_model)), 4) if lat_model else None,
@@ -669,14 +698,17 @@ def main():
                 out["cpu_baseline"]["best_effort"] = {"error": str(e)[:200]}
         if dist is not None:
             out["dist"] = {"backend": dist.get_backend(), "world": world,
-                           "collectives": "barrier x4, all_reduce(MAX, SUM) of f64, all_gather of the per-rank figures"}
+                           "rccl_init": "eager" if os.environ.get("LASR_BENCH_EAGER_RCCL") else "lazy",
+                           "collectives": "all_reduce(MAX, SUM) of f64 and all_gather of the per-rank figures on " + dist.get_backend()
+                                          + " (device tensors), after the timed region; the barriers around the timed region on a gloo "
+                                            "group beside it (host_barrier)"}
         line = json.dumps(out)
         if out.get("tokens_equal") is False:
             print("bench.py: SELF-CHECK FAILED: " + json.dumps(out.get("self_check")), file=sys.stderr, flush=True)
             rc_final = 3
     eng.close()
     if dist is not None:
-        dist.barrier()
+        host_barrier(dist)
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:

@@ -158,7 +158,9 @@ int lasr_step_window(lasr_ctx* c, const int* slots, int n, const float* pcm, int
 int lasr_step_submit(lasr_ctx* c, const int* slots, int n);
 /* lasr_push_pcm_ex + lasr_step_submit for the same slot list in ONE call (same results): when the chunk completes a model
  * step the front-end launch takes the newest chunk from `pcm` and appends it to the PCM ring itself -- one launch less on
- * the critical stream per model step.  At the in-flight limit it returns LASR_ESTATE and NOTHING is pushed. */
+ * the critical stream per model step.  LASR_ESTATE (in-flight limit reached, unsupported shape for the pipelined protocol) and
+ * LASR_EINVAL mean NOTHING was pushed: call lasr_step_wait and repeat the call.  LASR_EHIP (the runtime failed underneath) leaves
+ * the chunk pushed. */
 int lasr_push_submit(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket);
 int lasr_step_wait(lasr_ctx* c, int* n_ran);
 int lasr_step_pending(lasr_ctx* c);   /* submitted model steps not yet collected (0..lasr_max_inflight()) */
@@ -281,6 +283,11 @@ int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights
  * layer `layer`), `iters` back-to-back launches timed with HIP events on the ctx stream.
  * Returns average microseconds per launch in *us. */
 int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us);
+
+/* Diagnostic of the pipelined protocol's premise: one wave per engine stream (the ctx stream, the decode stream) holds its stream
+ * for delay_us microseconds; *ratio = wall time / delay_us -- about 1 when the two streams run concurrently, about 2 when the
+ * runtime has put both on one hardware queue.  Needs an idle engine (no submitted step). */
+int lasr_overlap_probe(lasr_ctx* c, int delay_us, double* ratio);
 
 /* In-job timing of the dominant kernel (bench.py `roofline`): while on, the encoder-cell sequence of every model
  * step (enc_layers x frames back-to-back launches of the fused LSTM-cell GEMM) is bracketed by one HIP-event pair

@@ -130,6 +130,17 @@ struct lasr_ctx {
     int work_left = 0;              // rows that still had encoded frames to decode when the last consumed group ended
     long long model_steps = 0, cont_iters = 0, iters_reported = 0;
     bool group_inflight = false;    // a decode group has been launched and its flag not yet consumed
+    // native pump thread of the pipelined protocol (lasr_engine.hip, pump_main): owns the group launches while steps are in flight.
+    // mu guards the decode-side host state: pending, h_avail, h_cur_seen, work_left, group_inflight, cont_iters, pred_par / lm.par,
+    // the beam's host trees and results
+    std::mutex mu;
+    std::condition_variable cv_pump;
+    std::thread pump_th;
+    bool pump_started = false, pump_on = false;
+    std::atomic<bool> pump_stop{false};
+    int pump_G = 3;                 // iterations per group launched by the pump; LASR_PUMP_G
+    std::atomic<long long> kick{0}, progress{0};   // steps handed over by the API thread / groups consumed by the pump
+    int pump_rc = 0; std::string pump_err;
     int kick_n = 3, wait_n = 1;     // iterations per group: kicked from submit / launched while waiting (swept on configs[1])
     // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
     // predictor parity at group start, frames)
@@ -265,7 +276,7 @@ struct lasr_ctx {
     std::vector<int> tr_prev_cur, tr_prev_ntot;    // per-row cursors / token counts at the previous consumed group
     int tr_last_G = 0;
     hipEvent_t tr_base = nullptr;
-    int tr_n = 0;
+    std::atomic<int> tr_n{0};
 
     // stats
     bool profiling = false;

@@ -123,6 +123,13 @@ void run_encoder(lasr_ctx* c, int T_max) {
         for (int t = 0; t < T_max; ++t) key.push_back(c->tile_masks.empty() ? ~0ull : c->tile_masks[t]);
         auto it = c->mgraphs.find(key);
         bool ok = true;
+        if (it == c->mgraphs.end() && c->mgraphs.size() >= 64) {
+            // the key holds the per-frame masks of the active m-tiles: with many slots and churning streams the combinations do
+            // not repeat, and every new one costs a capture + instantiation on the submit path and memory for good.  Past 64
+            // cached graphs the cache is dropped (the steady state of a full server -- all tiles active -- is one entry)
+            for (auto& kv : c->mgraphs) (void)hipGraphExecDestroy(kv.second);
+            c->mgraphs.clear();
+        }
         if (it == c->mgraphs.end()) {
             if (!c->stream_cap && hipStreamCreateWithFlags(&c->stream_cap, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ok = false; }
             hipGraph_t gr = nullptr;
@@ -425,7 +432,13 @@ int check_slots(lasr_ctx* c, const int* slots, int n, bool need_open) {
 }
 
 int require_idle(lasr_ctx* c) {
+    std::lock_guard<std::mutex> lk(c->mu);
     if (!c->pending.empty()) return fail(c, LASR_ESTATE, "%d submitted step(s) not collected: call lasr_step_wait first", (int)c->pending.size());
+    if (c->group_inflight) {        // the last group of the pipelined protocol may still be running: the calls that need an idle engine
+        HIPCHK(c, hipStreamSynchronize(c->stream_dec));      // use the same decode state on the ctx stream
+        c->group_inflight = false;
+        c->work_left = 0;
+    }
     return LASR_OK;
 }
 

@@ -66,7 +66,13 @@ size_t lasr_weight_count(const lasr_model_desc* d) {
 void lasr_destroy(lasr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->pump_started) {
+        { std::lock_guard<std::mutex> lk(c->mu); c->pump_stop.store(true); }
+        c->cv_pump.notify_all();
+        c->pump_th.join();
+    }
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream_dec) (void)hipStreamSynchronize(c->stream_dec);
     for (void* p : c->dev_allocs) (void)hipFree(p);
     if (c->cmd_host) (void)hipHostFree(c->cmd_host);
     if (c->res_host) (void)hipHostFree(c->res_host);
@@ -126,6 +132,11 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         // hypothesis rows x 1536) the rounds launched past the need cost more (10.3 -> 10.0 k): profiles/r03/r03_experiments.txt O
         else if (c->W > 1 && (size_t)Md * H <= (size_t)256 * 1024) c->wait_n = 4;
     }
+    // groups launched by the pump thread (see pump_main): greedy 2 iterations (f32 52.1-52.6 k at 2, 51.7-52.1 at 3, 51.8 at 4 against
+    // 51.8-51.9 without the pump; bf16 96.0 / 93.4 / 93.1 against 92.6: profiles/r04/r04_pump_ab.txt); beam: the group size of
+    // round 3's wait path
+    c->pump_G = c->W > 1 ? c->wait_n : 2;
+    if (getenv("LASR_PUMP_G")) c->pump_G = std::max(1, std::min(8, atoi(getenv("LASR_PUMP_G"))));
     const size_t Mj = (size_t)c->MTj * 16;
     c->G_pred = d.pred_cell ? 4 : 3;
     c->bf = d.dtype == 1; c->kch = c->bf ? 32 : 16; c->esz = c->bf ? 2 : 4;
@@ -288,7 +299,8 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     }
     RC(dalloc(c, (char**)&c->ja, Mj * J * c->esz)); HIPCHK(c, hipMemset(c->ja, 0, Mj * J * c->esz));
     RC(dalloc(c, (char**)&c->cvt_a, (size_t)M * H * c->esz)); RC(dalloc(c, (char**)&c->cvt_b, (size_t)M * H * c->esz));
-    RC(dalloc(c, &c->logits, Mj * V));
+    HIPCHK(c, hipMemset(c->cvt_a, 0, (size_t)M * H * c->esz)); HIPCHK(c, hipMemset(c->cvt_b, 0, (size_t)M * H * c->esz));
+    RC(dalloc(c, &c->logits, Mj * V)); HIPCHK(c, hipMemset(c->logits, 0, sizeof(float) * Mj * V));
     RC(dalloc(c, &c->ds.t_idx, M)); RC(dalloc(c, &c->ds.iters, M)); RC(dalloc(c, &c->ds.token, Md));
     RC(dalloc(c, &c->ds.emit, Md)); RC(dalloc(c, &c->ds.logp_sum, M));
     RC(dalloc(c, &c->ds.sum_iters, M)); RC(dalloc(c, &c->ds.n_ones, M)); RC(dalloc(c, &c->zero_rows, M));
@@ -385,7 +397,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     lasr_ctx::Cmd tmp;
     c->cmd_bytes = cmd_layout(tmp, nullptr, M);
     HIPCHK(c, hipHostMalloc((void**)&c->cmd_host, c->cmd_bytes * NCMD));
-    RC(dalloc(c, &c->cmd_dev, c->cmd_bytes * NCMD));
+    RC(dalloc(c, &c->cmd_dev, c->cmd_bytes * NCMD)); HIPCHK(c, hipMemset(c->cmd_dev, 0, c->cmd_bytes * NCMD));
     RC(ensure_T(c, std::max(d.n_buffer, 4)));
 
     // ---- predictor input tables (one-time, on device, always exact f32: the table is f32 in both
@@ -474,6 +486,7 @@ int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
         RC(cmd_begin(c));
         c->hc.what[slot] = what & 7;
         RC(cmd_commit(c));
+        std::lock_guard<std::mutex> lk(c->mu);            // (decode-side launches: the pump thread stays out)
         if (c->pending.empty() && !c->group_inflight) {
             RC(apply_reset(c, (what & 2) != 0));
         } else {
@@ -906,9 +919,9 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
     return LASR_OK;
 }
 
-static int cont_launch_group(lasr_ctx* c, int G);
-static void cont_poll(lasr_ctx* c);
 static int cont_pump(lasr_ctx* c, int G);
+static int pump_start(lasr_ctx* c);
+static void pump_kick(lasr_ctx* c);
 
 // Pipelined + continuous form of lasr_step_stream.  submit: front-end + encoder of this chunk on the
 // main stream (the encoder half of the joint goes to a per-row frame ring).  ONE greedy loop runs on
@@ -938,8 +951,17 @@ int lasr_push_submit(lasr_ctx* c, const int* slots, int n, const float* pcm, int
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
     if (!pcm) return fail(c, LASR_EINVAL, "pcm is null");
+    // every check without side effects comes BEFORE the push: LASR_ESTATE / LASR_EINVAL from this call mean nothing was pushed
+    // (what can still fail after the push is the HIP runtime: LASR_EHIP, with the chunk pushed)
     if ((int)c->pending.size() + 1 > lasr_max_inflight(c))
         return fail(c, LASR_ESTATE, "%d steps already in flight (limit %d): call lasr_step_wait (nothing was pushed)", (int)c->pending.size(), lasr_max_inflight(c));
+    if (c->W > 1 && c->M > 512) return fail(c, LASR_ESTATE, "the pipelined protocol with beam > 1 takes up to 512 stream slots (nothing was pushed)");
+    {
+        int nf = 0;
+        (void)stream_frame0(c, &nf);
+        if (nf < c->d.n_stack || (long long)c->d.n_window * c->d.chunk <= c->d.n_fft / 2)
+            return fail(c, LASR_EINVAL, "chunk of %d samples is too short for the streaming window (nothing was pushed)", c->d.chunk);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->pending.empty()) RC(cont_pump(c, c->kick_n));
     PushSrc ps;
@@ -971,7 +993,7 @@ static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fuse
                         (int)c->pending.size(), lasr_max_inflight(c), Tm, c->d.max_iters_stream);
     }
     HIPCHK(c, hipSetDevice(c->device));
-    // keep the decode stream busy while the host enqueues (and the GPU runs) this chunk's encoder
+    // keep the decode stream busy while the host enqueues (and the GPU runs) this chunk's encoder (a no-op with the pump thread)
     RC(cont_pump(c, c->kick_n));
     const int idx = (int)(c->model_steps % lasr_ctx::NFLY);
     float* pe_keep = c->pe;
@@ -998,16 +1020,21 @@ static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fuse
     p.serial = c->model_steps;
     p.target.assign(c->M, 0);
     for (int r : model_rows) { c->h_frames_sub[r] += Tm; p.target[r] = (int)c->h_frames_sub[r]; }
-    c->pending.push_back(std::move(p));
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->pump_on || c->cgraphs.empty()) RC(pump_start(c));      // (first step, or the graphs were dropped while idle)
+        c->pending.push_back(std::move(p));
+    }
     c->model_steps++;
     HIPCHK(c, hipGetLastError());
+    if (c->pump_on) { pump_kick(c); return LASR_OK; }
     // the enqueue above took tens of microseconds of host time: a group may have finished meanwhile.  If nothing is
     // left to decode the next group is queued behind this step's encoder event (stream-side wait)
     RC(cont_pump(c, c->kick_n));
     return LASR_OK;
 }
 
-int lasr_step_pending(lasr_ctx* c) { return c ? (int)c->pending.size() : 0; }
+int lasr_step_pending(lasr_ctx* c) { return c ? (int)c->pending.size() : 0; }     // (only the API thread changes the size)
 
 int lasr_max_inflight(const lasr_ctx* c) {
     if (!c) return 0;
@@ -1037,59 +1064,29 @@ struct ContScope {
     ~ContScope() { c->stream = st; c->pe = pe; c->pe_ring_R = ring; c->dec_t_idx = tidx; c->T_row_dec = trow; }
 };
 
-// One group of G greedy iterations on stream_dec for whatever rows have frames to decode; its last k_select
-// publishes the rows' frame cursors and the "rows with frames left" word to pinned memory.  Does not wait.
-static int cont_launch_group(lasr_ctx* c, int G) {
-    const int M = c->M, V = c->d.vocab, J = c->d.joint;
-    c->la = c->la_stream;
-    ContScope scope(c);
-    DecState s = c->ds;
+// ---- the decode loop of the pipelined protocol: groups of G iterations on stream_dec --------------------------------
+// Decode-side state (c->pending, h_avail, h_cur_seen, work_left, group_inflight, cont_iters, the predictor / LM parities, the
+// beam's host trees) is guarded by c->mu.  Groups are launched by the NATIVE PUMP THREAD (pump_main) while steps are in flight:
+// it spins on the pinned flag word and replays the next group's hipGraph the moment the previous one has published its cursors,
+// whatever the API thread is doing (its push_submit spends ~60 us per chunk enqueueing the front-end and the encoder cells on
+// the main stream; round 3 launched groups only from inside API calls, so a finished group waited for the host: 5 % of the
+// decode stream).  The pump never uses the launch helpers (they take the stream and the pe buffer from the ctx, which the API
+// thread is using for the main stream at that moment): its path is event waits, one admission kernel with explicit arguments
+// and a graph replay; the graphs are captured by the API thread (ensure_group_graphs) before it hands the first step over.
+// Without graphs (LASR_NO_GRAPH, LASR_DBG_TIMING), with more than 512 slots, or with LASR_PUMP=0 there is no pump thread and
+// the API calls launch the groups themselves, as in round 3.
+
+// decode-side kernel state of the continuous loop
+static void cont_states(lasr_ctx* c, DecState& s, BeamState& bs) {
+    const int M = c->M, V = c->d.vocab;
+    s = c->ds;
     s.t_idx = c->c_cur; s.iters = c->c_iters; s.step_ntok = c->c_ntotal; s.step_tok = c->c_tok_ring;
     s.tok_cap = lasr_ctx::TOKRING; s.unfinished = c->c_behind; s.cont = 1; s.host_cur = c->c_hcur_dev;
     s.host_ntot = c->tr_on ? c->c_hcur_dev + M : nullptr;
     s.ntok_end = c->c_ntok_end; s.step_T = c->d.n_buffer; s.end_slots = lasr_ctx::ENDSLOTS; s.done_blocks = c->c_done;
     s.iter_ctr = c->c_iter;
     s.dbg = c->dbg ? c->dbg + ((size_t)4 * 4096 + 4095) * 16 : nullptr;
-    int* flag = c->cont_host;
-    // admit encoded steps in order.  While rows still have frames to decode only steps whose encoder has finished are
-    // admitted (the loop must not stall behind an encoder); when nothing is left the first one is admitted unconditionally:
-    // the decode stream then waits for that encoder on the GPU and resumes by itself
-    bool admitted_any = false;
-    tr_mark(c, 10, c->stream);
-    const bool by_value = M <= 512;
-    for (auto& q : c->pending) {
-        if (q.admitted) continue;
-        const bool must = c->work_left == 0 && !admitted_any;
-        if (!must && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_enc[q.idx], 0));
-        if (by_value) { for (int r : q.rows) c->h_avail[r] = q.target[r]; }
-        else hipLaunchKernelGGL(k_advance, dim3(grid1(M)), dim3(256), 0, c->stream, c->c_avail, q.T_row_ptr, M);
-        q.admitted = true;
-        admitted_any = true;
-    }
-    if (admitted_any && c->W > 1) {     // beam: every hypothesis slot of the streams that have a frame to decode
-        AvailV av;
-        for (int r = 0; r < 512; ++r) av.v[r] = r < M ? c->h_avail[r] : 0;
-        hipLaunchKernelGGL(k_ja_admit_beam, dim3(grid1((size_t)c->Md * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)cur_pp(c),
-                           (const int*)c->c_cur, av, c->c_avail, c->ja, J, c->Md, c->W, M, c->MTj, c->pe_ring_R, c->bf);
-    } else
-    if (admitted_any) {  // rows that were idle need their joint activation for the new frames
-        if (by_value) {
-            AvailV av;
-            for (int r = 0; r < 512; ++r) av.v[r] = r < M ? c->h_avail[r] : 0;
-            hipLaunchKernelGGL(k_ja_admit, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, (const float*)c->pe, (const float*)c->pp,
-                               (const int*)c->c_cur, av, c->c_avail, c->ja, J, M, c->MTj, c->pe_ring_R, c->bf, c->la);
-        } else {
-            hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, c->stream, c->pe, c->pp, c->c_cur,
-                               c->c_avail, c->ja, J, M, c->MTj, c->pe_ring_R, c->bf, 1, M, c->la);
-        }
-    }
-    tr_mark(c, 11 + 100 * G + (admitted_any ? 1000 : 0), c->stream);
-    __atomic_store_n(flag, -1, __ATOMIC_RELEASE);      // before the launch that will overwrite it
-    c->dbg_gate = false;
-    // the G iterations are launch-invariant (the flag-ring slot comes from a device counter, the last k_select
-    // publishes the cursors and the "rows with frames left" word): replayed as one hipGraph per (G, ping-pong parities)
-    BeamState bs{};
+    bs = BeamState{};
     if (c->W > 1) {
         bs.W = c->W; bs.V = V; bs.blank = c->d.blank; bs.max_iters = c->d.max_iters_stream; bs.Md = c->Md;
         bs.t_idx = c->c_cur; bs.iters = c->c_iters; bs.T_row = c->c_avail;
@@ -1099,50 +1096,136 @@ static int cont_launch_group(lasr_ctx* c, int G) {
         bs.host_cur = c->c_hcur_dev; bs.step_T = c->d.n_buffer; bs.end_slots = lasr_ctx::ENDSLOTS;
         bs.end_score = c->b_endsc_dev; bs.end_alive = c->b_endal_dev;
     }
-    auto enqueue = [&]() {
-        for (int q = 0; q < G; ++q) {
-            if (c->W > 1) {                 // one selection round: logits of every hypothesis slot -> ordered top-W -> predictor / joint
-                bs.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
-                launch_logits(c, c->logits, c->Md, true);
-                launch_beam_select(c, bs, 0);
-                launch_predictor(c, true);
-                launch_ppj(c, true);
-                launch_lm(c, true);
-                continue;
-            }
-            s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
-            launch_logits(c, c->logits, c->la * M, true);
-            launch_select<false>(c->stream, M, c->logits, V, c->d.blank, c->d.max_iters_stream, c->c_avail, s, 0, nullptr, nullptr, c->la, M);
-            launch_predictor(c);
-            launch_ppj(c);
-            launch_lm(c);
-            static const int dly = getenv("LASR_DELAY_DEC_US") ? atoi(getenv("LASR_DELAY_DEC_US")) : 0;    // experiment: see k_delay
-            if (dly > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream, (unsigned long long)dly * 100ull);
+}
+
+// the G iterations of a group through the launch helpers (API thread only, c->mu held, inside a ContScope): launch-invariant
+// (the flag-ring slot comes from a device counter, the last selection kernel publishes the cursors and the "rows with frames
+// left" word), so a group is one hipGraph per (G, ping-pong parities)
+static void cont_enqueue(lasr_ctx* c, int G) {
+    const int M = c->M, V = c->d.vocab;
+    DecState s; BeamState bs;
+    cont_states(c, s, bs);
+    c->dbg_gate = false;
+    for (int q = 0; q < G; ++q) {
+        if (c->W > 1) {                 // one selection round: logits of every hypothesis slot -> ordered top-W -> predictor / joint
+            bs.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
+            launch_logits(c, c->logits, c->Md, true);
+            launch_beam_select(c, bs, 0);
+            launch_predictor(c, true);
+            launch_ppj(c, true);
+            launch_lm(c, true);
+            continue;
         }
-    };
-    if (c->use_graphs && !c->dbg) {
-        const auto key = std::make_tuple(G, c->pred_par, c->lm.par);
-        auto it = c->cgraphs.find(key);
-        if (it == c->cgraphs.end()) {
-            const int pp0 = c->pred_par, lp0 = c->lm.par;
-            hipGraph_t gr = nullptr;
-            hipGraphExec_t ex = nullptr;
-            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            enqueue();
-            hipError_t e = hipStreamEndCapture(c->stream, &gr);
-            c->pred_par = pp0; c->lm.par = lp0;            // the capture only recorded; parities advance at launch
-            if (e != hipSuccess || !gr) return fail(c, LASR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-            e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(gr);
-            if (e != hipSuccess) return fail(c, LASR_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-            it = c->cgraphs.emplace(key, ex).first;
+        s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
+        launch_logits(c, c->logits, c->la * M, true);
+        launch_select<false>(c->stream, M, c->logits, V, c->d.blank, c->d.max_iters_stream, c->c_avail, s, 0, nullptr, nullptr, c->la, M);
+        launch_predictor(c);
+        launch_ppj(c);
+        launch_lm(c);
+        static const int dly = getenv("LASR_DELAY_DEC_US") ? atoi(getenv("LASR_DELAY_DEC_US")) : 0;    // experiment: see k_delay
+        if (dly > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream, (unsigned long long)dly * 100ull);
+    }
+}
+
+// the group graph for (G, current parities): captured on first use (API thread, c->mu held)
+static int cont_group_graph(lasr_ctx* c, int G, int pred_par, int lm_par, hipGraphExec_t* out) {
+    const auto key = std::make_tuple(G, pred_par, lm_par);
+    auto it = c->cgraphs.find(key);
+    if (it == c->cgraphs.end()) {
+        const int pp0 = c->pred_par, lp0 = c->lm.par;
+        c->la = c->la_stream;
+        ContScope scope(c);
+        c->pred_par = pred_par; c->lm.par = lm_par;
+        hipGraph_t gr = nullptr;
+        hipGraphExec_t ex = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        cont_enqueue(c, G);
+        hipError_t e = hipStreamEndCapture(c->stream, &gr);
+        c->pred_par = pp0; c->lm.par = lp0;            // the capture only recorded; parities advance at launch
+        if (e != hipSuccess || !gr) return fail(c, LASR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        if (e != hipSuccess) return fail(c, LASR_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        it = c->cgraphs.emplace(key, ex).first;
+    }
+    *out = it->second;
+    return LASR_OK;
+}
+// every graph the pump thread can need (it never captures): G = pump_G at each parity the loop can be in
+static int ensure_group_graphs(lasr_ctx* c) {
+    hipGraphExec_t ex;
+    for (int pp = 0; pp < 2; ++pp)
+        for (int lp = 0; lp < (c->lm.on ? 2 : 1); ++lp)
+            RC(cont_group_graph(c, c->pump_G, pp, c->lm.on ? lp : c->lm.par, &ex));
+    return LASR_OK;
+}
+
+// One group of G iterations on stream_dec for whatever rows have frames to decode; its last selection kernel publishes the
+// rows' frame cursors and the "rows with frames left" word to pinned memory.  Does not wait.  c->mu held.  from_pump: called
+// by the pump thread -- explicit stream / buffers only, never a capture (rc 1 = the graph is missing, nothing was launched)
+static int cont_launch_group(lasr_ctx* c, int G, bool from_pump = false) {
+    const int M = c->M, J = c->d.joint;
+    hipStream_t sd = c->stream_dec;
+    float* pe = c->pe_ring;
+    const int R = lasr_ctx::RING, la = c->W > 1 ? 1 : c->la_stream;
+    int* flag = c->cont_host;
+    hipGraphExec_t ex = nullptr;
+    const bool graphs = c->use_graphs && !c->dbg;
+    if (graphs) {
+        if (from_pump) {
+            auto it = c->cgraphs.find(std::make_tuple(G, c->pred_par, c->lm.par));
+            if (it == c->cgraphs.end()) return 1;
+            ex = it->second;
+        } else {
+            RC(cont_group_graph(c, G, c->pred_par, c->lm.par, &ex));
         }
-        HIPCHK(c, hipGraphLaunch(it->second, c->stream));
+    } else if (from_pump) {
+        return 1;
+    }
+    // admit encoded steps in order.  While rows still have frames to decode only steps whose encoder has finished are
+    // admitted (the loop must not stall behind an encoder); when nothing is left the first one is admitted unconditionally:
+    // the decode stream then waits for that encoder on the GPU and resumes by itself
+    bool admitted_any = false;
+    tr_mark(c, 10, sd);
+    const bool by_value = M <= 512;
+    for (auto& q : c->pending) {
+        if (q.admitted) continue;
+        const bool must = c->work_left == 0 && !admitted_any;
+        if (!must && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
+        HIPCHK(c, hipStreamWaitEvent(sd, c->ev_enc[q.idx], 0));
+        if (by_value) { for (int r : q.rows) c->h_avail[r] = q.target[r]; }
+        else hipLaunchKernelGGL(k_advance, dim3(grid1(M)), dim3(256), 0, sd, c->c_avail, q.T_row_ptr, M);
+        q.admitted = true;
+        admitted_any = true;
+    }
+    if (admitted_any && c->W > 1) {     // beam: every hypothesis slot of the streams that have a frame to decode
+        AvailV av;
+        for (int r = 0; r < 512; ++r) av.v[r] = r < M ? c->h_avail[r] : 0;
+        hipLaunchKernelGGL(k_ja_admit_beam, dim3(grid1((size_t)c->Md * J)), dim3(256), 0, sd, (const float*)pe, (const float*)cur_pp(c),
+                           (const int*)c->c_cur, av, c->c_avail, c->ja, J, c->Md, c->W, M, c->MTj, R, c->bf);
+    } else
+    if (admitted_any) {  // rows that were idle need their joint activation for the new frames
+        if (by_value) {
+            AvailV av;
+            for (int r = 0; r < 512; ++r) av.v[r] = r < M ? c->h_avail[r] : 0;
+            hipLaunchKernelGGL(k_ja_admit, dim3(grid1((size_t)M * J)), dim3(256), 0, sd, (const float*)pe, (const float*)c->pp,
+                               (const int*)c->c_cur, av, c->c_avail, c->ja, J, M, c->MTj, R, c->bf, la);
+        } else {
+            hipLaunchKernelGGL(k_ja, dim3(grid1((size_t)M * J)), dim3(256), 0, sd, pe, c->pp, c->c_cur,
+                               c->c_avail, c->ja, J, M, c->MTj, R, c->bf, 1, M, la);
+        }
+    }
+    tr_mark(c, 11 + 100 * G + (admitted_any ? 1000 : 0), sd);
+    __atomic_store_n(flag, -1, __ATOMIC_RELEASE);      // before the launch that will overwrite it
+    if (graphs) {
+        HIPCHK(c, hipGraphLaunch(ex, sd));
         if (G & 1) { c->pred_par ^= 1; if (c->lm.on) c->lm.par ^= 1; }
     } else {
-        enqueue();
+        c->la = c->la_stream;
+        ContScope scope(c);
+        cont_enqueue(c, G);
     }
-    tr_mark(c, 12, c->stream);
+    tr_mark(c, 12, sd);
     c->tr_last_G = G;
     c->cont_iters += G;
     c->group_inflight = true;
@@ -1183,7 +1266,7 @@ static void beam_replay(lasr_ctx* c) {
 }
 
 // non-blocking: if the in-flight group has finished, consume its flag and snapshot the rows' frame cursors
-// (nothing writes them again until the next group is launched)
+// (nothing writes them again until the next group is launched).  c->mu held.
 static void cont_poll(lasr_ctx* c) {
     if (!c->group_inflight) return;
     const int v = __atomic_load_n((volatile int*)c->cont_host, __ATOMIC_ACQUIRE);
@@ -1204,17 +1287,81 @@ static void cont_poll(lasr_ctx* c) {
         }
         tr_note(c, 20, need * 1000.0 + c->tr_last_G * 100.0 + v + rows / 1000.0);
     }
+    c->progress.fetch_add(1, std::memory_order_release);
 }
 
 // non-blocking: launch the next group of G iterations if none is in flight and frames are waiting (or the encoder
-// of a submitted step is still to be admitted)
-static int cont_pump(lasr_ctx* c, int G) {
+// of a submitted step is still to be admitted).  c->mu held.
+static int cont_pump_locked(lasr_ctx* c, int G, bool from_pump = false) {
     cont_poll(c);
     if (c->group_inflight || c->pending.empty()) return LASR_OK;
     bool unadmitted = false;
     for (const auto& q : c->pending) unadmitted |= !q.admitted;
     if (c->work_left == 0 && !unadmitted) return LASR_OK;        // everything encoded so far is decoded
-    return cont_launch_group(c, G);
+    return cont_launch_group(c, G, from_pump);
+}
+// API-thread form: a no-op while the pump thread owns the launches
+static int cont_pump(lasr_ctx* c, int G) {
+    if (c->pump_on) return LASR_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return cont_pump_locked(c, G);
+}
+
+// ---- the pump thread
+static void pump_main(lasr_ctx* c) {
+    (void)hipSetDevice(c->device);
+    long long seen_kick = -1;
+    for (;;) {
+        bool inflight = false, idle = false;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            if (c->pump_stop.load(std::memory_order_acquire)) return;
+            if (c->pump_on && c->pump_rc == 0) {
+                const int rc = cont_pump_locked(c, c->pump_G, true);
+                if (rc < 0) { c->pump_rc = rc; c->pump_err = c->err; c->progress.fetch_add(1, std::memory_order_release); }
+                // (rc 1: the graph for this parity is missing -- the API thread captures it with its next call)
+            }
+            inflight = c->group_inflight;
+            idle = !inflight;
+        }
+        if (inflight) {
+            // the group's flag: a plain spin (the pump is the only thing this thread does); a submit in the meantime changes nothing
+            // before the group has finished
+            unsigned long long spins = 0;
+            while (__atomic_load_n((volatile int*)c->cont_host, __ATOMIC_ACQUIRE) == -1 && !c->pump_stop.load(std::memory_order_relaxed)) {
+                __builtin_ia32_pause();
+                if (++spins > (1ull << 31)) break;
+            }
+            continue;
+        }
+        if (idle) {
+            // nothing to launch: wait for the next submitted step (spin briefly -- steps come every ~200 us under load -- then sleep)
+            for (int spins = 0; c->kick.load(std::memory_order_acquire) == seen_kick && !c->pump_stop.load(std::memory_order_relaxed); ++spins) {
+                if (spins < 40000) { __builtin_ia32_pause(); continue; }
+                std::unique_lock<std::mutex> lk(c->mu);
+                c->cv_pump.wait_for(lk, std::chrono::milliseconds(20), [&] { return c->kick.load() != seen_kick || c->pump_stop.load(); });
+                break;
+            }
+            seen_kick = c->kick.load(std::memory_order_acquire);
+        }
+    }
+}
+// called by the API thread (c->mu held) when the first step is handed to the decode loop
+static int pump_start(lasr_ctx* c) {
+    static const int pump_env = getenv("LASR_PUMP") ? atoi(getenv("LASR_PUMP")) : 1;
+    const bool can = pump_env != 0 && c->use_graphs && !c->dbg && c->M <= 512;
+    if (!can) { c->pump_on = false; return LASR_OK; }
+    RC(ensure_group_graphs(c));
+    if (!c->pump_started) {
+        c->pump_started = true;
+        c->pump_th = std::thread(pump_main, c);
+    }
+    c->pump_on = true;
+    return LASR_OK;
+}
+static void pump_kick(lasr_ctx* c) {
+    c->kick.fetch_add(1, std::memory_order_release);
+    c->cv_pump.notify_one();
 }
 
 static bool cont_step_done(const lasr_ctx* c, const lasr_ctx::PendingStep& P) {
@@ -1226,21 +1373,46 @@ static bool cont_step_done(const lasr_ctx* c, const lasr_ctx::PendingStep& P) {
 int lasr_step_wait(lasr_ctx* c, int* n_ran) {
     if (!c) return LASR_EINVAL;
     if (n_ran) *n_ran = 0;
-    if (c->pending.empty()) return LASR_OK;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->pending.empty()) return LASR_OK;
+    }
     HIPCHK(c, hipSetDevice(c->device));
     const int M = c->M;
     int* flag = c->cont_host;
     int* h_end = c->cont_host + 16 + (size_t)lasr_ctx::NFLY * M;
     int* h_ring = h_end + (size_t)M * lasr_ctx::ENDSLOTS;
-    for (int guard = 0;; ++guard) {
-        cont_poll(c);
-        if (cont_step_done(c, c->pending.front())) break;
-        if (!c->group_inflight) RC(cont_launch_group(c, c->wait_n));
-        RC(spin_flag(c, flag, c->stream_dec));
-        if (guard > 4096) return fail(c, LASR_EHIP, "decode loop did not converge");
+    if (c->pump_on) {
+        // the pump thread launches the groups and consumes their flags: wait for its progress counter
+        for (unsigned long long guard = 0;; ++guard) {
+            const long long seen = c->progress.load(std::memory_order_acquire);
+            {
+                std::lock_guard<std::mutex> lk(c->mu);
+                if (c->pump_rc) return fail(c, c->pump_rc, "decode pump: %s", c->pump_err.c_str());
+                if (cont_step_done(c, c->pending.front())) break;
+            }
+            unsigned long long spins = 0;
+            while (c->progress.load(std::memory_order_acquire) == seen) {
+                __builtin_ia32_pause();
+                if (++spins > (1ull << 22)) { pump_kick(c); break; }      // (~10 ms: re-check; wakes a sleeping pump)
+            }
+            if (guard > (1u << 16)) return fail(c, LASR_EHIP, "decode loop did not converge");
+        }
+    } else {
+        for (int guard = 0;; ++guard) {
+            {
+                std::lock_guard<std::mutex> lk(c->mu);
+                cont_poll(c);
+                if (cont_step_done(c, c->pending.front())) break;
+                if (!c->group_inflight) RC(cont_launch_group(c, c->wait_n));
+            }
+            RC(spin_flag(c, flag, c->stream_dec));
+            if (guard > 4096) return fail(c, LASR_EHIP, "decode loop did not converge");
+        }
     }
     // results of the oldest step: tokens between the previous and this step boundary of every row, already
     // in pinned memory (written by the kernels of the groups that completed before the cursors were published)
+    std::lock_guard<std::mutex> lk(c->mu);
     lasr_ctx::PendingStep& P = c->pending.front();
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if (c->W > 1) {      // beam: the whole best hypothesis as of this model step (lasr_fetch semantics of beam > 1)
@@ -1265,7 +1437,7 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran) {
     if (n_ran) *n_ran = (int)P.rows.size();
     c->pending.erase(c->pending.begin());
     c->cmd_inflight = 0;
-    RC(cont_pump(c, c->wait_n));
+    if (!c->pump_on) RC(cont_pump_locked(c, c->wait_n));
     return LASR_OK;
 }
 
@@ -2013,7 +2185,8 @@ int lasr_trace_read(lasr_ctx* c, double* us, int* tags, int cap, int* n) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
     *n = 0;
-    for (int i = 0; i < c->tr_n && i < cap; ++i) {
+    const int n_marks = std::min(c->tr_n.load(), (int)lasr_ctx::NTRACE);
+    for (int i = 0; i < n_marks && i < cap; ++i) {
         float ms = 0.f;
         tags[i] = c->tr_tag[i];
         if (tags[i] == 20) { us[i] = c->tr_val[i]; *n = i + 1; continue; }      // value record
@@ -2097,6 +2270,34 @@ int lasr_sync(lasr_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cmd_inflight = 0;
+    return LASR_OK;
+}
+
+// Do the two streams of the pipelined protocol (the ctx stream and the decode stream) run CONCURRENTLY on this process's
+// hardware queues?  One wave per stream holds its stream for delay_us; *ratio = wall time / delay_us: ~1 when the streams
+// overlap, ~2 when the runtime has mapped both onto one hardware queue (seen with an eagerly initialised RCCL communicator:
+// the job then runs at 0.74 of its rate, profiles/r03/r03_experiments.txt M).  bench.py reports it per rank.
+int lasr_overlap_probe(lasr_ctx* c, int delay_us, double* ratio) {
+    if (!c || !ratio || delay_us < 1 || delay_us > 1000000) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    RC(require_idle(c));
+    HIPCHK(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1, e2;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
+    const unsigned long long ticks = (unsigned long long)delay_us * 100ull;      // 100 MHz wall clock
+    for (int rep = 0; rep < 2; ++rep) {                                            // (first pass: code object load, queue creation)
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream_dec, e0, 0));
+        hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream, rep ? ticks : 100ull);
+        hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream_dec, rep ? ticks : 100ull);
+        HIPCHK(c, hipEventRecord(e2, c->stream_dec));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, e2, 0));
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipEventSynchronize(e1));
+    }
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    *ratio = 1e3 * (double)ms / (double)delay_us;
     return LASR_OK;
 }
 

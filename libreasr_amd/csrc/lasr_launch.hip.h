@@ -16,16 +16,21 @@ void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g0, co
 int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
 
 // lasr_trace: a value record (no event): lasr_trace_read returns `val` in the time field
+// (marks come from the API thread -- main stream -- and from the pump thread -- decode stream: slots are drawn atomically)
 void tr_note(lasr_ctx* c, int tag, double val) {
-    if (!c->tr_on || c->tr_n >= lasr_ctx::NTRACE) return;
-    c->tr_val[c->tr_n] = val;
-    c->tr_tag[c->tr_n++] = tag;
+    if (!c->tr_on) return;
+    const int i = c->tr_n.fetch_add(1, std::memory_order_relaxed);
+    if (i >= lasr_ctx::NTRACE) return;
+    c->tr_val[i] = val;
+    c->tr_tag[i] = tag;
 }
 // lasr_trace: one timestamped mark on stream `st` (no-op unless tracing)
 void tr_mark(lasr_ctx* c, int tag, hipStream_t st) {
-    if (!c->tr_on || c->tr_n >= lasr_ctx::NTRACE) return;
-    (void)hipEventRecord(c->tr_ev[c->tr_n], st);
-    c->tr_tag[c->tr_n++] = tag;
+    if (!c->tr_on) return;
+    const int i = c->tr_n.fetch_add(1, std::memory_order_relaxed);
+    if (i >= lasr_ctx::NTRACE) return;
+    (void)hipEventRecord(c->tr_ev[i], st);
+    c->tr_tag[i] = tag;
 }
 
 // encoder LSTM cell (layer l, step t): x from `xsrc` (fragment-major, K = I); tiling "C"
@@ -411,16 +416,16 @@ int ensure_T(lasr_ctx* c, int T) {
     RC(dalloc(c, (char**)&c->x0, (size_t)cap * M * F * c->esz));
     RC(dalloc(c, (char**)&c->ybuf[0], (size_t)cap * M * H * c->esz));
     RC(dalloc(c, (char**)&c->ybuf[1], (size_t)cap * M * H * c->esz));
-    RC(dalloc(c, &c->pe_sync, (size_t)cap * M * J));
+    RC(dalloc(c, &c->pe_sync, (size_t)cap * M * J)); HIPCHK(c, hipMemset(c->pe_sync, 0, sizeof(float) * (size_t)cap * M * J));
     c->pe = c->pe_sync;
     const int mi = std::max(c->d.max_iters_offline, c->d.max_iters_stream);
     c->tok_cap_alloc = cap * mi;
     // [ntok M][tokens M x tok_cap]: one contiguous block so a group's results reach the host in one copy
     RC(dalloc(c, &c->ds.step_ntok, (size_t)M + (size_t)M * c->tok_cap_alloc));
-    HIPCHK(c, hipMemset(c->ds.step_ntok, 0, sizeof(int) * M));
+    HIPCHK(c, hipMemset(c->ds.step_ntok, 0, sizeof(int) * ((size_t)M + (size_t)M * c->tok_cap_alloc)));
     c->ds.step_tok = c->ds.step_ntok + M;
     c->n_iter_slots = cap * mi + 8;
-    RC(dalloc(c, &c->ds.unfinished, (size_t)c->n_iter_slots));
+    RC(dalloc(c, &c->ds.unfinished, (size_t)c->n_iter_slots)); HIPCHK(c, hipMemset(c->ds.unfinished, 0, sizeof(int) * (size_t)c->n_iter_slots));
     if (c->W > 1) {
         dfree(c, c->b_trellis); c->b_trellis = nullptr;
         RC(dalloc(c, &c->b_trellis, (size_t)c->n_iter_slots * c->Md));

@@ -373,6 +373,12 @@ class Engine:
         self._chk(self.lib.lasr_cell_prof_read(self.ctx, C.byref(us), C.byref(n)))
         return us.value, n.value
 
+    def overlap_probe(self, delay_us=10000):
+        """wall time / delay of two delay kernels, one per engine stream: ~1 = the streams overlap, ~2 = one hardware queue."""
+        r = C.c_double(0.0)
+        self._chk(self.lib.lasr_overlap_probe(self.ctx, int(delay_us), C.byref(r)))
+        return r.value
+
     def bench_cell(self, layer=1, iters=200):
         us = C.c_double(0.0)
         self._chk(self.lib.lasr_bench_cell(self.ctx, int(layer), int(iters), C.byref(us)))

@@ -109,6 +109,7 @@ class Scheduler(threading.Thread):
         self.held_depth = max(1, min(int(held_depth), self.depth))
         self.any_held = False
         self.beam = engine.beam
+        self._beam_cap = 1024               # tokens per stream fetch_many makes room for with beam > 1 (grows on LASR_EFULL)
         self.inflight = collections.deque() # per submitted model step: (slots of its streams, {slot: result cell} | None)
         self.batch_outq = queue.SimpleQueue()   # trunk interface (push_batch): one item per collected model step
         self.downsample = downsample or engine.desc.stride
@@ -304,7 +305,7 @@ class Scheduler(threading.Thread):
         ran = self.eng.wait()
         if ran != len(sl):                   # the host mirror of the window / Buffer bookkeeping and the engine disagree
             raise RuntimeError(f"scheduler: expected a model step of {len(sl)} streams, the engine ran {ran}")
-        toks = self.eng.fetch_many(sl, cap=256 if self.beam == 1 else 8192)
+        toks = self._fetch(sl)
         self.infl[sl] -= 1
         self.stp[sl] += 1
         streams = self.streams
@@ -332,6 +333,20 @@ class Scheduler(threading.Thread):
                 self._flush(s)
         if t_streams:
             self.batch_outq.put((t_streams, t_toks))
+
+    def _fetch(self, sl):
+        """New tokens of the slots of a collected step.  Beam search hands out the whole best hypothesis, which grows with the
+        stream: the buffer grows with it (LASR_EFULL leaves the engine's queues untouched) instead of ending the scheduler."""
+        if self.beam == 1:
+            return self.eng.fetch_many(sl, cap=256)
+        from ._native import LASR_EFULL, LasrError
+        while True:
+            try:
+                return self.eng.fetch_many(sl, cap=self._beam_cap)
+            except LasrError as e:
+                if e.code != LASR_EFULL or self._beam_cap >= (1 << 22):
+                    raise
+                self._beam_cap *= 4
 
     def _drain(self):
         while self.inflight:
@@ -436,7 +451,9 @@ class Scheduler(threading.Thread):
                 c0 = int(cur[0])
                 if (cur == c0).all():        # the common case: every taken stream of the trunk reads the same batch
                     arr = T.batches[c0 - T.base]
-                    mats.append(arr if len(sl) == arr.shape[0] else arr[T.lut[sl]])
+                    cols = T.lut[sl]         # row of every taken slot in the trunk's arrays (slot order != row order in general:
+                                             # a trunk built from re-opened slots, or a sorted intersection)
+                    mats.append(arr if (len(sl) == arr.shape[0] and (cols == np.arange(len(sl))).all()) else arr[cols])
                     order.append(sl)
                 else:
                     cols = T.lut[sl]
@@ -582,7 +599,7 @@ class Scheduler(threading.Thread):
             try:
                 slots = [s.slot for s, _, _ in group]
                 self.eng.step_window(slots, np.stack([w for _, _, w in group]), sr)
-                toks = self.eng.fetch_many(slots, cap=8192 if self.eng.beam > 1 else 256)
+                toks = self._fetch(slots)
                 for (s, cell, _), t in zip(group, toks):
                     s.n_pend += 1
                     if s.n_pend == d.n_buffer:

@@ -23,14 +23,20 @@ def decode(path):
                 tag = struct.unpack("<H", body[24:26])[0]
             fmt = (tag, nch, sr, align, bits)
         elif cid == b"data":
+            if size in (0, 0xFFFFFFFF):                             # written to a pipe (ffmpeg / sox): "to the end of the file"
+                body, size = data[pos + 8:], len(data) - pos - 8
             pcm = body
         pos += 8 + size + (size & 1)                                # chunks are word-aligned
     if fmt is None or pcm is None:
         raise ValueError("WAVE file without fmt / data chunk")
     tag, nch, sr, align, bits = fmt
-    if nch < 1 or align != nch * bits // 8:
+    if bits not in (8, 16, 24, 32, 64):
+        raise ValueError(f"unsupported PCM width {bits}")
+    if nch < 1 or align == 0 or align != nch * bits // 8:
         raise ValueError("inconsistent WAVE header")
     n = len(pcm) // align
+    if n == 0:
+        raise ValueError("WAVE file without samples")
     raw = np.frombuffer(pcm, dtype=np.uint8, count=n * align).reshape(n, nch, bits // 8)[:, 0, :]      # first channel
     if tag == 1:                                                    # integer PCM, little-endian; 8-bit is unsigned
         if bits == 8:

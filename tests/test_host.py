@@ -321,3 +321,29 @@ def test_wav_reader_formats(tmp_path):
         open(p, "wb").write(bad)
         with pytest.raises(ValueError):
             wav.decode(p)
+
+
+def test_wav_reader_header_edge_cases(tmp_path):
+    """zero / odd bit widths are refused with ValueError (not ZeroDivisionError or a numpy reshape error), a streamed
+    file (data size 0 or 0xFFFFFFFF, as ffmpeg / sox write to a pipe) is read to the end, an empty file is an error."""
+    import struct
+    from libreasr_amd import wav
+
+    def riff(fmt, data, size=None):
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(data) if size is None else size) + data
+        return b"RIFF" + struct.pack("<I", len(body)) + body
+
+    p = str(tmp_path / "x.wav")
+    for fmt in (struct.pack("<HHIIHH", 1, 1, 16000, 0, 0, 0), struct.pack("<HHIIHH", 1, 1, 16000, 16000, 1, 12),
+                struct.pack("<HHIIHH", 1, 1, 16000, 32000, 0, 16)):
+        open(p, "wb").write(riff(fmt, b"\0" * 16))
+        with pytest.raises(ValueError):
+            wav.decode(p)
+    v = np.arange(-50, 50, dtype=np.int16)
+    for size in (0, 0xFFFFFFFF):
+        open(p, "wb").write(riff(struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16), v.tobytes(), size=size))
+        y, sr, bits = wav.decode(p)
+        assert (sr, bits) == (16000, 16) and np.array_equal(y, v.astype(np.float32) / 32768.0)
+    open(p, "wb").write(riff(struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16), b""))
+    with pytest.raises(ValueError):
+        wav.decode(p)

@@ -464,3 +464,89 @@ def test_shutdown_unblocks_everyone():
         sched.open()
     with pytest.raises(RuntimeError):
         sched.push_nowait(st, np.zeros(4, np.float32))
+
+
+def test_a_trunk_whose_slots_are_not_ascending_keeps_every_stream_on_its_own_audio():
+    """slot order != row order of the trunk's arrays as soon as a lower slot was freed before a later open().
+    Streams in slots [3, 1] (and a per-stream client beside them, so that the tick is not 'exactly the trunk'): every stream's
+    tokens are those of ITS chunks."""
+    eng = FakeEngine(max_streams=8)
+    sched = srv.Scheduler(eng, depth=4)
+    sched.start()
+    try:
+        rng = np.random.default_rng(11)
+        n = 24
+        sts = [sched.open() for _ in range(4)]                  # slots 0..3
+        sched.close(sts[1])
+        re = sched.open()                                       # slot 1 again
+        assert re.slot == 1
+        trunk = [sts[3], re]                                    # slots [3, 1]: descending
+        chunks = rng.integers(0, 9, (n, 2, 4)).astype(np.float32)
+        solo = [rng.integers(0, 9, 4).astype(np.float32) for _ in range(n)]
+        out_solo = []
+        t = threading.Thread(target=run_stream, args=(sched, sts[0], solo, out_solo))
+        t.start()
+        for k in range(n):
+            sched.push_batch(trunk, chunks[k])
+        got = {s.slot: [] for s in trunk}
+        while sum(len(g) for g in got.values()) < 2 * ((n - 2) // 2):
+            rows, toks = sched.batch_outq.get(timeout=20)
+            for st, tk in zip(rows, toks):
+                got[st.slot].append(tk)
+        t.join(timeout=20)
+        for i, st in enumerate(trunk):
+            exp = [x for x in expected([chunks[k, i] for k in range(n)], text_rule=False) if x is not None]
+            assert got[st.slot] == exp, f"trunk stream {i} (slot {st.slot}) got another stream's audio"
+        assert out_solo == expected(solo, text_rule=False)
+        # ... and the all-of-the-trunk tick (no client beside it) with descending slots
+        eng2 = FakeEngine(max_streams=8)
+        sched2 = srv.Scheduler(eng2, depth=4)
+        sched2.start()
+        try:
+            a = [sched2.open() for _ in range(3)]
+            sched2.close(a[0])
+            b = sched2.open()                                   # slot 0, opened last
+            tr = [a[2], a[1], b]                                # slots [2, 1, 0]
+            ch = rng.integers(0, 9, (n, 3, 4)).astype(np.float32)
+            for k in range(n):
+                sched2.push_batch(tr, ch[k])
+            got = {s.slot: [] for s in tr}
+            while sum(len(g) for g in got.values()) < 3 * ((n - 2) // 2):
+                rows, toks = sched2.batch_outq.get(timeout=20)
+                for st, tk in zip(rows, toks):
+                    got[st.slot].append(tk)
+            for i, st in enumerate(tr):
+                exp = [x for x in expected([ch[k, i] for k in range(n)], text_rule=False) if x is not None]
+                assert got[st.slot] == exp
+        finally:
+            sched2.shutdown()
+    finally:
+        sched.shutdown()
+
+
+def test_a_long_beam_hypothesis_grows_the_fetch_buffer_instead_of_ending_the_scheduler():
+    """with beam > 1 every fetch is the whole best hypothesis; when it outgrows the buffer the engine reports
+    LASR_EFULL (and keeps its queues): the scheduler retries with a larger buffer."""
+    from libreasr_amd._native import LASR_EFULL, LasrError
+
+    class Strict(FakeEngine):
+        def fetch_many(self, slots, cap=256):
+            if any(len(self.queue[s]) > cap for s in slots):
+                raise LasrError(LASR_EFULL, "token buffer too small")
+            return super().fetch_many(slots, cap)
+
+    eng = Strict(beam=4)
+    sched = srv.Scheduler(eng, depth=3)
+    sched._beam_cap = 8                                         # (as if the stream had been running for hours)
+    sched.start()
+    try:
+        rng = np.random.default_rng(5)
+        data = [rng.integers(0, 9, 4).astype(np.float32) for _ in range(2 + 2 * 30)]
+        st = sched.open()
+        out = []
+        run_stream(sched, st, data, out)
+        hyps = [o for o in out if o is not None]
+        assert len(hyps) == 30 and len(hyps[-1]) == 60
+        assert sched._beam_cap >= 60 and sched.error is None
+    finally:
+        sched.shutdown()
