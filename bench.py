@@ -163,15 +163,29 @@ def workload_name(args, cfg, B):
             "3-chunk window, 2-frame buffer (model every 160 ms)")
 
 
-def cpu_reference_path(cfg, sd, n_streams, n_chunks, threads=2):
+def cpu_reference_path(cfg, sd, n_streams, n_chunks, threads=2, rows=None, gpu_steps=None):
     """The reference's CPU execution path (torch-CPU operators, batch 1 per stream, set_num_threads(2) as
-    inference.py:21) on the host cores, on its OWN bounded sample of the same synthetic workload."""
+    inference.py:21) on the host cores, on a bounded sample of the same synthetic workload: the FIRST n_chunks chunks of the
+    job's own first streams (`rows`), so that its tokens can be laid beside what the GPU run fetched for those streams
+    (`gpu_steps[r]` = the token lists of stream r's model steps from chunk 0): `tokens_equal_gpu`."""
     from libreasr_amd import synth
     from oracle import torch_cpu as TC       # baseline leg only; never on the product path
-    rows = [synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in range(n_streams)]
+    if rows is None:
+        rows = [synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in range(n_streams)]
+    rows = [np.asarray(r[:n_chunks * CHUNK], dtype=np.float32) for r in rows[:n_streams]]
+    n_streams = len(rows)
     TC.time_stream_path(sd, cfg, rows[:1], min(n_chunks, 12), threads=threads)          # warm-up (thread pools, mkldnn)
     dt, toks = TC.time_stream_path(sd, cfg, rows, n_chunks, threads=threads)
-    return {"value": round(n_streams * n_chunks * CHUNK / SR / dt, 2), "unit": "audio-sec/sec", "cores": int(threads),
+    check = {}
+    if gpu_steps:
+        n_model = max(0, (n_chunks - 2) // 2)          # window full at chunk 3, then every second chunk: model steps within n_chunks
+        rows_chk = [r for r in range(min(n_streams, len(gpu_steps))) if len(gpu_steps[r]) >= n_model]
+        bad = [r for r in rows_chk if [t for st in gpu_steps[r][:n_model] for t in st] != [int(t) for t in toks[r]]]
+        check = {"tokens_equal_gpu": (not bad) if rows_chk else None, "rows_compared": len(rows_chk),
+                 "tokens_compared": int(sum(len(toks[r]) for r in rows_chk)), "rows_differing": bad,
+                 "what": "the streams' first chunks through the reference's torch-CPU path against the token lists the GPU run "
+                         "fetched for the same streams and model steps"}
+    return {"value": round(n_streams * n_chunks * CHUNK / SR / dt, 2), "unit": "audio-sec/sec", "cores": int(threads), **check,
             "kind": "port",
             "path": "the reference's torch-CPU execution path restated on the installed torch (oracle/torch_cpu.py: "
                     "nn.LayerNorm, nn.LSTM + BatchNorm1d per layer, NBRC as torch matmuls, Linear/tanh/Linear, log_softmax, "
@@ -685,7 +699,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would stall the other ranks' teardown)
             gc.enable()
             try:
-                out["cpu_baseline"] = cpu_reference_path(cfg, sd, args.cpu_streams, args.cpu_chunks)
+                can_cmp = args.beam == 1 and args.dtype == "f32" and (P + W + K) >= args.cpu_chunks and args.cpu_chunks <= n_chunks
+                out["cpu_baseline"] = cpu_reference_path(cfg, sd, args.cpu_streams, args.cpu_chunks, rows=list(pcm_host) if can_cmp else None,
+                                                         gpu_steps=rec_steps if can_cmp else None)
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "error": str(e)[:300]}
             try:

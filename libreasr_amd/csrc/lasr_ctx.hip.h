@@ -57,6 +57,8 @@ struct lasr_ctx {
     std::vector<void*> enc_h[2], pred_h[2], pred_y;      // element-typed (A operands)
     std::vector<float*> enc_c, pred_c;
     int cell_nw = 0;                // waves per encoder-cell workgroup (0: 4 for f32, 8 for bf16); LASR_CELL_NW
+    bool enc_u12 = false;           // encoder cell tiling D (12 units x 64 rows per workgroup, EpiLSTMe): bf16, H % 12 == 0, M % 64 == 0,
+                                    // H / 12 * M / 64 >= 256 workgroups; LASR_ENC_U12 overrides
     int dec_prio = 1, cell_prio = 0;   // s_setprio of the decode-stream GEMMs / of everything else (experiments)
     int logits_mt = 2;              // m-tiles per workgroup of the logits GEMM (1 | 2 | 4); LASR_LOGITS_MT
     int dec_nw_mask = 0;            // LASR_DEC_NW4: bit 1 predictor cells, bit 2 PPJ, bit 4 linear (logits, pe) run with 4 waves
@@ -106,6 +108,8 @@ struct lasr_ctx {
     // the main stream while ONE greedy loop keeps running on stream_dec across chunk boundaries: a row
     // that finished chunk k moves on to chunk k+1's frames while a bursty row is still on chunk k.
     hipStream_t stream_dec = nullptr;
+    int dec_stream_attempts = 0;    // streams tried at creation until one ran concurrently with the ctx stream (see create_impl)
+    double dec_stream_ratio = 0.0;  // the chosen stream's probe (wall / delay: ~1 concurrent, ~2 one hardware queue)
     hipStream_t stream_main_own = nullptr;   // LASR_MAIN_CUS experiment: CU-masked stream used instead of the caller's
     static constexpr int NFLY = 16; // steps in flight (ring of encoder-done events)
     static constexpr int RING = 64; // pe ring, frames per row

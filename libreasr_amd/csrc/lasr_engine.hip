@@ -111,6 +111,8 @@ void lasr_destroy(lasr_ctx* c) {
 
 const char* lasr_last_error(const lasr_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
+static int overlap_probe_impl(lasr_ctx* c, int delay_us, double* ratio);
+
 static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     const lasr_model_desc& d = c->d;
     const int F = d.feat, H = d.hidden, E = d.embed, V = d.vocab, J = d.joint;
@@ -141,12 +143,20 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     c->G_pred = d.pred_cell ? 4 : 3;
     c->bf = d.dtype == 1; c->kch = c->bf ? 32 : 16; c->esz = c->bf ? 2 : 4;
     Reader rd{weights, n_weights};
+    {   // encoder cell tiling D (see EpiLSTMe): where tiling C needs more than one 32 x 32 workgroup per CU and the hidden size divides
+        c->enc_u12 = c->bf && H % 12 == 0 && M % 64 == 0 && (H / 12) * (M / 64) >= 256 && (H / 8) * (M / 32) > 256
+                     && F % 32 == 0 && (F / 32) % 8 == 0 && (H / 32) % 8 == 0;
+        if (getenv("LASR_ENC_U12")) c->enc_u12 = atoi(getenv("LASR_ENC_U12")) != 0 && H % 12 == 0 && M % 64 == 0;
+    }
     {
         if (getenv("LASR_NO_GRAPH")) c->use_graphs = false;
         if (getenv("LASR_CELL_NW")) c->cell_nw = atoi(getenv("LASR_CELL_NW")) == 4 ? 4 : 8;
         // encoder pass as a layer wavefront: bf16 cells are load-paced with idle MFMA time, two of them per CU overlap (streaming
         // +4 %, offline +14 %); f32 cells are MFMA-paced, two per CU only contend (-4 %)
         c->enc_wave = c->bf ? 1 : 0;
+        // (tiling D -- one 100 KB-LDS workgroup per CU and cell -- has nothing to overlap inside a launch: plain launches.  cfg5,
+        //  128 streams, greedy / beam 8: 46.8 / 14.6 k against 45.9 / 14.4 k as a wavefront, profiles/r04/r04_cell_tiling_d.txt)
+        if (c->enc_u12) c->enc_wave = 0;
         if (getenv("LASR_ENC_WAVE")) c->enc_wave = atoi(getenv("LASR_ENC_WAVE"));
         // decode-stream GEMMs (predictor cells, PPJ, logits): 4 waves per workgroup with f32 operands (next to the encoder cells
         // of the main stream fewer waves per CU interfere less: whole job +5 %), 8 with bf16 (4: -3 %)
@@ -352,6 +362,30 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
     }
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_misc, hipEventDisableTiming));
+    {   // The pipelined protocol needs the decode stream and the ctx stream on DIFFERENT hardware queues.  The runtime multiplexes
+        // the process's streams onto a few queues (GPU_MAX_HW_QUEUES, 4 by default); in a process that already owns several
+        // streams (other contexts, torch, an RCCL communicator) a new stream can land on the ctx stream's queue, and the two
+        // streams then run strictly one after the other (the job at 0.73 of its rate: profiles/r04/r04_dist_ab.txt).  So the
+        // stream is probed (two 0.3 ms delay kernels, one per stream) and replaced until it overlaps; the rejected ones are kept
+        // alive until then, so that the next one is placed elsewhere.  LASR_DEC_STREAM_PICK=0 switches this off.
+        static const int pick = getenv("LASR_DEC_STREAM_PICK") ? atoi(getenv("LASR_DEC_STREAM_PICK")) : 1;
+        const bool plain = !(getenv("LASR_DEC_CUS") && atoi(getenv("LASR_DEC_CUS")) > 0) && !getenv("LASR_DEC_STREAM_PRIO");
+        std::vector<hipStream_t> rejected;
+        c->dec_stream_attempts = 1;
+        for (int attempt = 0; pick && plain && attempt < 8; ++attempt) {
+            double ratio = 0.0;
+            if (overlap_probe_impl(c, 300, &ratio) != LASR_OK) { (void)hipGetLastError(); break; }
+            c->dec_stream_ratio = ratio;
+            if (ratio < 1.5) break;
+            rejected.push_back(c->stream_dec);
+            c->stream_dec = nullptr;
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
+            c->dec_stream_attempts++;
+        }
+        for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
+        if (getenv("LASR_VERBOSE"))
+            fprintf(stderr, "[lasr] decode stream: %d stream(s) tried, overlap probe %.2f\n", c->dec_stream_attempts, c->dec_stream_ratio);
+    }
     RC(dalloc(c, &c->pe_ring, (size_t)lasr_ctx::RING * M * J));
     HIPCHK(c, hipMemset(c->pe_ring, 0, sizeof(float) * (size_t)lasr_ctx::RING * M * J));
     RC(dalloc(c, &c->c_cur, M)); RC(dalloc(c, &c->c_avail, M)); RC(dalloc(c, &c->c_iters, M)); RC(dalloc(c, &c->c_target, M));
@@ -2281,6 +2315,9 @@ int lasr_overlap_probe(lasr_ctx* c, int delay_us, double* ratio) {
     if (!c || !ratio || delay_us < 1 || delay_us > 1000000) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
     RC(require_idle(c));
     HIPCHK(c, hipSetDevice(c->device));
+    return overlap_probe_impl(c, delay_us, ratio);
+}
+static int overlap_probe_impl(lasr_ctx* c, int delay_us, double* ratio) {
     hipEvent_t e0, e1, e2;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
     const unsigned long long ticks = (unsigned long long)delay_us * 100ull;      // 100 MHz wall clock

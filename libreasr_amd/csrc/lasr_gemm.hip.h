@@ -565,6 +565,44 @@ struct EpiLSTM {
     }
 };
 
+// ---- encoder LSTM cell, tiling "D": U = 12 units x 4 gates = 48 columns (3 n-tiles) x 64 rows (4 m-tiles) per workgroup, 8 waves.
+// For hidden sizes that are multiples of 12 and >= 128 rows (configs[4]: 1536 units, 128 streams): H / 12 x M / 64 = 256
+// workgroups, exactly one per CU, 7 fragment loads per 12 MFMAs (tiling C: 4 per 4, three 32 x 32 workgroups per CU): the
+// operand bytes a CU pulls through L2 per launch drop from 1.18 MB to 0.69 MB.  64 x 12 = 768 (row, unit) items per workgroup:
+// an item loop, operands loaded in the epilogue.  Same arithmetic per item as EpiLSTM<enc>.
+template <class Ops, int U_>
+struct EpiLSTMe {
+    static constexpr int U = U_, NT = U_ / 4;
+    static constexpr int PH0_TILES = (1 << NT) - 1, PH1_TILES = (1 << NT) - 1;
+    static constexpr int PH0_DEAD = -1, PH1_DEAD = -1;
+    static constexpr bool COMPACT = false;
+    using Args = typename EpiLSTM<Ops, false, false, 8>::Args;
+    struct Pre {};
+    __device__ static bool tile_active(const Args& a, int mt, int lane) { return (a.tile_mask >> mt) & 1ull; }
+    template <int MTB>
+    __device__ static __forceinline__ Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
+    template <int MTB, class Red>
+    __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int, const int*, const Pre&, int nthr) {
+        constexpr int ROWS = MTB * 16;
+        const int H = a.H;
+        for (int item = tid; item < ROWS * U; item += nthr) {
+            const int row = item % ROWS, uu = item / ROWS, vr = mg * ROWS + row, u = jb * U + uu;
+            const size_t ho = Ops::aoff(vr, u, a.MT);
+            if (!(a.t < a.flag[vr])) {                   // the row does not advance: carried to the other parity
+                Ops::st(a.h_out, ho, Ops::ld(a.h_in, ho));
+                continue;
+            }
+            const float gi = red.sum(row, 0 * U + uu) + a.bias[u], gf = red.sum(row, 1 * U + uu) + a.bias[H + u];
+            const float gg = red.sum(row, 2 * U + uu) + a.bias[2 * H + u], go = red.sum(row, 3 * U + uu) + a.bias[3 * H + u];
+            const float c2 = sigmoid_(gf) * a.c[(size_t)u * a.M + vr] + sigmoid_(gi) * tanhf(gg);
+            const float h2 = sigmoid_(go) * tanhf(c2);
+            a.c[(size_t)u * a.M + vr] = c2;
+            Ops::st(a.h_out, ho, h2);
+            if (a.y) Ops::st(a.y, Ops::aoff(vr + 16 * a.y_mt_off, u, a.y_mt_total), h2 * a.bn_s[u] + a.bn_t[u]);
+        }
+    }
+};
+
 // ---- NBRC / GRU-v1 cell (haste/nbrc.py:30-64; layout z,r,g), predictor only (COMPACT, row-major):
 //   z = s(Wx_z + Rh_z), r = s(Wx_r + Rh_r), g = tanh(Wx_g + r * Rh_g), h' = z h + (1 - z) g.
 // Pseudo-gates {z, r, gx, gh} in one 16-column tile (4 units): the x phase feeds z,r,gx (gh columns

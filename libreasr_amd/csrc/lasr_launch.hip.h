@@ -57,6 +57,11 @@ void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_tot
     // K split over 4 waves for f32 operands (12.8 us against 17.2 us with 8: fewer requests in flight, half the
     // LDS reduction), 8 waves for bf16 (5.4 us against 6.6 us); LASR_CELL_NW overrides
     const int nw = c->cell_nw ? c->cell_nw : (Ops::BF ? 8 : 4);
+    if (c->enc_u12) {
+        if (c->cell_nw == 4) launch_gemm<Ops, EpiLSTMe<Ops, 12>, 4, false, 3, 4>(c, H / 12, c->M / 64, g, ea);
+        else launch_gemm<Ops, EpiLSTMe<Ops, 12>, 4, false, 3, NW>(c, H / 12, c->M / 64, g, ea);
+        return;
+    }
     if (nw == 4) launch_gemm<Ops, E, 2, false, 3, 4>(c, H / 8, c->M / 32, g, ea);
     else launch_gemm<Ops, E, 2, false>(c, H / 8, c->M / 32, g, ea);
 }
@@ -93,6 +98,15 @@ void launch_enc_wave_t(lasr_ctx* c, const EncCellRef* cells, int n, int par0, in
         ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
     }
     const int nw = c->cell_nw ? c->cell_nw : (Ops::BF ? 8 : 4);
+    if (c->enc_u12) {
+        using E12 = EpiLSTMe<Ops, 12>;
+        MultiArgs<E12> m12;
+        static_assert(sizeof(m12) == sizeof(m), "same Args layout");
+        memcpy((void*)&m12, (const void*)&m, sizeof(m12));
+        if (c->cell_nw == 4) hipLaunchKernelGGL((k_gemm_multi<Ops, E12, 4, 4, false, 3>), dim3(H / 12, c->M / 64, n), dim3(256), 0, c->stream, m12);
+        else hipLaunchKernelGGL((k_gemm_multi<Ops, E12, 4, NW, false, 3>), dim3(H / 12, c->M / 64, n), dim3(NW * 64), 0, c->stream, m12);
+        return;
+    }
     const dim3 grid(H / 8, c->M / 32, n);
     if (nw == 4) hipLaunchKernelGGL((k_gemm_multi<Ops, E, 2, 4, false, 3>), grid, dim3(256), 0, c->stream, m);
     else hipLaunchKernelGGL((k_gemm_multi<Ops, E, 2, NW, false, 3>), grid, dim3(NW * 64), 0, c->stream, m);

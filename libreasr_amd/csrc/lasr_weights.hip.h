@@ -31,6 +31,7 @@ int fold_bn(lasr_ctx* c, Reader& rd, int H, float** s_dev, float** t_dev) {
 // LSTM layer in torch layout: W_ih [4H,I], W_hh [4H,H].
 //   tiling C (encoder): tile t = (jb = t/2, nt = t%2): column col -> gate 2*nt + col/8, unit 8*jb + col%8
 //   tiling A (predictor): tile jb = 4 units x 4 gates (col = gate*4 + unit)
+//   tiling D (encoder, c->enc_u12): tile t = (jb = t/3, nt = t%3): column c48 = 16*nt + col -> gate c48/12, unit 12*jb + c48%12
 int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, bool tiling_a, std::vector<float>* keep_wih,
               std::vector<float>* keep_bias) {
     L.I = I;
@@ -38,6 +39,13 @@ int load_lstm(lasr_ctx* c, Reader& rd, Cell& L, int I, int H, bool tiling_a, std
     const float* bih = rd.take(4 * H); const float* bhh = rd.take(4 * H);
     if (!bhh) return fail(c, LASR_EINVAL, "weight blob too short (lstm)");
     Packed pk;
+    if (!tiling_a && c->enc_u12) {          // (packed into the WxC / WhC slots: one encoder tiling per context)
+        auto src_row = [&](int t, int col) { const int c48 = 16 * (t % 3) + col; return (size_t)(c48 / 12) * H + 12 * (t / 3) + c48 % 12; };
+        pack_tiles(pk, c->bf, (H / 12) * 3, I, [&](int t, int col, int k) { return wih[src_row(t, col) * I + k]; });
+        RC(upload_packed(c, &L.WxC, pk));
+        pack_tiles(pk, c->bf, (H / 12) * 3, H, [&](int t, int col, int k) { return whh[src_row(t, col) * H + k]; });
+        RC(upload_packed(c, &L.WhC, pk));
+    } else
     if (!tiling_a) {
         pack_tiles(pk, c->bf, (H / 8) * 2, I, [&](int t, int col, int k) { return wih[((size_t)(2 * (t & 1) + (col >> 3)) * H + 8 * (t >> 1) + (col & 7)) * I + k]; });
         RC(upload_packed(c, &L.WxC, pk));

@@ -1,0 +1,121 @@
+"""Round-4 GPU tests:
+
+  * encoder cell tiling D (12 units x 64 rows per workgroup, `EpiLSTMe`, what configs[4]'s 1536-unit / 128-stream shape selects):
+    against tiling C on the same weights -- bf16 bit-identical (same K split, same reduction order), f32 against the oracle --
+    and streaming tokens equal
+  * the pump thread (decode groups launched by a library thread) against LASR_PUMP=0 on the pipelined protocol: same tokens per
+    model step
+  * lasr_overlap_probe: the two engine streams run concurrently in a plain process (ratio ~1)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from libreasr_amd import synth
+from oracle import rnnt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG12 = dict(feat=1280, embed=32, vocab=64, hidden=96, joint=64, enc_layers=3, pred_layers=2, pred_cell="NBRC",
+             blank_bias=10.8, out_scale=8.0)
+
+
+def make(cfg, **kw):
+    import __graft_entry__ as graft
+    from libreasr_amd.engine import Engine
+    graft.build()
+    sd = synth.synth_state_dict(cfg, seed=0)
+    return Engine(sd, cfg, **kw), sd
+
+
+def stream_tokens(eng, pcm, n_chunks):
+    slots = [eng.open() for _ in range(pcm.shape[0])]
+    got = [[] for _ in slots]
+    try:
+        for k in range(n_chunks):
+            eng.push(slots, torch.as_tensor(np.ascontiguousarray(pcm[:, k * 1280:(k + 1) * 1280])).cuda())
+            if eng.step(slots):
+                for i, t in enumerate(eng.fetch_many(slots, 64)):
+                    got[i] += t
+    finally:
+        for s in slots:
+            eng.close_slot(s)
+    return got
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_encoder_cell_tiling_d_equals_tiling_c(dtype, monkeypatch):
+    B, n = 70, 20                                      # 70 rows: two 64-row m-groups, the second partly filled
+    pcm = np.stack([synth.synth_pcm(1, n * 1280, seed=300 + s)[0] for s in range(B)])
+    feats = np.stack([O.features_offline(p[:16000]) for p in pcm[:B]]).astype(np.float32)
+    outs, toks = {}, {}
+    for u12 in (0, 1):
+        monkeypatch.setenv("LASR_ENC_U12", str(u12))
+        eng, sd = make(CFG12, max_streams=128, dtype=dtype)
+        try:
+            out, h, c = eng.encoder(torch.as_tensor(feats).cuda(), return_state=True)
+            outs[u12] = (out.cpu().numpy(), h.cpu().numpy(), c.cpu().numpy())
+            toks[u12] = stream_tokens(eng, pcm, n)
+        finally:
+            eng.close()
+    if dtype == "bf16":                                # same K split over 8 waves, same reduction order: bit-identical
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b)
+        assert toks[0] == toks[1]
+    else:
+        m = O.OracleTransducer(sd, CFG12)
+        ref, st = m.encoder(feats[:8])
+        assert np.abs(outs[1][0][:8] - ref).max() < 5e-4
+        assert np.abs(outs[1][0] - outs[0][0]).max() < 5e-4
+        n_diff = sum(a != b for a, b in zip(toks[0], toks[1]))
+        assert n_diff == 0, f"{n_diff} of {B} streams differ between the tilings"
+    assert sum(len(t) for t in toks[1]) > 50
+
+
+def test_pump_thread_equals_api_launched_groups():
+    """The same pipelined run (4 streams out of phase, depth 4, push_submit) in two processes: LASR_PUMP=1 (default) and 0."""
+    code = r'''
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from libreasr_amd import synth
+from libreasr_amd.engine import Engine
+cfg = synth.model_cfg("tiny"); sd = synth.synth_state_dict(cfg, seed=0)
+eng = Engine(sd, cfg, max_streams=16)
+B, n = 4, 40
+pcm = np.stack([synth.synth_pcm(1, n * 1280, seed=900 + s)[0] for s in range(B)])
+slots = [eng.open() for _ in range(B)]
+steps = [[] for _ in range(B)]
+def collect():
+    if eng.wait():
+        for i, t in enumerate(eng.fetch_many(slots, 64)):
+            steps[i].append(t)
+for k in range(n + B):
+    act = [s for s in range(B) if 0 <= k - s < n]
+    if not act: continue
+    eng.push_submit([slots[s] for s in act], torch.as_tensor(np.stack([pcm[s, (k - s) * 1280:(k - s + 1) * 1280] for s in act])).cuda())
+    while eng.pending() >= 4: collect()
+while eng.pending(): collect()
+print("RESULT" + json.dumps(steps))
+''' % ROOT
+    res = {}
+    for pump in ("1", "0"):
+        env = dict(os.environ, LASR_PUMP=pump)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, r.stdout[-2000:] + r.stderr[-2000:]
+        res[pump] = line[0]
+    assert res["1"] == res["0"]
+    assert res["1"].count(",") > 50
+
+
+def test_overlap_probe_sees_two_concurrent_streams():
+    eng, _ = make(synth.model_cfg("tiny"), max_streams=16)
+    try:
+        r = eng.overlap_probe(5000)
+        assert 0.9 < r < 1.4, r
+    finally:
+        eng.close()
