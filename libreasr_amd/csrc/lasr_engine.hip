@@ -868,7 +868,10 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
                 t.x0 = c->x0; t.MT = c->MT; t.mt_total = c->Tcap * c->MT; t.bf = c->bf;
                 static bool attr = false;
                 if (!attr) { (void)hipFuncSetAttribute((const void*)k_ln_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1284 * 4); attr = true; }
-                hipLaunchKernelGGL(k_ln_tile, dim3(c->MT, Tm), dim3(1024), 16 * 1284 * 4, fe_st, t);
+                // store phase of the tile kernel on 4 z-slices (8 -> 32 workgroups; bit-identical): f32 52.5-52.7 -> 52.6-53.3 k, bf16
+                // 92.8 -> 95.4 k (profiles/r04/r04_lnz_ab.txt); LASR_LN_Z overrides
+                static const int ln_z = getenv("LASR_LN_Z") ? std::max(1, std::min(8, atoi(getenv("LASR_LN_Z")))) : 4;
+                hipLaunchKernelGGL(k_ln_tile, dim3(c->MT, Tm, ln_z), dim3(1024), 16 * 1284 * 4, fe_st, t);
             } else {
                 LAUNCH_STACK_LN( dim3((Tm + 3) / 4, c->M), dim3(256), 0, fe_st, a);
             }

@@ -1795,16 +1795,20 @@ __global__ __launch_bounds__(1024) void k_ln_tile(const LnTileArgs a) {
     }
     __syncthreads();
     // the tile's fragments: chunk c of K, lane = g * 16 + i holds row i, k = KCH c + EPL g + e
+    // (gridDim.z > 1: every z-slice recomputes the tile's statistics -- 80 KB of L2 reads -- and stores its share of the K chunks:
+    //  the store phase, the longer half of this kernel, then runs on gridDim.z times as many CUs)
     const size_t frag0 = (size_t)tp * a.MT + mt;
     if (!a.bf) {
-        for (int idx = threadIdx.x; idx < (F / 16) * 64; idx += 1024) {
+        const int c_lo = (F / 16) * blockIdx.z / gridDim.z, c_hi = (F / 16) * (blockIdx.z + 1) / gridDim.z;
+        for (int idx = c_lo * 64 + threadIdx.x; idx < c_hi * 64; idx += 1024) {
             const int c = idx >> 6, l = idx & 63, g = l >> 4, i = l & 15;
             if (tp >= a.T_row[16 * mt + i]) continue;
             const float* src = xs + i * LD + 16 * c + 4 * g;
             ((float4*)a.x0)[((size_t)c * a.mt_total + frag0) * 64 + l] = float4{src[0], src[1], src[2], src[3]};
         }
     } else {
-        for (int idx = threadIdx.x; idx < (F / 32) * 64; idx += 1024) {
+        const int c_lo = (F / 32) * blockIdx.z / gridDim.z, c_hi = (F / 32) * (blockIdx.z + 1) / gridDim.z;
+        for (int idx = c_lo * 64 + threadIdx.x; idx < c_hi * 64; idx += 1024) {
             const int c = idx >> 6, l = idx & 63, g = l >> 4, i = l & 15;
             if (tp >= a.T_row[16 * mt + i]) continue;
             const float* src = xs + i * LD + 32 * c + 8 * g;
