@@ -109,6 +109,13 @@ def dump_state(eng, slot, tr, j):
     return out
 
 
+HOST_PCM = [False]          # --host-pcm: chunks are handed over as numpy arrays (pageable host memory: staging ring + DMA path)
+
+
+def _buf(T, x):
+    return np.ascontiguousarray(x) if HOST_PCM[0] else T.dev(x)
+
+
 def scenario_sync(T, name, n_sec, n_streams, iters, dump, golden_dir, stop_after):
     """Body of test_streaming_matches_reference, `iters` times."""
     from libreasr_amd import synth
@@ -131,7 +138,7 @@ def scenario_sync(T, name, n_sec, n_streams, iters, dump, golden_dir, stop_after
             step_no = 0
             dumped = False
             for k in range(len(chunks[0])):
-                eng.push(slots, T.dev(np.stack([c[k] for c in chunks])))
+                eng.push(slots, _buf(T, np.stack([c[k] for c in chunks])))
                 ran = eng.step(slots)
                 for s, slot in enumerate(slots):
                     t, _, _ = eng.fetch(slot)
@@ -184,7 +191,7 @@ def scenario_pipe(T, name, n_sec, n_streams, iters, golden_dir, depth, stop_afte
                 if not act:
                     continue
                 sl = [slots[s] for s in act]
-                buf = T.dev(np.stack([chunks[s][k - start[s]] for s in act]))
+                buf = _buf(T, np.stack([chunks[s][k - start[s]] for s in act]))
                 if fused:
                     eng.push_submit(sl, buf)
                 else:
@@ -219,15 +226,17 @@ def main():
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--no-dump", action="store_true")
+    ap.add_argument("--host-pcm", action="store_true", help="push numpy arrays (pageable host memory) instead of device tensors")
     ap.add_argument("--stop-after", type=int, default=0, help="stop after this many mismatching streams (0: run all iterations)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
 
+    HOST_PCM[0] = a.host_pcm
     import test_gpu_parity as T          # the driver's module: shared engine cache, same helper functions
     golden_dir = os.path.join(ROOT, "tests", "golden")
     t0 = time.time()
     run_preamble(a.preamble)
-    summary = dict(event="summary", preamble=a.preamble, model=a.model, env={k: v for k, v in os.environ.items() if k.startswith(("LASR_", "AMD_", "HSA_", "GPU_", "HIP_"))})
+    summary = dict(event="summary", preamble=a.preamble, model=a.model, host_pcm=a.host_pcm, streams=a.streams, env={k: v for k, v in os.environ.items() if k.startswith(("LASR_", "AMD_", "HSA_", "GPU_", "HIP_"))})
     if a.scenario in ("sync", "both"):
         bad, n = scenario_sync(T, a.model, a.n_sec, a.streams, a.iters, not a.no_dump, golden_dir, a.stop_after)
         summary.update(sync_bad_streams=bad, sync_iters=n)
