@@ -51,6 +51,8 @@ SYMBOLS = [
     ("lasr_step_window", C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     ("lasr_step_submit", C.c_int, [_P, _P, C.c_int]),
     ("lasr_step_wait", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("lasr_peek_slot", C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("lasr_peek_many", C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, _P]),
     ("lasr_step_pending", C.c_int, [_P]),
     ("lasr_max_inflight", C.c_int, [_P]),
     ("lasr_transcribe_pcm", C.c_int, [_P, _P, C.c_int, _P, _P]),

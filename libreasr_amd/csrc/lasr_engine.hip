@@ -496,6 +496,8 @@ int lasr_create(int device, const lasr_model_desc* d, const float* weights, size
 }
 
 // ---------------------------------------------------------------------------- slots
+static void cont_poll(lasr_ctx* c);
+
 int lasr_stream_open(lasr_ctx* c, int* slot) {
     if (!c || !slot) return LASR_EINVAL;
     for (int s = 0; s < c->d.max_streams; ++s)
@@ -510,9 +512,21 @@ int lasr_stream_open(lasr_ctx* c, int* slot) {
 int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
     if (!c) return LASR_EINVAL;
     if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
-    for (const auto& p : c->pending)
-        if (std::find(p.rows.begin(), p.rows.end(), slot) != p.rows.end())
+    {
+        // A slot with submitted steps can be reset once the decode loop has FINISHED them for this slot (lasr_peek_slot says so),
+        // collected or not: its encoder steps are behind on the ctx stream, its frames are decoded, the tokens sit in the pinned
+        // ring until lasr_step_wait hands them out.  Model state only (bits 1 | 2 | 4); greedy decode.
+        std::lock_guard<std::mutex> lk(c->mu);
+        bool inflight = false, undecoded = false;
+        for (const auto& p : c->pending)
+            if (std::find(p.rows.begin(), p.rows.end(), slot) != p.rows.end()) {
+                inflight = true;
+                if (!c->pump_on) cont_poll(c);
+                undecoded |= c->h_cur_seen[slot] < p.target[slot];
+            }
+        if (inflight && (undecoded || (what & 8) || c->W > 1))
             return fail(c, LASR_ESTATE, "slot %d has a submitted step in flight: call lasr_step_wait first", slot);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); c->neg_logp[slot] = 0.0; }
     if (what & 2) beam_host_reset(c, slot, (what & 8) != 0);
@@ -554,6 +568,7 @@ int lasr_stream_close(lasr_ctx* c, int slot) {
 
 // ---------------------------------------------------------------------------- streaming
 static int cont_pump(lasr_ctx* c, int G);
+static void cont_poll(lasr_ctx* c);
 
 static void fill_mel_args(lasr_ctx* c, MelArgs& m) {
     const lasr_model_desc& d = c->d;
@@ -1068,6 +1083,84 @@ static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fuse
     // the enqueue above took tens of microseconds of host time: a group may have finished meanwhile.  If nothing is
     // left to decode the next group is queued behind this step's encoder event (stream-side wait)
     RC(cont_pump(c, c->kick_n));
+    return LASR_OK;
+}
+
+// Non-consuming look at the submitted, uncollected model steps of one slot (greedy decode): how many there are, how many of
+// them (oldest first) the decode loop has finished for this slot, and the tokens of those -- counts[k] tokens for step k,
+// concatenated in `tokens`.  lasr_step_wait / lasr_fetch hand the same tokens out later, in step order, as if nobody had looked.
+// What it is for: a scheduler that must judge a stream's step before it may submit the stream's next one (the servicer's
+// reset rule, api-server.py:131-134) learns the verdict when the row is decoded, not `steps in flight` collections later.
+int lasr_peek_slot(lasr_ctx* c, int slot, int32_t* tokens, int cap, int32_t* counts, int cap_steps, int* n_decoded, int* n_inflight) {
+    if (!c || !n_decoded || !n_inflight) return LASR_EINVAL;
+    *n_decoded = 0; *n_inflight = 0;
+    if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
+    if (c->W > 1) return fail(c, LASR_ESTATE, "lasr_peek_slot serves greedy decode (beam = 1)");
+    const int M = c->M;
+    const int* h_end = c->cont_host + 16 + (size_t)lasr_ctx::NFLY * M;
+    const int* h_ring = h_end + (size_t)M * lasr_ctx::ENDSLOTS;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->pump_on) cont_poll(c);
+    long long from = c->h_fetched[slot];
+    int used = 0;
+    bool open_run = true;
+    for (const auto& P : c->pending) {
+        if (std::find(P.rows.begin(), P.rows.end(), slot) == P.rows.end()) continue;
+        const int k = (*n_inflight)++;
+        if (!open_run || c->h_cur_seen[slot] < P.target[slot]) { open_run = false; continue; }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const int j = P.target[slot] / P.Tm - 1;
+        const long long end = h_end[(size_t)slot * lasr_ctx::ENDSLOTS + (j % lasr_ctx::ENDSLOTS)];
+        const int n = (int)(end - from);
+        if (k >= cap_steps || used + n > cap) return fail(c, LASR_EFULL, "lasr_peek_slot: buffers too small");
+        if (counts) counts[k] = n;
+        for (long long q = from; q < end; ++q)
+            if (tokens) tokens[used++] = h_ring[(size_t)slot * lasr_ctx::TOKRING + (q % lasr_ctx::TOKRING)];
+        from = end;
+        (*n_decoded)++;
+    }
+    return LASR_OK;
+}
+
+// lasr_peek_slot for n slots in one call: skip[i] oldest steps of slots[i] are of no interest (the caller has seen them);
+// row i of tokens [n][cap] / counts [n][cap_steps] holds the decoded steps behind them; n_decoded[i] counts ALL decoded steps
+// of the slot (the skipped ones included), n_inflight[i] its submitted steps.
+int lasr_peek_many(lasr_ctx* c, const int* slots, int n, const int* skip, int32_t* tokens, int cap, int32_t* counts, int cap_steps,
+                   int* n_decoded, int* n_inflight) {
+    if (!c || !slots || !n_decoded || !n_inflight || n < 0) return LASR_EINVAL;
+    if (c->W > 1) return fail(c, LASR_ESTATE, "lasr_peek_many serves greedy decode (beam = 1)");
+    const int M = c->M;
+    const int* h_end = c->cont_host + 16 + (size_t)lasr_ctx::NFLY * M;
+    const int* h_ring = h_end + (size_t)M * lasr_ctx::ENDSLOTS;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->pump_on) cont_poll(c);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int i = 0; i < n; ++i) {
+        const int slot = slots[i];
+        n_decoded[i] = 0; n_inflight[i] = 0;
+        if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
+        long long from = c->h_fetched[slot];
+        int used = 0, kept = 0;
+        bool open_run = true;
+        const int sk = skip ? skip[i] : 0;
+        for (const auto& P : c->pending) {
+            if (P.target[slot] == 0) continue;                       // the slot is not part of this step
+            const int k = n_inflight[i]++;
+            if (!open_run || c->h_cur_seen[slot] < P.target[slot]) { open_run = false; continue; }
+            const int j = P.target[slot] / P.Tm - 1;
+            const long long end = h_end[(size_t)slot * lasr_ctx::ENDSLOTS + (j % lasr_ctx::ENDSLOTS)];
+            if (k >= sk) {
+                const int cnt = (int)(end - from);
+                if (kept >= cap_steps || used + cnt > cap) return fail(c, LASR_EFULL, "lasr_peek_many: buffers too small");
+                if (counts) counts[(size_t)i * cap_steps + kept] = cnt;
+                if (tokens)
+                    for (long long q = from; q < end; ++q) tokens[(size_t)i * cap + used++] = h_ring[(size_t)slot * lasr_ctx::TOKRING + (q % lasr_ctx::TOKRING)];
+                kept++;
+            }
+            from = end;
+            n_decoded[i]++;
+        }
+    }
     return LASR_OK;
 }
 

@@ -194,6 +194,47 @@ class Engine:
         self._chk(self.lib.lasr_step_wait(self.ctx, C.byref(ran)))
         return ran.value
 
+    def peek(self, slot, cap=1024, cap_steps=32):
+        """-> (token lists of the slot's submitted model steps that are already decoded, oldest first; steps in flight).  Non-consuming
+        (lasr_peek_slot): wait() / fetch hand the same tokens out later.  A slot whose steps in flight are all decoded may be reset."""
+        buf = np.empty(cap, dtype=np.int32)
+        cnt = np.zeros(cap_steps, dtype=np.int32)
+        nd, nf = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.lasr_peek_slot(self.ctx, int(slot), buf.ctypes.data_as(C.c_void_p), cap, cnt.ctypes.data_as(C.c_void_p), cap_steps,
+                                          C.byref(nd), C.byref(nf)))
+        out, o = [], 0
+        for k in range(nd.value):
+            out.append(buf[o:o + cnt[k]].tolist())
+            o += int(cnt[k])
+        return out, nf.value
+
+    _peek_bufs = None
+
+    def peek_many(self, slots, skip, cap=256, cap_steps=16):
+        """lasr_peek_many: for every listed slot the token lists of its decoded, uncollected model steps behind the first skip[i]
+        ones, and its steps in flight -> (list of lists of token lists, n_decoded array, n_inflight array)."""
+        a, p, n = self._slots(slots)
+        sk = np.ascontiguousarray(np.asarray(skip, dtype=np.int32))
+        b = self._peek_bufs
+        if b is None or b[0].shape[0] < n or b[0].shape[1] != cap or b[1].shape[1] != cap_steps:
+            b = self._peek_bufs = (np.empty((max(n, 64), cap), np.int32), np.zeros((max(n, 64), cap_steps), np.int32),
+                                   np.zeros(max(n, 64), np.int32), np.zeros(max(n, 64), np.int32))
+        tok, cnt, nd, nf = b
+        self._chk(self.lib.lasr_peek_many(self.ctx, p, n, sk.ctypes.data_as(C.c_void_p), tok.ctypes.data_as(C.c_void_p), cap,
+                                          cnt.ctypes.data_as(C.c_void_p), cap_steps, nd.ctypes.data_as(C.c_void_p), nf.ctypes.data_as(C.c_void_p)))
+        out = []
+        for i in range(n):
+            k_new = int(nd[i]) - int(sk[i])
+            if k_new <= 0:
+                out.append([])
+                continue
+            o, steps = 0, []
+            for k in range(k_new):
+                steps.append(tok[i, o:o + cnt[i, k]].tolist())
+                o += int(cnt[i, k])
+            out.append(steps)
+        return out, nd[:n].copy(), nf[:n].copy()
+
     def step_feats(self, slots, feats):
         """feats [n, T, feat] (torch cuda/cpu or numpy): one streaming model call with carried state."""
         a, p, n = self._slots(slots)

@@ -94,7 +94,7 @@ class Scheduler(threading.Thread):
     The per-stream bookkeeping (frames queued, frames to the next model step, steps in flight, steps since the last reset) lives
     in arrays indexed by slot: a tick classifies all streams with a dozen vector operations whatever their number."""
 
-    def __init__(self, engine, depth=12, downsample=None, n_buffer=None, held_depth=3):
+    def __init__(self, engine, depth=12, downsample=None, n_buffer=None, held_depth=None):
         super().__init__(daemon=True, name="lasr-scheduler")
         self.eng, self.cv = engine, threading.Condition()
         self.streams, self.ctl, self.stop_flag = {}, collections.deque(), False
@@ -106,9 +106,16 @@ class Scheduler(threading.Thread):
         # meanwhile run without it: fewer steps in flight then (faster-than-real-time replays with the reset rule, 64 streams of
         # configs[1] on the GPU: 13.9 k audio-s/s at 12, 20.1 k at 6, 21.4 k at 3, 20.3 k at 1, tools/served_depth_sweep.py; a
         # real-time stream is never run ahead at all)
+        self.beam = engine.beam
+        # Early verdicts (round 4): the engine lets the scheduler LOOK at a slot's decoded-but-uncollected steps (lasr_peek_slot) and
+        # reset a slot whose steps in flight are all decoded, so a held stream is judged when its row is decoded -- a few hundred
+        # microseconds after the submit -- instead of `steps in flight` collections later, and the other streams keep the full depth
+        # meanwhile.  (Greedy decode; with beam > 1, or an engine without peek, the round-3 behaviour: held_depth 3.)
+        self.can_peek = self.beam == 1 and hasattr(engine, "peek_many")
+        if held_depth is None:               # (tools/served_depth_sweep.py with early verdicts: 12 -> 17-25 k, 6 -> 23.5 k, 3 -> 23.0 k, 1 -> 20.9 k)
+            held_depth = 6 if self.can_peek else 3
         self.held_depth = max(1, min(int(held_depth), self.depth))
         self.any_held = False
-        self.beam = engine.beam
         self._beam_cap = 1024               # tokens per stream fetch_many makes room for with beam > 1 (grows on LASR_EFULL)
         self.inflight = collections.deque() # per submitted model step: (slots of its streams, {slot: result cell} | None)
         self.batch_outq = queue.SimpleQueue()   # trunk interface (push_batch): one item per collected model step
@@ -127,6 +134,7 @@ class Scheduler(threading.Thread):
         self.phase = z()                    # frames up to and including the one that completes the next model step (1: the next frame does)
         self.infl = z()                     # model steps submitted and not collected
         self.stp = z()                      # model steps since the last reset (api-server.py:117,133)
+        self.judged = z()                   # steps in flight that have already been judged (and counted in stp) through peek
         self.rat = z(_FAR)                  # steps since the last reset from which the reset rule can fire (_FAR: no text function)
         self.cur = z()                      # trunk streams: serial of the next batch to take
         self.is_trunk = np.zeros(N, bool)
@@ -242,7 +250,7 @@ class Scheduler(threading.Thread):
             self.qn[i], self.eofp[i], self.fast[i], self.is_trunk[i] = 0, False, False, False
             self.n_slow += 1
             self.n_ruled += text_of is not None
-        self.infl[i], self.stp[i], self.cur[i] = 0, 0, 0
+        self.infl[i], self.stp[i], self.cur[i], self.judged[i] = 0, 0, 0, 0
         self.rat[i] = self.reset_steps if text_of is not None else _FAR
         self.phase[i] = d.n_window + d.n_buffer - 1      # window full at frame n_window, then every n_buffer-th frame completes a step
         return st
@@ -307,7 +315,12 @@ class Scheduler(threading.Thread):
             raise RuntimeError(f"scheduler: expected a model step of {len(sl)} streams, the engine ran {ran}")
         toks = self._fetch(sl)
         self.infl[sl] -= 1
-        self.stp[sl] += 1
+        pre = self.judged[sl] > 0            # judged (and counted) when the row was decoded: see _early_verdicts
+        if pre.any():
+            self.judged[sl[pre]] -= 1
+            self.stp[sl[~pre]] += 1
+        else:
+            self.stp[sl] += 1
         streams = self.streams
         rows = [streams[i] for i in sl.tolist()]
         if self.beam > 1:                    # (the hypothesis of the previous step is needed for every later judgement)
@@ -315,7 +328,7 @@ class Scheduler(threading.Thread):
                 if s.text_of is not None:
                     self._judge(s, t)
         elif self.n_ruled:
-            hot = np.flatnonzero(self.stp[sl] >= self.rat[sl])
+            hot = np.flatnonzero((self.stp[sl] >= self.rat[sl]) & ~pre)
             for k in hot.tolist():           # only the streams within reach of the reset rule
                 self._judge(rows[k], toks[k])
         self.n_blocked = 0                   # (a judged step may have released a held stream: the next tick finds out)
@@ -347,6 +360,28 @@ class Scheduler(threading.Thread):
                 if e.code != LASR_EFULL or self._beam_cap >= (1 << 22):
                     raise
                 self._beam_cap *= 4
+
+    def _early_verdicts(self):
+        """Streams whose next model step waits for the verdict on a step in flight (see _take): look at the engine's decoded,
+        uncollected steps of the slot and judge them now, in order -- the servicer's rule, api-server.py:131-134, between the
+        step and the stream's next one exactly as if the step had been collected."""
+        unj = self.infl - self.judged
+        cand = np.flatnonzero((unj > 0) & (self.stp + unj + 1 >= self.rat))
+        if not len(cand):
+            return
+        steps_of, n_dec, n_inflight = self.eng.peek_many(cand, self.judged[cand])      # ONE engine call for all of them
+        for q, i in enumerate(cand.tolist()):
+            st = self.streams.get(i)
+            if st is None or st.text_of is None:
+                continue
+            for new in steps_of[q]:
+                self.judged[i] += 1
+                self.stp[i] += 1
+                if self.stp[i] >= self.rat[i] and (not new or st.text_of(new) == ""):
+                    # (past the threshold a stream has ONE step in flight at a time: this was its last, and it is decoded)
+                    if int(self.judged[i]) != int(n_inflight[q]):
+                        raise RuntimeError(f"scheduler: slot {i} ran ahead of the reset threshold ({int(n_inflight[q])} steps in flight)")
+                    self._reset(i)
 
     def _drain(self):
         while self.inflight:
@@ -403,7 +438,8 @@ class Scheduler(threading.Thread):
         step_f = ready & (self.phase == 1)
         if self.n_ruled:                     # at the reset threshold: the step in flight is judged before the next one starts
             infl = self.infl
-            held = step_f & (infl > 0) & (self.stp + infl + 1 >= self.rat)
+            unj = infl - self.judged         # steps in flight whose verdict is still out
+            held = step_f & (unj > 0) & (self.stp + unj + 1 >= self.rat)
             self.n_blocked = int(qn[held].sum()) + (int(np.count_nonzero(self.eofp & held)) if self.n_eof else 0)
             self.any_held = self.n_blocked > 0
             steps_m = step_f & ~held
@@ -503,6 +539,8 @@ class Scheduler(threading.Thread):
     def _run(self):
         d = self.eng.desc
         while True:
+            if self.can_peek and self.n_ruled and self.inflight:
+                self._early_verdicts()
             with self.cv:
                 while not (self.stop_flag or self.ctl or self.inflight or self.n_wait > 0):
                     self.cv.wait()

@@ -30,6 +30,8 @@ class FakeEngine:
         self.hyp = {}                       # beam > 1: the whole best hypothesis since the last reset (what lasr_fetch hands out)
         self.max_pending = 0
         self.lock_owner = None
+        self.peek_lag = 0
+        self.clock = 0                      # engine calls so far
 
     def _own(self):                         # a lasr_ctx is single-caller: every call must come from ONE thread
         me = threading.get_ident()
@@ -54,15 +56,39 @@ class FakeEngine:
         assert not any(s in rows for rows in self.steps), "close with a step in flight"
         self.open_.discard(s)
 
+    def peek(self, s):
+        """The real engine's lasr_peek_slot: (token lists of the slot's decoded, uncollected steps, steps in flight).  A step counts as
+        decoded `peek_lag` engine calls after its submit (0: at once): time passes with every call."""
+        self._own()
+        assert self.beam == 1
+        self.clock += 1
+        mine = [out for out in self.steps if s in out]
+        done = []
+        for out in mine:                    # decoded steps are a prefix
+            if self.clock - out["_t"] < self.peek_lag:
+                break
+            done.append(list(out[s]))
+        return done, len(mine)
+
+    def peek_many(self, slots, skip):
+        res, nd, nf = [], [], []
+        for s, sk in zip(np.asarray(slots).tolist(), np.asarray(skip).tolist()):
+            done, n_in = self.peek(s)
+            res.append(done[sk:])
+            nd.append(len(done))
+            nf.append(n_in)
+        return res, np.array(nd), np.array(nf)
+
     def reset(self, s, what):
         self._own()
-        assert not any(s in rows for rows in self.steps), "reset with a step in flight"
+        assert all(self.clock - out["_t"] >= self.peek_lag for out in self.steps if s in out), "reset with an undecoded step in flight"
         self.resets.append((s, self.total_steps[s]))
         self.since_reset[s] = 0
         self.hyp[s] = []
 
     def push_submit(self, slots, pcm):
         self._own()
+        self.clock += 1
         assert len(self.steps) < self._inflight
         rows = []
         for s, ch in zip(slots, np.asarray(pcm)):
@@ -83,6 +109,7 @@ class FakeEngine:
                     if self.silent_after is None or self.since_reset[s] <= self.silent_after:
                         self.hyp[s] = self.hyp[s] + out[s]
                     out[s] = list(self.hyp[s])
+            out["_t"] = self.clock
             self.steps.append(out)
             self.max_pending = max(self.max_pending, len(self.steps))
 
@@ -91,7 +118,9 @@ class FakeEngine:
 
     def wait(self):
         self._own()
+        self.clock += 1
         out = self.steps.popleft()
+        out.pop("_t", None)
         for s, t in out.items():
             self.queue[s] = t
         return len(out)
@@ -550,3 +579,44 @@ def test_a_long_beam_hypothesis_grows_the_fetch_buffer_instead_of_ending_the_sch
         assert sched._beam_cap >= 60 and sched.error is None
     finally:
         sched.shutdown()
+
+
+@pytest.mark.parametrize("lag", [0, 2])
+def test_early_verdicts_keep_held_streams_in_the_batch_and_place_resets_where_the_reference_does(lag):
+    """Round 4: with lasr_peek_slot the verdict on a held stream's step arrives when its row is decoded (here: `lag` submits after
+    its own), not `depth` collections later.  Same tokens, same resets as the reference's rule (expected()); and the streams at
+    the threshold miss far fewer model steps than without peek."""
+    rng = np.random.default_rng(9)
+    B, n = 8, 170
+    chunks = rng.integers(0, 9, (n, B, 4)).astype(np.float32)
+
+    def run(can_peek):
+        eng = FakeEngine(max_streams=8, silent={1, 4, 6})
+        eng.peek_lag = lag
+        sched = srv.Scheduler(eng, depth=8)
+        if not can_peek:
+            sched.can_peek, sched.held_depth = False, 3
+        sched.start()
+        try:
+            sts = [sched.open(text_of=lambda t: "x" if t else "") for _ in range(B)]
+            for k in range(n):
+                sched.push_batch(sts, chunks[k])
+            got = {st.slot: [] for st in sts}
+            while sum(len(g) for g in got.values()) < B * ((n - 2) // 2):
+                item = sched.batch_outq.get(timeout=20)
+                assert not isinstance(item, Exception), item
+                for st, t in zip(*item):
+                    got[st.slot].append(t)
+            for i, st in enumerate(sts):
+                exp = [t for t in expected([chunks[k, i] for k in range(n)], slot_silent=st.slot in eng.silent) if t is not None]
+                assert got[st.slot] == exp, (can_peek, i)
+            assert sorted(eng.resets) == sorted((s, k) for s in (1, 4, 6) for k in (25, 50, 75))
+            assert sched.error is None
+            return float(np.mean(sched.step_rows)), len(sched.step_rows)
+        finally:
+            sched.shutdown()
+
+    rows_peek, steps_peek = run(True)
+    rows_old, steps_old = run(False)
+    assert steps_peek <= steps_old and rows_peek >= rows_old
+    assert rows_peek > 0.9 * B, (rows_peek, rows_old)         # held streams rejoin within a step or two

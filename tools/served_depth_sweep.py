@@ -15,7 +15,8 @@ from libreasr_amd.lib.inference import load_stuff
 
 conf, language, model, _, _ = load_stuff("en", config_path="/nonexistent.yaml", synthetic="cfg2", max_streams=64)
 eng = model.engine
-B, n = 64, 128
+B = 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128          # chunks per stream
 pcm = np.stack([synth.synth_pcm(1, n * 1280, seed=4321 + s)[0] for s in range(B)])
 chunks = np.ascontiguousarray(pcm.reshape(B, n, 1280).transpose(1, 0, 2))
 out = {}
