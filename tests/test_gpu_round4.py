@@ -119,3 +119,70 @@ def test_overlap_probe_sees_two_concurrent_streams():
         assert 0.9 < r < 1.4, r
     finally:
         eng.close()
+
+
+def test_peek_and_reset_of_a_slot_whose_submitted_steps_are_decoded():
+    """lasr_peek_slot / lasr_peek_many: the tokens seen early are the tokens lasr_step_wait hands out later; a slot may be reset
+    (model state) while its decoded steps are still uncollected, and the stream then continues exactly as the oracle does after
+    reset() between those two model steps (the servicer's reset rule applied without draining the pipeline); the neighbour
+    stream is untouched."""
+    import time
+    from libreasr_amd._native import LasrError
+    cfg = synth.model_cfg("tiny")
+    eng, sd = make(cfg, max_streams=16)
+    try:
+        m = O.OracleTransducer(sd, cfg)
+        n = 44
+        pcm = np.stack([synth.synth_pcm(1, n * 1280, seed=4100 + s)[0] for s in range(2)])
+        RESET_AFTER = 6                                    # model steps of stream 0 before its reset
+        want = []
+        for s in range(2):
+            fe, dec = O.StreamFrontend(), m.stream_decoder()
+            steps = []
+            for k in range(n):
+                o = fe.push(pcm[s, k * 1280:(k + 1) * 1280])
+                if o is not None:
+                    steps.append(dec.step(o))
+                    if s == 0 and len(steps) == RESET_AFTER:
+                        dec.reset()
+            want.append(steps)
+        slots = [eng.open(), eng.open()]
+        got = [[], []]
+        peeked = {}
+        n_sub = 0
+
+        def collect():
+            if eng.wait():
+                for i, t in enumerate(eng.fetch_many(slots, 64)):
+                    got[i].append(t)
+
+        for k in range(n):
+            before = eng.pending()
+            eng.push_submit(slots, torch.as_tensor(np.ascontiguousarray(pcm[:, k * 1280:(k + 1) * 1280])).cuda())
+            if eng.pending() > before:
+                n_sub += 1
+                if n_sub == RESET_AFTER:
+                    # steps in flight: wait (without collecting) until the decode loop has finished them for slot 0, reset it
+                    t0 = time.time()
+                    while True:
+                        steps, n_in = eng.peek(slots[0])
+                        if len(steps) == n_in:
+                            break
+                        assert time.time() - t0 < 10
+                    assert n_in >= 1
+                    many, nd, nf = eng.peek_many(slots, [0, 0])
+                    assert many[0] == steps and int(nf[0]) == n_in
+                    peeked[0] = steps
+                    eng.reset(slots[0], 7)
+                    with pytest.raises(LasrError):          # front-end state cannot be reset under steps in flight
+                        eng.reset(slots[0], 8)
+            while eng.pending() >= 3:
+                collect()
+        while eng.pending():
+            collect()
+        assert got[0] == want[0] and got[1] == want[1]
+        n_col = len(peeked[0])
+        assert peeked[0] == want[0][RESET_AFTER - n_col:RESET_AFTER]      # what peek showed == what wait handed out later
+        assert sum(len(t) for t in got[0]) > 10
+    finally:
+        eng.close()
