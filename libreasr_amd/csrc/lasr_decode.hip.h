@@ -345,7 +345,7 @@ int run_decode_beam(lasr_ctx* c, int T_max, int max_iters, bool offline, const s
     int iter = 0;
     int group = offline ? std::min(total_cap, T_max + 16) : std::min(total_cap, T_max + 4);
     const int next_group = offline ? 32 : 4;
-    c->dbg_gate = false;
+    c->dbg_gate = c->dbg && getenv("LASR_DBG_BEAM");        // (LASR_DBG_TIMING + LASR_DBG_BEAM: phase stamps of the beam round's GEMMs)
     while (iter < total_cap) {
         const int n = std::min(group, total_cap - iter);
         for (int q = 0; q < n; ++q) {

@@ -97,6 +97,7 @@ struct GemmArgs {
     unsigned long long* prof; // optional: per-workgroup entry (prof[wg % PROF_W]) and exit (prof_x[wg % PROF_W]) wall_clock64(), plain stores --
     unsigned long long* prof_x; //   max exit - min entry over the workgroups = the kernel's own duration (atomics on one word cost the job 7 %)
     int prio;                // wave priority for the whole kernel (s_setprio 0..3); experiments: LASR_DEC_PRIO / LASR_CELL_PRIO
+    int skip_idle;           // COMPACT: an m-group without a compacted row returns at once (its rows' carry is done by k_beam_carry)
 };
 
 // beam search: physical row of the parent hypothesis of row r (W slots per stream, contiguous)
@@ -294,19 +295,30 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
 
     int n_act = g.M;
     if constexpr (Epi::COMPACT) {
-        if (w == 0) {   // ballot prefix scan over the row flags (M <= 1024)
+        if (w == 0) {   // ballot prefix scan over the row flags (M <= 1024).  The flags of all (up to 16) 64-row chunks are loaded
+            // up front: one round trip instead of one per chunk (1024 hypothesis rows: 6 us of every workgroup's life before)
             int cnt = 0;
-            for (int base = 0; base < g.M; base += 64) {
-                const int r = base + lane;
-                const bool f = r < g.M && g.compact[r] != 0;
-                const unsigned long long m = __ballot(f);
-                if (f) row_map[cnt + __popcll(m & ((1ull << lane) - 1ull))] = r;
-                cnt += __popcll(m);
+            const int nch = (g.M + 63) >> 6;
+            int fl[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = i * 64 + lane;
+                fl[i] = (i < nch && r < g.M) ? g.compact[r] : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < nch) {
+                    const bool f = fl[i] != 0;
+                    const unsigned long long m = __ballot(f);
+                    if (f) row_map[cnt + __popcll(m & ((1ull << lane) - 1ull))] = i * 64 + lane;
+                    cnt += __popcll(m);
+                }
             }
             if (lane == 0) n_act_s = cnt;
         }
         __syncthreads();
         n_act = __builtin_amdgcn_readfirstlane(n_act_s);
+        if (g.skip_idle && mg * ROWS >= n_act) return;       // uniform over the workgroup
     }
 
     bool tile_on[MT];
@@ -494,6 +506,7 @@ struct EpiLSTM {
         int W;
         const float* c_in;
         const void* y_in;
+        int no_carry;          // beam: the rows that are not extended have been carried by k_beam_carry
     };
     struct Pre {
         int r;                 // row this thread finishes (-1: none)
@@ -515,7 +528,7 @@ struct EpiLSTM {
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
         const bool beam = PRED && a.W > 1;
         if (PRED) {
-            if (vr < a.M && !a.flag[vr]) {
+            if (!a.no_carry && vr < a.M && !a.flag[vr]) {
                 const int pr = beam ? beam_prow(a.parent, a.W, vr) : vr;
                 p.carry = true; p.carry_h = Ops::ld(a.h_in, hidx(a, pr, u));
                 if (beam) { p.carry_c = a.c_in[(size_t)u * a.M + pr]; p.carry_y = Ops::ld(a.y_in, hidx(a, pr, u)); }
@@ -632,6 +645,7 @@ struct EpiNBRC {
         const int* parent;     // beam search (W > 1): see EpiLSTM::Args
         int W;
         const void* y_in;
+        int no_carry;
     };
     struct Pre {
         int r;
@@ -647,7 +661,7 @@ struct EpiNBRC {
         if (tid >= 256) return p;
         const int row = tid % ROWS, uu = tid / ROWS, vr = mg * ROWS + row, u = jb * U + uu, H = a.H;
         const bool beam = a.W > 1;
-        if (vr < a.M && !a.emit[vr]) {
+        if (!a.no_carry && vr < a.M && !a.emit[vr]) {
             const int pr = beam ? beam_prow(a.parent, a.W, vr) : vr;
             p.carry = true; p.carry_h = Ops::ld(a.h_in, (size_t)pr * H + u);
             if (beam) p.carry_y = Ops::ld(a.y_in, (size_t)pr * H + u);
@@ -713,7 +727,7 @@ struct EpiLSTMw {
         const bool beam = a.W > 1;
         for (int item = tid; item < ROWS * U; item += nthr) {
             const int row = item % ROWS, uu = item / ROWS, vr = mg * ROWS + row, u = jb * U + uu;
-            if (vr < a.M && !a.flag[vr]) {          // a row that did not emit: carried to the other parity
+            if (!a.no_carry && vr < a.M && !a.flag[vr]) {          // a row that did not emit: carried to the other parity
                 const int pr = beam ? beam_prow(a.parent, a.W, vr) : vr;
                 Ops::st(a.h_out, (size_t)vr * H + u, Ops::ld(a.h_in, (size_t)pr * H + u));
                 if (beam) {
@@ -761,7 +775,7 @@ struct EpiNBRCw {
         const bool beam = a.W > 1;
         for (int item = tid; item < ROWS * U; item += nthr) {
             const int row = item % ROWS, uu = item / ROWS, vr = mg * ROWS + row, u = jb * U + uu;
-            if (vr < a.M && !a.emit[vr]) {
+            if (!a.no_carry && vr < a.M && !a.emit[vr]) {
                 const int pr = beam ? beam_prow(a.parent, a.W, vr) : vr;
                 Ops::st(a.h_out, (size_t)vr * H + u, Ops::ld(a.h_in, (size_t)pr * H + u));
                 if (beam) Ops::st(a.y, (size_t)vr * H + u, Ops::ld(a.y_in, (size_t)pr * H + u));
@@ -870,6 +884,7 @@ struct EpiPPJ {
         int W, M_enc;
         const float* pp_in;
         int la;               // greedy lookahead: ja is also produced for frames t+1 .. t+la-1 (rows k*M + r)
+        int no_carry;         // beam: pp / ja of the rows that are not extended are done by k_beam_carry
     };
     struct Pre {};
     template <int MTB>
@@ -899,7 +914,7 @@ struct EpiPPJ {
                 }
             }
             const int r = vr;                           // original row of this range, if it did not emit
-            if (r < a.M && !a.emit[r]) {
+            if (!a.no_carry && r < a.M && !a.emit[r]) {
                 const int q = beam ? r / a.W : r;
                 const int t = a.t_idx[q];
                 float p;

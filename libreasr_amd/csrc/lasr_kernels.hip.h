@@ -1091,6 +1091,63 @@ __global__ void k_ja_admit_beam(const float* __restrict__ pe, const float* __res
     act_st(bf, ja, act_off(bf, r, j, MT), tanhf(pe[((size_t)(t % ring) * M_enc + q) * J + j] + pp[(size_t)r * J + j]));
 }
 
+// Beam search, one selection round: every hypothesis slot that was NOT extended takes the state of its parent slot (current
+// parity) into its own slot of the other parity -- predictor h / c / BN(h) of every layer, the predictor half of the joint -- and,
+// if its stream still has a frame to decode, its joint activation.  This used to ride in the epilogues of the predictor / joint
+// GEMMs, 16 units (32 bytes) of a row per workgroup: 1536 workgroups of scattered 2-byte copies, 7 us each whether or not they
+// had a row to compute (profiles/r04/r04_pred_timeline_cfg5.txt).  Here a row is one workgroup and the copies are whole rows.
+// blockIdx.y == 0: row-major parts (h, y, pp, ja), one workgroup per slot; blockIdx.y == 1: the unit-major cell state c
+// ([H][Md]: threads run over the slots, blockIdx.x over 16-unit slices).
+struct BeamCarryArgs {
+    const int* emit; const int* parent; int W, Md, H, J, Lp, bf, lstm;
+    const void* h_in[8]; void* h_out[8];
+    const void* y_in[8]; void* y_out[8];
+    const float* c_in[8]; float* c_out[8];
+    const float* pp_in; float* pp_out;
+    const float* pe; const int* t_idx; const int* T_row; void* ja; int MTj, ring, M_enc;
+};
+__global__ __launch_bounds__(256) void k_beam_carry(const BeamCarryArgs a) {
+    if (blockIdx.y == 1) {
+        const int u0 = blockIdx.x * 16;
+        if (!a.lstm || u0 >= a.H) return;
+        for (int r = threadIdx.x; r < a.Md; r += blockDim.x) {
+            if (a.emit[r]) continue;
+            const int pr = (r / a.W) * a.W + a.parent[r];
+            for (int l = 0; l < a.Lp; ++l)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a.c_out[l][(size_t)(u0 + q) * a.Md + r] = a.c_in[l][(size_t)(u0 + q) * a.Md + pr];
+        }
+        return;
+    }
+    const int r = blockIdx.x;
+    if (r >= a.Md || a.emit[r]) return;
+    const int pr = (r / a.W) * a.W + a.parent[r], H = a.H, J = a.J;
+    for (int l = 0; l < a.Lp; ++l) {
+        if (a.bf) {          // (H % 32 == 0 with bf16 operands: whole 16-byte pieces)
+            const uint4* hs = (const uint4*)((const unsigned short*)a.h_in[l] + (size_t)pr * H);
+            const uint4* ys = (const uint4*)((const unsigned short*)a.y_in[l] + (size_t)pr * H);
+            uint4* hd = (uint4*)((unsigned short*)a.h_out[l] + (size_t)r * H);
+            uint4* yd = (uint4*)((unsigned short*)a.y_out[l] + (size_t)r * H);
+            for (int i = threadIdx.x; i < H / 8; i += blockDim.x) { hd[i] = hs[i]; yd[i] = ys[i]; }
+        } else {
+            const float4* hs = (const float4*)((const float*)a.h_in[l] + (size_t)pr * H);
+            const float4* ys = (const float4*)((const float*)a.y_in[l] + (size_t)pr * H);
+            float4* hd = (float4*)((float*)a.h_out[l] + (size_t)r * H);
+            float4* yd = (float4*)((float*)a.y_out[l] + (size_t)r * H);
+            for (int i = threadIdx.x; i < H / 4; i += blockDim.x) { hd[i] = hs[i]; yd[i] = ys[i]; }
+        }
+    }
+    const int q = r / a.W;
+    const int t = a.t_idx[q];
+    const bool live = t < a.T_row[q];
+    const float* pes = a.pe + ((size_t)(t % a.ring) * a.M_enc + q) * J;
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        const float p = a.pp_in[(size_t)pr * J + j];
+        a.pp_out[(size_t)r * J + j] = p;
+        if (live) act_st(a.bf, a.ja, act_off(a.bf, r, j, a.MTj), tanhf(pes[j] + p));
+    }
+}
+
 // start of a beam decode step: per-stream cursors and the iteration flags
 __global__ void k_beam_begin(BeamState s, int M, int n_iter_slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -116,6 +116,12 @@ void launch_enc_wave(lasr_ctx* c, const EncCellRef* cells, int n, int par0, int 
     else launch_enc_wave_t<OpsF32>(c, cells, n, par0, mt_total);
 }
 
+// beam search: the slots that are not extended are carried by k_beam_carry instead of the GEMM epilogues (LASR_BEAM_CARRY=0: as in round 3)
+bool beam_carry_on() {
+    static const int v = getenv("LASR_BEAM_CARRY") ? atoi(getenv("LASR_BEAM_CARRY")) : 1;
+    return v != 0;
+}
+
 // one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels); predictor
 // state is row-major [M][H]; toggles pred_par
 template <class Ops>
@@ -129,9 +135,24 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
     const bool wide = wide_env >= 0 ? wide_env == 1 : c->Md >= 512;
     const int w8_min = getenv("LASR_W8_MIN") ? atoi(getenv("LASR_W8_MIN")) : 256;
     const bool wide8 = wide_env >= 0 ? wide_env == 2 : (c->bf && c->Md >= w8_min && c->Md < 512);   // 8 units per workgroup, 8 waves
+    const bool split_carry = beam && beam_carry_on();
+    if (split_carry) {      // the slots that are not extended: whole-row copies by their own launch (see k_beam_carry)
+        BeamCarryArgs a{};
+        a.emit = c->ds.emit; a.parent = c->b_parent; a.W = c->W; a.Md = c->Md; a.H = H; a.J = c->d.joint; a.Lp = c->d.pred_layers;
+        a.bf = c->bf; a.lstm = c->d.pred_cell;
+        for (int l = 0; l < a.Lp; ++l) {
+            a.h_in[l] = c->pred_h[p][l]; a.h_out[l] = c->pred_h[p ^ 1][l];
+            a.y_in[l] = p ? c->pred_y1[l] : c->pred_y[l]; a.y_out[l] = p ? c->pred_y[l] : c->pred_y1[l];
+            if (a.lstm) { a.c_in[l] = p ? c->pred_c1[l] : c->pred_c[l]; a.c_out[l] = p ? c->pred_c[l] : c->pred_c1[l]; }
+        }
+        a.pp_in = p ? c->pp1 : c->pp; a.pp_out = p ? c->pp : c->pp1;
+        a.pe = c->pe; a.t_idx = c->dec_t_idx; a.T_row = c->T_row_dec; a.ja = c->ja; a.MTj = c->MTj; a.ring = c->pe_ring_R; a.M_enc = c->M;
+        hipLaunchKernelGGL(k_beam_carry, dim3(std::max(c->Md, (H + 15) / 16), 2), dim3(256), 0, c->stream, a);
+    }
     for (int l = 0; l < c->d.pred_layers; ++l) {
         const Cell& L = c->pred[l];
         GemmArgs g{};
+        g.skip_idle = split_carry ? 1 : 0;
         // beam: parity p holds the current state; everything is written to parity p ^ 1
         void* y_out = (beam && !p) ? c->pred_y1[l] : c->pred_y[l];
         const void* y_in = (beam && p) ? c->pred_y1[l] : c->pred_y[l];
@@ -149,6 +170,7 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
             ea.y = y_out; ea.y_mt_total = 0; ea.y_mt_off = 0;
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md; ea.MT = c->MTd;
             if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.c_in = p ? c->pred_c1[l] : c->pred_c[l]; ea.y_in = y_in; }
+            ea.no_carry = split_carry ? 1 : 0;
             if (l == 0) {
                 if (wide8) launch_gemm<Ops, EpiLSTMw<Ops, true, 2>, MTA, true, -1>(c, H / 8, mgroups, g, ea);
                 else if (wide) launch_gemm<Ops, EpiLSTMw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
@@ -167,6 +189,7 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
             ea.h_in = c->pred_h[p][l]; ea.h_out = c->pred_h[p ^ 1][l]; ea.y = y_out;
             ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->Md;
             if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.y_in = y_in; }
+            ea.no_carry = split_carry ? 1 : 0;
             if (l == 0) {
                 if (wide8) launch_gemm<Ops, EpiNBRCw<Ops, true, 2>, MTA, true, -1>(c, H / 8, mgroups, g, ea);
                 else if (wide) launch_gemm<Ops, EpiNBRCw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
@@ -200,6 +223,7 @@ void launch_ppj_t(lasr_ctx* c, bool beam) {
     ea.b1 = c->b1; ea.pp = (beam && !p) ? c->pp1 : c->pp; ea.pe = c->pe; ea.t_idx = c->dec_t_idx; ea.T_row = c->T_row_dec; ea.emit = c->ds.emit;
     ea.ja = c->ja; ea.J = J; ea.M = c->Md; ea.MT = c->MTj; ea.ring = c->pe_ring_R; ea.la = beam ? 1 : c->la;
     if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.M_enc = c->M; ea.pp_in = p ? c->pp1 : c->pp; }
+    if (beam && beam_carry_on()) { ea.no_carry = 1; g.skip_idle = 1; }      // (k_beam_carry, launched with the predictor pass)
     static const int ppj_wide_env = getenv("LASR_PPJ_WIDE") ? atoi(getenv("LASR_PPJ_WIDE")) : -1;
     const bool ppj_wide = (ppj_wide_env >= 0 ? ppj_wide_env != 0 : c->Md >= 512) && c->MTd % 4 == 0;   // 64-row workgroups for many decoder rows
     if (ppj_wide) launch_gemm<Ops, EpiPPJ<Ops>, 4, true, -1, 4>(c, J / 16, c->MTd / 4, g, ea);
