@@ -104,7 +104,10 @@ const char* lasr_last_error(const lasr_ctx* c);
 int lasr_stream_open(lasr_ctx* c, int* slot);
 /* what: 1 = encoder state, 2 = predictor (re-run on BOS), 4 = LM state (reset_lm, models.py:491-492; no-op without an attached LM), 8 = front-end
  * window + frame buffer; OR-able.  reset() of models.py:494-497 == 1|2|4. */
-int lasr_stream_reset(lasr_ctx* c, int slot, int what);   /* LASR_ESTATE while a submitted step of the slot is still being decoded */
+#define LASR_RESET_IF_DECODED 16   /* OR into `what` (with bits 1 | 2 | 4 only): accept a slot whose submitted steps are uncollected  */
+                                   /* but already DECODED for this slot (see lasr_peek_slot); without it a slot with a submitted,    */
+                                   /* uncollected step is always refused (LASR_ESTATE)                                                */
+int lasr_stream_reset(lasr_ctx* c, int slot, int what);
 int lasr_stream_close(lasr_ctx* c, int slot);
 
 /* ---- streaming hot path, batched over n slots ------------------------------------------------
@@ -166,7 +169,7 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran);
 /* Non-consuming look at ONE slot's submitted, uncollected model steps (greedy decode): *n_inflight of them, of which the
  * oldest *n_decoded are finished for this slot; counts[k] (k < *n_decoded, at most cap_steps) = tokens of step k, concatenated
  * in tokens[cap].  lasr_step_wait / lasr_fetch still hand the same tokens out later.  A slot whose submitted steps are all
- * decoded may be reset (lasr_stream_reset, bits 1 | 2 | 4) before they are collected: this is how a scheduler applies the
+ * decoded may be reset (lasr_stream_reset with bits 1 | 2 | 4 and LASR_RESET_IF_DECODED) before they are collected: this is how a scheduler applies the
  * servicer's reset rule (api-server.py:44-50, 131-134: judge the step, maybe reset, only then run the stream's next step)
  * without waiting for `steps in flight` collections.  LASR_EFULL: buffers too small; LASR_ESTATE with beam > 1. */
 int lasr_peek_slot(lasr_ctx* c, int slot, int32_t* tokens, int cap, int32_t* counts, int cap_steps, int* n_decoded,

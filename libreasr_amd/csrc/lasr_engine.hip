@@ -513,11 +513,13 @@ int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
     if (!c) return LASR_EINVAL;
     if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
     {
-        // A slot with submitted steps can be reset once the decode loop has FINISHED them for this slot (lasr_peek_slot says so),
-        // collected or not: its encoder steps are behind on the ctx stream, its frames are decoded, the tokens sit in the pinned
+        // With LASR_RESET_IF_DECODED a slot with submitted steps can be reset once the decode loop has FINISHED them for this slot
+        // (lasr_peek_slot says so), collected or not: its encoder steps are behind on the ctx stream, its frames are decoded, the tokens sit in the pinned
         // ring until lasr_step_wait hands them out.  Model state only (bits 1 | 2 | 4); greedy decode.
+        const bool if_decoded = (what & LASR_RESET_IF_DECODED) != 0;
+        what &= ~LASR_RESET_IF_DECODED;
         std::lock_guard<std::mutex> lk(c->mu);
-        bool inflight = false, undecoded = false;
+        bool inflight = false, undecoded = !if_decoded;      // (without the flag: refused whenever a step of the slot is uncollected)
         for (const auto& p : c->pending)
             if (std::find(p.rows.begin(), p.rows.end(), slot) != p.rows.end()) {
                 inflight = true;

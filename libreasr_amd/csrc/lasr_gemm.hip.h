@@ -803,10 +803,13 @@ struct EpiNBRCw {
     }
 };
 
-// ---- plain linear: out[row][col] = acc + bias[col], row-major f32.
-struct EpiLinear {
-    static constexpr int NT = 1;
-    static constexpr int PH0_TILES = 1, PH1_TILES = 0, PH0_DEAD = -1, PH1_DEAD = -1;
+// ---- plain linear: out[row][col] = acc + bias[col], row-major f32.  NTW n-tiles (16 * NTW columns) per workgroup: 1 for the
+// skinny problems (every weight byte fetched once per m-group), 4 for hundreds of rows (beam search: 1024 hypothesis rows x
+// 1536 -- with 16-column workgroups the ACTIVATIONS are what moves, 128 n-groups x 3 MB = 400 MB through L2 per launch).
+template <int NTW>
+struct EpiLinearT {
+    static constexpr int NT = NTW;
+    static constexpr int PH0_TILES = (1 << NTW) - 1, PH1_TILES = 0, PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = false;
     struct Args {
         const float* bias;    // may be nullptr
@@ -838,12 +841,12 @@ struct EpiLinear {
     template <int MTB, class Red>
     __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int, const int*, const Pre&,
                                int nthr) {
-        constexpr int ROWS = MTB * 16;
-        for (int it = tid; it < ROWS * 16; it += nthr) {
-            const int col = it & 15, row = it >> 4;        // consecutive threads -> consecutive columns
+        constexpr int ROWS = MTB * 16, CW = 16 * NTW;
+        for (int it = tid; it < ROWS * CW; it += nthr) {
+            const int col = it % CW, row = it / CW;        // consecutive threads -> consecutive columns
             const int r = mg * ROWS + row;
             if (!row_on(a, r)) continue;
-            const int n = jb * 16 + col;
+            const int n = jb * CW + col;
             size_t orow = (size_t)r;
             if (a.ring_base) {
                 const int t = r / a.M, q = r - t * a.M;
@@ -856,6 +859,8 @@ struct EpiLinear {
     }
 };
 
+using EpiLinear = EpiLinearT<1>;
+
 // ---- predictor half of the joint + fused joint activation (COMPACT over emitting rows):
 //   pp[r] = h_pred[r] W1p^T + b1                 for rows that emitted
 //   ja[r] = tanh(pe[t_idx[r]][r] + pp[r])        for every row still decoding (fragment-major:
@@ -863,10 +868,10 @@ struct EpiLinear {
 // Joint.forward 'concat' (models.py:132-140): Linear(cat(pred, enc)) == W1p pred + W1e enc + b1.
 // Workgroup (jb, mg) refreshes ja for its compacted (emitting) rows and for the NON-emitting rows
 // of the original row range [mg*ROWS, (mg+1)*ROWS).
-template <class Ops>
+template <class Ops, int NTW = 1>
 struct EpiPPJ {
-    static constexpr int NT = 1;
-    static constexpr int PH0_TILES = 1, PH1_TILES = 0, PH0_DEAD = -1, PH1_DEAD = -1;
+    static constexpr int NT = NTW;
+    static constexpr int PH0_TILES = (1 << NTW) - 1, PH1_TILES = 0, PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = true;
     struct Args {
         const float* b1;
@@ -892,11 +897,11 @@ struct EpiPPJ {
     template <int MTB, class Red>
     __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int n_act, const int* row_map,
                                const Pre&, int nthr) {
-        constexpr int ROWS = MTB * 16;
+        constexpr int ROWS = MTB * 16, CW = 16 * NTW;
         const bool beam = a.W > 1;
-        for (int it = tid; it < ROWS * 16; it += nthr) {
-            const int col = it & 15, row = it >> 4;
-            const int j = jb * 16 + col;
+        for (int it = tid; it < ROWS * CW; it += nthr) {
+            const int col = it % CW, row = it / CW;
+            const int j = jb * CW + col;
             const int vr = mg * ROWS + row;
             if (vr < n_act) {                           // an emitting row compacted into this group
                 const int r = row_map[vr];

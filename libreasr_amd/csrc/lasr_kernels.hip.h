@@ -1108,43 +1108,73 @@ struct BeamCarryArgs {
 };
 __global__ __launch_bounds__(256) void k_beam_carry(const BeamCarryArgs a) {
     if (blockIdx.y == 1) {
-        const int u0 = blockIdx.x * 16;
-        if (!a.lstm || u0 >= a.H) return;
-        for (int r = threadIdx.x; r < a.Md; r += blockDim.x) {
-            if (a.emit[r]) continue;
-            const int pr = (r / a.W) * a.W + a.parent[r];
-            for (int l = 0; l < a.Lp; ++l)
+        // cell state: block = (16-unit slice, 256-slot block); a thread moves its slot's 16 units of every layer (the slots of a
+        // stream sit next to each other: the gathered parent values come from the same 32-byte neighbourhood)
+        const int nrb = (a.Md + 255) / 256;
+        const int u0 = (blockIdx.x / nrb) * 16, r = (blockIdx.x % nrb) * 256 + threadIdx.x;
+        if (!a.lstm || u0 >= a.H || r >= a.Md || a.emit[r]) return;
+        const int pr = (r / a.W) * a.W + a.parent[r];
+        for (int l = 0; l < a.Lp; ++l) {
+            float v[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a.c_out[l][(size_t)(u0 + q) * a.Md + r] = a.c_in[l][(size_t)(u0 + q) * a.Md + pr];
+            for (int q = 0; q < 16; ++q) v[q] = a.c_in[l][(size_t)(u0 + q) * a.Md + pr];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a.c_out[l][(size_t)(u0 + q) * a.Md + r] = v[q];
         }
         return;
     }
     const int r = blockIdx.x;
     if (r >= a.Md || a.emit[r]) return;
     const int pr = (r / a.W) * a.W + a.parent[r], H = a.H, J = a.J;
-    for (int l = 0; l < a.Lp; ++l) {
-        if (a.bf) {          // (H % 32 == 0 with bf16 operands: whole 16-byte pieces)
-            const uint4* hs = (const uint4*)((const unsigned short*)a.h_in[l] + (size_t)pr * H);
-            const uint4* ys = (const uint4*)((const unsigned short*)a.y_in[l] + (size_t)pr * H);
-            uint4* hd = (uint4*)((unsigned short*)a.h_out[l] + (size_t)r * H);
-            uint4* yd = (uint4*)((unsigned short*)a.y_out[l] + (size_t)r * H);
-            for (int i = threadIdx.x; i < H / 8; i += blockDim.x) { hd[i] = hs[i]; yd[i] = ys[i]; }
-        } else {
-            const float4* hs = (const float4*)((const float*)a.h_in[l] + (size_t)pr * H);
-            const float4* ys = (const float4*)((const float*)a.y_in[l] + (size_t)pr * H);
-            float4* hd = (float4*)((float*)a.h_out[l] + (size_t)r * H);
-            float4* yd = (float4*)((float*)a.y_out[l] + (size_t)r * H);
-            for (int i = threadIdx.x; i < H / 4; i += blockDim.x) { hd[i] = hs[i]; yd[i] = ys[i]; }
-        }
-    }
     const int q = r / a.W;
     const int t = a.t_idx[q];
     const bool live = t < a.T_row[q];
     const float* pes = a.pe + ((size_t)(t % a.ring) * a.M_enc + q) * J;
-    for (int j = threadIdx.x; j < J; j += blockDim.x) {
-        const float p = a.pp_in[(size_t)pr * J + j];
-        a.pp_out[(size_t)r * J + j] = p;
-        if (live) act_st(a.bf, a.ja, act_off(a.bf, r, j, a.MTj), tanhf(pes[j] + p));
+    if (a.bf) {
+        // everything in 16-byte pieces: H % 32 == 0 and J % 32 == 0 with bf16 operands; 8 consecutive joint columns of a row are
+        // one 16-byte piece of the fragment-major activation (k & 7 contiguous)
+        for (int l = 0; l < a.Lp; ++l) {
+            const uint4* hs = (const uint4*)((const unsigned short*)a.h_in[l] + (size_t)pr * H);
+            const uint4* ys = (const uint4*)((const unsigned short*)a.y_in[l] + (size_t)pr * H);
+            uint4* hd = (uint4*)((unsigned short*)a.h_out[l] + (size_t)r * H);
+            uint4* yd = (uint4*)((unsigned short*)a.y_out[l] + (size_t)r * H);
+            for (int i = threadIdx.x; i < H / 8; i += blockDim.x) { const uint4 hv = hs[i], yv = ys[i]; hd[i] = hv; yd[i] = yv; }
+        }
+        const float4* ps = (const float4*)(a.pp_in + (size_t)pr * J);
+        float4* pd = (float4*)(a.pp_out + (size_t)r * J);
+        const float4* es = (const float4*)pes;
+        for (int i = threadIdx.x; i < J / 8; i += blockDim.x) {
+            const float4 p0 = ps[2 * i], p1 = ps[2 * i + 1];
+            pd[2 * i] = p0; pd[2 * i + 1] = p1;
+            if (live) {
+                const float4 e0 = es[2 * i], e1 = es[2 * i + 1];
+                uint4 o;
+                o.x = (unsigned)f32_to_bf16(tanhf(e0.x + p0.x)) | ((unsigned)f32_to_bf16(tanhf(e0.y + p0.y)) << 16);
+                o.y = (unsigned)f32_to_bf16(tanhf(e0.z + p0.z)) | ((unsigned)f32_to_bf16(tanhf(e0.w + p0.w)) << 16);
+                o.z = (unsigned)f32_to_bf16(tanhf(e1.x + p1.x)) | ((unsigned)f32_to_bf16(tanhf(e1.y + p1.y)) << 16);
+                o.w = (unsigned)f32_to_bf16(tanhf(e1.z + p1.z)) | ((unsigned)f32_to_bf16(tanhf(e1.w + p1.w)) << 16);
+                *(uint4*)((unsigned short*)a.ja + OpsBF16::aoff(r, 8 * i, a.MTj)) = o;
+            }
+        }
+        return;
+    }
+    for (int l = 0; l < a.Lp; ++l) {
+        const float4* hs = (const float4*)((const float*)a.h_in[l] + (size_t)pr * H);
+        const float4* ys = (const float4*)((const float*)a.y_in[l] + (size_t)pr * H);
+        float4* hd = (float4*)((float*)a.h_out[l] + (size_t)r * H);
+        float4* yd = (float4*)((float*)a.y_out[l] + (size_t)r * H);
+        for (int i = threadIdx.x; i < H / 4; i += blockDim.x) { const float4 hv = hs[i], yv = ys[i]; hd[i] = hv; yd[i] = yv; }
+    }
+    const float4* ps = (const float4*)(a.pp_in + (size_t)pr * J);
+    float4* pd = (float4*)(a.pp_out + (size_t)r * J);
+    const float4* es = (const float4*)pes;
+    for (int i = threadIdx.x; i < J / 4; i += blockDim.x) {      // 4 consecutive joint columns = one 16-byte piece of the f32 fragment
+        const float4 p0 = ps[i];
+        pd[i] = p0;
+        if (live) {
+            const float4 e0 = es[i];
+            *(float4*)((float*)a.ja + OpsF32::aoff(r, 4 * i, a.MTj)) = float4{tanhf(e0.x + p0.x), tanhf(e0.y + p0.y), tanhf(e0.z + p0.z), tanhf(e0.w + p0.w)};
+        }
     }
 }
 

@@ -147,7 +147,7 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
         }
         a.pp_in = p ? c->pp1 : c->pp; a.pp_out = p ? c->pp : c->pp1;
         a.pe = c->pe; a.t_idx = c->dec_t_idx; a.T_row = c->T_row_dec; a.ja = c->ja; a.MTj = c->MTj; a.ring = c->pe_ring_R; a.M_enc = c->M;
-        hipLaunchKernelGGL(k_beam_carry, dim3(std::max(c->Md, (H + 15) / 16), 2), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_beam_carry, dim3(std::max(c->Md, ((H + 15) / 16) * ((c->Md + 255) / 256)), 2), dim3(256), 0, c->stream, a);
     }
     for (int l = 0; l < c->d.pred_layers; ++l) {
         const Cell& L = c->pred[l];
@@ -226,6 +226,13 @@ void launch_ppj_t(lasr_ctx* c, bool beam) {
     if (beam && beam_carry_on()) { ea.no_carry = 1; g.skip_idle = 1; }      // (k_beam_carry, launched with the predictor pass)
     static const int ppj_wide_env = getenv("LASR_PPJ_WIDE") ? atoi(getenv("LASR_PPJ_WIDE")) : -1;
     const bool ppj_wide = (ppj_wide_env >= 0 ? ppj_wide_env != 0 : c->Md >= 512) && c->MTd % 4 == 0;   // 64-row workgroups for many decoder rows
+    static const int ppj_nt4 = getenv("LASR_PPJ_NT4") ? atoi(getenv("LASR_PPJ_NT4")) : 0;      // 64-column workgroups: measured slower (19.9 against 14.3 us at 1024 rows)
+    if (ppj_wide && ppj_nt4 && J % 64 == 0) {
+        typename EpiPPJ<Ops, 4>::Args e4{};
+        static_assert(sizeof(e4) == sizeof(ea), "same Args layout");
+        memcpy((void*)&e4, (const void*)&ea, sizeof(e4));
+        launch_gemm<Ops, EpiPPJ<Ops, 4>, 4, true, -1, 4>(c, J / 64, c->MTd / 4, g, e4);
+    } else
     if (ppj_wide) launch_gemm<Ops, EpiPPJ<Ops>, 4, true, -1, 4>(c, J / 16, c->MTd / 4, g, ea);
     else if (c->dec_nw_mask & 2) launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1, 4>(c, J / 16, c->MTd, g, ea); else launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
     if (beam) c->pred_par ^= 1;
@@ -376,6 +383,17 @@ void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
     ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M; ea.W = c->W;
+    static const int lg_nt4 = getenv("LASR_LOGITS_NT4") ? atoi(getenv("LASR_LOGITS_NT4")) : 1;      // 64 x 64 workgroups for >= 512 rows (A/B)
+    if (lg_nt4 && n_rows >= 512 && V % 64 == 0) {
+        GemmArgs g4 = g;
+        g4.KC[0] = J / c->kch;
+        EpiLinearT<4>::Args e4{};
+        static_assert(sizeof(e4) == sizeof(ea), "same Args layout");
+        memcpy((void*)&e4, (const void*)&ea, sizeof(e4));
+        if (c->bf) launch_gemm<OpsBF16, EpiLinearT<4>, 4, false, -1, 4>(c, V / 64, (n_rows + 63) / 64, g4, e4);
+        else launch_gemm<OpsF32, EpiLinearT<4>, 4, false, -1, 4>(c, V / 64, (n_rows + 63) / 64, g4, e4);
+        return;
+    }
     static const int lw_env = getenv("LASR_LOGITS_WIDE") ? atoi(getenv("LASR_LOGITS_WIDE")) : -1;
     if (c->logits_mt == 4 || (c->logits_mt == 2 && (lw_env >= 0 ? lw_env != 0 : n_rows >= 512))) { launch_logits_t<4>(c, g, n_rows, J, ea); return; }
     if (c->logits_mt == 2) { launch_logits_t<2>(c, g, n_rows, J, ea); return; }

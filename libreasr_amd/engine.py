@@ -114,8 +114,10 @@ class Engine:
         self._chk(self.lib.lasr_stream_open(self.ctx, C.byref(s)))
         return s.value
 
-    def reset(self, slot, what=7):
-        self._chk(self.lib.lasr_stream_reset(self.ctx, int(slot), int(what)))
+    def reset(self, slot, what=7, if_decoded=False):
+        """what: 1 encoder | 2 predictor | 4 LM | 8 front-end.  if_decoded: accept a slot whose submitted steps are uncollected but
+        already decoded for it (peek says so); otherwise a slot with a step in flight is refused."""
+        self._chk(self.lib.lasr_stream_reset(self.ctx, int(slot), int(what) | (N.LASR_RESET_IF_DECODED if if_decoded else 0)))
 
     def close_slot(self, slot):
         self._chk(self.lib.lasr_stream_close(self.ctx, int(slot)))

@@ -274,8 +274,11 @@ class Scheduler(threading.Thread):
                     self.trunks.remove(T)
         self.eng.close_slot(i)
 
-    def _reset(self, i):
-        self.eng.reset(i, 1 | 2 | 4)                                       # models.py:494-497
+    def _reset(self, i, if_decoded=False):
+        if if_decoded:                       # (early verdict: the slot's steps in flight are decoded, not collected)
+            self.eng.reset(i, 1 | 2 | 4, if_decoded=True)
+        else:
+            self.eng.reset(i, 1 | 2 | 4)                                   # models.py:494-497
         self.stp[i] = 0
 
     def _offline(self, pcm, sr=16000):
@@ -381,7 +384,7 @@ class Scheduler(threading.Thread):
                     # (past the threshold a stream has ONE step in flight at a time: this was its last, and it is decoded)
                     if int(self.judged[i]) != int(n_inflight[q]):
                         raise RuntimeError(f"scheduler: slot {i} ran ahead of the reset threshold ({int(n_inflight[q])} steps in flight)")
-                    self._reset(i)
+                    self._reset(i, if_decoded=True)
 
     def _drain(self):
         while self.inflight:

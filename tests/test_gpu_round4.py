@@ -173,9 +173,11 @@ def test_peek_and_reset_of_a_slot_whose_submitted_steps_are_decoded():
                     many, nd, nf = eng.peek_many(slots, [0, 0])
                     assert many[0] == steps and int(nf[0]) == n_in
                     peeked[0] = steps
-                    eng.reset(slots[0], 7)
+                    with pytest.raises(LasrError):          # without the flag a slot with uncollected steps is refused, decoded or not
+                        eng.reset(slots[0], 7)
                     with pytest.raises(LasrError):          # front-end state cannot be reset under steps in flight
-                        eng.reset(slots[0], 8)
+                        eng.reset(slots[0], 8, if_decoded=True)
+                    eng.reset(slots[0], 7, if_decoded=True)
             while eng.pending() >= 3:
                 collect()
         while eng.pending():

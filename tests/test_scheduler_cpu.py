@@ -79,9 +79,12 @@ class FakeEngine:
             nf.append(n_in)
         return res, np.array(nd), np.array(nf)
 
-    def reset(self, s, what):
+    def reset(self, s, what, if_decoded=False):
         self._own()
-        assert all(self.clock - out["_t"] >= self.peek_lag for out in self.steps if s in out), "reset with an undecoded step in flight"
+        if if_decoded:
+            assert all(self.clock - out["_t"] >= self.peek_lag for out in self.steps if s in out), "reset with an undecoded step in flight"
+        else:
+            assert not any(s in out for out in self.steps), "reset with a step in flight"
         self.resets.append((s, self.total_steps[s]))
         self.since_reset[s] = 0
         self.hyp[s] = []
