@@ -544,9 +544,10 @@ int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
             // stream, the predictor / LM side (BOS pass) on the decode stream, between two iteration groups
             if (what & 1) RC(apply_reset(c, false, 1));
             if (what & 6) {
-                HIPCHK(c, hipEventRecord(c->ev_misc, c->stream));
+                // the command block reaches the decode stream by a copy of its own: an event edge from the main stream would make
+                // the decode loop wait for everything queued there (up to `steps in flight` encoder passes, ~2 ms at depth 12)
                 hipStream_t keep = c->stream;
-                HIPCHK(c, hipStreamWaitEvent(c->stream_dec, c->ev_misc, 0));
+                HIPCHK(c, hipMemcpyAsync((char*)c->dc.T_row, (char*)c->hc.T_row, c->cmd_bytes, hipMemcpyHostToDevice, c->stream_dec));
                 c->stream = c->stream_dec;
                 int rc = apply_reset(c, (what & 2) != 0, 2);
                 c->stream = keep;
