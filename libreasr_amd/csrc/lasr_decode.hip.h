@@ -436,8 +436,8 @@ int require_idle(lasr_ctx* c) {
     if (!c->pending.empty()) return fail(c, LASR_ESTATE, "%d submitted step(s) not collected: call lasr_step_wait first", (int)c->pending.size());
     if (c->group_inflight) {        // the last group of the pipelined protocol may still be running: the calls that need an idle engine
         HIPCHK(c, hipStreamSynchronize(c->stream_dec));      // use the same decode state on the ctx stream
+        cont_poll(c);                                        // (its flag and cursors are there now)
         c->group_inflight = false;
-        c->work_left = 0;
     }
     return LASR_OK;
 }

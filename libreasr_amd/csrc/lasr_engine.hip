@@ -25,6 +25,7 @@
 using namespace lasr;
 
 #include "lasr_ctx.hip.h"
+static void cont_poll(lasr_ctx* c);       // (pipelined protocol, below; require_idle consumes a group that was still running)
 #include "lasr_launch.hip.h"
 #include "lasr_decode.hip.h"
 #include "lasr_weights.hip.h"

@@ -810,8 +810,9 @@ __global__ __launch_bounds__(NT) void k_beam_select(const float* __restrict__ lo
         }
     };
     const bool dbg = s.dbg && q == 0 && tid == 0;
-    if (dbg) s.dbg[0] = wall_clock64();
+    const unsigned long long t_entry = dbg ? wall_clock64() : 0ull;
     const int t = s.t_idx[q], Tr = s.T_row[q];
+    if (dbg && t < Tr) s.dbg[0] = t_entry;           // (stamps of the last round in which stream 0 was decoding: one consistent set)
     if (t >= Tr) {                                   // stream has nothing to decode: identity round
         if (tid < W) { s.emit[r0 + tid] = 0; s.parent[r0 + tid] = tid; tre[tid] = -1; }
         if (tid == 0 && s.cont) {

@@ -61,3 +61,12 @@ def test_debug_read_matches_the_oracle_state_after_a_model_step(golden_dir):
         assert j == len(tr.build()) and j >= 5
     finally:
         eng.close_slot(slot)
+
+
+def test_soak_beam_on_the_pipelined_protocol():
+    """The pipelined beam protocol (selection rounds replayed into the host trees by the pump thread, non-extended slots carried by
+    k_beam_carry) against the oracle after every model step, 30 times per predictor cell."""
+    import test_gpu_beam as B
+    for name in ("tiny", "tiny_lstm"):
+        for _ in range(30):
+            B.test_beam_on_the_pipelined_protocol_equals_the_oracle_per_model_step(name, 4)
