@@ -156,6 +156,9 @@ def workload_name(args, cfg, B):
             (args.model == "cfg5" and args.dtype == "bf16" and args.beam == 8 and B == 128)
     if not exact and base is not None:
         tag += " variant"
+    lm = getattr(args, "lm", "none")
+    if lm != "none":
+        tag += f" + LM shallow fusion (4x768, {lm})"
     return (f"{tag}: {B} concurrent 16 kHz streams/GPU, {cfg['enc_layers']}x{cfg['hidden']} uni-LSTM encoder, "
             f"{cfg['pred_layers']}x{cfg['pred_cell']} predictor, J={cfg['joint']}, V={cfg['vocab']}, "
             f"{'greedy' if args.beam == 1 else 'beam width ' + str(args.beam)}, "
@@ -289,6 +292,9 @@ def main():
                     help="self-check: rows replayed through the synchronous protocol after the timed region (0 = off)")
     ap.add_argument("--split-push", action="store_true",
                     help="lasr_push_pcm + lasr_step_submit as two calls instead of lasr_push_submit (A/B)")
+    ap.add_argument("--lm", choices=["none", "fp32", "int8"], default="none",
+                    help="extra line: LM shallow fusion in the greedy loop (the reference's served configuration, config/testing.yaml: "
+                         "lm.enable) with a synthetic 4 x 768 LM: fp32 / bf16 operands like the model, or int8-served as load_lm does")
     ap.add_argument("--trace", default=None, help="diagnostics: dump the two-stream mark timeline (lasr_trace) of the timed region to this file")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU-only: exercise sharding + aggregation over gloo (no GPU work)")
@@ -336,6 +342,8 @@ def main():
     sd = synth.synth_state_dict(cfg, seed=0)
     B = args.streams
     eng = Engine(sd, cfg, max_streams=B, device=local, dtype=args.dtype, beam=args.beam)
+    if args.lm != "none":
+        eng.attach_lm(synth.synth_lm_state_dict("lm768"), int8=args.lm == "int8")
     my_streams = shard_streams(B * world, world, rank)
     CPS = max(1, args.chunks_per_step)
     K, W = args.steps * CPS, args.warmup * CPS            # in chunks from here on

@@ -182,6 +182,7 @@ struct lasr_ctx {
         std::vector<int> Kp_ih; int Kp_h = 0;          // padded K of the x side per layer / of every H-wide operand
         float *gx = nullptr, *gh = nullptr;            // [M][4H]
         unsigned short* qa = nullptr; float* sx = nullptr;   // quantised activations [M][Kmax], per-row scales [M]
+        std::vector<unsigned short*> qh; std::vector<float*> sxh;   // per layer: the quantised image of h [M][Kp_h] and its scales [M]
     } lm;
 
     // resampling filters per client sample rate (lasr_resample)

@@ -32,6 +32,7 @@ int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3, bool plain_rows = fals
         la.W = lb ? c->W : 1; la.Md = lb ? c->Md : c->M;
         la.lm_valid = (lb && c->lm.par) ? c->lm.valid1 : c->lm.valid;
         for (int l = 0; l < c->lm.L; ++l) { la.h[l] = c->lm.h[c->lm.par][l]; la.c[l] = (lb && c->lm.par) ? c->lm.cst1[l] : c->lm.cst[l]; }
+        if (c->lm.q8) { la.Kp = c->lm.Kp_h; for (int l = 0; l < c->lm.L; ++l) { la.qh[l] = c->lm.qh[l]; la.sxh[l] = c->lm.sxh[l]; } }
         hipLaunchKernelGGL(k_lm_reset, dim3(grid1((size_t)c->M * c->lm.H)), dim3(256), 0, c->stream, la);
     }
     if (any_pred) {

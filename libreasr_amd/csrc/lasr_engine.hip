@@ -2108,7 +2108,9 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
     c->graphs.clear();
     for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
     c->cgraphs.clear();
-    c->la = c->la_stream = c->la_offline = c->la_sync = 1;   // the fused re-pick needs the LM state of exactly this decision
+    // (round 4: lookahead stays on with an LM -- blank frames change neither the predictor nor the LM state, k_select re-picks the
+    //  token of the first non-blank frame of its window; LASR_LM_LOOKAHEAD=0 restores one frame per iteration)
+    if (getenv("LASR_LM_LOOKAHEAD") && atoi(getenv("LASR_LM_LOOKAHEAD")) == 0) c->la = c->la_stream = c->la_offline = c->la_sync = 1;
     c->ds.lmz = m.lmz; c->ds.lm_valid = m.valid; c->ds.lm_alpha = m.alpha; c->ds.lm_theta = m.theta; c->ds.lm_min = m.min_val;
     m.on = true;
     return LASR_OK;
@@ -2117,7 +2119,7 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
 // The LM as the reference serves it: load_lm (lm.py:86-100) runs maybe_quantize (utils.py:197-210) =
 // torch.quantization.quantize_dynamic({nn.LSTM, nn.Linear}, qint8) on it.  Same blob as lasr_attach_lm; the weights are
 // quantised here (per tensor, symmetric: scale = max|w| / 127.5, q = clamp(rint(w * (1 / scale)), -128, 127)), activations per
-// row and per matmul at run time (k_lm_quant).  Numerics of the installed torch's x86 / fbgemm engine (restated in
+// row and per matmul (at run time the quantised image of every h is made once, by the cell kernel that produces it: k_lm_cell_q).  Numerics of the installed torch's x86 / fbgemm engine (restated in
 // oracle/rnnt_oracle.py:dq_linear and pinned to the reference's quantised LM there).
 int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, size_t n_weights) {
     if (!c) return LASR_EINVAL;
@@ -2192,6 +2194,14 @@ int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights
         m.h[0][l] = m.h[1][l] = h;                              // row-local in-place update: no ping-pong
         RC(dalloc(c, &m.cst[l], (size_t)M * H)); HIPCHK(c, hipMemset(m.cst[l], 0, sizeof(float) * (size_t)M * H));
     }
+    m.qh.assign(L, nullptr); m.sxh.assign(L, nullptr);
+    {   // quantised image of h = 0: zeros with scale 0.1 (what ChooseQuantizationParams makes of an all-zero row)
+        std::vector<float> tenth(M, 0.1f);
+        for (int l = 0; l < L; ++l) {
+            RC(dalloc(c, &m.qh[l], (size_t)M * m.Kp_h)); HIPCHK(c, hipMemset(m.qh[l], 0, sizeof(unsigned short) * (size_t)M * m.Kp_h));
+            RC(upload(c, &m.sxh[l], tenth.data(), (size_t)M));
+        }
+    }
     RC(dalloc(c, &m.gx, (size_t)M * 4 * H)); RC(dalloc(c, &m.gh, (size_t)M * 4 * H));
     RC(dalloc(c, &m.qa, (size_t)M * Kmax)); RC(dalloc(c, &m.sx, M));
     RC(dalloc(c, &m.raw, (size_t)M * V)); RC(dalloc(c, &m.lmz, (size_t)M * V)); RC(dalloc(c, &m.valid, M));
@@ -2200,7 +2210,9 @@ int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights
     c->graphs.clear();
     for (auto& kv : c->cgraphs) (void)hipGraphExecDestroy(kv.second);
     c->cgraphs.clear();
-    c->la = c->la_stream = c->la_offline = c->la_sync = 1;   // the fused re-pick needs the LM state of exactly this decision
+    // (round 4: lookahead stays on with an LM -- blank frames change neither the predictor nor the LM state, k_select re-picks the
+    //  token of the first non-blank frame of its window; LASR_LM_LOOKAHEAD=0 restores one frame per iteration)
+    if (getenv("LASR_LM_LOOKAHEAD") && atoi(getenv("LASR_LM_LOOKAHEAD")) == 0) c->la = c->la_stream = c->la_offline = c->la_sync = 1;
     c->ds.lmz = m.lmz; c->ds.lm_valid = m.valid; c->ds.lm_alpha = m.alpha; c->ds.lm_theta = m.theta; c->ds.lm_min = m.min_val;
     m.q8 = true;
     m.on = true;

@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     __shared__ float sv[LAT][4];
     __shared__ int si[LAT][4];
     __shared__ float ss[LAT][4];
-    float best[LAT], logp[LAT], sum0 = 0.f;
+    float best[LAT], logp[LAT], sums[LAT];
     int arg[LAT];
     // ---- argmax of every frame (ascending j per thread: first max wins), all frames through ONE barrier
 #pragma unroll
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     for (int k = 0; k < LAT; ++k) {
         if (k >= nla) continue;
         const float sum = ss[k][0] + ss[k][1] + ss[k][2] + ss[k][3];
-        if (k == 0) sum0 = sum;
+        sums[k] = sum;
         logp[k] = -logf(sum);                // log_softmax at the argmax = z_max - logsumexp
     }
     if (PLAIN) {
@@ -446,66 +446,83 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         return;
     }
     if (dbgt) s.dbg[2] = wall_clock64();                          // statistics of all frames done
-    int tok0 = arg[0];                       // the token frame 0 emits if its decision is non-blank
-    if constexpr (LAT == 1) {
-        if (s.lmz && arg[0] != blank && s.lm_valid[r]) {
-            // LMFuser.fuse (lm.py:59-79), only for a non-blank decision (models.py:427-431; uniform over
-            // the workgroup): standardise the joint log-softmax (utils.py:162-164: subtract the mean,
-            // divide by the unbiased std + 1e-5), entry 0 = MIN_VAL, re-pick argmax(alpha*lm + theta*joint).
-            // V <= 4096 (checked at lasr_attach_lm): every value of the row is in zv[].
-            __shared__ float sh4[4];
-            const float lse = logf(sum0);
-            float part = 0.f;
+    // The frame that emits in this launch, if any: the first non-blank decision among the frames the row may decide (blank frames in
+    // front of it are consumed with the predictor AND the LM state unchanged, so the re-pick below sees exactly the state the
+    // one-frame loop would have at that decision: lookahead and LM fusion compose).
+    int ke = -1;
 #pragma unroll
-            for (int q = 0; q < KEEP; ++q) {
-                const int j = tid + 256 * q;
-                zv[0][q] = j < V ? (zv[0][q] - best[0]) - lse : 0.f;        // log-softmax; padding contributes nothing
-                part += zv[0][q];
+    for (int k = 0; k < LAT; ++k)
+        if (ke < 0 && k < nla && arg[k] != blank) ke = k;
+    int tok_e = 0;
+#pragma unroll
+    for (int k = 0; k < LAT; ++k)
+        if (k == ke) tok_e = arg[k];
+    if (s.lmz && ke >= 0 && s.lm_valid[r]) {
+        // LMFuser.fuse (lm.py:59-79), only for a non-blank decision (models.py:427-431; uniform over
+        // the workgroup): standardise the joint log-softmax (utils.py:162-164: subtract the mean,
+        // divide by the unbiased std + 1e-5), entry 0 = MIN_VAL, re-pick argmax(alpha*lm + theta*joint).
+        // V <= 4096 (checked at lasr_attach_lm): every value of the row is in zv[].
+        __shared__ float sh4[4];
+        float zl[KEEP];                              // the emitting frame's logits
+        float bestk = 0.f, sumk = 1.f;
+#pragma unroll
+        for (int k = 0; k < LAT; ++k)
+            if (k == ke) {
+                bestk = best[k]; sumk = sums[k];
+#pragma unroll
+                for (int q = 0; q < KEEP; ++q) zl[q] = zv[k][q];
             }
-            const float mean = block_sum_256(part, sh4, lane, w) / (float)V;
-            part = 0.f;
+        const float lse = logf(sumk);
+        float part = 0.f;
 #pragma unroll
-            for (int q = 0; q < KEEP; ++q) {
-                const int j = tid + 256 * q;
-                zv[0][q] = j < V ? zv[0][q] - mean : 0.f;                // t.add_(-t.mean())
-                part += zv[0][q];
-            }
-            const float mean2 = block_sum_256(part, sh4, lane, w) / (float)V;   // torch.std subtracts its own mean again
-            part = 0.f;
-#pragma unroll
-            for (int q = 0; q < KEEP; ++q) {
-                const int j = tid + 256 * q;
-                const float d = j < V ? zv[0][q] - mean2 : 0.f;
-                part += d * d;
-            }
-            const float sd = sqrtf(block_sum_256(part, sh4, lane, w) / (float)(V - 1));
-            const float den = sd + 1e-5f;
-            const float* lz = s.lmz + (size_t)r * V;
-            float fb = -INFINITY;
-            int fa = 0x7fffffff;
-#pragma unroll
-            for (int q = 0; q < KEEP; ++q) {
-                const int j = tid + 256 * q;
-                if (j >= V) continue;
-                const float jo = j == 0 ? s.lm_min : zv[0][q] / den;
-                const float f = __fadd_rn(__fmul_rn(s.lm_alpha, lz[j]), __fmul_rn(s.lm_theta, jo));   // no FMA contraction
-                if (f > fb) { fb = f; fa = j; }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(fb, o);
-                const int oa = __shfl_xor(fa, o);
-                if (ob > fb || (ob == fb && oa < fa)) { fb = ob; fa = oa; }
-            }
-            __syncthreads();
-            if (lane == 0) { sv[0][w] = fb; si[0][w] = fa; }
-            __syncthreads();
-            fb = sv[0][0]; fa = si[0][0];
-#pragma unroll
-            for (int q = 1; q < 4; ++q)
-                if (sv[0][q] > fb || (sv[0][q] == fb && si[0][q] < fa)) { fb = sv[0][q]; fa = si[0][q]; }
-            tok0 = fa;                       // the emitted token; log p stays the unfused one (models.py:422)
+        for (int q = 0; q < KEEP; ++q) {
+            const int j = tid + 256 * q;
+            zl[q] = j < V ? (zl[q] - bestk) - lse : 0.f;        // log-softmax; padding contributes nothing
+            part += zl[q];
         }
+        const float mean = block_sum_256(part, sh4, lane, w) / (float)V;
+        part = 0.f;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) {
+            const int j = tid + 256 * q;
+            zl[q] = j < V ? zl[q] - mean : 0.f;                // t.add_(-t.mean())
+            part += zl[q];
+        }
+        const float mean2 = block_sum_256(part, sh4, lane, w) / (float)V;   // torch.std subtracts its own mean again
+        part = 0.f;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) {
+            const int j = tid + 256 * q;
+            const float d = j < V ? zl[q] - mean2 : 0.f;
+            part += d * d;
+        }
+        const float sd = sqrtf(block_sum_256(part, sh4, lane, w) / (float)(V - 1));
+        const float den = sd + 1e-5f;
+        const float* lz = s.lmz + (size_t)r * V;
+        float fb = -INFINITY;
+        int fa = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) {
+            const int j = tid + 256 * q;
+            if (j >= V) continue;
+            const float jo = j == 0 ? s.lm_min : zl[q] / den;
+            const float f = __fadd_rn(__fmul_rn(s.lm_alpha, lz[j]), __fmul_rn(s.lm_theta, jo));   // no FMA contraction
+            if (f > fb) { fb = f; fa = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(fb, o);
+            const int oa = __shfl_xor(fa, o);
+            if (ob > fb || (ob == fb && oa < fa)) { fb = ob; fa = oa; }
+        }
+        __syncthreads();
+        if (lane == 0) { sv[0][w] = fb; si[0][w] = fa; }
+        __syncthreads();
+        fb = sv[0][0]; fa = si[0][0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (sv[0][q] > fb || (sv[0][q] == fb && si[0][q] < fa)) { fb = sv[0][q]; fa = si[0][q]; }
+        tok_e = fa;                          // the emitted token; log p stays the unfused one (models.py:422)
     }
     // ---- the decisions, in frame order (models.py:405-443, 530-571): a row consumes its run of blank frames and, if it
     // comes, the first token after it.  Every thread tracks t and the per-frame evaluation count; thread 0 owns the rest.
@@ -520,7 +537,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
         if (nonblank) {
             emitted = 1;
             if (tid == 0) {
-                const int tok = k == 0 ? tok0 : arg[k];
+                const int tok = tok_e;               // (k == ke: the first non-blank frame, re-picked above when an LM is attached)
                 if (s.cont) s.step_tok[(size_t)r * s.tok_cap + (n0 % s.tok_cap)] = tok;
                 else if (n0 < s.tok_cap) s.step_tok[(size_t)r * s.tok_cap + n0] = tok;
                 n0 += 1;
@@ -650,6 +667,8 @@ struct LmResetArgs {
     void* h[8];          // current parity, row-major [Md][H]
     float* c[8];         // [H][Md]
     int* lm_valid;
+    // int8-served LM: the quantised image of every layer's h kept beside it (see k_lm_cell_q): zeros with scale 0.1 for h = 0
+    unsigned short* qh[8]; float* sxh[8]; int Kp;
 };
 __global__ void k_lm_reset(const LmResetArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -662,6 +681,7 @@ __global__ void k_lm_reset(const LmResetArgs a) {
         for (int l = 0; l < a.L; ++l) {
             act_st(a.bf, a.h[l], (size_t)rp * a.H + u, 0.f);
             a.c[l][(size_t)u * a.Md + rp] = 0.f;
+            if (a.qh[l]) { a.qh[l][(size_t)rp * a.Kp + u] = 0; if (u == 0) a.sxh[l][rp] = 0.1f; }
         }
     }
 }
@@ -673,15 +693,12 @@ __global__ void k_lm_reset(const LmResetArgs a) {
 // (q - zp) and the int8 weights are small integers: stored as bf16 they are exact, and so is their f32-accumulated MFMA
 // dot product below K = 1032, i.e. the integer arithmetic of fbgemm is reproduced bit for bit by the bf16 GEMM core.
 // One workgroup per row; dst row stride ldd >= K (columns [K, ldd) are zero padding up to the 32-wide MFMA chunk).
-__global__ __launch_bounds__(256) void k_lm_quant(const float* __restrict__ src, int lds, int K, unsigned short* __restrict__ dst,
-                                                  int ldd, float* __restrict__ scale_out) {
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const float* x = src + (size_t)r * lds;
-    float mn = 0.f, mx = 0.f;                                  // the range always contains 0
-    for (int k = tid; k < K; k += 256) { const float v = x[k]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+// (scale, zero point) of a row from its range [mn, mx] (which contains 0): every thread of the 256-thread block passes its partial
+// range; sqp[0] = scale, sqp[1] = zero point afterwards (block-wide barriers inside)
+__device__ __forceinline__ void lm_qparams(float mn, float mx, float* smn, float* smx, float* sqp, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
-    __shared__ float smn[4], smx[4], sqp[2];
     if (lane == 0) { smn[w] = mn; smx[w] = mx; }
     __syncthreads();
     if (tid == 0) {
@@ -694,9 +711,18 @@ __global__ __launch_bounds__(256) void k_lm_quant(const float* __restrict__ src,
         const double izp = emin < emax ? zmin : zmax;
         const float zp = izp < 0.0 ? 0.f : izp > 127.0 ? 127.f : (float)rint(izp);
         sqp[0] = (float)scale; sqp[1] = zp;
-        scale_out[r] = (float)scale;
     }
     __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_lm_quant(const float* __restrict__ src, int lds, int K, unsigned short* __restrict__ dst,
+                                                  int ldd, float* __restrict__ scale_out) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* x = src + (size_t)r * lds;
+    float mn = 0.f, mx = 0.f;                                  // the range always contains 0
+    for (int k = tid; k < K; k += 256) { const float v = x[k]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    __shared__ float smn[4], smx[4], sqp[2];
+    lm_qparams(mn, mx, smn, smx, sqp, tid);
+    if (tid == 0) scale_out[r] = sqp[0];
     const float inv = 1.0f / sqp[0], zp = sqp[1];
     unsigned short* d = dst + (size_t)r * ldd;
     for (int k = tid; k < ldd; k += 256) {
@@ -708,18 +734,43 @@ __global__ __launch_bounds__(256) void k_lm_quant(const float* __restrict__ src,
 
 // LSTM cell of the int8-served LM for the rows that emitted: gates = (layer 0: tab[token] | x-side GEMV) + h-side GEMV (each
 // already dequantised + its bias, torch gate order i, f, g, o); fp32 state, h row-major [M][H], c [H][M].
+// The new h is also QUANTISED here (qh / sxh: the image every dynamically quantised matmul that takes this h as its input would
+// compute for itself -- the x side of the layer above in this step, the h side of this layer in the next one; the parameters
+// depend on the vector alone, so one image serves both and equals what k_lm_quant makes of the stored h bit for bit): the LM
+// step needs no quantisation launch (21 -> 13 launches per decode iteration).  H <= 1024.
 __global__ __launch_bounds__(256) void k_lm_cell_q(const float* __restrict__ gx, const float* __restrict__ tab, const int* __restrict__ token,
                                                    const float* __restrict__ gh, const int* __restrict__ emit, float* __restrict__ h,
-                                                   float* __restrict__ c, int H, int M) {
-    const int r = blockIdx.x;
+                                                   float* __restrict__ c, int H, int M, unsigned short* __restrict__ qh,
+                                                   float* __restrict__ sxh, int Kp) {
+    const int r = blockIdx.x, tid = threadIdx.x;
     if (!emit[r]) return;
     const float* a = tab ? tab + (size_t)token[r] * 4 * H : gx + (size_t)r * 4 * H;
     const float* b = gh + (size_t)r * 4 * H;
-    for (int u = threadIdx.x; u < H; u += 256) {
+    float hv[4];
+    float mn = 0.f, mx = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int u = tid + 256 * q;
+        hv[q] = 0.f;
+        if (u >= H) continue;
         const float gi = a[u] + b[u], gf = a[H + u] + b[H + u], gg = a[2 * H + u] + b[2 * H + u], go = a[3 * H + u] + b[3 * H + u];
         const float c2 = sigmoid_(gf) * c[(size_t)u * M + r] + sigmoid_(gi) * tanhf(gg);
         c[(size_t)u * M + r] = c2;
-        h[(size_t)r * H + u] = sigmoid_(go) * tanhf(c2);
+        hv[q] = sigmoid_(go) * tanhf(c2);
+        h[(size_t)r * H + u] = hv[q];
+        mn = fminf(mn, hv[q]); mx = fmaxf(mx, hv[q]);
+    }
+    __shared__ float smn[4], smx[4], sqp[2];
+    lm_qparams(mn, mx, smn, smx, sqp, tid);
+    if (tid == 0) sxh[r] = sqp[0];
+    const float inv = 1.0f / sqp[0], zp = sqp[1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int u = tid + 256 * q;
+        if (u >= Kp) continue;
+        float v = 0.f;
+        if (u < H) v = fminf(fmaxf(rintf(__fmul_rn(hv[q], inv)) + zp, 0.f), 127.f) - zp;
+        qh[(size_t)r * Kp + u] = f32_to_bf16(v);
     }
 }
 
