@@ -108,6 +108,11 @@ struct lasr_ctx {
     // the main stream while ONE greedy loop keeps running on stream_dec across chunk boundaries: a row
     // that finished chunk k moves on to chunk k+1's frames while a bursty row is still on chunk k.
     hipStream_t stream_dec = nullptr;
+    // LM branch of a decode iteration (pipelined protocol): the LM step and the predictor / joint chain both start from the
+    // token a selection kernel has just written and both end at the next selection -- two branches of the group's hipGraph
+    hipStream_t stream_lm = nullptr;
+    hipEvent_t ev_lm_fork = nullptr, ev_lm_join = nullptr;
+    double lm_stream_ratio[2] = {0.0, 0.0};   // overlap probe of stream_lm against the main / the decode stream
     int dec_stream_attempts = 0;    // streams tried at creation until one ran concurrently with the ctx stream (see create_impl)
     double dec_stream_ratio = 0.0;  // the chosen stream's probe (wall / delay: ~1 concurrent, ~2 one hardware queue)
     hipStream_t stream_main_own = nullptr;   // LASR_MAIN_CUS experiment: CU-masked stream used instead of the caller's

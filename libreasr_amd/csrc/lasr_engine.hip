@@ -106,13 +106,16 @@ void lasr_destroy(lasr_ctx* c) {
     for (auto& kv : c->mgraphs) (void)hipGraphExecDestroy(kv.second);
     if (c->stream_cap) (void)hipStreamDestroy(c->stream_cap);
     if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
+    if (c->stream_lm) { (void)hipStreamSynchronize(c->stream_lm); (void)hipStreamDestroy(c->stream_lm); }
+    if (c->ev_lm_fork) (void)hipEventDestroy(c->ev_lm_fork);
+    if (c->ev_lm_join) (void)hipEventDestroy(c->ev_lm_join);
     if (c->stream_main_own) { (void)hipStreamSynchronize(c->stream_main_own); (void)hipStreamDestroy(c->stream_main_own); }
     delete c;
 }
 
 const char* lasr_last_error(const lasr_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
-static int overlap_probe_impl(lasr_ctx* c, int delay_us, double* ratio);
+static int overlap_probe_impl(lasr_ctx* c, int delay_us, double* ratio, hipStream_t sa = nullptr, hipStream_t sb = nullptr);
 
 static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     const lasr_model_desc& d = c->d;
@@ -1240,25 +1243,50 @@ static void cont_enqueue(lasr_ctx* c, int G) {
     DecState s; BeamState bs;
     cont_states(c, s, bs);
     c->dbg_gate = false;
+    // LM branch (stream_lm): forked behind the selection kernel whose tokens it consumes, joined in front of the next one (which
+    // reads its scores and rewrites token / emit) or at the end of the group -- the predictor, the joint half and the next
+    // logits GEMM run beside it (captured: two branches of the group graph)
+    const bool side = c->lm.on && c->stream_lm != nullptr;
+    bool lm_open = false;
+    auto lm_join = [&]() {
+        if (lm_open) (void)hipStreamWaitEvent(c->stream, c->ev_lm_join, 0);
+        lm_open = false;
+    };
+    auto lm_step = [&](bool beam) {
+        if (!side) { launch_lm(c, beam); return; }
+        hipStream_t keep = c->stream;
+        (void)hipEventRecord(c->ev_lm_fork, keep);
+        (void)hipStreamWaitEvent(c->stream_lm, c->ev_lm_fork, 0);
+        c->stream = c->stream_lm;
+        launch_lm(c, beam);
+        c->stream = keep;
+        (void)hipEventRecord(c->ev_lm_join, c->stream_lm);
+        lm_open = true;
+    };
     for (int q = 0; q < G; ++q) {
         if (c->W > 1) {                 // one selection round: logits of every hypothesis slot -> ordered top-W -> predictor / joint
             bs.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
             launch_logits(c, c->logits, c->Md, true);
+            lm_join();
             launch_beam_select(c, bs, 0);
+            if (side) lm_step(true);
             launch_predictor(c, true);
             launch_ppj(c, true);
-            launch_lm(c, true);
+            if (!side) lm_step(true);
             continue;
         }
         s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
         launch_logits(c, c->logits, c->la * M, true);
+        lm_join();
         launch_select<false>(c->stream, M, c->logits, V, c->d.blank, c->d.max_iters_stream, c->c_avail, s, 0, nullptr, nullptr, c->la, M);
+        if (side) lm_step(false);
         launch_predictor(c);
         launch_ppj(c);
-        launch_lm(c);
+        if (!side) lm_step(false);
         static const int dly = getenv("LASR_DELAY_DEC_US") ? atoi(getenv("LASR_DELAY_DEC_US")) : 0;    // experiment: see k_delay
         if (dly > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream, (unsigned long long)dly * 100ull);
     }
+    lm_join();
 }
 
 // the group graph for (G, current parities): captured on first use (API thread, c->mu held)
@@ -2040,6 +2068,37 @@ size_t lasr_lm_weight_count(const lasr_lm_desc* d) {
     return n + V * H + V;
 }
 
+// The LM's own stream (see cont_enqueue): created when an LM is attached, on a hardware queue shared with neither the main nor
+// the decode stream (probed like the decode stream at lasr_create; a stream that cannot be placed is given up and the LM step
+// stays in line on the decode stream).  LASR_LM_SIDE=0: in line.
+static int lm_side_setup(lasr_ctx* c) {
+    static const int on = getenv("LASR_LM_SIDE") ? atoi(getenv("LASR_LM_SIDE")) : 1;
+    if (!on || !c->stream_dec || c->stream_lm) return LASR_OK;
+    static const int pick = getenv("LASR_DEC_STREAM_PICK") ? atoi(getenv("LASR_DEC_STREAM_PICK")) : 1;
+    std::vector<hipStream_t> rejected;
+    bool ok = false;
+    for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_lm, hipStreamNonBlocking));
+        if (!pick) { ok = true; break; }
+        double r0 = 0.0, r1 = 0.0;
+        if (overlap_probe_impl(c, 300, &r0, c->stream, c->stream_lm) != LASR_OK ||
+            overlap_probe_impl(c, 300, &r1, c->stream_dec, c->stream_lm) != LASR_OK) { (void)hipGetLastError(); break; }
+        c->lm_stream_ratio[0] = r0; c->lm_stream_ratio[1] = r1;
+        ok = r0 < 1.5 && r1 < 1.5;
+        if (!ok) { rejected.push_back(c->stream_lm); c->stream_lm = nullptr; }
+    }
+    for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
+    if (!ok && c->stream_lm) { (void)hipStreamDestroy(c->stream_lm); c->stream_lm = nullptr; }
+    if (c->stream_lm) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_lm_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_lm_join, hipEventDisableTiming));
+    }
+    if (getenv("LASR_VERBOSE"))
+        fprintf(stderr, "[lasr] LM stream: %s, overlap probe %.2f (main) %.2f (decode)\n", c->stream_lm ? "own" : "in line",
+                c->lm_stream_ratio[0], c->lm_stream_ratio[1]);
+    return LASR_OK;
+}
+
 int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, size_t n_weights) {
     if (!c) return LASR_EINVAL;
     if (c->lm.on) return fail(c, LASR_ESTATE, "an LM is already attached");
@@ -2113,6 +2172,7 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
     if (getenv("LASR_LM_LOOKAHEAD") && atoi(getenv("LASR_LM_LOOKAHEAD")) == 0) c->la = c->la_stream = c->la_offline = c->la_sync = 1;
     c->ds.lmz = m.lmz; c->ds.lm_valid = m.valid; c->ds.lm_alpha = m.alpha; c->ds.lm_theta = m.theta; c->ds.lm_min = m.min_val;
     m.on = true;
+    RC(lm_side_setup(c));
     return LASR_OK;
 }
 
@@ -2216,6 +2276,7 @@ int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights
     c->ds.lmz = m.lmz; c->ds.lm_valid = m.valid; c->ds.lm_alpha = m.alpha; c->ds.lm_theta = m.theta; c->ds.lm_min = m.min_val;
     m.q8 = true;
     m.on = true;
+    RC(lm_side_setup(c));
     return LASR_OK;
 }
 
@@ -2429,18 +2490,19 @@ int lasr_overlap_probe(lasr_ctx* c, int delay_us, double* ratio) {
     HIPCHK(c, hipSetDevice(c->device));
     return overlap_probe_impl(c, delay_us, ratio);
 }
-static int overlap_probe_impl(lasr_ctx* c, int delay_us, double* ratio) {
+static int overlap_probe_impl(lasr_ctx* c, int delay_us, double* ratio, hipStream_t sa, hipStream_t sb) {
+    if (!sb) { sa = c->stream; sb = c->stream_dec; }
     hipEvent_t e0, e1, e2;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
     const unsigned long long ticks = (unsigned long long)delay_us * 100ull;      // 100 MHz wall clock
     for (int rep = 0; rep < 2; ++rep) {                                            // (first pass: code object load, queue creation)
-        HIPCHK(c, hipEventRecord(e0, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream_dec, e0, 0));
-        hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream, rep ? ticks : 100ull);
-        hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream_dec, rep ? ticks : 100ull);
-        HIPCHK(c, hipEventRecord(e2, c->stream_dec));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, e2, 0));
-        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipEventRecord(e0, sa));
+        HIPCHK(c, hipStreamWaitEvent(sb, e0, 0));
+        hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, sa, rep ? ticks : 100ull);
+        hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, sb, rep ? ticks : 100ull);
+        HIPCHK(c, hipEventRecord(e2, sb));
+        HIPCHK(c, hipStreamWaitEvent(sa, e2, 0));
+        HIPCHK(c, hipEventRecord(e1, sa));
         HIPCHK(c, hipEventSynchronize(e1));
     }
     float ms = 0.f;

@@ -591,11 +591,13 @@ inline void launch_select(hipStream_t st, int rows, const float* logits, int V, 
 // layer, standardise (utils.py:162-164), entry 0 = MIN_VAL.  One workgroup per row, V <= 4096.
 // Beam search (W > 1): rows are hypothesis slots; a slot that was not extended takes the LM output of its PARENT slot from
 // the other parity (lmz_in / valid_in), like the predictor state.
+// KEEP: register slots per thread for the row (8 covers V <= 2048, 16 V <= 4096); a slot past V holds -inf / 0 and contributes an
+// exact zero to every sum, so the results do not depend on KEEP (LASR_KEEP16=1: 16 slots whatever V, round 3's kernel)
+template <int KEEP>
 __global__ __launch_bounds__(256) void k_lm_post(const float* __restrict__ raw, const int* __restrict__ emit,
                                                  float* __restrict__ lmz, int* __restrict__ lm_valid, int V, float min_val,
                                                  const int* __restrict__ parent, int W, const float* __restrict__ lmz_in,
                                                  const int* __restrict__ valid_in) {
-    constexpr int KEEP = 16;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (!emit[r]) {
         if (W > 1) {
@@ -1242,10 +1244,11 @@ __global__ void k_beam_begin(BeamState s, int M, int n_iter_slots) {
 // by its parent's best non-blank token in this round is re-picked as LMFuser.fuse does (lm.py:59-79) from the PARENT's joint
 // log-softmax and LM output; the round's record is patched accordingly.  One workgroup per hypothesis slot.  In continuous mode
 // this launch, not k_beam_select, publishes the round to the host (the records are final only now).
+// KEEP: as in k_lm_post.
+template <int KEEP>
 __global__ __launch_bounds__(256) void k_beam_fuse(const float* __restrict__ logits, BeamState s, int iter_slot,
                                                    const float* __restrict__ lmz, const int* __restrict__ lm_valid, float alpha,
                                                    float theta, float lm_min) {
-    constexpr int KEEP = 16;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int W = s.W, V = s.V, q = r / W;
     const int iter_no = s.cont ? (int)((*(const unsigned*)s.iter_ctr - 1u) & 0x3fffffffu) : iter_slot;   // k_beam_select has moved on by one

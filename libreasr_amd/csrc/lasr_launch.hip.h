@@ -9,7 +9,7 @@ namespace {
 template <class Ops, class Epi, int MT, bool AROW, int D = 3, int NWV = NW>
 void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g0, const typename Epi::Args& ea) {
     GemmArgs g = g0;
-    g.prio = (c->stream == c->stream_dec && c->stream_dec) ? c->dec_prio : c->cell_prio;
+    g.prio = (c->stream && (c->stream == c->stream_dec || c->stream == c->stream_lm)) ? c->dec_prio : c->cell_prio;
     hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NWV, AROW, D>), dim3(n_groups, m_groups), dim3(NWV * 64), 0, c->stream, g, ea);
 }
 
@@ -246,6 +246,14 @@ float* cur_pp(lasr_ctx* c) { return (c->W > 1 && c->pred_par) ? c->pp1 : c->pp; 
 template <bool AROW, int D>
 void launch_linear(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea);
 
+// k_lm_post / k_beam_fuse with the register slots their vocabulary needs (bit-identical either way, see k_lm_post)
+inline bool keep16(int V) {
+    static const int force = getenv("LASR_KEEP16") ? atoi(getenv("LASR_KEEP16")) : 0;
+    return force || V > 2048;
+}
+#define LAUNCH_LM_POST(V_, ...) do { if (keep16(V_)) hipLaunchKernelGGL(k_lm_post<16>, __VA_ARGS__); else hipLaunchKernelGGL(k_lm_post<8>, __VA_ARGS__); } while (0)
+#define LAUNCH_BEAM_FUSE(V_, ...) do { if (keep16(V_)) hipLaunchKernelGGL(k_beam_fuse<16>, __VA_ARGS__); else hipLaunchKernelGGL(k_beam_fuse<8>, __VA_ARGS__); } while (0)
+
 // LMFuser.advance (lm.py:49-53) for the rows with emit != 0: LM step on the token just emitted, then
 // log_softmax + standardise + [0] = MIN_VAL into lmz (read by the next k_select of that row)
 template <class Ops>
@@ -281,11 +289,11 @@ void launch_lm_t(lasr_ctx* c, bool beam) {
     ea.bias = m.bout; ea.out = m.raw; ea.ldo = V; ea.n_rows = R; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = R;
     launch_linear<true, -1>(c, V / 16, R / 16, g, H, ea);
     if (beam)
-        hipLaunchKernelGGL(k_lm_post, dim3(R), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, p ? m.lmz : m.lmz1,
+        LAUNCH_LM_POST(V, dim3(R), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, p ? m.lmz : m.lmz1,
                            p ? m.valid : m.valid1, V, m.min_val, (const int*)c->b_parent, c->W, (const float*)(p ? m.lmz1 : m.lmz),
                            (const int*)(p ? m.valid1 : m.valid));
     else
-        hipLaunchKernelGGL(k_lm_post, dim3(R), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val,
+        LAUNCH_LM_POST(V, dim3(R), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val,
                            (const int*)nullptr, 1, (const float*)m.lmz, (const int*)m.valid);
     m.par ^= 1;
 }
@@ -325,7 +333,7 @@ void launch_lm_q8(lasr_ctx* c) {
     }
     m.par ^= 1;
     lm_q_gemv_pre(c, m.qh[m.L - 1], m.sxh[m.L - 1], m.Kp_h, m.qWout, m.s_out, m.bout, m.raw, V, M);
-    hipLaunchKernelGGL(k_lm_post, dim3(M), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val,
+    LAUNCH_LM_POST(V, dim3(M), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val,
                        (const int*)nullptr, 1, (const float*)m.lmz, (const int*)m.valid);
 }
 void launch_lm(lasr_ctx* c, bool beam = false) {
@@ -354,7 +362,7 @@ void launch_beam_select(lasr_ctx* c, BeamState& b, int iter_slot) {
         else hipLaunchKernelGGL((k_beam_select<8, 1024>), dim3(M), dim3(1024), 0, c->stream, lg, b, iter_slot);
     }
     if (c->lm.on)
-        hipLaunchKernelGGL(k_beam_fuse, dim3(c->Md), dim3(256), 0, c->stream, (const float*)c->logits, b, iter_slot, cur_lmz(c), cur_lm_valid(c),
+        LAUNCH_BEAM_FUSE(c->d.vocab, dim3(c->Md), dim3(256), 0, c->stream, (const float*)c->logits, b, iter_slot, cur_lmz(c), cur_lm_valid(c),
                            c->lm.alpha, c->lm.theta, c->lm.min_val);
 }
 

@@ -188,3 +188,66 @@ def test_peek_and_reset_of_a_slot_whose_submitted_steps_are_decoded():
         assert sum(len(t) for t in got[0]) > 10
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("int8", [False, True])
+def test_lm_fusion_with_lookahead_equals_one_frame_per_iteration(int8, monkeypatch):
+    """An attached LM no longer turns the decode lookahead off (k_select re-picks the token at the first non-blank frame of its
+    window with that frame's fused scores; blank frames change neither predictor nor LM state, models.py:475-520): same tokens
+    as LASR_LM_LOOKAHEAD=0 on 12 s of 8 streams, fp32 LM and int8-served LM (whose h images are now quantised
+    by the cell kernel)."""
+    cfg = synth.model_cfg("tiny_soft")
+    lsd = synth.synth_lm_state_dict("tiny_lm")
+    pcm = synth.synth_pcm(8, 16000 * 12, seed=4321)
+    out = []
+    for la in ("0", "1"):
+        monkeypatch.setenv("LASR_LM_LOOKAHEAD", la)
+        eng, _ = make(cfg, max_streams=8, dtype="f32")
+        eng.attach_lm(lsd, int8=int8)
+        out.append(stream_tokens(eng, pcm, pcm.shape[1] // 1280))
+        del eng
+    assert out[0] == out[1]
+    assert sum(len(s) for s in out[0]) > 50
+
+
+def test_lm_register_slots_and_lm_stream_are_bit_identical_switches():
+    """k_lm_post / k_beam_fuse with 8 register slots per thread (V <= 2048) against LASR_KEEP16=1 (round 3's kernels), and the LM
+    branch on its own stream against LASR_LM_SIDE=0: the same tokens AND the same -log p bits, greedy (offline + pipelined) and
+    beam 4 with the LM inside the beam."""
+    code = r'''
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from libreasr_amd import synth
+from libreasr_amd.engine import Engine
+cfg = synth.model_cfg("tiny_soft"); sd = synth.synth_state_dict(cfg, seed=0); lsd = synth.synth_lm_state_dict("tiny_lm")
+out = {}
+for beam in (1, 4):
+    eng = Engine(sd, cfg, max_streams=8, beam=beam)
+    eng.attach_lm(lsd)
+    pcm = synth.synth_pcm(4, 16000 * 4, seed=55 + beam)
+    slots = [eng.open() for _ in range(4)]
+    eng.transcribe_pcm(slots, [pcm[i] for i in range(4)])
+    off = [eng.fetch(s) for s in slots]
+    out["off%%d" %% beam] = [[t, float(lp).hex()] for t, lp, _ in off]
+    for s in slots: eng.reset(s, 15)
+    got = [[] for _ in slots]
+    def collect():
+        if eng.wait():
+            for i, t in enumerate(eng.fetch_many(slots, 256)): got[i].append(t)
+    for k in range(pcm.shape[1] // 1280):
+        eng.push_submit(slots, torch.as_tensor(np.ascontiguousarray(pcm[:, k * 1280:(k + 1) * 1280])).cuda())
+        while eng.pending() >= 3: collect()
+    while eng.pending(): collect()
+    out["pipe%%d" %% beam] = got
+    eng.close()
+print("RESULT" + json.dumps(out))
+''' % ROOT
+    res = {}
+    for tag, env in (("default", {}), ("keep16", {"LASR_KEEP16": "1"}), ("inline", {"LASR_LM_SIDE": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = line[0]
+    assert res["default"] == res["keep16"]
+    assert res["default"] == res["inline"]
+    assert res["default"].count(",") > 100
