@@ -108,6 +108,10 @@ int lasr_stream_open(lasr_ctx* c, int* slot);
                                    /* but already DECODED for this slot (see lasr_peek_slot); without it a slot with a submitted,    */
                                    /* uncollected step is always refused (LASR_ESTATE)                                                */
 int lasr_stream_reset(lasr_ctx* c, int slot, int what);
+/* lasr_stream_reset of n distinct slots with the same `what` in one call (one command block, one set of launches): every slot is
+ * checked before anything changes -- an error leaves all of them as they were.  A scheduler's tick that applies the servicer's
+ * reset rule (api-server.py:131-134) to several streams at once. */
+int lasr_stream_reset_many(lasr_ctx* c, const int* slots, int n, int what);
 int lasr_stream_close(lasr_ctx* c, int slot);
 
 /* ---- streaming hot path, batched over n slots ------------------------------------------------
@@ -165,6 +169,11 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n);
  * LASR_EINVAL mean NOTHING was pushed: call lasr_step_wait and repeat the call.  LASR_EHIP (the runtime failed underneath) leaves
  * the chunk pushed. */
 int lasr_push_submit(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket);
+/* lasr_push_submit with the chunk of slots[i] at rows[i] (HOST memory, pageable or pinned, `chunk` floats each; free on return):
+ * what a server holds when every connection's frame sits in its own receive buffer (api-server.py:88-91 tensorizes one message
+ * per stream; a scheduler that batches them would otherwise gather the rows into one array first).  The gather is the copy into
+ * the engine's staging ring that a host push makes anyway.  Same error contract as lasr_push_submit. */
+int lasr_push_submit_rows(lasr_ctx* c, const int* slots, int n, const float* const* rows, long long* ticket);
 int lasr_step_wait(lasr_ctx* c, int* n_ran);
 /* Non-consuming look at ONE slot's submitted, uncollected model steps (greedy decode): *n_inflight of them, of which the
  * oldest *n_decoded are finished for this slot; counts[k] (k < *n_decoded, at most cap_steps) = tokens of step k, concatenated

@@ -43,11 +43,13 @@ SYMBOLS = [
     ("lasr_last_error", C.c_char_p, [_P]),
     ("lasr_stream_open", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("lasr_stream_reset", C.c_int, [_P, C.c_int, C.c_int]),
+    ("lasr_stream_reset_many", C.c_int, [_P, _P, C.c_int, C.c_int]),
     ("lasr_stream_close", C.c_int, [_P, C.c_int]),
     ("lasr_push_pcm", C.c_int, [_P, _P, C.c_int, _P]),
     ("lasr_push_pcm_ex", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_longlong)]),
     ("lasr_push_consumed", C.c_int, [_P, C.c_longlong]),
     ("lasr_push_submit", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_longlong)]),
+    ("lasr_push_submit_rows", C.c_int, [_P, _P, C.c_int, _P, C.POINTER(C.c_longlong)]),
     ("lasr_step_stream", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     ("lasr_step_window", C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     ("lasr_step_submit", C.c_int, [_P, _P, C.c_int]),

@@ -98,6 +98,8 @@ struct lasr_ctx {
     int n_iter_slots = 0;
     int* T_row_dev = nullptr;       // [M] current step's frames per row: points INTO the step's device command block
     int* zero_rows = nullptr;       // [M] zeros (reset passes: "no row is decoding")
+    // greedy decode: predictor state after the BOS step + its joint half, captured once (see ResetArgs); LASR_BOS_CACHE=0: BOS pass per reset
+    std::vector<float*> bos_h, bos_c; float* bos_pp = nullptr; bool bos_ready = false;
     int* T_row_dec = nullptr;       // what the decode kernels read (T_row_fix; frames-available counters when continuous)
     int* T_row_fix = nullptr;       // [M] fixed-address copy of the current synchronous step's T_row: the decode kernels are
                                     // replayed from cached hipGraphs, which bake their pointer arguments in, while the
@@ -228,6 +230,7 @@ struct lasr_ctx {
         std::vector<std::thread> th;
         std::mutex m; std::condition_variable cv;                 // the job below is read and claimed under m
         const char* src = nullptr; char* dst = nullptr; size_t bytes = 0, part_bytes = 0;
+        const float* const* rows = nullptr; size_t row_bytes = 0;   // gather job: destination row r from rows[r]
         int parts = 0, next = 0, done = 0; long long gen = 0;
         std::atomic<long long> gen_hint{0}, done_hint{0};         // spin targets: a new job exists / job g is complete
         std::atomic<bool> stop{false};

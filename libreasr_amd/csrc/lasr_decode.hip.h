@@ -24,6 +24,12 @@ int apply_reset(lasr_ctx* c, bool any_pred, int mask = 3, bool plain_rows = fals
         a.pred_h0[l] = c->pred[l].h0; a.pred_c0[l] = c->pred[l].c0;
     }
     a.token = c->ds.token; a.emit = c->ds.emit;
+    const bool use_bos = c->bos_ready && !beam && !plain_rows && c->W == 1 && (mask & 2);
+    if (use_bos) {
+        for (int l = 0; l < a.Lp; ++l) { a.bos_h[l] = c->bos_h[l]; a.bos_c[l] = c->d.pred_cell ? c->bos_c[l] : nullptr; }
+        a.bos_pp = c->bos_pp; a.pp = c->pp; a.J = c->d.joint;
+        any_pred = false;                    // the state after the BOS step is stored, not computed
+    }
     hipLaunchKernelGGL(k_reset_rows, dim3(grid1((size_t)c->M * c->d.hidden)), dim3(256), 0, c->stream, a);
     if (c->lm.on && (mask & 2)) {      // LM state lives on the decode side, like the predictor's
         LmResetArgs la{};

@@ -474,6 +474,32 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     c->ev_ok = true;
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) c->ev_ok = false;
+    // Greedy decode: what a reset leaves in a row's predictor state -- the learned initial state advanced by one step on BOS, and the
+    // joint's predictor half of it (models.py:489) -- does not depend on the row: computed ONCE here, through the same kernels a
+    // reset used to launch (row 0), and stored by k_reset_rows from then on.  A reset then costs the decode stream one small launch
+    // instead of one + three weight-streaming GEMMs (the servicer's reset rule resets ~2 streams per model step in a replay).
+    static const int bos_cache = getenv("LASR_BOS_CACHE") ? atoi(getenv("LASR_BOS_CACHE")) : 1;
+    if (bos_cache && c->W == 1) {
+        RC(cmd_begin(c));
+        c->hc.what[0] = 2;
+        RC(cmd_commit(c));
+        RC(apply_reset(c, true));
+        BosArgs b{};
+        b.H = H; b.J = J; b.Lp = d.pred_layers; b.M = M; b.lstm = d.pred_cell; b.bf = c->bf;
+        c->bos_h.assign(d.pred_layers, nullptr); c->bos_c.assign(d.pred_layers, nullptr);
+        for (int l = 0; l < d.pred_layers; ++l) {
+            RC(dalloc(c, &c->bos_h[l], H));
+            if (d.pred_cell) RC(dalloc(c, &c->bos_c[l], H));
+            b.pred_h[l] = c->pred_h[c->pred_par][l]; b.pred_c[l] = d.pred_cell ? c->pred_c[l] : nullptr;
+            b.bos_h[l] = c->bos_h[l]; b.bos_c[l] = c->bos_c[l];
+        }
+        RC(dalloc(c, &c->bos_pp, J));
+        b.pp = c->pp; b.bos_pp = c->bos_pp;
+        hipLaunchKernelGGL(k_bos_capture, dim3(grid1(std::max(H, J))), dim3(256), 0, c->stream, b);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        c->bos_ready = true;
+    }
     return LASR_OK;
 }
 
@@ -513,9 +539,12 @@ int lasr_stream_open(lasr_ctx* c, int* slot) {
     return fail(c, LASR_EFULL, "all %d stream slots are open", c->d.max_streams);
 }
 
-int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
-    if (!c) return LASR_EINVAL;
-    if (slot < 0 || slot >= c->d.max_streams || !c->open_[slot]) return fail(c, LASR_ESTATE, "slot %d is not open", slot);
+// lasr_stream_reset for n slots: all of them are checked before anything is changed (an error leaves every slot as it was), then
+// ONE command block and one set of launches serve them all
+static int reset_impl(lasr_ctx* c, const int* slots, int n, int what) {
+    if (n <= 0) return LASR_OK;
+    for (int i = 0; i < n; ++i)
+        if (slots[i] < 0 || slots[i] >= c->d.max_streams || !c->open_[slots[i]]) return fail(c, LASR_ESTATE, "slot %d is not open", slots[i]);
     {
         // With LASR_RESET_IF_DECODED a slot with submitted steps can be reset once the decode loop has FINISHED them for this slot
         // (lasr_peek_slot says so), collected or not: its encoder steps are behind on the ctx stream, its frames are decoded, the tokens sit in the pinned
@@ -523,22 +552,29 @@ int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
         const bool if_decoded = (what & LASR_RESET_IF_DECODED) != 0;
         what &= ~LASR_RESET_IF_DECODED;
         std::lock_guard<std::mutex> lk(c->mu);
-        bool inflight = false, undecoded = !if_decoded;      // (without the flag: refused whenever a step of the slot is uncollected)
-        for (const auto& p : c->pending)
-            if (std::find(p.rows.begin(), p.rows.end(), slot) != p.rows.end()) {
-                inflight = true;
-                if (!c->pump_on) cont_poll(c);
-                undecoded |= c->h_cur_seen[slot] < p.target[slot];
-            }
-        if (inflight && (undecoded || (what & 8) || c->W > 1))
-            return fail(c, LASR_ESTATE, "slot %d has a submitted step in flight: call lasr_step_wait first", slot);
+        bool polled = false;
+        for (int i = 0; i < n; ++i) {
+            const int slot = slots[i];
+            bool inflight = false, undecoded = !if_decoded;      // (without the flag: refused whenever a step of the slot is uncollected)
+            for (const auto& p : c->pending)
+                if (std::find(p.rows.begin(), p.rows.end(), slot) != p.rows.end()) {
+                    inflight = true;
+                    if (!c->pump_on && !polled) { cont_poll(c); polled = true; }
+                    undecoded |= c->h_cur_seen[slot] < p.target[slot];
+                }
+            if (inflight && (undecoded || (what & 8) || c->W > 1))
+                return fail(c, LASR_ESTATE, "slot %d has a submitted step in flight: call lasr_step_wait first", slot);
+        }
     }
     HIPCHK(c, hipSetDevice(c->device));
-    if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); c->neg_logp[slot] = 0.0; }
-    if (what & 2) beam_host_reset(c, slot, (what & 8) != 0);
+    for (int i = 0; i < n; ++i) {
+        const int slot = slots[i];
+        if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); c->neg_logp[slot] = 0.0; }
+        if (what & 2) beam_host_reset(c, slot, (what & 8) != 0);
+    }
     if (what & 7) {
         RC(cmd_begin(c));
-        c->hc.what[slot] = what & 7;
+        for (int i = 0; i < n; ++i) c->hc.what[slots[i]] = what & 7;
         RC(cmd_commit(c));
         std::lock_guard<std::mutex> lk(c->mu);            // (decode-side launches: the pump thread stays out)
         if (c->pending.empty() && !c->group_inflight) {
@@ -560,6 +596,15 @@ int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
         }
     }
     return LASR_OK;
+}
+int lasr_stream_reset(lasr_ctx* c, int slot, int what) {
+    if (!c) return LASR_EINVAL;
+    return reset_impl(c, &slot, 1, what);
+}
+int lasr_stream_reset_many(lasr_ctx* c, const int* slots, int n, int what) {
+    if (!c) return LASR_EINVAL;
+    RC(check_slots(c, slots, n, true));
+    return reset_impl(c, slots, n, what);
 }
 
 int lasr_stream_close(lasr_ctx* c, int slot) {
@@ -652,14 +697,17 @@ static void pool_worker(lasr_ctx::CopyPool* P) {
             const int i = P->next++;
             const size_t lo = (size_t)i * P->part_bytes, hi = std::min(P->bytes, lo + P->part_bytes);
             const char* s = P->src; char* d = P->dst;
+            const float* const* rows = P->rows; const size_t rb = P->row_bytes;
             lk.unlock();
-            memcpy(d + lo, s + lo, hi - lo);
+            if (rows) for (size_t r = lo / rb; r < hi / rb; ++r) memcpy(d + r * rb, rows[r], rb);
+            else memcpy(d + lo, s + lo, hi - lo);
             lk.lock();
             if (++P->done == P->parts) P->done_hint.store(P->gen, std::memory_order_release);
         }
     }
 }
-static void staged_copy(lasr_ctx* c, void* dst, const void* src, size_t bytes) {
+// rows != nullptr: gather -- row r of the destination (row_bytes each) comes from rows[r]
+static void staged_copy(lasr_ctx* c, void* dst, const void* src, size_t bytes, const float* const* rows = nullptr, size_t row_bytes = 0) {
     lasr_ctx::CopyPool& P = c->pool;
     if (!P.init) {
         P.init = true;
@@ -667,10 +715,15 @@ static void staged_copy(lasr_ctx* c, void* dst, const void* src, size_t bytes) {
         if (getenv("LASR_PUSH_THREADS")) nth = std::max(0, std::min(8, atoi(getenv("LASR_PUSH_THREADS"))));
         for (int i = 0; i < nth; ++i) P.th.emplace_back(pool_worker, &P);
     }
-    if (P.th.empty() || bytes < (size_t)(96 << 10)) { memcpy(dst, src, bytes); return; }
+    if (P.th.empty() || bytes < (size_t)(96 << 10)) {
+        if (rows) for (size_t r = 0; r < bytes / row_bytes; ++r) memcpy((char*)dst + r * row_bytes, rows[r], row_bytes);
+        else memcpy(dst, src, bytes);
+        return;
+    }
     std::unique_lock<std::mutex> lk(P.m);                    // (the previous job is complete: done == parts, nobody is copying)
-    P.src = (const char*)src; P.dst = (char*)dst; P.bytes = bytes;
+    P.src = (const char*)src; P.dst = (char*)dst; P.bytes = bytes; P.rows = rows; P.row_bytes = row_bytes;
     P.part_bytes = ((bytes / (4 * (P.th.size() + 1))) + 4095) & ~(size_t)4095;
+    if (rows) P.part_bytes = std::max<size_t>(1, (bytes / row_bytes + 4 * (P.th.size() + 1) - 1) / (4 * (P.th.size() + 1))) * row_bytes;   // whole rows
     P.parts = (int)((bytes + P.part_bytes - 1) / P.part_bytes);
     P.next = 0; P.done = 0;
     const long long g = ++P.gen;
@@ -680,7 +733,8 @@ static void staged_copy(lasr_ctx* c, void* dst, const void* src, size_t bytes) {
         const int i = P.next++;
         const size_t lo = (size_t)i * P.part_bytes, hi = std::min(bytes, lo + P.part_bytes);
         lk.unlock();
-        memcpy((char*)dst + lo, (const char*)src + lo, hi - lo);
+        if (rows) for (size_t r = lo / row_bytes; r < hi / row_bytes; ++r) memcpy((char*)dst + r * row_bytes, rows[r], row_bytes);
+        else memcpy((char*)dst + lo, (const char*)src + lo, hi - lo);
         lk.lock();
         if (++P.done == P.parts) P.done_hint.store(g, std::memory_order_release);
     }
@@ -688,10 +742,10 @@ static void staged_copy(lasr_ctx* c, void* dst, const void* src, size_t bytes) {
     while (P.done_hint.load(std::memory_order_acquire) != g) __builtin_ia32_pause();      // parts still being copied by helpers
 }
 
-static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, PushSrc& ps) {
+static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, PushSrc& ps, const float* const* rows = nullptr) {
     const int CH = c->d.chunk;
     ps.src = pcm;
-    if (is_device_ptr(pcm)) {
+    if (!rows && is_device_ptr(pcm)) {
         if (flags & LASR_PUSH_PINNED_NOCOPY) return fail(c, LASR_EINVAL, "LASR_PUSH_PINNED_NOCOPY needs pinned HOST memory");
         return LASR_OK;
     }
@@ -719,7 +773,7 @@ static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, 
             HIPCHK(c, hipHostGetDevicePointer(&dp, c->push_stage_host, 0));
             c->push_stage_host_dev = (float*)dp;
         }
-        staged_copy(c, c->push_stage_host + (size_t)ps.ev_i * c->M * CH, pcm, sizeof(float) * (size_t)n * CH);
+        staged_copy(c, c->push_stage_host + (size_t)ps.ev_i * c->M * CH, pcm, sizeof(float) * (size_t)n * CH, rows, sizeof(float) * (size_t)CH);
         ps.src = c->push_stage_host_dev + (size_t)ps.ev_i * c->M * CH;
         host_src = c->push_stage_host + (size_t)ps.ev_i * c->M * CH;
     }
@@ -1004,8 +1058,24 @@ int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
 
 // lasr_push_pcm_ex + lasr_step_submit in one call: when the chunk completes a model step, the front-end launch reads the newest
 // chunk straight from the source buffer and appends it to the PCM ring itself (one launch less per model step).
+static int push_submit_impl(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket, const float* const* rows);
 int lasr_push_submit(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket) {
     if (!c) return LASR_EINVAL;
+    return push_submit_impl(c, slots, n, pcm, flags, ticket, nullptr);
+}
+// lasr_push_submit with the chunk of slots[i] at rows[i] (host memory, pageable or pinned; chunk floats each): what a server has
+// when every connection's frame sits in its own receive buffer (api-server.py:88-91 tensorizes one message per stream) -- the
+// gather into one batch is the copy into the staging ring that a host push makes anyway, not an extra pass on the caller's side.
+int lasr_push_submit_rows(lasr_ctx* c, const int* slots, int n, const float* const* rows, long long* ticket) {
+    if (!c) return LASR_EINVAL;
+    if (n > 0 && !rows) return fail(c, LASR_EINVAL, "rows is null");
+    for (int i = 0; i < n; ++i)
+        if (!rows[i]) return fail(c, LASR_EINVAL, "rows[%d] is null", i);
+    // (the runtime is asked about the first row only: a pointer query costs ~1 us, a server's rows all come from one allocator)
+    if (n > 0 && is_device_ptr(rows[0])) return fail(c, LASR_EINVAL, "lasr_push_submit_rows takes host memory (rows[0] is a device pointer)");
+    return push_submit_impl(c, slots, n, n > 0 ? rows[0] : nullptr, 0, ticket, rows);
+}
+static int push_submit_impl(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket, const float* const* rows) {
     if (ticket) *ticket = -1;
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
@@ -1024,7 +1094,7 @@ int lasr_push_submit(lasr_ctx* c, const int* slots, int n, const float* pcm, int
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->pending.empty()) RC(cont_pump(c, c->kick_n));
     PushSrc ps;
-    RC(push_prepare(c, slots, n, pcm, flags, ps));
+    RC(push_prepare(c, slots, n, pcm, flags, ps, rows));
     tr_mark(c, 1, c->stream);
     if (c->fe_fused) RC(materialize_pending(c, slots, n));
     const bool can_fuse = c->fe_fused && c->fe_mode == 1;

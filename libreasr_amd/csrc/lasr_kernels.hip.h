@@ -140,7 +140,29 @@ struct ResetArgs {
     const float* pred_c0[8];
     int* token;
     int* emit;
+    // greedy decode: the predictor state AFTER its BOS step and the joint's predictor half for it (models.py:489) are constants of
+    // the model -- captured once at lasr_create (k_bos_capture) and stored here instead of running the predictor on BOS per reset
+    const float* bos_h[8];    // [H] per layer (null: the caller runs the BOS pass)
+    const float* bos_c[8];
+    const float* bos_pp;      // [J]
+    float* pp;                // [M][J]
+    int J;
 };
+struct BosArgs {
+    const void* pred_h[8]; const float* pred_c[8]; const float* pp;
+    float* bos_h[8]; float* bos_c[8]; float* bos_pp;
+    int H, J, Lp, M, lstm, bf;
+};
+// row 0 of the predictor state / pp (just refreshed by a BOS pass) -> the constants of ResetArgs
+__global__ void k_bos_capture(const BosArgs a) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < a.H)
+        for (int l = 0; l < a.Lp; ++l) {
+            a.bos_h[l][u] = act_ld(a.bf, a.pred_h[l], (size_t)u);
+            if (a.lstm) a.bos_c[l][u] = a.pred_c[l][(size_t)u * a.M];
+        }
+    if (u < a.J) a.bos_pp[u] = a.pp[u];
+}
 __global__ void k_reset_rows(const ResetArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.M * a.H) return;
@@ -148,8 +170,9 @@ __global__ void k_reset_rows(const ResetArgs a) {
     const int wh = a.what[r] & a.mask;
     const int W = a.W > 1 ? a.W : 1;
     const int rp = r * W;                                  // predictor row (slot 0 of the stream)
+    const bool bos = a.bos_pp != nullptr && W == 1;
     if (u == 0 && (a.mask & 2)) {
-        a.emit[rp] = (wh & 2) ? 1 : 0;
+        a.emit[rp] = ((wh & 2) && !bos) ? 1 : 0;
         if (wh & 2) a.token[rp] = a.bos;
         if (W > 1)
             for (int b = 0; b < W; ++b) {
@@ -164,11 +187,14 @@ __global__ void k_reset_rows(const ResetArgs a) {
             act_st(a.bf, a.enc_h[l], ho, a.enc_h0[l][u]);
             a.enc_c[l][(size_t)u * a.M + r] = a.enc_c0[l][u];
         }
-    if (wh & 2)
+    if (wh & 2) {
         for (int l = 0; l < a.Lp; ++l) {
-            act_st(a.bf, a.pred_h[l], (size_t)rp * a.H + u, a.pred_h0[l][u]);
-            if (a.pred_lstm) a.pred_c[l][(size_t)u * (W > 1 ? a.Md : a.M) + rp] = a.pred_c0[l][u];
+            act_st(a.bf, a.pred_h[l], (size_t)rp * a.H + u, bos ? a.bos_h[l][u] : a.pred_h0[l][u]);
+            if (a.pred_lstm) a.pred_c[l][(size_t)u * (W > 1 ? a.Md : a.M) + rp] = bos ? a.bos_c[l][u] : a.pred_c0[l][u];
         }
+        if (bos)
+            for (int j = u; j < a.J; j += a.H) a.pp[(size_t)rp * a.J + j] = a.bos_pp[j];
+    }
 }
 
 // per-step decode state

@@ -119,6 +119,12 @@ class Engine:
         already decoded for it (peek says so); otherwise a slot with a step in flight is refused."""
         self._chk(self.lib.lasr_stream_reset(self.ctx, int(slot), int(what) | (N.LASR_RESET_IF_DECODED if if_decoded else 0)))
 
+    def reset_many(self, slots, what=7, if_decoded=False):
+        """reset(slot, what, if_decoded) for several distinct slots in ONE call (lasr_stream_reset_many): all or nothing."""
+        a, p, n = self._slots(slots)
+        if n:
+            self._chk(self.lib.lasr_stream_reset_many(self.ctx, p, n, int(what) | (N.LASR_RESET_IF_DECODED if if_decoded else 0)))
+
     def close_slot(self, slot):
         self._chk(self.lib.lasr_stream_close(self.ctx, int(slot)))
 
@@ -150,6 +156,17 @@ class Engine:
         pcm = self._pcm(pcm, n)
         t = C.c_longlong(-1)
         self._chk(self.lib.lasr_push_submit(self.ctx, p, n, _ptr(pcm), N.LASR_PUSH_PINNED_NOCOPY if pinned_nocopy else 0, C.byref(t)))
+        return t.value
+
+    def push_submit_rows(self, slots, addrs):
+        """push_submit with the chunk of slots[i] at host address addrs[i] (uint64 array; `chunk` float32 each, e.g.
+        arr.ctypes.data + row * arr.strides[0]): lasr_push_submit_rows -- no gather into one array on this side.  The memory must
+        stay alive until the call returns (it is copied before that)."""
+        a, p, n = self._slots(slots)
+        addrs = np.ascontiguousarray(addrs, dtype=np.uint64)
+        assert addrs.size == n
+        t = C.c_longlong(-1)
+        self._chk(self.lib.lasr_push_submit_rows(self.ctx, p, n, addrs.ctypes.data_as(C.c_void_p), C.byref(t)))
         return t.value
 
     def push_consumed(self, ticket):

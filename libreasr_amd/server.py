@@ -61,7 +61,7 @@ class _Stream:
 
 class _Trunk:
     """Streams fed together through push_batch: the frames stay in the caller's [n, chunk] arrays, every stream has a cursor."""
-    __slots__ = ("streams", "slots", "live", "batches", "base", "pushed", "lut")
+    __slots__ = ("streams", "slots", "live", "batches", "base", "pushed", "lut", "addr", "addr_base", "addr_n")
 
     def __init__(self, streams, n_slots):
         self.streams = list(streams)
@@ -70,6 +70,21 @@ class _Trunk:
         self.lut = np.full(n_slots, -1, np.int64)              # slot -> column of the batches
         self.lut[self.slots] = np.arange(len(self.slots))
         self.batches, self.base, self.pushed = collections.deque(), 0, 0   # batches[k] has serial base + k
+        self.addr = np.zeros(64, np.uint64)                    # host address of the batch with serial addr_base + k (push_submit_rows)
+        self.addr_base, self.addr_n = 0, 0
+
+    def note_addr(self, a):
+        """Address of the batch just appended (serial addr_base + addr_n); entries of batches every stream has passed are dropped."""
+        if self.addr_n == len(self.addr):
+            drop = self.base - self.addr_base
+            if drop >= len(self.addr) // 2:
+                self.addr[:self.addr_n - drop] = self.addr[drop:self.addr_n]
+                self.addr_base += drop
+                self.addr_n -= drop
+            else:
+                self.addr = np.concatenate((self.addr, np.zeros(len(self.addr), np.uint64)))
+        self.addr[self.addr_n] = a
+        self.addr_n += 1
 
 
 _FAR = 1 << 60
@@ -112,6 +127,12 @@ class Scheduler(threading.Thread):
         # microseconds after the submit -- instead of `steps in flight` collections later, and the other streams keep the full depth
         # meanwhile.  (Greedy decode; with beam > 1, or an engine without peek, the round-3 behaviour: held_depth 3.)
         self.can_peek = self.beam == 1 and hasattr(engine, "peek_many")
+        # the frames of a tick go to the engine as ROW ADDRESSES (lasr_push_submit_rows): no gather into one matrix on this side
+        # when the streams of a trunk stand at different batches or only some of them run (the replay with the reset rule spent
+        # 70 us per tick there); several resets of a tick are one engine call (lasr_stream_reset_many)
+        self.can_rows = hasattr(engine, "push_submit_rows")
+        self.can_reset_many = hasattr(engine, "reset_many")
+        self._keep = []                      # arrays whose rows the tick's addresses point into (alive until the submit has returned)
         if held_depth is None:               # (tools/served_depth_sweep.py with early verdicts: 12 -> 17-25 k, 6 -> 23.5 k, 3 -> 23.0 k, 1 -> 20.9 k)
             held_depth = 6 if self.can_peek else 3
         self.held_depth = max(1, min(int(held_depth), self.depth))
@@ -146,6 +167,8 @@ class Scheduler(threading.Thread):
         self.n_eof = 0                      # EOF markers waiting
         self.n_blocked = 0                  # frames waiting in streams that the last tick found held at the reset threshold
         self._rows = np.zeros((N, engine.desc.chunk), np.float32)          # per-stream form: the frames of a tick, row by row
+        self._take_mask = np.zeros(N, bool)
+        self._arange = np.arange(N, dtype=np.int64)
 
     # ---- called from RPC threads -----------------------------------------------------------
     def _call(self, fn):
@@ -219,6 +242,10 @@ class Scheduler(threading.Thread):
                 raise ValueError("push_batch: the stream list of a trunk is fixed by its first call")
             if chunks.shape[0] != len(T.streams) or chunks.shape[1] != self.eng.desc.chunk:
                 raise ValueError(f"push_batch: chunks must be [{len(T.streams)}, {self.eng.desc.chunk}]")
+            if self.can_rows:
+                if chunks.dtype != np.float32 or not chunks.flags.c_contiguous:
+                    chunks = np.ascontiguousarray(chunks, np.float32)
+                T.note_addr(chunks.ctypes.data)
             T.batches.append(chunks)
             T.pushed += 1
             self.qn[T.live] += 1
@@ -281,6 +308,21 @@ class Scheduler(threading.Thread):
             self.eng.reset(i, 1 | 2 | 4)                                   # models.py:494-497
         self.stp[i] = 0
 
+    def _reset_all(self, slots, if_decoded=False):
+        """The resets a tick has decided on (models.py:494-497 per stream), in one engine call when it offers that."""
+        if not slots:
+            return
+        if len(slots) == 1 or not self.can_reset_many:
+            for i in slots:
+                self._reset(i, if_decoded)
+            return
+        sl = np.array(slots, np.int64)
+        if if_decoded:
+            self.eng.reset_many(sl, 1 | 2 | 4, if_decoded=True)
+        else:
+            self.eng.reset_many(sl, 1 | 2 | 4)
+        self.stp[sl] = 0
+
     def _offline(self, pcm, sr=16000):
         slot = self.eng.open()
         try:
@@ -307,8 +349,8 @@ class Scheduler(threading.Thread):
             while n < min(len(st.y_prev), len(tokens)) and st.y_prev[n] == tokens[n]:
                 n += 1
             st.y_prev, new = list(tokens), tokens[n:]
-        if self.stp[st.slot] >= self.rat[st.slot] and (not new or st.text_of(new) == ""):
-            self._reset(st.slot)            # (the stream has nothing in flight: see _take)
+        # (True: reset wanted -- the stream has nothing in flight, see _take; the caller resets all such streams of the step together)
+        return bool(self.stp[st.slot] >= self.rat[st.slot] and (not new or st.text_of(new) == ""))
 
     def _collect(self):
         """Tokens of the oldest model step in flight -> its streams."""
@@ -327,13 +369,11 @@ class Scheduler(threading.Thread):
         streams = self.streams
         rows = [streams[i] for i in sl.tolist()]
         if self.beam > 1:                    # (the hypothesis of the previous step is needed for every later judgement)
-            for s, t in zip(rows, toks):
-                if s.text_of is not None:
-                    self._judge(s, t)
+            self._reset_all([s.slot for s, t in zip(rows, toks) if s.text_of is not None and self._judge(s, t)])
         elif self.n_ruled:
             hot = np.flatnonzero((self.stp[sl] >= self.rat[sl]) & ~pre)
-            for k in hot.tolist():           # only the streams within reach of the reset rule
-                self._judge(rows[k], toks[k])
+            if len(hot):                     # only the streams within reach of the reset rule
+                self._reset_all([rows[k].slot for k in hot.tolist() if self._judge(rows[k], toks[k])])
         self.n_blocked = 0                   # (a judged step may have released a held stream: the next tick finds out)
         if cells is None:                    # a step of trunk streams only
             self.batch_outq.put((rows, toks))
@@ -373,6 +413,7 @@ class Scheduler(threading.Thread):
         if not len(cand):
             return
         steps_of, n_dec, n_inflight = self.eng.peek_many(cand, self.judged[cand])      # ONE engine call for all of them
+        resets = []
         for q, i in enumerate(cand.tolist()):
             st = self.streams.get(i)
             if st is None or st.text_of is None:
@@ -384,7 +425,9 @@ class Scheduler(threading.Thread):
                     # (past the threshold a stream has ONE step in flight at a time: this was its last, and it is decoded)
                     if int(self.judged[i]) != int(n_inflight[q]):
                         raise RuntimeError(f"scheduler: slot {i} ran ahead of the reset threshold ({int(n_inflight[q])} steps in flight)")
-                    self._reset(i, if_decoded=True)
+                    resets.append(i)
+                    self.stp[i] = 0
+        self._reset_all(resets, if_decoded=True)
 
     def _drain(self):
         while self.inflight:
@@ -477,34 +520,41 @@ class Scheduler(threading.Thread):
         self.n_wait -= len(take)
         mats, order, cells = [], [], None
         n_trunk = 0
+        rows_mode = self.can_rows            # addresses of the rows instead of a gathered matrix (see __init__)
         if self.trunks:
             whole = len(self.trunks) == 1 and len(take) == len(self.trunks[0].live) and len(take) == len(self.streams)
             for T in self.trunks:
+                if len(T.live):
+                    lo = int(self.cur[T.live].min())
+                    while T.base < lo:       # batches every live stream has passed -- dropped a tick late: the previous tick's row
+                        T.batches.popleft()  # addresses pointed into them until its submit returned
+                        T.base += 1
                 sl = T.live                  # (whole: the tick took exactly the trunk's streams)
                 if not whole:
-                    sl = np.intersect1d(sl, take, assume_unique=True)
+                    sl = sl[self._mask(take)[sl]]
                     if not len(sl):
                         continue
                 n_trunk += len(sl)
                 cur = self.cur[sl]
                 c0 = int(cur[0])
-                if (cur == c0).all():        # the common case: every taken stream of the trunk reads the same batch
-                    arr = T.batches[c0 - T.base]
-                    cols = T.lut[sl]         # row of every taken slot in the trunk's arrays (slot order != row order in general:
-                                             # a trunk built from re-opened slots, or a sorted intersection)
-                    mats.append(arr if (len(sl) == arr.shape[0] and (cols == np.arange(len(sl))).all()) else arr[cols])
+                cols = T.lut[sl]             # row of every taken slot in the trunk's arrays (slot order != row order in general:
+                                             # a trunk built from re-opened slots)
+                same = bool((cur == c0).all())
+                if same and len(sl) == len(T.slots) and (cols == self._arange[:len(sl)]).all():
+                    mats.append(T.batches[c0 - T.base])      # the common case: every stream of the trunk, the same batch, in row order
+                    order.append(sl)
+                elif rows_mode:
+                    mats.append(T.addr[cur - T.addr_base] + (cols * (4 * CH)).astype(np.uint64))
+                    order.append(sl)
+                elif same:
+                    mats.append(T.batches[c0 - T.base][cols])
                     order.append(sl)
                 else:
-                    cols = T.lut[sl]
                     for c in np.unique(cur).tolist():
                         m = cur == c
                         mats.append(T.batches[c - T.base][cols[m]])
                         order.append(sl[m])
                 self.cur[sl] += 1
-                lo = int(self.cur[T.live].min())
-                while T.base < lo:           # batches every live stream has passed
-                    T.batches.popleft()
-                    T.base += 1
         if n_trunk != len(take):
             cells = {}
             sl, k = [], 0
@@ -532,7 +582,21 @@ class Scheduler(threading.Thread):
             return _EMPTY, None, cells
         if len(mats) == 1:
             return order[0], mats[0], cells
+        if rows_mode:                        # several sources: everything as row addresses
+            mats = [m if m.ndim == 1 else self._row_addrs(m) for m in mats]
         return np.concatenate(order), np.concatenate(mats), cells
+
+    def _mask(self, take):
+        """Boolean mask over the slots for the tick's `take` (one buffer, cleared after use by the next call)."""
+        m = self._take_mask
+        m[:] = False
+        m[take] = True
+        return m
+
+    @staticmethod
+    def _row_addrs(m):
+        """Host addresses of the rows of a C-contiguous float32 matrix."""
+        return np.uint64(m.ctypes.data) + np.arange(m.shape[0], dtype=np.uint64) * np.uint64(m.strides[0])
 
     def _work_waiting(self):
         # frames are waiting in streams that can go (n_blocked: frames and EOF markers behind a stream held at the reset threshold,
@@ -598,7 +662,10 @@ class Scheduler(threading.Thread):
                 return
         try:
             self.batches.append(len(order))
-            self.eng.push_submit(order, mat)
+            if mat.ndim == 1:                                   # row addresses (see _gather)
+                self.eng.push_submit_rows(order, mat)
+            else:
+                self.eng.push_submit(order, mat)
         except Exception as e:
             if cells is None or len(cells) != len(order):
                 self.batch_outq.put(e)

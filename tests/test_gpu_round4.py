@@ -251,3 +251,83 @@ print("RESULT" + json.dumps(out))
     assert res["default"] == res["keep16"]
     assert res["default"] == res["inline"]
     assert res["default"].count(",") > 100
+
+
+def test_push_submit_rows_and_reset_many_equal_the_one_array_one_slot_forms():
+    """lasr_push_submit_rows (the chunk of slots[i] at its own host address) against lasr_push_submit on one array, and
+    lasr_stream_reset_many against a loop of lasr_stream_reset: same tokens per model step, resets in the middle included."""
+    cfg = synth.model_cfg("tiny")
+    B, n = 6, 48
+    pcm = synth.synth_pcm(B, n * 1280, seed=777)
+    res = []
+    for form in ("array", "rows"):
+        eng, _ = make(cfg, max_streams=16)
+        slots = [eng.open() for _ in range(B)]
+        steps = [[] for _ in range(B)]
+
+        def collect():
+            if eng.wait():
+                for i, t in enumerate(eng.fetch_many(slots, 64)):
+                    steps[i].append(t)
+        scattered = [np.ascontiguousarray(pcm[i].reshape(n, 1280)) for i in range(B)]      # one array per stream, as a server has them
+        for k in range(n):
+            if form == "array":
+                eng.push_submit(slots, np.stack([scattered[i][k] for i in range(B)]))
+            else:
+                addrs = np.array([scattered[i].ctypes.data + k * 1280 * 4 for i in range(B)], np.uint64)
+                eng.push_submit_rows(slots, addrs)
+            while eng.pending() >= 3:
+                collect()
+            if k in (15, 31):                 # everything collected, then streams 1, 2, 4 start over (encoder + predictor state)
+                while eng.pending():
+                    collect()
+                if form == "array":
+                    for i in (1, 2, 4):
+                        eng.reset(slots[i], 7)
+                else:
+                    eng.reset_many([slots[i] for i in (1, 2, 4)], 7)
+        while eng.pending():
+            collect()
+        res.append(steps)
+        with pytest.raises(Exception):
+            eng.reset_many([slots[0], slots[0]], 7)
+        eng.close()
+    assert res[0] == res[1]
+    assert sum(len(t) for s in res[0] for t in s) > 50
+
+
+def test_stored_bos_state_equals_the_predictor_pass_on_bos():
+    """A reset stores the predictor state after the BOS step and its joint half, captured once at lasr_create, instead of running
+    the predictor on BOS (LASR_BOS_CACHE=0): same tokens with resets in the middle, NBRC and LSTM predictors, f32 and bf16."""
+    code = r'''
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from libreasr_amd import synth
+from libreasr_amd.engine import Engine
+out = {}
+for name in ("tiny", "tiny_lstm"):
+    for dtype in ("f32", "bf16"):
+        cfg = synth.model_cfg(name); sd = synth.synth_state_dict(cfg, seed=0)
+        eng = Engine(sd, cfg, max_streams=8, dtype=dtype)
+        pcm = synth.synth_pcm(4, 16000 * 4, seed=31)
+        slots = [eng.open() for _ in range(4)]
+        got = [[] for _ in slots]
+        for k in range(pcm.shape[1] // 1280):
+            eng.push(slots, torch.as_tensor(np.ascontiguousarray(pcm[:, k * 1280:(k + 1) * 1280])).cuda())
+            if eng.step(slots):
+                for i, t in enumerate(eng.fetch_many(slots, 64)): got[i].append(t)
+            if k %% 13 == 12:
+                eng.reset(slots[k %% 4], 7)
+        eng.transcribe_pcm(slots, [pcm[i] for i in range(4)])
+        out[name + dtype] = [got, [[t, float(lp).hex()] for t, lp, _ in (eng.fetch(s) for s in slots)]]
+        eng.close()
+print("RESULT" + json.dumps(out))
+''' % ROOT
+    res = {}
+    for tag, env in (("stored", {}), ("pass", {"LASR_BOS_CACHE": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = line[0]
+    assert res["stored"] == res["pass"]
+    assert res["stored"].count(",") > 100

@@ -209,11 +209,14 @@ def test_scheduler_64_streams_on_the_pipelined_protocol_with_served_rates():
         pcm2 = np.stack([synth.synth_pcm(1, n2 * 1280, seed=4321 + s)[0] for s in range(B)])
         chunks2 = np.ascontiguousarray(pcm2.reshape(B, n2, 1280).transpose(1, 0, 2))
 
-        def run_trunk(depth):
+        def run_trunk(depth, clock0=None):
             sc = srv.Scheduler(eng, depth=depth)
             sc.start()
             try:
                 sts = [sc.open(text_of=language.denumericalize) for _ in range(B)]
+                if clock0 is not None:               # streams whose silence clocks (api-server.py:117 `steps`) stand at different counts,
+                    for st, k0 in zip(sts, clock0):  # as for clients that connected at different times (scheduler thread idle: no race)
+                        sc.stp[st.slot] = k0
                 out = {st.slot: [] for st in sts}
                 t0 = time.perf_counter()
                 for k in range(n2):
@@ -233,6 +236,7 @@ def test_scheduler_64_streams_on_the_pipelined_protocol_with_served_rates():
                 sc.shutdown()
                 sc.join(timeout=30)
 
+        sc_reset_steps = srv.Scheduler(eng, depth=1).reset_steps      # 25 model steps of 160 ms = 4 s (api-server.py:25,44-50)
         deep, rate_deep, rows_deep = run_trunk(12)
         flat, rate_flat, rows_flat = run_trunk(1)
         assert deep == flat, "tokens depend on the number of steps in flight"
@@ -240,6 +244,14 @@ def test_scheduler_64_streams_on_the_pipelined_protocol_with_served_rates():
         rates["trunk_reset_rule"] = rate_deep
         rates["trunk_reset_rule_rows_per_step"] = rows_deep
         rates["trunk_reset_rule_depth1"] = rate_flat
+        # (d) the same with the streams' silence clocks out of phase (stream i starts at i * 25 / 64 steps): the worst case above has
+        # all 64 streams reach the threshold in the same model step, so the whole pipeline drains for every verdict
+        clock0 = [(i * sc_reset_steps) // B for i in range(B)]
+        deep_s, rate_s, rows_s = run_trunk(12, clock0)
+        flat_s, _, _ = run_trunk(1, clock0)
+        assert deep_s == flat_s, "tokens depend on the number of steps in flight (staggered clocks)"
+        rates["trunk_reset_rule_staggered"] = rate_s
+        rates["trunk_reset_rule_staggered_rows_per_step"] = rows_s
         print("served audio-s/s:", json.dumps(rates))
         os.makedirs("gpurun_out", exist_ok=True)
         with open("gpurun_out/served_rate.json", "w") as f:

@@ -89,6 +89,35 @@ class FakeEngine:
         self.since_reset[s] = 0
         self.hyp[s] = []
 
+    ROWS = False                            # set by the `engine_form` fixture: the engine also offers push_submit_rows / reset_many
+
+    def __getattr__(self, name):            # (hasattr() of the optional entry points follows ROWS)
+        if name in ("push_submit_rows", "reset_many") and type(self).ROWS:
+            return getattr(self, "_opt_" + name)
+        raise AttributeError(name)
+
+    def _opt_push_submit_rows(self, slots, addrs):
+        """lasr_push_submit_rows: the chunk of slots[i] is read from host address addrs[i]."""
+        import ctypes
+        addrs = np.asarray(addrs)
+        assert addrs.dtype == np.uint64 and addrs.ndim == 1 and len(addrs) == len(slots)
+        self.n_row_pushes = getattr(self, "n_row_pushes", 0) + 1
+        ch = self.desc.chunk
+        pcm = np.stack([np.ctypeslib.as_array((ctypes.c_float * ch).from_address(int(a))).copy() for a in addrs])
+        self.push_submit(slots, pcm)
+
+    def _opt_reset_many(self, slots, what, if_decoded=False):
+        slots = np.asarray(slots).tolist()
+        assert len(set(slots)) == len(slots)
+        self.n_reset_many = getattr(self, "n_reset_many", 0) + 1
+        for s in slots:                     # all or nothing: checked before anything changes
+            if if_decoded:
+                assert all(self.clock - out["_t"] >= self.peek_lag for out in self.steps if s in out), "reset with an undecoded step in flight"
+            else:
+                assert not any(s in out for out in self.steps), "reset with a step in flight"
+        for s in slots:
+            self.reset(s, what, if_decoded)
+
     def push_submit(self, slots, pcm):
         self._own()
         self.clock += 1
@@ -169,6 +198,15 @@ def expected(chunks, slot_silent=False, text_rule=True, thresh_steps=25):
         if text_rule and not toks and srv.should_reset(steps, 8, 2):
             since, steps = 0, 0
     return out
+
+
+@pytest.fixture(autouse=True, params=["matrix", "rows"])
+def engine_form(request):
+    """Every test runs against an engine with only lasr_push_submit / lasr_stream_reset and against one that also offers
+    lasr_push_submit_rows / lasr_stream_reset_many (the scheduler then hands over row addresses and batches a tick's resets)."""
+    FakeEngine.ROWS = request.param == "rows"
+    yield request.param
+    FakeEngine.ROWS = False
 
 
 def test_results_in_order_steps_in_flight_and_eof():
@@ -623,3 +661,40 @@ def test_early_verdicts_keep_held_streams_in_the_batch_and_place_resets_where_th
     rows_old, steps_old = run(False)
     assert steps_peek <= steps_old and rows_peek >= rows_old
     assert rows_peek > 0.9 * B, (rows_peek, rows_old)         # held streams rejoin within a step or two
+
+
+def test_row_addresses_and_batched_resets_give_what_the_matrix_form_gives():
+    """The same replay (trunk of 6 streams, two silent ones that hit the reset threshold in the same model step and are then held
+    while the others run on, so the streams of the trunk stand at different batches) against an engine with and without
+    lasr_push_submit_rows / lasr_stream_reset_many: same tokens, same resets; the address form was really used, and the two
+    silent streams' first reset went out as ONE call."""
+    res = {}
+    for form in (False, True):
+        FakeEngine.ROWS = form
+        eng = FakeEngine(max_streams=8, silent={1, 4})
+        eng.peek_lag = 9                     # a verdict takes a few ticks: the other streams run ahead meanwhile
+        sched = srv.Scheduler(eng, depth=6)
+        sched.start()
+        try:
+            rng = np.random.default_rng(5)
+            B, n = 6, 150
+            chunks = rng.integers(0, 9, (n, B, 4)).astype(np.float32)
+            sts = [sched.open(text_of=lambda t: "x" if t else "") for _ in range(B)]
+            for k in range(n):
+                sched.push_batch(sts, chunks[k].copy())          # a fresh array per call, as the interface asks
+            got = {st.slot: [] for st in sts}
+            while sum(len(g) for g in got.values()) < B * ((n - 2) // 2):
+                rows, toks = sched.batch_outq.get(timeout=20)
+                for st, t in zip(rows, toks):
+                    got[st.slot].append(t)
+            res[form] = (got, sorted(eng.resets))
+            if form:
+                assert getattr(eng, "n_row_pushes", 0) > 10
+                assert getattr(eng, "n_reset_many", 0) >= 1
+            else:
+                assert not hasattr(eng, "n_row_pushes")
+        finally:
+            sched.shutdown()
+            sched.join(timeout=10)
+    assert res[False] == res[True]
+    assert len(res[True][1]) >= 4
