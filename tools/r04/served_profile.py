@@ -20,6 +20,7 @@ depth = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 stagger = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 held = int(sys.argv[3]) if len(sys.argv) > 3 else None
 prof_on = os.environ.get("PROF", "1") != "0"
+rule = os.environ.get("RULE", "1") != "0"          # RULE=0: the trunk form without the servicer's reset rule
 conf, language, model, _, _ = load_stuff("en", config_path="/nonexistent.yaml", synthetic="cfg2", max_streams=64)
 eng = model.engine
 B, n2 = 64, 256
@@ -43,7 +44,7 @@ for rep in range(2):
     kw = {} if held is None else {"held_depth": held}
     sc = Sched(eng, depth=depth, **kw)
     sc.start()
-    sts = [sc.open(text_of=language.denumericalize) for _ in range(B)]
+    sts = [sc.open(text_of=language.denumericalize if rule else None) for _ in range(B)]
     if stagger:
         for i, st in enumerate(sts):
             sc.stp[st.slot] = (i * sc.reset_steps) // B
@@ -62,7 +63,7 @@ for rep in range(2):
     sc.shutdown()
     sc.join(timeout=30)
     rows = np.array(sc.step_rows)
-    print(f"rep {rep}: depth {depth} stagger {stagger} held_depth {sc.held_depth}: {B * n2 * 0.08 / dt:.0f} audio-s/s, {len(rows)} model steps of "
+    print(f"rep {rep}: rule {int(rule)} depth {depth} stagger {stagger} held_depth {sc.held_depth}: {B * n2 * 0.08 / dt:.0f} audio-s/s, {len(rows)} model steps of "
           f"{rows.mean():.1f} rows (p10 {np.percentile(rows, 10):.0f}), {dt / len(rows) * 1e6:.0f} us per model step, {items} result items")
 if prof_on:
     s = io.StringIO()
