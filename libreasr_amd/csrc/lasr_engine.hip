@@ -2138,11 +2138,13 @@ size_t lasr_lm_weight_count(const lasr_lm_desc* d) {
     return n + V * H + V;
 }
 
-// The LM's own stream (see cont_enqueue): created when an LM is attached, on a hardware queue shared with neither the main nor
-// the decode stream (probed like the decode stream at lasr_create; a stream that cannot be placed is given up and the LM step
-// stays in line on the decode stream).  LASR_LM_SIDE=0: in line.
+// The LM's own stream (see cont_enqueue), LASR_LM_SIDE=1 (default: the LM step in line on the decode stream): created when an
+// LM is attached, on a hardware queue shared with neither the main nor the decode stream (probed like the decode stream at
+// lasr_create; a stream that cannot be placed is given up).  Opt-in because what it buys depends on where the RUNTIME places the
+// branches of the replayed group graph, which the probe does not control: the same build measured 32.7 against 30.7 k in line on
+// one lease / process shape and 27.0 against 30.5 k on another (profiles/r04/r04_experiments.txt N).
 static int lm_side_setup(lasr_ctx* c) {
-    static const int on = getenv("LASR_LM_SIDE") ? atoi(getenv("LASR_LM_SIDE")) : 1;
+    static const int on = getenv("LASR_LM_SIDE") ? atoi(getenv("LASR_LM_SIDE")) : 0;
     if (!on || !c->stream_dec || c->stream_lm) return LASR_OK;
     static const int pick = getenv("LASR_DEC_STREAM_PICK") ? atoi(getenv("LASR_DEC_STREAM_PICK")) : 1;
     std::vector<hipStream_t> rejected;

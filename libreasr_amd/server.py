@@ -134,8 +134,9 @@ class Scheduler(threading.Thread):
         self.can_reset_many = hasattr(engine, "reset_many")
         self._keep = []                      # arrays whose rows the tick's addresses point into (alive until the submit has returned)
         if held_depth is None:               # (tools/r04/served_profile.py, early verdicts + row addresses + stored BOS state, 64 streams in
-            # phase / clocks out of phase: 3 -> 31.3 / 25.9 k, 6 -> 35.3 / 31.5 k, 9 -> 36.6 / 32.4 k, 12 -> 34.5 / 31.2 k)
-            held_depth = 9 if self.can_peek else 3
+            # phase / clocks out of phase, medians of 7 replays: 6 -> 34.6 / 30.6 k, 9 -> 33.3 / 29.7 k; single runs: 3 -> 31.3 / 25.9 k,
+            # 12 -> 34.5 / 31.2 k -- run-to-run spread +-4 %)
+            held_depth = 6 if self.can_peek else 3
         self.held_depth = max(1, min(int(held_depth), self.depth))
         self.any_held = False
         self._beam_cap = 1024               # tokens per stream fetch_many makes room for with beam > 1 (grows on LASR_EFULL)

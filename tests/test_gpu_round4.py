@@ -212,7 +212,7 @@ def test_lm_fusion_with_lookahead_equals_one_frame_per_iteration(int8, monkeypat
 
 def test_lm_register_slots_and_lm_stream_are_bit_identical_switches():
     """k_lm_post / k_beam_fuse with 8 register slots per thread (V <= 2048) against LASR_KEEP16=1 (round 3's kernels), and the LM
-    branch on its own stream against LASR_LM_SIDE=0: the same tokens AND the same -log p bits, greedy (offline + pipelined) and
+    branch on its own stream (LASR_LM_SIDE=1) against the LM step in line: the same tokens AND the same -log p bits, greedy (offline + pipelined) and
     beam 4 with the LM inside the beam."""
     code = r'''
 import json, sys, numpy as np, torch
@@ -243,13 +243,13 @@ for beam in (1, 4):
 print("RESULT" + json.dumps(out))
 ''' % ROOT
     res = {}
-    for tag, env in (("default", {}), ("keep16", {"LASR_KEEP16": "1"}), ("inline", {"LASR_LM_SIDE": "0"})):
+    for tag, env in (("default", {}), ("keep16", {"LASR_KEEP16": "1"}), ("branch", {"LASR_LM_SIDE": "1"})):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
         assert line, r.stdout[-2000:] + r.stderr[-2000:]
         res[tag] = line[0]
     assert res["default"] == res["keep16"]
-    assert res["default"] == res["inline"]
+    assert res["default"] == res["branch"]
     assert res["default"].count(",") > 100
 
 

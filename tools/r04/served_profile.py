@@ -40,7 +40,9 @@ class Sched(srv.Scheduler):
             self.prof.disable()
 
 
-for rep in range(2):
+reps = int(os.environ.get("REPS", "2"))
+rates = []
+for rep in range(reps):
     kw = {} if held is None else {"held_depth": held}
     sc = Sched(eng, depth=depth, **kw)
     sc.start()
@@ -63,8 +65,11 @@ for rep in range(2):
     sc.shutdown()
     sc.join(timeout=30)
     rows = np.array(sc.step_rows)
+    rates.append(B * n2 * 0.08 / dt)
     print(f"rep {rep}: rule {int(rule)} depth {depth} stagger {stagger} held_depth {sc.held_depth}: {B * n2 * 0.08 / dt:.0f} audio-s/s, {len(rows)} model steps of "
           f"{rows.mean():.1f} rows (p10 {np.percentile(rows, 10):.0f}), {dt / len(rows) * 1e6:.0f} us per model step, {items} result items")
+if reps > 2:
+    print(f"median of reps 1..{reps - 1}: {np.median(rates[1:]):.0f} audio-s/s (min {min(rates[1:]):.0f}, max {max(rates[1:]):.0f})")
 if prof_on:
     s = io.StringIO()
     pstats.Stats(sc.prof, stream=s).sort_stats("tottime").print_stats(22)
