@@ -414,6 +414,25 @@ void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
         else launch_gemm<OpsF32, EpiLinearT<4>, 4, false, -1, 4>(c, V / 64, (n_rows + 63) / 64, g4, e4);
         return;
     }
+    // 32 x 32 workgroups for the greedy loop's 64-128 rows (experiment, LASR_LOGITS_NT2=1): half the workgroups of the 32 x 16
+    // tiling, each activation row fetched by 64 n-groups instead of 128 (same waves per workgroup, same K split: bit-identical)
+    static const int lg_nt2 = getenv("LASR_LOGITS_NT2") ? atoi(getenv("LASR_LOGITS_NT2")) : 0;
+    if (lg_nt2 && c->logits_mt == 2 && n_rows < 512 && V % 32 == 0) {
+        GemmArgs g2 = g;
+        g2.KC[0] = J / c->kch;
+        EpiLinearT<2>::Args e2{};
+        static_assert(sizeof(e2) == sizeof(ea), "same Args layout");
+        memcpy((void*)&e2, (const void*)&ea, sizeof(e2));
+        const int mg = (n_rows + 31) / 32;
+        if (c->dec_nw_mask & 4) {
+            if (c->bf) launch_gemm<OpsBF16, EpiLinearT<2>, 2, false, -1, 4>(c, V / 32, mg, g2, e2);
+            else launch_gemm<OpsF32, EpiLinearT<2>, 2, false, -1, 4>(c, V / 32, mg, g2, e2);
+        } else {
+            if (c->bf) launch_gemm<OpsBF16, EpiLinearT<2>, 2, false, -1>(c, V / 32, mg, g2, e2);
+            else launch_gemm<OpsF32, EpiLinearT<2>, 2, false, -1>(c, V / 32, mg, g2, e2);
+        }
+        return;
+    }
     static const int lw_env = getenv("LASR_LOGITS_WIDE") ? atoi(getenv("LASR_LOGITS_WIDE")) : -1;
     if (c->logits_mt == 4 || (c->logits_mt == 2 && (lw_env >= 0 ? lw_env != 0 : n_rows >= 512))) { launch_logits_t<4>(c, g, n_rows, J, ea); return; }
     if (c->logits_mt == 2) { launch_logits_t<2>(c, g, n_rows, J, ea); return; }
