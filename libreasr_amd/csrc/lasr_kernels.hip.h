@@ -1186,13 +1186,14 @@ struct BeamCarryArgs {
     const float* pp_in; float* pp_out;
     const float* pe; const int* t_idx; const int* T_row; void* ja; int MTj, ring, M_enc;
 };
-__global__ __launch_bounds__(256) void k_beam_carry(const BeamCarryArgs a) {
-    if (blockIdx.y == 1) {
+// the work of carry block (bx, by) -- by 0: slot bx's row-major parts, by 1: block bx of the cell state; any block size >= 256
+__device__ __forceinline__ void beam_carry_body(const BeamCarryArgs& a, const int bx, const int by) {
+    if (by == 1) {
         // cell state: block = (16-unit slice, 256-slot block); a thread moves its slot's 16 units of every layer (the slots of a
         // stream sit next to each other: the gathered parent values come from the same 32-byte neighbourhood)
         const int nrb = (a.Md + 255) / 256;
-        const int u0 = (blockIdx.x / nrb) * 16, r = (blockIdx.x % nrb) * 256 + threadIdx.x;
-        if (!a.lstm || u0 >= a.H || r >= a.Md || a.emit[r]) return;
+        const int u0 = (bx / nrb) * 16, r = (bx % nrb) * 256 + threadIdx.x;
+        if (!a.lstm || threadIdx.x >= 256 || u0 >= a.H || r >= a.Md || a.emit[r]) return;
         const int pr = (r / a.W) * a.W + a.parent[r];
         for (int l = 0; l < a.Lp; ++l) {
             float v[16];
@@ -1203,7 +1204,7 @@ __global__ __launch_bounds__(256) void k_beam_carry(const BeamCarryArgs a) {
         }
         return;
     }
-    const int r = blockIdx.x;
+    const int r = bx;
     if (r >= a.Md || a.emit[r]) return;
     const int pr = (r / a.W) * a.W + a.parent[r], H = a.H, J = a.J;
     const int q = r / a.W;
@@ -1256,6 +1257,25 @@ __global__ __launch_bounds__(256) void k_beam_carry(const BeamCarryArgs a) {
             *(float4*)((float*)a.ja + OpsF32::aoff(r, 4 * i, a.MTj)) = float4{tanhf(e0.x + p0.x), tanhf(e0.y + p0.y), tanhf(e0.z + p0.z), tanhf(e0.w + p0.w)};
         }
     }
+}
+__global__ __launch_bounds__(256) void k_beam_carry(const BeamCarryArgs a) { beam_carry_body(a, blockIdx.x, blockIdx.y); }
+// The carry as extra workgroups of a GEMM launch of the same round (the joint-half GEMM, the last of the predictor chain): rows
+// blockIdx.y >= m_groups of the grid are carry blocks -- Md slot blocks, then the cell-state blocks.  The carry depends on the
+// selection kernel only and touches no row the chain's GEMMs touch, so it needs no launch (and no launch boundary) of its own:
+// its copies run beside the (mostly idle-skipping) GEMM workgroups.
+template <class Ops, class Epi, int MT, int NW, bool AROW, int D>
+__global__ __launch_bounds__(NW * 64) void k_gemm_carry(const GemmArgs g, const typename Epi::Args ea, const BeamCarryArgs ca, const int m_groups) {
+    constexpr int NT = Epi::NT, ROWS = MT * 16, LD = NT * 16 + 1;
+    __shared__ float red[NW * ROWS * LD];
+    __shared__ int row_map[Epi::COMPACT ? 1024 : 1];
+    __shared__ int n_act_s;
+    if ((int)blockIdx.y >= m_groups) {
+        const int bid = ((int)blockIdx.y - m_groups) * (int)gridDim.x + (int)blockIdx.x;
+        if (bid < ca.Md) beam_carry_body(ca, bid, 0);
+        else beam_carry_body(ca, bid - ca.Md, 1);
+        return;
+    }
+    gemm_body<Ops, Epi, MT, NW, AROW, D>(g, ea, blockIdx.x, blockIdx.y, red, row_map, n_act_s);
 }
 
 // start of a beam decode step: per-stream cursors and the iteration flags

@@ -117,9 +117,38 @@ void launch_enc_wave(lasr_ctx* c, const EncCellRef* cells, int n, int par0, int 
 }
 
 // beam search: the slots that are not extended are carried by k_beam_carry instead of the GEMM epilogues (LASR_BEAM_CARRY=0: as in round 3)
-bool beam_carry_on() {
-    static const int v = getenv("LASR_BEAM_CARRY") ? atoi(getenv("LASR_BEAM_CARRY")) : 1;
-    return v != 0;
+// LASR_BEAM_CARRY: 0 = non-extended hypothesis slots carried inside the cell / joint kernels' epilogues (round 3), 1 = by a launch of
+// their own (k_beam_carry), 2 = as extra workgroups of the joint-half GEMM's launch (k_gemm_carry)
+int beam_carry_mode() {
+    static const int v = getenv("LASR_BEAM_CARRY") ? atoi(getenv("LASR_BEAM_CARRY")) : 2;
+    return v;
+}
+bool beam_carry_on() { return beam_carry_mode() != 0; }
+void fill_beam_carry(lasr_ctx* c, BeamCarryArgs& a) {
+    const int H = c->d.hidden, p = c->pred_par;
+    a.emit = c->ds.emit; a.parent = c->b_parent; a.W = c->W; a.Md = c->Md; a.H = H; a.J = c->d.joint; a.Lp = c->d.pred_layers;
+    a.bf = c->bf; a.lstm = c->d.pred_cell;
+    for (int l = 0; l < a.Lp; ++l) {
+        a.h_in[l] = c->pred_h[p][l]; a.h_out[l] = c->pred_h[p ^ 1][l];
+        a.y_in[l] = p ? c->pred_y1[l] : c->pred_y[l]; a.y_out[l] = p ? c->pred_y[l] : c->pred_y1[l];
+        if (a.lstm) { a.c_in[l] = p ? c->pred_c1[l] : c->pred_c[l]; a.c_out[l] = p ? c->pred_c[l] : c->pred_c1[l]; }
+    }
+    a.pp_in = p ? c->pp1 : c->pp; a.pp_out = p ? c->pp : c->pp1;
+    a.pe = c->pe; a.t_idx = c->dec_t_idx; a.T_row = c->T_row_dec; a.ja = c->ja; a.MTj = c->MTj; a.ring = c->pe_ring_R; a.M_enc = c->M;
+}
+// carry blocks of a launch: Md slot blocks + (LSTM predictor) the cell-state blocks
+int beam_carry_blocks(lasr_ctx* c) {
+    return c->Md + (c->d.pred_cell ? ((c->d.hidden + 15) / 16) * ((c->Md + 255) / 256) : 0);
+}
+// a GEMM launch whose grid carries the round's carry blocks behind its own m-groups (see k_gemm_carry)
+template <class Ops, class Epi, int MT, bool AROW, int D = 3, int NWV = NW>
+void launch_gemm_carry(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g0, const typename Epi::Args& ea) {
+    GemmArgs g = g0;
+    g.prio = (c->stream && (c->stream == c->stream_dec || c->stream == c->stream_lm)) ? c->dec_prio : c->cell_prio;
+    BeamCarryArgs ca{};
+    fill_beam_carry(c, ca);
+    const int extra = (beam_carry_blocks(c) + n_groups - 1) / n_groups;
+    hipLaunchKernelGGL((k_gemm_carry<Ops, Epi, MT, NWV, AROW, D>), dim3(n_groups, m_groups + extra), dim3(NWV * 64), 0, c->stream, g, ea, ca, m_groups);
 }
 
 // one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels); predictor
@@ -136,19 +165,11 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
     const int w8_min = getenv("LASR_W8_MIN") ? atoi(getenv("LASR_W8_MIN")) : 256;
     const bool wide8 = wide_env >= 0 ? wide_env == 2 : (c->bf && c->Md >= w8_min && c->Md < 512);   // 8 units per workgroup, 8 waves
     const bool split_carry = beam && beam_carry_on();
-    if (split_carry) {      // the slots that are not extended: whole-row copies by their own launch (see k_beam_carry)
+    if (split_carry && beam_carry_mode() == 1) {      // the slots that are not extended: whole-row copies by their own launch (see k_beam_carry)
         BeamCarryArgs a{};
-        a.emit = c->ds.emit; a.parent = c->b_parent; a.W = c->W; a.Md = c->Md; a.H = H; a.J = c->d.joint; a.Lp = c->d.pred_layers;
-        a.bf = c->bf; a.lstm = c->d.pred_cell;
-        for (int l = 0; l < a.Lp; ++l) {
-            a.h_in[l] = c->pred_h[p][l]; a.h_out[l] = c->pred_h[p ^ 1][l];
-            a.y_in[l] = p ? c->pred_y1[l] : c->pred_y[l]; a.y_out[l] = p ? c->pred_y[l] : c->pred_y1[l];
-            if (a.lstm) { a.c_in[l] = p ? c->pred_c1[l] : c->pred_c[l]; a.c_out[l] = p ? c->pred_c[l] : c->pred_c1[l]; }
-        }
-        a.pp_in = p ? c->pp1 : c->pp; a.pp_out = p ? c->pp : c->pp1;
-        a.pe = c->pe; a.t_idx = c->dec_t_idx; a.T_row = c->T_row_dec; a.ja = c->ja; a.MTj = c->MTj; a.ring = c->pe_ring_R; a.M_enc = c->M;
+        fill_beam_carry(c, a);
         hipLaunchKernelGGL(k_beam_carry, dim3(std::max(c->Md, ((H + 15) / 16) * ((c->Md + 255) / 256)), 2), dim3(256), 0, c->stream, a);
-    }
+    }                                                   // (mode 2: the carry rides in launch_ppj's launch of the same pass)
     for (int l = 0; l < c->d.pred_layers; ++l) {
         const Cell& L = c->pred[l];
         GemmArgs g{};
@@ -227,11 +248,16 @@ void launch_ppj_t(lasr_ctx* c, bool beam) {
     static const int ppj_wide_env = getenv("LASR_PPJ_WIDE") ? atoi(getenv("LASR_PPJ_WIDE")) : -1;
     const bool ppj_wide = (ppj_wide_env >= 0 ? ppj_wide_env != 0 : c->Md >= 512) && c->MTd % 4 == 0;   // 64-row workgroups for many decoder rows
     static const int ppj_nt4 = getenv("LASR_PPJ_NT4") ? atoi(getenv("LASR_PPJ_NT4")) : 0;      // 64-column workgroups: measured slower (19.9 against 14.3 us at 1024 rows)
-    if (ppj_wide && ppj_nt4 && J % 64 == 0) {
+    if (ppj_wide && ppj_nt4 && J % 64 == 0 && !(beam && beam_carry_mode() == 2)) {
         typename EpiPPJ<Ops, 4>::Args e4{};
         static_assert(sizeof(e4) == sizeof(ea), "same Args layout");
         memcpy((void*)&e4, (const void*)&ea, sizeof(e4));
         launch_gemm<Ops, EpiPPJ<Ops, 4>, 4, true, -1, 4>(c, J / 64, c->MTd / 4, g, e4);
+    } else
+    if (beam && beam_carry_mode() == 2) {      // the round's carry as extra workgroups of this launch
+        if (ppj_wide) launch_gemm_carry<Ops, EpiPPJ<Ops>, 4, true, -1, 4>(c, J / 16, c->MTd / 4, g, ea);
+        else if (c->dec_nw_mask & 2) launch_gemm_carry<Ops, EpiPPJ<Ops>, 1, true, -1, 4>(c, J / 16, c->MTd, g, ea);
+        else launch_gemm_carry<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
     } else
     if (ppj_wide) launch_gemm<Ops, EpiPPJ<Ops>, 4, true, -1, 4>(c, J / 16, c->MTd / 4, g, ea);
     else if (c->dec_nw_mask & 2) launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1, 4>(c, J / 16, c->MTd, g, ea); else launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
