@@ -109,6 +109,15 @@ struct lasr_ctx {
     // continuous decode (lasr_step_submit / lasr_step_wait): front-end + encoder of later chunks run on
     // the main stream while ONE greedy loop keeps running on stream_dec across chunk boundaries: a row
     // that finished chunk k moves on to chunk k+1's frames while a bursty row is still on chunk k.
+    // a GEMM launch recorded instead of issued (launch_gemm with `cap` set): what pair launches are assembled from (k_gemm2)
+    struct Captured {
+        const void* fn = nullptr;             // the k_gemm instantiation that would have run
+        unsigned gx = 0, gy = 0, threads = 0;
+        alignas(16) unsigned char g[256];     // GemmArgs
+        alignas(16) unsigned char ea[768];    // the epilogue's Args
+        size_t g_size = 0, ea_size = 0;
+    };
+    Captured* cap = nullptr;
     hipStream_t stream_dec = nullptr;
     // LM branch of a decode iteration (pipelined protocol): the LM step and the predictor / joint chain both start from the
     // token a selection kernel has just written and both end at the next selection -- two branches of the group's hipGraph

@@ -1317,6 +1317,11 @@ static void cont_enqueue(lasr_ctx* c, int G) {
     // reads its scores and rewrites token / emit) or at the end of the group -- the predictor, the joint half and the next
     // logits GEMM run beside it (captured: two branches of the group graph)
     const bool side = c->lm.on && c->stream_lm != nullptr;
+    // pair launches (LASR_LM_PAIR, greedy, fp32 / bf16 LM of >= 3 layers beside a 2 x NBRC predictor -- configs[1] with the
+    // reference's LM; other shapes keep the LM step in line)
+    static const int pair_env = getenv("LASR_LM_PAIR") ? atoi(getenv("LASR_LM_PAIR")) : 1;
+    const bool pair = pair_env && !side && c->W == 1 && c->lm.on && !c->lm.q8 && c->d.pred_cell == 0 && c->d.pred_layers == 2 && c->lm.L >= 3;
+    bool lm_tail = false;
     bool lm_open = false;
     auto lm_join = [&]() {
         if (lm_open) (void)hipStreamWaitEvent(c->stream, c->ev_lm_join, 0);
@@ -1346,6 +1351,35 @@ static void cont_enqueue(lasr_ctx* c, int G) {
             continue;
         }
         s.host_flag = (q == G - 1) ? c->c_flag_dev : nullptr;
+        if (pair) {
+            // LM step and predictor / joint chain of an iteration as PAIR launches (k_gemm2): LM layer l beside stage l of the chain;
+            // the step's last layers run beside the NEXT iteration's logits GEMM (or alone, at the end of the group)
+            lasr_ctx::Captured A, B;
+            auto rec = [&](lasr_ctx::Captured& k, auto&& fn) { c->cap = &k; fn(); c->cap = nullptr; };
+            if (lm_tail) {
+                rec(A, [&] { launch_logits(c, c->logits, c->la * M, true); });
+                rec(B, [&] { launch_lm(c, false, 3, 4, false); });
+                launch_pair(c, 3, false, A, B);
+                launch_lm(c, false, 4, -1);                       // deeper layers (if any), output layer, k_lm_post, parity
+                lm_tail = false;
+            } else {
+                launch_logits(c, c->logits, c->la * M, true);
+            }
+            launch_select<false>(c->stream, M, c->logits, V, c->d.blank, c->d.max_iters_stream, c->c_avail, s, 0, nullptr, nullptr, c->la, M);
+            rec(A, [&] { launch_predictor(c, false, 0, 1); });
+            rec(B, [&] { launch_lm(c, false, 0, 1, false); });
+            launch_pair(c, 0, true, A, B);
+            rec(A, [&] { launch_predictor(c, false, 1, 2); });
+            rec(B, [&] { launch_lm(c, false, 1, 2, false); });
+            launch_pair(c, 1, false, A, B);
+            rec(A, [&] { launch_ppj(c); });
+            rec(B, [&] { launch_lm(c, false, 2, 3, false); });
+            launch_pair(c, 2, false, A, B);
+            if (c->lm.L > 3) lm_tail = true;
+            else launch_lm(c, false, 3, -1);                      // (3 layers: only the output layer is left)
+            if (q == G - 1 && lm_tail) { launch_lm(c, false, 3, -1); lm_tail = false; }
+            continue;
+        }
         launch_logits(c, c->logits, c->la * M, true);
         lm_join();
         launch_select<false>(c->stream, M, c->logits, V, c->d.blank, c->d.max_iters_stream, c->c_avail, s, 0, nullptr, nullptr, c->la, M);

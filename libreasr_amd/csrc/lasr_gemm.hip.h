@@ -460,6 +460,31 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_multi(const MultiArgs<Epi> m) 
     gemm_body<Ops, Epi, MT, NW, AROW, D>(m.g[p], m.ea[p], blockIdx.x, blockIdx.y, red, row_map, n_act_s);
 }
 
+// Two INDEPENDENT problems of different kinds in one launch (1-D grid: the first na workgroups are problem A's, in its own
+// (n-group fastest) order, the rest problem B's): the LM step and the predictor / joint chain of a decode iteration both start
+// from the token the selection kernel has just written and meet again at the next selection -- layer l of the one and stage l of
+// the other share a launch, so the two chains overlap without a second stream (whose hardware queue the runtime picks at graph
+// replay: see DESIGN.md, LM shallow fusion).  A problem built for fewer waves than the launch has leaves the surplus waves at
+// entry (s_barrier counts the surviving waves of a workgroup).
+template <class Ops, class EpiA, int MTa, int NWa, bool AROWa, int Da, class EpiB, int MTb, int NWb, bool AROWb, int Db>
+__global__ __launch_bounds__((NWa > NWb ? NWa : NWb) * 64) void k_gemm2(const GemmArgs ga, const typename EpiA::Args ea, const int nga,
+                                                                          const int na, const GemmArgs gb, const typename EpiB::Args eb,
+                                                                          const int ngb) {
+    constexpr int SA = NWa * (MTa * 16) * (EpiA::NT * 16 + 1), SB = NWb * (MTb * 16) * (EpiB::NT * 16 + 1);
+    __shared__ float red[SA > SB ? SA : SB];
+    __shared__ int row_map[(EpiA::COMPACT || EpiB::COMPACT) ? 1024 : 1];
+    __shared__ int n_act_s;
+    const int id = blockIdx.x;
+    if (id < na) {
+        if (NWa < NWb && (int)threadIdx.x >= NWa * 64) return;
+        gemm_body<Ops, EpiA, MTa, NWa, AROWa, Da>(ga, ea, id % nga, id / nga, red, row_map, n_act_s);
+    } else {
+        if (NWb < NWa && (int)threadIdx.x >= NWb * 64) return;
+        const int j = id - na;
+        gemm_body<Ops, EpiB, MTb, NWb, AROWb, Db>(gb, eb, j % ngb, j / ngb, red, row_map, n_act_s);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Epilogues.  prefetch / run are force-inlined: left to itself hipcc emitted EpiNBRC<f32, non-table>::run out of line
 // (kernel arguments copied to scratch, a call, flat loads through the argument pointer: +2 % whole job when inlined).  A tile column of (gate g, unit uu) is g*U + uu.  Buffers that are A operands of another

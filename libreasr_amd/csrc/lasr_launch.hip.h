@@ -10,7 +10,37 @@ template <class Ops, class Epi, int MT, bool AROW, int D = 3, int NWV = NW>
 void launch_gemm(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g0, const typename Epi::Args& ea) {
     GemmArgs g = g0;
     g.prio = (c->stream && (c->stream == c->stream_dec || c->stream == c->stream_lm)) ? c->dec_prio : c->cell_prio;
+    if (c->cap) {           // recorded for a pair launch (see launch_pair)
+        static_assert(sizeof(GemmArgs) <= sizeof(c->cap->g) && sizeof(typename Epi::Args) <= sizeof(c->cap->ea), "Captured too small");
+        lasr_ctx::Captured& k = *c->cap;
+        k.fn = (const void*)&k_gemm<Ops, Epi, MT, NWV, AROW, D>;
+        k.gx = (unsigned)n_groups; k.gy = (unsigned)m_groups; k.threads = NWV * 64;
+        memcpy(k.g, &g, sizeof(g)); k.g_size = sizeof(g);
+        memcpy(k.ea, (const void*)&ea, sizeof(ea)); k.ea_size = sizeof(ea);
+        return;
+    }
     hipLaunchKernelGGL((k_gemm<Ops, Epi, MT, NWV, AROW, D>), dim3(n_groups, m_groups), dim3(NWV * 64), 0, c->stream, g, ea);
+}
+// a recorded launch issued on its own
+void replay_captured(lasr_ctx* c, lasr_ctx::Captured& k) {
+    if (!k.fn) return;
+    void* args[2] = {(void*)k.g, (void*)k.ea};
+    (void)hipLaunchKernel(k.fn, dim3(k.gx, k.gy), dim3(k.threads), args, 0, c->stream);
+    k.fn = nullptr;
+}
+// two recorded launches as ONE (k_gemm2) when they are the kinds the template names; otherwise one after the other
+template <class Ops, class EpiA, int MTa, int NWa, bool AROWa, int Da, class EpiB, int MTb, int NWb, bool AROWb, int Db>
+bool launch_pair_t(lasr_ctx* c, lasr_ctx::Captured& A, lasr_ctx::Captured& B) {
+    if (A.fn != (const void*)&k_gemm<Ops, EpiA, MTa, NWa, AROWa, Da> || B.fn != (const void*)&k_gemm<Ops, EpiB, MTb, NWb, AROWb, Db>) return false;
+    GemmArgs ga, gb;
+    typename EpiA::Args ea; typename EpiB::Args eb;
+    memcpy(&ga, A.g, sizeof(ga)); memcpy(&gb, B.g, sizeof(gb));
+    memcpy((void*)&ea, A.ea, sizeof(ea)); memcpy((void*)&eb, B.ea, sizeof(eb));
+    const int na = (int)(A.gx * A.gy), nb = (int)(B.gx * B.gy);
+    hipLaunchKernelGGL((k_gemm2<Ops, EpiA, MTa, NWa, AROWa, Da, EpiB, MTb, NWb, AROWb, Db>), dim3(na + nb), dim3((NWa > NWb ? NWa : NWb) * 64), 0,
+                       c->stream, ga, ea, (int)A.gx, na, gb, eb, (int)B.gx);
+    A.fn = B.fn = nullptr;
+    return true;
 }
 
 int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
@@ -153,9 +183,11 @@ void launch_gemm_carry(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& 
 
 // one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels); predictor
 // state is row-major [M][H]; toggles pred_par
+// (l0, l1: layers [l0, l1) of the pass -- the pair launches of cont_enqueue issue a pass layer by layer; the parity flips with the last one)
 template <class Ops>
-void launch_predictor_t(lasr_ctx* c, bool beam) {
+void launch_predictor_t(lasr_ctx* c, bool beam, int l0 = 0, int l1 = -1) {
     const int H = c->d.hidden;
+    if (l1 < 0) l1 = c->d.pred_layers;
     const int mgroups = c->Md / (16 * MTA);
     const int p = c->pred_par;
     // many decoder rows (beam 8 x 64+ streams, >= 512 streams): 16-unit workgroups, a quarter of the activation traffic
@@ -165,12 +197,12 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
     const int w8_min = getenv("LASR_W8_MIN") ? atoi(getenv("LASR_W8_MIN")) : 256;
     const bool wide8 = wide_env >= 0 ? wide_env == 2 : (c->bf && c->Md >= w8_min && c->Md < 512);   // 8 units per workgroup, 8 waves
     const bool split_carry = beam && beam_carry_on();
-    if (split_carry && beam_carry_mode() == 1) {      // the slots that are not extended: whole-row copies by their own launch (see k_beam_carry)
+    if (split_carry && beam_carry_mode() == 1 && l0 == 0) {      // the slots that are not extended: whole-row copies by their own launch (see k_beam_carry)
         BeamCarryArgs a{};
         fill_beam_carry(c, a);
         hipLaunchKernelGGL(k_beam_carry, dim3(std::max(c->Md, ((H + 15) / 16) * ((c->Md + 255) / 256)), 2), dim3(256), 0, c->stream, a);
     }                                                   // (mode 2: the carry rides in launch_ppj's launch of the same pass)
-    for (int l = 0; l < c->d.pred_layers; ++l) {
+    for (int l = l0; l < l1; ++l) {
         const Cell& L = c->pred[l];
         GemmArgs g{};
         g.skip_idle = split_carry ? 1 : 0;
@@ -225,11 +257,11 @@ void launch_predictor_t(lasr_ctx* c, bool beam) {
             }
         }
     }
-    if (!beam) c->pred_par ^= 1;      // beam: launch_ppj (same pass, same parities) toggles
+    if (!beam && l1 == c->d.pred_layers) c->pred_par ^= 1;      // beam: launch_ppj (same pass, same parities) toggles
 }
-void launch_predictor(lasr_ctx* c, bool beam = false) {
-    if (c->bf) launch_predictor_t<OpsBF16>(c, beam);
-    else launch_predictor_t<OpsF32>(c, beam);
+void launch_predictor(lasr_ctx* c, bool beam = false, int l0 = 0, int l1 = -1) {
+    if (c->bf) launch_predictor_t<OpsBF16>(c, beam, l0, l1);
+    else launch_predictor_t<OpsF32>(c, beam, l0, l1);
 }
 
 // pp (for emitting rows) and the joint activation ja = tanh(pe[t_idx] + pp) for all rows still decoding
@@ -282,12 +314,14 @@ inline bool keep16(int V) {
 
 // LMFuser.advance (lm.py:49-53) for the rows with emit != 0: LM step on the token just emitted, then
 // log_softmax + standardise + [0] = MIN_VAL into lmz (read by the next k_select of that row)
+// (l0, l1: LSTM layers [l0, l1) of the step; the output layer, k_lm_post and the parity flip come with the last one unless tail = false)
 template <class Ops>
-void launch_lm_t(lasr_ctx* c, bool beam) {
+void launch_lm_t(lasr_ctx* c, bool beam, int l0 = 0, int l1 = -1, bool tail = true) {
     lasr_ctx::LM& m = c->lm;
     const int H = m.H, V = c->d.vocab, p = m.par;
     const int R = beam ? c->Md : c->M;                   // LM rows: streams, or hypothesis slots (beam: parity p -> p ^ 1, parent-indirected)
-    for (int l = 0; l < m.L; ++l) {
+    if (l1 < 0) l1 = m.L;
+    for (int l = l0; l < l1; ++l) {
         const Cell& L = m.cells[l];
         GemmArgs g{};
         void* y_out = (beam && !p) ? m.y1[l] : m.y[l];
@@ -309,6 +343,7 @@ void launch_lm_t(lasr_ctx* c, bool beam) {
             launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, R / (16 * MTA), g, eb);
         }
     }
+    if (l1 < m.L || !tail) return;
     GemmArgs g{};
     g.A[0] = (beam && !p) ? m.y1[m.L - 1] : m.y[m.L - 1]; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.W[0] = m.Wout; g.a_rows = R;
     EpiLinear::Args ea{};
@@ -362,11 +397,32 @@ void launch_lm_q8(lasr_ctx* c) {
     LAUNCH_LM_POST(V, dim3(M), dim3(256), 0, c->stream, (const float*)m.raw, (const int*)c->ds.emit, m.lmz, m.valid, V, m.min_val,
                        (const int*)nullptr, 1, (const float*)m.lmz, (const int*)m.valid);
 }
-void launch_lm(lasr_ctx* c, bool beam = false) {
+void launch_lm(lasr_ctx* c, bool beam = false, int l0 = 0, int l1 = -1, bool tail = true) {
     if (!c->lm.on) return;
     if (c->lm.q8) { launch_lm_q8(c); return; }
-    if (c->bf) launch_lm_t<OpsBF16>(c, beam);
-    else launch_lm_t<OpsF32>(c, beam);
+    if (c->bf) launch_lm_t<OpsBF16>(c, beam, l0, l1, tail);
+    else launch_lm_t<OpsF32>(c, beam, l0, l1, tail);
+}
+// Pair launches of the greedy loop with an fp32 / bf16 LM (cont_enqueue): stage `kind` of the predictor / joint chain (0, 1: NBRC
+// layers 0, 1; 2: joint half; 3: the next iteration's logits GEMM), recorded in A, with LM layer l (0: through the token table),
+// recorded in B.  The kinds the templates name are the ones configs[1] runs (2 x NBRC predictor, decode GEMMs on 4 waves with f32
+// operands and 8 with bf16); anything else is issued one after the other.
+void launch_pair(lasr_ctx* c, int kind, bool lm_first, lasr_ctx::Captured& A, lasr_ctx::Captured& B) {
+    bool ok = false;
+    if (!c->bf) {
+        using LT = EpiLSTM<OpsF32, true, true, 4>; using LF = EpiLSTM<OpsF32, true, false, 4>;
+        if (kind == 0 && lm_first) ok = launch_pair_t<OpsF32, EpiNBRC<OpsF32, true>, MTA, 4, true, -1, LT, MTA, NW, true, -1>(c, A, B);
+        else if (kind == 1 && !lm_first) ok = launch_pair_t<OpsF32, EpiNBRC<OpsF32, false>, MTA, 4, true, -1, LF, MTA, NW, true, -1>(c, A, B);
+        else if (kind == 2 && !lm_first) ok = launch_pair_t<OpsF32, EpiPPJ<OpsF32>, 1, 4, true, -1, LF, MTA, NW, true, -1>(c, A, B);
+        else if (kind == 3 && !lm_first) ok = launch_pair_t<OpsF32, EpiLinear, 2, 4, false, -1, LF, MTA, NW, true, -1>(c, A, B);
+    } else {
+        using LT = EpiLSTM<OpsBF16, true, true, 4>; using LF = EpiLSTM<OpsBF16, true, false, 4>;
+        if (kind == 0 && lm_first) ok = launch_pair_t<OpsBF16, EpiNBRC<OpsBF16, true>, MTA, NW, true, -1, LT, MTA, NW, true, -1>(c, A, B);
+        else if (kind == 1 && !lm_first) ok = launch_pair_t<OpsBF16, EpiNBRC<OpsBF16, false>, MTA, NW, true, -1, LF, MTA, NW, true, -1>(c, A, B);
+        else if (kind == 2 && !lm_first) ok = launch_pair_t<OpsBF16, EpiPPJ<OpsBF16>, 1, NW, true, -1, LF, MTA, NW, true, -1>(c, A, B);
+        else if (kind == 3 && !lm_first) ok = launch_pair_t<OpsBF16, EpiLinear, 2, NW, false, -1, LF, MTA, NW, true, -1>(c, A, B);
+    }
+    if (!ok) { replay_captured(c, A); replay_captured(c, B); }
 }
 // current-parity LM output of the hypothesis slots (beam): parity 0 = lmz / valid, parity 1 = lmz1 / valid1
 const float* cur_lmz(lasr_ctx* c) { return (c->W > 1 && c->lm.par) ? c->lm.lmz1 : c->lm.lmz; }

@@ -331,3 +331,48 @@ print("RESULT" + json.dumps(out))
         res[tag] = line[0]
     assert res["stored"] == res["pass"]
     assert res["stored"].count(",") > 100
+
+
+def test_lm_pair_launches_equal_the_lm_step_in_line():
+    """configs[1] with the reference's 4 x 768 LM on the pipelined protocol: LM layer l and stage l of the predictor / joint chain
+    in ONE launch (k_gemm2, the default for this shape) against LASR_LM_PAIR=0 -- same tokens per model step, f32 and bf16 --
+    and against the synchronous protocol (which never pairs and is pinned to the reference's goldens in tests/test_gpu_lm.py)."""
+    code = r'''
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from libreasr_amd import synth
+from libreasr_amd.engine import Engine
+cfg = synth.model_cfg("cfg2"); sd = synth.synth_state_dict(cfg, seed=0); lsd = synth.synth_lm_state_dict("lm768")
+out = {}
+for dtype in ("f32", "bf16"):
+    eng = Engine(sd, cfg, max_streams=8, dtype=dtype)
+    eng.attach_lm(lsd)
+    pcm = synth.synth_pcm(5, 16000 * 3, seed=91)
+    slots = [eng.open() for _ in range(5)]
+    got = [[] for _ in slots]
+    def collect():
+        if eng.wait():
+            for i, t in enumerate(eng.fetch_many(slots, 256)): got[i].append(t)
+    for k in range(pcm.shape[1] // 1280):
+        eng.push_submit(slots, torch.as_tensor(np.ascontiguousarray(pcm[:, k * 1280:(k + 1) * 1280])).cuda())
+        while eng.pending() >= 4: collect()
+    while eng.pending(): collect()
+    for s in slots: eng.reset(s, 15)
+    sync = [[] for _ in slots]
+    for k in range(pcm.shape[1] // 1280):
+        eng.push(slots, torch.as_tensor(np.ascontiguousarray(pcm[:, k * 1280:(k + 1) * 1280])).cuda())
+        if eng.step(slots):
+            for i, t in enumerate(eng.fetch_many(slots, 256)): sync[i].append(t)
+    assert got == sync, dtype
+    out[dtype] = got
+    eng.close()
+print("RESULT" + json.dumps(out))
+''' % ROOT
+    res = {}
+    for tag, env in (("pair", {}), ("inline", {"LASR_LM_PAIR": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = line[0]
+    assert res["pair"] == res["inline"]
+    assert res["pair"].count(",") > 100
