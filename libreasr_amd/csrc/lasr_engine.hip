@@ -1149,14 +1149,16 @@ static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fuse
     p.serial = c->model_steps;
     p.target.assign(c->M, 0);
     for (int r : model_rows) { c->h_frames_sub[r] += Tm; p.target[r] = (int)c->h_frames_sub[r]; }
+    bool kicked = false;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         if (!c->pump_on || c->cgraphs.empty()) RC(pump_start(c));      // (first step, or the graphs were dropped while idle)
         c->pending.push_back(std::move(p));
+        if (c->pump_on) { c->kick.fetch_add(1, std::memory_order_release); kicked = true; }     // (under c->mu: see pump_kick)
     }
     c->model_steps++;
     HIPCHK(c, hipGetLastError());
-    if (c->pump_on) { pump_kick(c); return LASR_OK; }
+    if (kicked) { c->cv_pump.notify_one(); return LASR_OK; }
     // the enqueue above took tens of microseconds of host time: a group may have finished meanwhile.  If nothing is
     // left to decode the next group is queued behind this step's encoder event (stream-side wait)
     RC(cont_pump(c, c->kick_n));
@@ -1605,7 +1607,7 @@ static void pump_main(lasr_ctx* c) {
             for (int spins = 0; c->kick.load(std::memory_order_acquire) == seen_kick && !c->pump_stop.load(std::memory_order_relaxed); ++spins) {
                 if (spins < 40000) { __builtin_ia32_pause(); continue; }
                 std::unique_lock<std::mutex> lk(c->mu);
-                c->cv_pump.wait_for(lk, std::chrono::milliseconds(20), [&] { return c->kick.load() != seen_kick || c->pump_stop.load(); });
+                c->cv_pump.wait_for(lk, std::chrono::milliseconds(2), [&] { return c->kick.load() != seen_kick || c->pump_stop.load(); });
                 break;
             }
             seen_kick = c->kick.load(std::memory_order_acquire);
@@ -1625,8 +1627,11 @@ static int pump_start(lasr_ctx* c) {
     c->pump_on = true;
     return LASR_OK;
 }
+// The counter moves UNDER c->mu: the sleeping pump checks it and blocks under the same mutex, so a kick cannot fall between its
+// check and its sleep.  (Round 4 first bumped it without the mutex: a kick in that window was lost and the pump slept out its
+// timeout -- 20 ms then -- while a step waited; seen once, as a 25 ms stall in an 81 ms timed region.  The timeout is 2 ms now.)
 static void pump_kick(lasr_ctx* c) {
-    c->kick.fetch_add(1, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(c->mu); c->kick.fetch_add(1, std::memory_order_release); }
     c->cv_pump.notify_one();
 }
 
