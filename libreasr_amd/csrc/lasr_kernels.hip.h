@@ -315,7 +315,7 @@ __device__ __forceinline__ void wave_argmax_f32(float& best, int& arg) {
 // pinned result block by zero-copy stores and the "rows still decoding" word is published LAST, by a system-scope release
 // store of the last workgroup to arrive -- the host spins on that word.  (Two hipMemcpyAsync calls "payload, then flag" are
 // NOT such a protocol: HIP orders the copies on the stream, not their visibility to a host that has not synchronised; a
-// fresh flag over a stale payload was observed at a rate of 3e-3 per stream, tools/soak.py.)
+// fresh flag over a stale payload was observed at a rate of 3e-3 per stream, tests/soak.py.)
 __global__ __launch_bounds__(256) void k_publish(const int* __restrict__ src, int* __restrict__ dst_host, int n,
                                                  const int* __restrict__ flag_src, int* __restrict__ flag_host, int* __restrict__ arrivals) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst_host[i] = src[i];

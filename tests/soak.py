@@ -9,9 +9,9 @@ the resident state of the engine (PCM ring, pending log-mel frames, LayerNorm'ed
 output, joint halves, predictor state: lasr_debug_read) is compared with the oracle's values for that step, so
 the stage that went wrong is named instead of guessed.
 
-  python tools/soak.py --preamble parity --iters 1000            # the driver's failing case
-  python tools/soak.py --scenario pipe --iters 300               # 4 streams out of phase, pipelined protocol
-  LASR_SPIN=0 LASR_POISON=1 python tools/soak.py ...             # bisect switches (read by liblasr_hip.so)
+  python tests/soak.py --preamble parity --iters 1000            # the driver's failing case
+  python tests/soak.py --scenario pipe --iters 300               # 4 streams out of phase, pipelined protocol
+  LASR_SPIN=0 LASR_POISON=1 python tests/soak.py ...             # bisect switches (read by liblasr_hip.so)
 
 Output: one JSON line per mismatch on stdout and a summary line at the end (also written to --out)."""
 import argparse

@@ -1,6 +1,6 @@
 """Repeat tests: the scenarios whose single runs were green on one box and red on another.
 
-Round 3's driver run failed test_streaming_matches_reference[tiny-3.0-3] on one token of one stream.  tools/soak.py
+Round 3's driver run failed test_streaming_matches_reference[tiny-3.0-3] on one token of one stream.  tests/soak.py
 reproduced it at 3e-3 per iteration once the tests that precede it had run in the same process, and its state dump showed
 the DEVICE had the right token and the right state: the host had read the step's token block before the copy of it had
 landed (the synchronous protocol sent "payload copy, then flag copy" with hipMemcpyAsync and spun on the flag).  The results
@@ -14,7 +14,7 @@ import pytest
 
 from libreasr_amd import synth
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))      # tests/soak.py
 
 pytestmark = pytest.mark.gpu
 

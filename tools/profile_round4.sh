@@ -42,6 +42,6 @@ rm -rf $O/kt_driver $O/kt_beam $O/kt_cfg5 $O/trace_f32.json $O/pf.log
 for lm in fp32 int8; do $B --lm $lm --steps 300 --warmup 50 > $O/bench_lm_$lm.json 2>/dev/null; done
 for a in "12 0" "12 1"; do PROF=0 timeout 100 python3 tools/r04/served_profile.py $a 2>/dev/null | grep rep >> $O/served_replay.txt; done
 RULE=0 PROF=0 timeout 100 python3 tools/r04/served_profile.py 12 0 2>/dev/null | grep rep >> $O/served_replay.txt
-(timeout 300 python tools/soak.py --preamble full --scenario both --iters 1000 --no-dump --out $O/soak_summary.jsonl 2>&1 | tail -2) > $O/soak.txt
+(timeout 300 python tests/soak.py --preamble full --scenario both --iters 1000 --no-dump --out $O/soak_summary.jsonl 2>&1 | tail -2) > $O/soak.txt
 python3 tools/r04/summ.py $O/bench_*.json $O/kt_driverform.json
 cat $O/timeline_f32.txt; head -14 $O/kernel_stats_driverform.txt | cut -c1-190
