@@ -288,9 +288,24 @@ def test_push_submit_rows_and_reset_many_equal_the_one_array_one_slot_forms():
                     eng.reset_many([slots[i] for i in (1, 2, 4)], 7)
         while eng.pending():
             collect()
-        res.append(steps)
+        res.append([list(x) for x in steps])
         with pytest.raises(Exception):
             eng.reset_many([slots[0], slots[0]], 7)
+        if form == "rows":                    # argument errors: nothing is pushed, the engine stays usable
+            from libreasr_amd._native import LasrError
+            good = np.array([scattered[i].ctypes.data for i in range(B)], np.uint64)
+            bad = good.copy(); bad[2] = 0
+            with pytest.raises(LasrError):
+                eng.push_submit_rows(slots, bad)                                  # a null row
+            dev = torch.zeros(B, 1280, device="cuda")
+            with pytest.raises(LasrError):
+                eng.push_submit_rows(slots, np.array([dev.data_ptr() + i * 5120 for i in range(B)], np.uint64))   # device memory
+            with pytest.raises(LasrError):
+                eng.push_submit_rows([slots[0], 15], good[:2])                    # a slot that is not open
+            eng.push_submit_rows([], np.zeros(0, np.uint64))                      # empty batch: a no-op
+            eng.push_submit_rows(slots, good)                                     # and the engine still takes a push
+            while eng.pending():
+                collect()
         eng.close()
     assert res[0] == res[1]
     assert sum(len(t) for s in res[0] for t in s) > 50
