@@ -1156,6 +1156,225 @@ __global__ __launch_bounds__(NT) void k_beam_select(const float* __restrict__ lo
     publish();
 }
 
+// k_beam_select with ONE WAVE PER HYPOTHESIS ROW (V <= 2048, the 512-thread form's arithmetic): wave b keeps row b's logits in
+// registers (32 per lane), so the row's statistics and its ordered top-W by log p are wave-local -- DPP reductions on floats, no
+// block barrier -- and only the W x W row winners meet in LDS, where wave 0 picks the ordered top-W in doubles as before.  The
+// 512-thread kernel spread every row over all waves: its per-wave top-W ran W passes of an f64 argmax over W rows' heads in
+// EVERY wave (12 of 25 us at W = 8) behind six block barriers.  Same results bit for bit: a lane holds the tokens of the
+// "virtual threads" lane + 64 vw (vw = 0..7) of the old layout, the exp-sums are taken per virtual wave with the same butterfly
+// and added in the same order, and the selection itself is a total order (score descending, ordinal ascending) -- any correct
+// algorithm returns the same list.  (A row's candidates in the global top-W are its best by log p: the score offset is per row.)
+template <int WT>
+__global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restrict__ logits, BeamState s, int iter_slot) {
+    constexpr int VW = 8, KEEP = 4, NTV = 512;      // virtual waves / slots per virtual thread / virtual threads (the old layout)
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int W = s.W, V = s.V, r0 = q * W;
+    const int b = w;                                  // this wave's row
+    float zl[VW][KEEP];
+    {
+        const float* z = logits + (size_t)(r0 + (b < W ? b : 0)) * V;
+#pragma unroll
+        for (int vw = 0; vw < VW; ++vw)
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const int v = lane + 64 * vw + NTV * k;
+                zl[vw][k] = v < V ? z[v] : -INFINITY;
+            }
+    }
+    const int iter_no = s.cont ? (int)(*(const unsigned*)s.iter_ctr & 0x3fffffffu) : iter_slot;     // same value in every workgroup
+    const int uslot = s.cont ? (iter_no & 63) : iter_slot;                                          // slot of the flag rings
+    int* tre = s.trellis + (size_t)(s.cont ? iter_no % s.tring : iter_slot) * s.Md + r0;
+    if (s.cont && q == 0 && tid == 0) {                                                             // recycle the flag rings
+        s.unfinished[(uslot + 32) & 63] = 0;
+        s.done_blocks[(uslot + 32) & 63] = 0;
+    }
+    auto publish = [&]() {           // thread 0 of every workgroup, after its last store of this launch (continuous mode)
+        if (!s.cont) return;
+        if (s.host_flag && !s.lm_on) __threadfence_system();     // this stream's records (pinned memory) before the count
+        if (atomicAdd(&s.done_blocks[uslot], 1) == (int)gridDim.x - 1) {      // last workgroup of the launch
+            if (s.host_flag && !s.lm_on) {
+                const int v = atomicAdd(&s.unfinished[uslot], 0);
+                __hip_atomic_store(s.host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            *s.iter_ctr = iter_no + 1;
+        }
+    };
+    const bool dbg = s.dbg && q == 0 && tid == 0;
+    const unsigned long long t_entry = dbg ? wall_clock64() : 0ull;
+    const int t = s.t_idx[q], Tr = s.T_row[q];
+    if (dbg && t < Tr) s.dbg[0] = t_entry;
+    if (t >= Tr) {                                   // stream has nothing to decode: identity round
+        if (tid < W) { s.emit[r0 + tid] = 0; s.parent[r0 + tid] = tid; tre[tid] = -1; }
+        if (tid == 0 && s.cont) {
+            s.frame_done[(size_t)(iter_no % s.tring) * gridDim.x + q] = 0;
+            if (s.host_flag) s.host_cur[q] = t;
+            publish();
+        }
+        return;
+    }
+    __shared__ double cand_sc[WT][WT];
+    __shared__ int cand_ord[WT][WT];
+    __shared__ double sel_sc[WT];
+    __shared__ int sel_ord[WT];
+    // ---- this wave's row: state, statistics, ordered top-W by log p
+    const bool in = b < W;
+    const double scb = in ? s.score[r0 + b] : -INFINITY;
+    const int alb = in ? s.alive[r0 + b] : 0, ibb = in ? s.inB[r0 + b] : 0;
+    const bool inA = alb && !ibb;                    // wave-uniform
+    if (dbg) s.dbg[1] = wall_clock64();
+    if (!inA) {
+#pragma unroll
+        for (int vw = 0; vw < VW; ++vw)
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) zl[vw][k] = -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int vw = 0; vw < VW; ++vw)
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) m = fmaxf(m, zl[vw][k]);
+    m = wave_max_f32(m);
+    float lg = 0.f;
+    if (inA) {
+        float x = 0.f;
+#pragma unroll
+        for (int vw = 0; vw < VW; ++vw) {             // the old layout's per-wave partial sums, in its order
+            float part = 0.f;
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) part += expf(zl[vw][k] - m);       // exp(-inf) = 0 for the padding
+            x += wave_sum_f32(part);
+        }
+        lg = logf(x);
+    }
+    int nb_arg = -1;
+    if (s.lm_on && inA) {                            // argmax of z over the non-blank tokens (first maximum)
+        float x = -INFINITY;
+        int a = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k)
+#pragma unroll
+            for (int vw = 0; vw < VW; ++vw) {         // ascending v per lane: the first maximum wins
+                const int v = lane + 64 * vw + NTV * k;
+                if (v != s.blank && v < V && zl[vw][k] > x) { x = zl[vw][k]; a = v; }
+            }
+        wave_argmax_f32(x, a);
+        nb_arg = a;
+    }
+    if (dbg) s.dbg[2] = wall_clock64();
+    if (!alb) {
+        if (lane < WT) { cand_sc[b][lane] = -INFINITY; cand_ord[b][lane] = 0x7fffffff; }
+    } else if (ibb) {                                // carried unchanged: ONE candidate, score sc (+ 0), ordinal b (V + 1)
+        if (lane < WT) { cand_sc[b][lane] = lane == 0 ? scb + 0.0 : -INFINITY; cand_ord[b][lane] = lane == 0 ? b * (V + 1) : 0x7fffffff; }
+    } else {
+#pragma unroll
+        for (int vw = 0; vw < VW; ++vw)
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                zl[vw][k] = (zl[vw][k] - m) - lg;      // log p (padding stays -inf)
+                if (s.lm_on) {                        // LM fusion: only the blank and the row's best non-blank token are candidates
+                    const int v = lane + 64 * vw + NTV * k;
+                    if (v != s.blank && v != nb_arg) zl[vw][k] = -INFINITY;
+                }
+            }
+        for (int j = 0; j < W; ++j) {
+            float best = -INFINITY;
+            int arg = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k)
+#pragma unroll
+                for (int vw = 0; vw < VW; ++vw)       // ascending v: among equal log p the lower token first
+                    if (zl[vw][k] > best) { best = zl[vw][k]; arg = lane + 64 * vw + NTV * k; }
+            wave_argmax_f32(best, arg);
+            if (!(best > -INFINITY)) {               // the row's candidates are exhausted (wave-uniform)
+                if (lane == 0)
+                    for (int k = j; k < WT; ++k) { cand_sc[b][k] = -INFINITY; cand_ord[b][k] = 0x7fffffff; }
+                break;
+            }
+            if (lane == 0) { cand_sc[b][j] = scb + (double)best; cand_ord[b][j] = b * (V + 1) + 1 + arg; }
+            if ((arg & 63) == lane) {                 // the winner's lane takes it out
+                const int kk = arg / NTV, vv = (arg - kk * NTV) >> 6;
+#pragma unroll
+                for (int vw = 0; vw < VW; ++vw)
+#pragma unroll
+                    for (int k = 0; k < KEEP; ++k)
+                        if (vw == vv && k == kk) zl[vw][k] = -INFINITY;
+            }
+        }
+        if (lane == 0)
+            for (int k = W; k < WT; ++k) { cand_sc[b][k] = -INFINITY; cand_ord[b][k] = 0x7fffffff; }
+    }
+    __syncthreads();
+    if (dbg) s.dbg[9] = wall_clock64();
+    if (w == 0) {
+        // WT x WT <= 64 row winners: one per lane; the ordered top-W under (score descending, ordinal ascending)
+        double c0 = -INFINITY;
+        int o0 = 0x7fffffff;
+        if (lane < WT * WT) { c0 = cand_sc[lane / WT][lane % WT]; o0 = cand_ord[lane / WT][lane % WT]; }
+        double last_sc = INFINITY;
+        int last_ord = -1;
+        for (int j = 0; j < W; ++j) {
+            double best = -INFINITY;
+            int bord = 0x7fffffff;
+            const bool after = c0 < last_sc || (c0 == last_sc && o0 > last_ord);
+            if ((c0 > -INFINITY) && after) { best = c0; bord = o0; }
+            wave_argmax_f64(best, bord);
+            if (lane == 0) { sel_sc[j] = best; sel_ord[j] = bord; }
+            if (!(best > -INFINITY)) {               // candidates exhausted: the remaining slots are dead
+                if (lane == 0)
+                    for (int k = j + 1; k < W; ++k) { sel_sc[k] = -INFINITY; sel_ord[k] = 0x7fffffff; }
+                break;
+            }
+            last_sc = best; last_ord = bord;
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    if (dbg) s.dbg[3] = wall_clock64();
+    const int round = s.iters[q] + 1;
+    bool all_b = true;
+    int nib[WT];
+    for (int j = 0; j < W; ++j) {
+        const int r = r0 + j;
+        nib[j] = 1;
+        if (!(sel_sc[j] > -INFINITY)) {
+            s.alive[r] = 0; s.emit[r] = 0; s.parent[r] = j; s.score[r] = -INFINITY; tre[j] = -2;
+            continue;
+        }
+        const int pb = sel_ord[j] / (V + 1), k = sel_ord[j] - pb * (V + 1);
+        s.alive[r] = 1; s.parent[r] = pb; s.score[r] = sel_sc[j];
+        int em = 0, inb = 1;
+        if (k > 0 && k - 1 != s.blank) {
+            em = 1;
+            s.token[r] = k - 1;
+            inb = round >= s.max_iters ? 1 : 0;
+        }
+        s.emit[r] = em;
+        nib[j] = inb;
+        tre[j] = (pb << 16) | (em ? k : 0);
+        all_b = all_b && inb;
+    }
+    int tn = t, rn = round;
+    if (all_b) { tn = t + 1; rn = 0; }
+    for (int j = 0; j < W; ++j) s.inB[r0 + j] = all_b ? 0 : (sel_sc[j] > -INFINITY ? nib[j] : 0);
+    s.t_idx[q] = tn; s.iters[q] = rn;
+    if (s.cont) {
+        s.frame_done[(size_t)(iter_no % s.tring) * gridDim.x + q] = all_b ? 1 : 0;
+        if (all_b && tn % s.step_T == 0) {           // the stream just finished one of its model steps: scores for the host
+            const int es = (tn / s.step_T - 1) % s.end_slots;
+            int am = 0;
+            for (int j = 0; j < W; ++j) {
+                s.end_score[((size_t)q * s.end_slots + es) * W + j] = sel_sc[j];
+                if (sel_sc[j] > -INFINITY) am |= 1 << j;
+            }
+            s.end_alive[(size_t)q * s.end_slots + es] = am;
+        }
+        if (s.host_flag) s.host_cur[q] = tn;
+    }
+    if (tn < Tr) atomicAdd(&s.unfinished[uslot], 1);
+    if (dbg) s.dbg[4] = wall_clock64();
+    publish();
+}
+
 // continuous beam loop, admission of newly encoded steps (<= 512 streams): frames-available counts by value (as k_ja_admit) and
 // the joint activation of every hypothesis slot of the streams that have a frame to decode (rows = stream * W + slot)
 __global__ void k_ja_admit_beam(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,

@@ -434,6 +434,13 @@ void launch_beam_select(lasr_ctx* c, BeamState& b, int iter_slot) {
     static const int nt_env = getenv("LASR_BEAM_NT") ? atoi(getenv("LASR_BEAM_NT")) : 0;      // experiment: 512 | 1024
     const bool small = nt_env ? nt_env == 512 && c->d.vocab <= 2048 : c->d.vocab <= 2048;
     const float* lg = (const float*)c->logits;
+    // one wave per hypothesis row (k_beam_select_rw; LASR_BEAM_SELECT_RW=0: every row spread over all waves, round 3's kernel)
+    static const int rw_env = getenv("LASR_BEAM_SELECT_RW") ? atoi(getenv("LASR_BEAM_SELECT_RW")) : 1;
+    if (small && rw_env && !nt_env) {
+        if (c->W <= 2) hipLaunchKernelGGL((k_beam_select_rw<2>), dim3(M), dim3(128), 0, c->stream, lg, b, iter_slot);
+        else if (c->W <= 4) hipLaunchKernelGGL((k_beam_select_rw<4>), dim3(M), dim3(256), 0, c->stream, lg, b, iter_slot);
+        else hipLaunchKernelGGL((k_beam_select_rw<8>), dim3(M), dim3(512), 0, c->stream, lg, b, iter_slot);
+    } else
     if (small) {
         if (c->W <= 2) hipLaunchKernelGGL((k_beam_select<2, 512>), dim3(M), dim3(512), 0, c->stream, lg, b, iter_slot);
         else if (c->W <= 4) hipLaunchKernelGGL((k_beam_select<4, 512>), dim3(M), dim3(512), 0, c->stream, lg, b, iter_slot);
