@@ -1276,14 +1276,26 @@ __global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restr
                     if (v != s.blank && v != nb_arg) zl[vw][k] = -INFINITY;
                 }
             }
+        // Two levels per lane: the best of each group k (its 8 tokens lane + 64 vw + 512 k, ascending v) is kept beside the values,
+        // so a pass compares 4 group heads instead of 32 values, and only the winner's group (wave-uniform index) is rescanned.
+        // Ascending v inside a group and ascending k across groups: among equal log p the lower token comes first, as before.
+        float gm[KEEP];
+        int ga[KEEP];
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            float x = -INFINITY;
+            int a = 0x7fffffff;
+#pragma unroll
+            for (int vw = 0; vw < VW; ++vw)
+                if (zl[vw][k] > x) { x = zl[vw][k]; a = lane + 64 * vw + NTV * k; }
+            gm[k] = x; ga[k] = a;
+        }
         for (int j = 0; j < W; ++j) {
             float best = -INFINITY;
             int arg = 0x7fffffff;
 #pragma unroll
             for (int k = 0; k < KEEP; ++k)
-#pragma unroll
-                for (int vw = 0; vw < VW; ++vw)       // ascending v: among equal log p the lower token first
-                    if (zl[vw][k] > best) { best = zl[vw][k]; arg = lane + 64 * vw + NTV * k; }
+                if (gm[k] > best) { best = gm[k]; arg = ga[k]; }
             wave_argmax_f32(best, arg);
             if (!(best > -INFINITY)) {               // the row's candidates are exhausted (wave-uniform)
                 if (lane == 0)
@@ -1291,13 +1303,19 @@ __global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restr
                 break;
             }
             if (lane == 0) { cand_sc[b][j] = scb + (double)best; cand_ord[b][j] = b * (V + 1) + 1 + arg; }
-            if ((arg & 63) == lane) {                 // the winner's lane takes it out
-                const int kk = arg / NTV, vv = (arg - kk * NTV) >> 6;
+            const int kk = arg / NTV, vv = (arg - kk * NTV) >> 6;       // wave-uniform (the winner is)
+            const bool mine = (arg & 63) == lane;                       // the winner's lane takes it out of its group
 #pragma unroll
-                for (int vw = 0; vw < VW; ++vw)
+            for (int k = 0; k < KEEP; ++k) {
+                if (k != kk) continue;
+                float x = -INFINITY;
+                int a = 0x7fffffff;
 #pragma unroll
-                    for (int k = 0; k < KEEP; ++k)
-                        if (vw == vv && k == kk) zl[vw][k] = -INFINITY;
+                for (int vw = 0; vw < VW; ++vw) {
+                    if (mine && vw == vv) zl[vw][k] = -INFINITY;
+                    if (zl[vw][k] > x) { x = zl[vw][k]; a = lane + 64 * vw + NTV * k; }
+                }
+                gm[k] = x; ga[k] = a;
             }
         }
         if (lane == 0)
