@@ -1216,6 +1216,9 @@ __global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restr
     __shared__ int cand_ord[WT][WT];
     __shared__ double sel_sc[WT];
     __shared__ int sel_ord[WT];
+    // (the table starts empty: a wave that looks at it while others are still writing -- the pruning below -- sees "no candidate")
+    if (tid < WT * WT) { cand_sc[tid / WT][tid % WT] = -INFINITY; cand_ord[tid / WT][tid % WT] = 0x7fffffff; }
+    __syncthreads();
     // ---- this wave's row: state, statistics, ordered top-W by log p
     const bool in = b < W;
     const double scb = in ? s.score[r0 + b] : -INFINITY;
@@ -1262,9 +1265,9 @@ __global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restr
     }
     if (dbg) s.dbg[2] = wall_clock64();
     if (!alb) {
-        if (lane < WT) { cand_sc[b][lane] = -INFINITY; cand_ord[b][lane] = 0x7fffffff; }
+        // no candidate
     } else if (ibb) {                                // carried unchanged: ONE candidate, score sc (+ 0), ordinal b (V + 1)
-        if (lane < WT) { cand_sc[b][lane] = lane == 0 ? scb + 0.0 : -INFINITY; cand_ord[b][lane] = lane == 0 ? b * (V + 1) : 0x7fffffff; }
+        if (lane == 0) { cand_sc[b][0] = scb + 0.0; cand_ord[b][0] = b * (V + 1); }
     } else {
 #pragma unroll
         for (int vw = 0; vw < VW; ++vw)
@@ -1297,12 +1300,19 @@ __global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restr
             for (int k = 0; k < KEEP; ++k)
                 if (gm[k] > best) { best = gm[k]; arg = ga[k]; }
             wave_argmax_f32(best, arg);
-            if (!(best > -INFINITY)) {               // the row's candidates are exhausted (wave-uniform)
-                if (lane == 0)
-                    for (int k = j; k < WT; ++k) { cand_sc[b][k] = -INFINITY; cand_ord[b][k] = 0x7fffffff; }
-                break;
+            if (!(best > -INFINITY)) break;           // the row's candidates are exhausted (wave-uniform)
+            const double myv = scb + (double)best;
+            if (lane == 0) { cand_sc[b][j] = myv; cand_ord[b][j] = b * (V + 1) + 1 + arg; }
+            {
+                // Pruning: once W candidates of ANY row are strictly better than this one, neither it nor anything this row could
+                // still offer is in the global top-W -- stop.  The other waves' entries are read while they write them: an entry is
+                // either a published candidate or still "none", and candidates only ever get added, so a stale view can only make
+                // the wave stop later, never too early.  (The final merge runs behind a barrier and sees everything.)
+                // (the margin makes the count immune to a torn 64-bit read, should the hardware ever split one: a half-written entry
+                //  is a NaN or the new value with its low word zero, 2^-20 relative off)
+                const double other = lane < WT * WT ? ((const volatile double*)&cand_sc[0][0])[lane] : -INFINITY;
+                if (__popcll(__ballot(other - myv > 1e-3 + 2e-6 * fabs(myv))) >= W) break;
             }
-            if (lane == 0) { cand_sc[b][j] = scb + (double)best; cand_ord[b][j] = b * (V + 1) + 1 + arg; }
             const int kk = arg / NTV, vv = (arg - kk * NTV) >> 6;       // wave-uniform (the winner is)
             const bool mine = (arg & 63) == lane;                       // the winner's lane takes it out of its group
 #pragma unroll
@@ -1318,8 +1328,6 @@ __global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restr
                 gm[k] = x; ga[k] = a;
             }
         }
-        if (lane == 0)
-            for (int k = W; k < WT; ++k) { cand_sc[b][k] = -INFINITY; cand_ord[b][k] = 0x7fffffff; }
     }
     __syncthreads();
     if (tid != 0) return;
