@@ -295,6 +295,9 @@ def main():
     ap.add_argument("--lm", choices=["none", "fp32", "int8"], default="none",
                     help="extra line: LM shallow fusion in the greedy loop (the reference's served configuration, config/testing.yaml: "
                          "lm.enable) with a synthetic 4 x 768 LM: fp32 / bf16 operands like the model, or int8-served as load_lm does")
+    ap.add_argument("--neighbour", default=None, metavar="KIND:WGS:MS",
+                    help="experiment: a synthetic neighbour beside the timed region (lasr_bench_neighbour) -- KIND mfma | load (HBM) | l2 | mall, WGS one-wave "
+                         "workgroups, MS milliseconds from the start of the timed region (shorter than the region: its closing synchronisation would wait for the rest); the line then carries what the neighbour achieved")
     ap.add_argument("--trace", default=None, help="diagnostics: dump the two-stream mark timeline (lasr_trace) of the timed region to this file")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU-only: exercise sharding + aggregation over gloo (no GPU work)")
@@ -438,11 +441,15 @@ def main():
             ntok += collect(lat_out)[1]
         return ntok
 
-    def timed_region(k0, n, lat_out, host=False, stats=None, barrier=True):
-        """barrier + sync | n steps, every token on the host | sync + barrier.  Returns (elapsed, tokens)."""
+    def timed_region(k0, n, lat_out, host=False, stats=None, barrier=True, before=None):
+        """barrier + sync | n steps, every token on the host | sync + barrier.  Returns (elapsed, tokens).
+        before: called behind the opening synchronisation (the --neighbour experiment starts its kernel there: started earlier, the
+        synchronisation would wait for it and the neighbour would run alone)."""
         torch.cuda.synchronize(device)
         if dist is not None and barrier:
             host_barrier(dist)
+        if before is not None:
+            before()
         tokens = 0
         t0 = time.perf_counter()
         for k in range(k0, k0 + n):
@@ -490,7 +497,17 @@ def main():
     if dist is not None:
         host_barrier(dist)                        # (creates the gloo group outside the timed region)
     overlap_before = eng.overlap_probe(10000) if pipelined else float("nan")      # 2 x 10 ms: do the engine's streams overlap?
-    elapsed, tokens = timed_region(P + W, K, lat_model, host=args.host_pcm, stats=on_stats)
+    nb, nb_start = None, None
+    if args.neighbour:
+        kind, wgs, ms = args.neighbour.split(":")
+        nb = {"kind": kind, "workgroups": int(wgs), "ms": int(ms)}
+        eng.bench_neighbour(1, 1, 1); eng.bench_neighbour(0)         # (stream, buffers, code: set up outside the timed region)
+        nb_start = lambda: eng.bench_neighbour({"mfma": 1, "load": 2, "l2": 3, "mall": 4}[kind], int(wgs), int(ms))
+    elapsed, tokens = timed_region(P + W, K, lat_model, host=args.host_pcm, stats=on_stats, before=nb_start)
+    if nb is not None:
+        nb["timed_region_ms"] = 1e3 * elapsed
+        nb["achieved"] = eng.bench_neighbour(0)
+        nb["unit"] = "TFLOP/s (f32 MFMA)" if nb["kind"] == "mfma" else "GB/s"
     host_timed = dict(host_us)
     recording[0] = False                          # the self-check compares everything up to the end of the timed region
     if args.trace:
@@ -588,6 +605,7 @@ def main():
                                          if os.environ.get("LASR_PUMP", "1") != "0" else "launched by the API calls (LASR_PUMP=0)") if pipelined else None,
                        "priming_chunks": P},
             "per_gpu_value": round(audio_total / elapsed_max / world, 1),
+            **({"neighbour": nb, "data_note": "EXPERIMENT: a synthetic neighbour ran beside the timed region -- not a benchmark line"} if nb else {}),
             "per_rank": [{"rank": int(v[0]), "value": round(v[1], 1), "elapsed_s": round(v[2], 5),
                           "host_us_per_model_step": {"push": round(v[3], 1), "submit": round(v[4], 1), "wait_incl_spin": round(v[5], 1),
                                                      "fetch": round(v[6], 1), "busy": round(v[3] + v[4] + v[6], 1)},

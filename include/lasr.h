@@ -312,6 +312,13 @@ int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us);
  * for delay_us microseconds; *ratio = wall time / delay_us -- about 1 when the two streams run concurrently, about 2 when the
  * runtime has put both on one hardware queue.  Needs an idle engine (no submitted step). */
 int lasr_overlap_probe(lasr_ctx* c, int delay_us, double* ratio);
+/* Experiment hook (no reference counterpart): a synthetic neighbour beside the job, on a stream and hardware queue of its own.
+ * kind 1: n_wg one-wave workgroups issue f32 MFMAs from registers for `ms` milliseconds (matrix-pipe cycles, no memory traffic);
+ * kind 2: they stream a 512 MB buffer with non-temporal loads (HBM bandwidth, no MFMA), kind 3: each wave re-reads its own 96 KB (hits in L2:
+ * the L2 -> CU path), kind 4: they stream a 128 MB buffer with ordinary loads (Infinity Cache); the call returns at once.  kind 0: wait for the neighbour, *rate = what it
+ * achieved (TFLOP/s for kind 1, GB/s for the others).  bench.py --neighbour: what a neighbour that takes only ONE resource costs the
+ * two-stream job says which resource the job is short of. */
+int lasr_bench_neighbour(lasr_ctx* c, int kind, int n_wg, int ms, double* rate);
 
 /* In-job timing of the dominant kernel (bench.py `roofline`): while on, the encoder-cell sequence of every model
  * step (enc_layers x frames back-to-back launches of the fused LSTM-cell GEMM) is bracketed by one HIP-event pair

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("lasr_debug_read", C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("lasr_bench_cell", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("lasr_overlap_probe", C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
+    ("lasr_bench_neighbour", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("lasr_resample", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, C.POINTER(C.c_int64)]),
     ("lasr_cell_prof", C.c_int, [_P, C.c_int]),
     ("lasr_cell_prof_kernel", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),

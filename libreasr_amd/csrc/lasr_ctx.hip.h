@@ -118,6 +118,9 @@ struct lasr_ctx {
         size_t g_size = 0, ea_size = 0;
     };
     Captured* cap = nullptr;
+    // lasr_bench_neighbour (experiment): a third stream on a hardware queue of its own, the neighbour's buffers
+    hipStream_t stream_nb = nullptr; unsigned long long* nb_done = nullptr; float* nb_buf = nullptr; size_t nb_floats = 0;
+    int nb_kind = 0, nb_wgs = 0; double nb_ms = 0.0;
     hipStream_t stream_dec = nullptr;
     // LM branch of a decode iteration (pipelined protocol): the LM step and the predictor / joint chain both start from the
     // token a selection kernel has just written and both end at the next selection -- two branches of the group's hipGraph

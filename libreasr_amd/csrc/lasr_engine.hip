@@ -107,6 +107,7 @@ void lasr_destroy(lasr_ctx* c) {
     if (c->stream_cap) (void)hipStreamDestroy(c->stream_cap);
     if (c->stream_dec) { (void)hipStreamSynchronize(c->stream_dec); (void)hipStreamDestroy(c->stream_dec); }
     if (c->stream_lm) { (void)hipStreamSynchronize(c->stream_lm); (void)hipStreamDestroy(c->stream_lm); }
+    if (c->stream_nb) { (void)hipStreamSynchronize(c->stream_nb); (void)hipStreamDestroy(c->stream_nb); }
     if (c->ev_lm_fork) (void)hipEventDestroy(c->ev_lm_fork);
     if (c->ev_lm_join) (void)hipEventDestroy(c->ev_lm_join);
     if (c->stream_main_own) { (void)hipStreamSynchronize(c->stream_main_own); (void)hipStreamDestroy(c->stream_main_own); }
@@ -2620,6 +2621,60 @@ static int overlap_probe_impl(lasr_ctx* c, int delay_us, double* ratio, hipStrea
     HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     *ratio = 1e3 * (double)ms / (double)delay_us;
+    return LASR_OK;
+}
+
+// Experiment: a synthetic neighbour beside the job (see k_nb_mfma / k_nb_load).  kind 1 = MFMA only, 2 = loads from HBM (non-temporal,
+// 512 MB), 3 = loads that hit in L2 (96 KB per wave, again and again), 4 = loads from the Infinity Cache (128 MB): n_wg one-wave
+// workgroups run for `ms` on a third stream whose hardware queue is shared with neither engine stream (probed; a long kernel on a
+// shared queue would simply block the stream behind it) -- the call returns at once.  kind 0: wait for the neighbour and report what
+// it got done in *rate (kind 1: TFLOP/s, kind 2: GB/s).  Which resource the two-stream job is short of shows in what a neighbour
+// that takes ONLY that resource costs it (bench.py --neighbour).
+int lasr_bench_neighbour(lasr_ctx* c, int kind, int n_wg, int ms, double* rate) {
+    if (!c || kind < 0 || kind > 4) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (kind == 0) {
+        if (rate) *rate = 0.0;
+        if (!c->stream_nb || !c->nb_kind) return LASR_OK;
+        HIPCHK(c, hipStreamSynchronize(c->stream_nb));
+        std::vector<unsigned long long> done(c->nb_wgs);
+        HIPCHK(c, hipMemcpy(done.data(), c->nb_done, sizeof(unsigned long long) * c->nb_wgs, hipMemcpyDeviceToHost));
+        double total = 0.0;
+        for (auto v : done) total += (double)v;
+        // k_nb_mfma: iterations are MFMAs of 2 * 16 * 16 * 4 flop; k_nb_load: 1 KB loads
+        if (rate) *rate = c->nb_kind == 1 ? total * 2048.0 / (c->nb_ms * 1e-3) * 1e-12 : total * 1024.0 / (c->nb_ms * 1e-3) * 1e-9;
+        c->nb_kind = 0;
+        return LASR_OK;
+    }
+    if (n_wg < 1 || n_wg > 4096 || ms < 1 || ms > 5000) return fail(c, LASR_EINVAL, "neighbour: 1..4096 workgroups, 1..5000 ms");
+    if (c->nb_kind) return fail(c, LASR_ESTATE, "a neighbour is already running: collect it with kind 0");
+    if (!c->stream_nb) {
+        std::vector<hipStream_t> rejected;
+        for (int attempt = 0; attempt < 8 && !c->stream_nb; ++attempt) {
+            hipStream_t st = nullptr;
+            HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            double r0 = 0.0, r1 = 0.0;
+            if (overlap_probe_impl(c, 300, &r0, c->stream, st) != LASR_OK || overlap_probe_impl(c, 300, &r1, c->stream_dec, st) != LASR_OK) {
+                (void)hipGetLastError(); rejected.push_back(st); break;
+            }
+            if (r0 < 1.5 && r1 < 1.5) c->stream_nb = st; else rejected.push_back(st);
+        }
+        for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
+        if (!c->stream_nb) return fail(c, LASR_EHIP, "no hardware queue left for the neighbour stream");
+        RC(dalloc(c, &c->nb_done, 4096));
+        c->nb_floats = (size_t)128 << 20;                 // 512 MB: twice the Infinity Cache
+        RC(dalloc(c, &c->nb_buf, c->nb_floats));
+        HIPCHK(c, hipMemset(c->nb_buf, 0, sizeof(float) * c->nb_floats));
+        HIPCHK(c, hipDeviceSynchronize());
+    }
+    HIPCHK(c, hipMemsetAsync(c->nb_done, 0, sizeof(unsigned long long) * 4096, c->stream_nb));
+    const unsigned long long ticks = (unsigned long long)ms * 100000ull;
+    if (kind == 1) hipLaunchKernelGGL(k_nb_mfma, dim3(n_wg), dim3(64), 0, c->stream_nb, ticks, c->nb_done, c->nb_buf);
+    else if (kind == 2) hipLaunchKernelGGL(k_nb_load, dim3(n_wg), dim3(64), 0, c->stream_nb, ticks, (const f32x4*)c->nb_buf, c->nb_floats / 4, (size_t)0, 0, c->nb_done, c->nb_buf);
+    else if (kind == 3) hipLaunchKernelGGL(k_nb_load, dim3(n_wg), dim3(64), 0, c->stream_nb, ticks, (const f32x4*)c->nb_buf, c->nb_floats / 4, (size_t)(96 << 10) / 16, 1, c->nb_done, c->nb_buf);
+    else hipLaunchKernelGGL(k_nb_load, dim3(n_wg), dim3(64), 0, c->stream_nb, ticks, (const f32x4*)c->nb_buf, (size_t)(128 << 20) / 16, (size_t)0, 1, c->nb_done, c->nb_buf);
+    HIPCHK(c, hipGetLastError());
+    c->nb_kind = kind; c->nb_wgs = n_wg; c->nb_ms = (double)ms;
     return LASR_OK;
 }
 

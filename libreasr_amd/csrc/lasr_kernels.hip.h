@@ -250,6 +250,59 @@ __global__ void k_delay(unsigned long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// experiment (lasr_bench_neighbour): a synthetic neighbour for the two-stream job, one wave per workgroup, running for `ticks` of the
+// 100 MHz wall clock on a stream of its own.  k_nb_mfma issues f32 MFMAs back to back from registers (no memory traffic: it takes
+// matrix-pipe cycles of the SIMD it sits on and nothing else); k_nb_load streams a large buffer with 8 x 1 KB loads in flight per
+// wave (no MFMA: it takes L2 / fabric / HBM bandwidth).  Each writes its iteration count to done[blockIdx.x].
+__global__ __launch_bounds__(64) void k_nb_mfma(unsigned long long ticks, unsigned long long* __restrict__ done, float* __restrict__ sink) {
+    f32x4 acc0{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    const float a = 1e-3f * (float)threadIdx.x, b = 1.0f - 1e-4f * (float)threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long n = 0;
+    while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {          // 64 MFMAs (16x16x4 f32: 2048 flop each) per check of the clock
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, b, acc3, 0, 0, 0);
+        }
+        n += 64;
+    }
+    if (threadIdx.x == 0) done[blockIdx.x] = n;
+    if (acc0[0] + acc1[1] + acc2[2] + acc3[3] == 12345.678f) sink[0] = acc0[0];      // (keeps the MFMAs alive)
+}
+// region_vec > 0: every wave walks its own region of that many 16-byte vectors again and again with ordinary loads (96 KB per wave:
+// larger than the CU's L1, and 32 CUs x 96 KB stay inside an XCD's 4 MB L2 -- the L2 -> CU path and nothing behind it); region_vec
+// == 0: all waves stream the whole buffer (temporal != 0: ordinary loads -- a 128 MB buffer then lives in the Infinity Cache;
+// temporal == 0: non-temporal loads of a 512 MB buffer -- HBM).
+__global__ __launch_bounds__(64) void k_nb_load(unsigned long long ticks, const f32x4* __restrict__ buf, size_t n_vec, size_t region_vec,
+                                                int temporal, unsigned long long* __restrict__ done, float* __restrict__ sink) {
+    const size_t span = region_vec ? region_vec : n_vec;
+    const size_t base = region_vec ? (size_t)blockIdx.x * region_vec : 0;
+    const size_t stride = region_vec ? 64 * 8 : (size_t)gridDim.x * 64 * 8;
+    size_t idx = region_vec ? threadIdx.x : ((size_t)blockIdx.x * 8) * 64 + threadIdx.x;
+    f32x4 s{0.f, 0.f, 0.f, 0.f};
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long n = 0;
+    while (wall_clock64() - t0 < ticks) {
+        f32x4 v[8];
+        if (temporal) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = buf[base + (idx + (size_t)i * 64) % span];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(buf + base + (idx + (size_t)i * 64) % span);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+        idx = (idx + stride) % span;
+        n += 8;                                   // 8 KB per wave and iteration
+    }
+    if (threadIdx.x == 0) done[blockIdx.x] = n;
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) sink[0] = s[0];
+}
+
 // ---- wave-wide reductions on DPP row operations + v_readlane instead of ds_bpermute butterflies (a __shfl_xor step is an LDS
 // crossbar round trip of ~90 cycles per dword; k_beam_select spent 17 of its 20 us in such steps).  Lane pairing: quad_perm for
 // xor 1 / xor 2, row_half_mirror / row_mirror for the 8- and 16-lane steps (after the quad steps all lanes of a quad hold the same

@@ -433,6 +433,13 @@ class Engine:
         self._chk(self.lib.lasr_cell_prof_read(self.ctx, C.byref(us), C.byref(n)))
         return us.value, n.value
 
+    def bench_neighbour(self, kind, n_wg=0, ms=0):
+        """Experiment: kind 1 (MFMA only) / 2 (HBM loads) / 3 (L2 hits) / 4 (Infinity Cache loads) starts a synthetic neighbour of n_wg one-wave workgroups for `ms` ms on a
+        stream of its own and returns at once; kind 0 waits for it and returns what it achieved (TFLOP/s / GB/s)."""
+        r = C.c_double(0.0)
+        self._chk(self.lib.lasr_bench_neighbour(self.ctx, int(kind), int(n_wg), int(ms), C.byref(r)))
+        return r.value
+
     def overlap_probe(self, delay_us=10000):
         """wall time / delay of two delay kernels, one per engine stream: ~1 = the streams overlap, ~2 = one hardware queue."""
         r = C.c_double(0.0)
