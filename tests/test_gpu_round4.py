@@ -436,3 +436,21 @@ print("RESULT" + json.dumps(out))
         res[tag] = line[0]
     assert res["rw"] == res["spread"]
     assert res["rw"].count(",") > 300
+
+
+def test_bench_neighbour_runs_and_reports():
+    """lasr_bench_neighbour (experiment hook): a neighbour of every kind runs on its own stream for a few milliseconds and reports a
+    positive rate; a second start before the first was collected is refused; the engine works afterwards."""
+    from libreasr_amd._native import LasrError
+    eng, _ = make(synth.model_cfg("tiny"), max_streams=16)
+    try:
+        for kind in (1, 2, 3, 4):
+            eng.bench_neighbour(kind, 8, 3)
+            with pytest.raises(LasrError):
+                eng.bench_neighbour(kind, 8, 3)
+            assert eng.bench_neighbour(0) > 0.0
+        assert eng.bench_neighbour(0) == 0.0          # nothing running
+        pcm = synth.synth_pcm(2, 16 * 1280, seed=5)
+        assert sum(len(t) for t in stream_tokens(eng, pcm, 16)) >= 0
+    finally:
+        eng.close()
