@@ -698,3 +698,47 @@ def test_row_addresses_and_batched_resets_give_what_the_matrix_form_gives():
             sched.join(timeout=10)
     assert res[False] == res[True]
     assert len(res[True][1]) >= 4
+
+
+@pytest.mark.parametrize("lag", [0, 5])
+def test_two_trunks_fed_at_different_paces_with_the_reset_rule(lag):
+    """Two trunks (3 + 4 streams; the second starts 7 batches later and one of its streams is opened into a freed lower slot, so its
+    rows are not in slot order) with silent members that reach the reset threshold: every stream sees exactly what the per-stream
+    rule gives on its own audio -- with a contiguous matrix per tick or row addresses, verdicts at once or a few engine calls late."""
+    eng = FakeEngine(max_streams=10, silent={1, 5})
+    eng.peek_lag = lag
+    sched = srv.Scheduler(eng, depth=5)
+    sched.start()
+    try:
+        rng = np.random.default_rng(11)
+        n = 140
+        text = lambda t: "x" if t else ""
+        a = [sched.open(text_of=text) for _ in range(3)]                  # slots 0, 1, 2
+        filler = sched.open()                                            # slot 3
+        b_hi = [sched.open(text_of=text) for _ in range(3)]              # slots 4, 5, 6
+        sched.close(filler)
+        b = [b_hi[2], sched.open(text_of=text), b_hi[0], b_hi[1]]        # slots 6, 3, 4, 5: not ascending
+        ca = rng.integers(0, 9, (n, 3, 4)).astype(np.float32)
+        cb = rng.integers(0, 9, (n, 4, 4)).astype(np.float32)
+        for k in range(n + 7):
+            if k < n:
+                sched.push_batch(a, ca[k].copy())
+            if k >= 7:
+                sched.push_batch(b, cb[k - 7].copy())
+        got = {st.slot: [] for st in a + b}
+        want = (len(a) + len(b)) * ((n - 2) // 2)
+        while sum(len(g) for g in got.values()) < want:
+            item = sched.batch_outq.get(timeout=20)
+            assert not isinstance(item, Exception), item
+            for st, t in zip(*item):
+                got[st.slot].append(t)
+        for i, st in enumerate(a):
+            exp = [t for t in expected([ca[k, i] for k in range(n)], slot_silent=st.slot in eng.silent) if t is not None]
+            assert got[st.slot] == exp, ("a", i)
+        for i, st in enumerate(b):
+            exp = [t for t in expected([cb[k, i] for k in range(n)], slot_silent=st.slot in eng.silent) if t is not None]
+            assert got[st.slot] == exp, ("b", i)
+        assert sorted(s for s, _ in eng.resets) == [1, 1, 5, 5]
+    finally:
+        sched.shutdown()
+        sched.join(timeout=10)
