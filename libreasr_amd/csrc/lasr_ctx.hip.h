@@ -162,6 +162,8 @@ struct lasr_ctx {
     bool pump_started = false, pump_on = false;
     std::atomic<bool> pump_stop{false};
     int pump_G = 3;                 // iterations per group launched by the pump; LASR_PUMP_G
+    int dec_min_rows = 0;           // decode throttle: with <= this many rows still holding frames and an encoder step not yet admitted, the
+                                    // next group waits (stream-side) for that encoder instead of iterating for the stragglers alone; LASR_DEC_MIN_ROWS
     std::atomic<long long> kick{0}, progress{0};   // steps handed over by the API thread / groups consumed by the pump
     int pump_rc = 0; std::string pump_err;
     int kick_n = 3, wait_n = 1;     // iterations per group: kicked from submit / launched while waiting (swept on configs[1])

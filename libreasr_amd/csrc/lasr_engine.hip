@@ -144,6 +144,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     // round 3's wait path
     c->pump_G = c->W > 1 ? c->wait_n : 2;
     if (getenv("LASR_PUMP_G")) c->pump_G = std::max(1, std::min(8, atoi(getenv("LASR_PUMP_G"))));
+    if (getenv("LASR_DEC_MIN_ROWS")) c->dec_min_rows = std::max(0, atoi(getenv("LASR_DEC_MIN_ROWS")));
     const size_t Mj = (size_t)c->MTj * 16;
     c->G_pred = d.pred_cell ? 4 : 3;
     c->bf = d.dtype == 1; c->kch = c->bf ? 32 : 16; c->esz = c->bf ? 2 : 4;
@@ -1459,7 +1460,9 @@ static int cont_launch_group(lasr_ctx* c, int G, bool from_pump = false) {
     const bool by_value = M <= 512;
     for (auto& q : c->pending) {
         if (q.admitted) continue;
-        const bool must = c->work_left == 0 && !admitted_any;
+        // (decode throttle, dec_min_rows > 0: an iteration streams the same ~50 MB of predictor / joint weights for 3 straggler rows
+        //  as for 64 -- with few rows left and an encoder on its way the group waits for that encoder and then runs on full rows)
+        const bool must = c->work_left <= c->dec_min_rows && !admitted_any;
         if (!must && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
         HIPCHK(c, hipStreamWaitEvent(sd, c->ev_enc[q.idx], 0));
         if (by_value) { for (int r : q.rows) c->h_avail[r] = q.target[r]; }

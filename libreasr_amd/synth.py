@@ -204,3 +204,24 @@ def stream_chunks(pcm_row, chunk=1280, lead=1, tail=10):
     out += [np.ascontiguousarray(pcm_row[i * chunk:(i + 1) * chunk]) for i in range(n)]
     out += [z.copy() for _ in range(tail)]
     return out
+
+
+# streams of the servicer goldens (tests/golden/servicer_tiny.npz, produced by the reference's own ASRServicer.TranscribeStream:
+# oracle/make_golden.py golden_servicer): (seed, spec); spec = seconds of speech-like PCM or a list of (kind, seconds) segments
+SERVICER_STREAMS = [
+    (1234, 3.0), (1235, 3.0), (1236, 3.0),
+    (77, 7.0),                                                      # runs past the 4 s threshold while emitting
+    (99, [("speech", 2.5), ("silence", 5.5), ("speech", 3.0)]),     # > 4 s silent stretch: reset inside the silence
+    (5, 12.5),                                                      # crosses the threshold more than once
+    (6, [("silence", 4.6), ("speech", 2.0)]),                       # silence first: reset before any token
+]
+
+
+def servicer_pcm(seed, spec, sr=16000):
+    if not isinstance(spec, list):
+        return synth_pcm(1, int(sr * spec), seed=seed)[0]
+    parts = []
+    for i, (kind, sec) in enumerate(spec):
+        n = int(sr * sec)
+        parts.append(synth_pcm(1, n, seed=seed + 100 * i)[0] if kind == "speech" else np.zeros(n, np.float32))
+    return np.concatenate(parts).astype(np.float32)

@@ -61,7 +61,9 @@ def golden_frontend():
     print("frontend:", {k: v.shape for k, v in out.items()})
 
 
-def golden_model(name, n_sec, n_streams, store_acts, lm_name=None, lm_int8=False):
+def golden_model(name, n_sec, n_streams, store_acts, lm_name=None, lm_int8=False, tag="", n_samples=None):
+    """tag: suffix of the file name (the *_long sets: SURVEY 8d's workload length, hundreds of recurrent steps pinned to the
+    reference directly instead of through GPU == oracle on long inputs and oracle == reference on short ones)."""
     cfg = synth.model_cfg(name)
     sd = synth.synth_state_dict(cfg, seed=0)
     m = rf.ref_transducer(cfg, sd)
@@ -69,8 +71,8 @@ def golden_model(name, n_sec, n_streams, store_acts, lm_name=None, lm_int8=False
         make = rf.ref_lm_int8 if lm_int8 else rf.ref_lm          # int8: what load_lm serves (lm.py:97)
         m.lm = make(synth.lm_cfg(lm_name), synth.synth_lm_state_dict(lm_name))
     x_tfm, s_tfm, AT = rf.ref_transforms()
-    pcm = synth.synth_pcm(n_streams, int(16000 * n_sec), seed=1234)
-    out = {}
+    pcm = synth.synth_pcm(n_streams, int(n_samples) if n_samples else int(16000 * n_sec), seed=1234)
+    out = {"n_samples": np.int64(len(pcm[0])), "n_streams": np.int32(n_streams)} if tag else {}
     with torch.no_grad():
         for s in range(n_streams):
             feats = x_tfm(AT(t(pcm[s][None]), 16000))[0]                 # [T',1280,1]
@@ -128,7 +130,36 @@ def golden_model(name, n_sec, n_streams, store_acts, lm_name=None, lm_int8=False
             lp2, _ = m.lm(torch.LongTensor([[7]]), st)
         out["lm_logp_tok5"] = lp.reshape(-1).numpy().astype(np.float32)
         out["lm_logp_tok5_7"] = lp2.reshape(-1).numpy().astype(np.float32)
-    np.savez_compressed(os.path.join(OUT, f"model_{name}{'__' + lm_name if lm_name else ''}{'_int8' if lm_int8 else ''}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"model_{name}{'__' + lm_name if lm_name else ''}{'_int8' if lm_int8 else ''}{tag}.npz"), **out)
+
+
+SERVICER_STREAMS, servicer_pcm = synth.SERVICER_STREAMS, synth.servicer_pcm
+
+
+def golden_servicer(name="tiny"):
+    """Message sequences of the reference's OWN ASRServicer.TranscribeStream (api-server.py:82-135: 3-frame window, char diff,
+    "same diff twice" bail-out, 4 s reset rule) driven with api-client.py:32-47 chunking (one zero frame, 80 ms frames, ten zero
+    frames), one stream at a time (the reference's stream Pipeline holds ONE Buffer for all streams, transforms.py:455-471)."""
+    cfg = synth.model_cfg(name)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    m = rf.ref_transducer(cfg, sd)
+    x_tfm, s_tfm, AT = rf.ref_transforms()
+    sv, mod, resets = rf.ref_servicer(m, s_tfm, x_tfm)
+    out = {"n": np.int32(len(SERVICER_STREAMS))}
+    for i, (seed, spec) in enumerate(SERVICER_STREAMS):
+        pcm = servicer_pcm(seed, spec)
+        s_tfm.fs[-1].saved.clear()
+        del resets[:]
+        reqs = [mod.ap.Audio(data=c.tobytes(), sr=16000) for c in synth.stream_chunks(pcm, 1280, lead=1, tail=10)]
+        with torch.no_grad():
+            msgs = [t_.data for t_ in sv.TranscribeStream(iter(reqs), None)]
+            text = sv.Transcribe(mod.ap.Audio(data=pcm.tobytes(), sr=16000), None).data
+        out[f"msgs_{i}"] = np.array(msgs if msgs else [""], dtype=np.str_)
+        out[f"n_msgs_{i}"] = np.int32(len(msgs))
+        out[f"resets_{i}"] = np.array(resets, dtype=np.int32)      # value of `steps` at each reset (>= 25 = 4 s / 160 ms)
+        out[f"unary_{i}"] = np.str_(text)
+        print(f"  servicer {name} stream {i}: {len(pcm) / 16000:.2f} s, {len(msgs)} messages, resets at steps {list(resets)}")
+    np.savez_compressed(os.path.join(OUT, f"servicer_{name}.npz"), **out)
 
 
 def golden_flac():
@@ -152,7 +183,7 @@ if __name__ == "__main__":
     assert rf.available(), "/root/reference is required to generate goldens"
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["frontend", "tiny", "tiny_lstm", "cfg2", "cfg2_lstm", "ref6", "cfg5", "flac", "lm"]
+    which = sys.argv[1:] or ["frontend", "tiny", "tiny_lstm", "cfg2", "cfg2_lstm", "ref6", "cfg5", "flac", "lm", "lm_int8", "long", "servicer"]
     if "frontend" in which:
         golden_frontend()
     if "tiny" in which:
@@ -175,6 +206,12 @@ if __name__ == "__main__":
         golden_model("tiny_soft", 3.0, 3, False, lm_name="tiny_lm", lm_int8=True)
         golden_model("tiny_lstm", 3.0, 2, False, lm_name="tiny_lm_untied", lm_int8=True)
         golden_model("cfg2", 3.0, 1, False, lm_name="lm768", lm_int8=True)
+    if "long" in which:                           # SURVEY 8d's offline unit: 330 400 samples = 20.65 s, T' = 258
+        golden_model("cfg2", 0, 3, False, tag="_long", n_samples=330400)
+        golden_model("ref6", 10.0, 1, False, tag="_long")
+        golden_model("cfg5", 10.0, 1, False, tag="_long")
+    if "servicer" in which:
+        golden_servicer("tiny")
     if "flac" in which:
         try:
             golden_flac()

@@ -259,3 +259,51 @@ def ref_transforms(n_stack=10, downsample=8, n_buffer=2):
          T.StackDownsample(n_stack=n_stack, downsample=downsample), T.FixDimensions(),
          T.Buffer(n_buffer=n_buffer)]
     return Pipeline(x), Pipeline(s), AudioTensor
+
+
+class _Msg:
+    """Stand-in for the generated protobuf messages (libreasr.proto:9-17: Audio{data, sr}, Transcript{data}) when the reference's
+    pre-3.20 generated module cannot be imported by the installed protobuf: transport, not servicer logic."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def ref_servicer(model, s_tfm, x_tfm=None, lang=None, downsample=8, n_buffer=2):
+    """The reference's OWN gRPC servicer class (/root/reference/api-server.py:53-135) around an already built reference
+    Transducer and the reference's stream Pipeline -- `load_stuff` (weights / tokenizer downloads, config parsing) is bypassed by
+    constructing the object without __init__; TranscribeStream / Transcribe / should_reset are the reference's code, unmodified.
+    Returns (servicer, module, resets): `resets` collects the value of `steps` every time the module's should_reset says True."""
+    install_stubs()
+    import importlib.util
+    try:
+        import interfaces.libreasr_pb2 as ap            # the reference's generated module (old protoc output)
+        import interfaces.libreasr_pb2_grpc  # noqa: F401
+    except Exception:
+        for k in [k for k in sys.modules if k == "interfaces" or k.startswith("interfaces.")]:
+            del sys.modules[k]
+        ap = _mod("interfaces.libreasr_pb2", Audio=_Msg, Transcript=_Msg)
+        _mod("interfaces", libreasr_pb2=ap)
+        _mod("interfaces.libreasr_pb2_grpc", ASRServicer=object, add_ASRServicer_to_server=lambda *a, **k: None)
+    # `from libreasr.lib.inference import *` (api-server.py:11) only has to provide torch and AudioTensor to the servicer's
+    # methods; the real module pulls in the training stack's imports (config.py -> data.py -> fastai2)
+    _mod("libreasr.lib.inference", torch=torch, AudioTensor=AudioTensor, load_stuff=None, __all__=["torch", "AudioTensor", "load_stuff"])
+    _mod("matplotlib"); _mod("matplotlib.pyplot")
+    spec = importlib.util.spec_from_file_location("ref_api_server", os.path.join(REF_ROOT, "api-server.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    resets = []
+    orig = mod.should_reset
+
+    def should_reset(steps, ds, nb):       # the reference's rule, observed
+        r = orig(steps, ds, nb)
+        if r:
+            resets.append(int(steps))
+        return r
+
+    mod.should_reset = should_reset
+    mod.log_print = lambda *a, **k: None
+    sv = object.__new__(mod.ASRServicer)
+    sv.lang_name = "en"; sv.conf = None; sv.downsample = downsample; sv.n_buffer = n_buffer
+    sv.lang = lang if lang is not None else IdLang(); sv.model = model; sv.x_tfm = x_tfm; sv.x_tfm_stream = s_tfm
+    return sv, mod, resets

@@ -639,3 +639,34 @@ class _StreamDecoder:
 def should_reset(steps, downsample=8, n_buffer=2, thresh=4000):
     """api-server.py:44-50."""
     return int(10.0 * downsample * n_buffer * steps) >= thresh
+
+
+def servicer_stream(m, pcm, denumericalize, sr=16000, chunk=1280, lead=1, tail=10):
+    """ASRServicer.TranscribeStream (api-server.py:82-135) on the oracle's per-call outputs: 3-frame window + stream Pipeline
+    (StreamFrontend), Transducer.transcribe_stream (stream_decoder), then the servicer's loop -- char diff of the running text
+    (:123-126), "same diff twice" bail-out (:127-129), reset once 4 s of model steps have passed and a step emits nothing
+    (:131-134).  Pinned to the reference's own servicer by tests/golden/servicer_tiny.npz.  -> (messages, steps-at-reset)."""
+    import itertools as it
+    from libreasr_amd import synth
+    fe, dec = StreamFrontend(sr=sr), m.stream_decoder()
+    out, resets, y, last, last_diff, steps = [], [], [], "", "", 0
+    for c in synth.stream_chunks(pcm, chunk, lead=lead, tail=tail):
+        o = fe.push(c)
+        if o is None:
+            continue
+        y_seq = dec.step(o)
+        steps += 1
+        y = y + y_seq
+        if denumericalize(y_seq) != "":
+            now = denumericalize(y)
+            diff = "".join(b for a, b in it.zip_longest(last, now) if a != b)
+            last = now
+            if diff == last_diff:
+                continue
+            last_diff = diff
+            out.append(diff)
+        elif should_reset(steps):
+            resets.append(steps)
+            dec.reset()
+            steps = 0
+    return out, resets

@@ -269,3 +269,57 @@ def test_beam_width_1_with_lm_is_the_greedy_loop_with_shallow_fusion(name, lm_na
         assert d1.best()[0] == dg.y
         n_tok += len(dg.y)
     assert n_tok > 10
+
+
+@pytest.mark.parametrize("name,n_streams", [("cfg2", 3), ("ref6", 1), ("cfg5", 1)])
+def test_long_utterances_match_reference(golden_dir, name, n_streams):
+    """SURVEY 8d's workload length (cfg2: 330 400 samples = 20.65 s, T' = 258; ref6 / cfg5: 10 s): hundreds of recurrent steps
+    pinned to the reference's own decode, offline and streaming (goldens: oracle/make_golden.py `long`)."""
+    g = load(golden_dir, f"model_{name}_long.npz")
+    assert int(g["n_streams"]) == n_streams
+    cfg = synth.model_cfg(name)
+    m = O.OracleTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
+    pcm = synth.synth_pcm(n_streams, int(g["n_samples"]), seed=1234)
+    for s in range(n_streams):
+        toks, neg_logp, score, iters, _ = m.decode_greedy(O.features_offline(pcm[s]), return_logits=True)
+        assert toks == list(g[f"off_tokens_{s}"])
+        assert iters == list(g[f"off_iters_{s}"])
+        assert abs(neg_logp - float(g[f"off_neglogp_{s}"])) < 2e-2
+        fe, dec = O.StreamFrontend(), m.stream_decoder()
+        counts = []
+        for c in synth.stream_chunks(pcm[s], 1280, lead=1, tail=10):
+            o = fe.push(c)
+            if o is not None:
+                counts.append(len(dec.step(o)))
+        assert dec.y == list(g[f"st_tokens_{s}"])
+        assert counts == list(g[f"st_counts_{s}"])
+
+
+def servicer_golden(golden_dir, name="tiny"):
+    g = load(golden_dir, f"servicer_{name}.npz")
+    out = []
+    for i in range(int(g["n"])):
+        n = int(g[f"n_msgs_{i}"])
+        out.append(([str(v) for v in g[f"msgs_{i}"][:n]], [int(v) for v in g[f"resets_{i}"]], str(g[f"unary_{i}"])))
+    return out
+
+
+def test_servicer_restatement_matches_the_reference_servicer(golden_dir):
+    """oracle.servicer_stream (window, diff, "same diff twice", 4 s reset) against the message sequences the reference's OWN
+    ASRServicer.TranscribeStream produced (api-server.py:82-135 imported by oracle/ref_fixture.py:ref_servicer), including a
+    stream with a > 4 s silent stretch, one that starts with silence and one that crosses the threshold three times."""
+    from libreasr_amd.lib.language import IdLanguage
+    gold = servicer_golden(golden_dir)
+    assert len(gold) == len(synth.SERVICER_STREAMS)
+    cfg = synth.model_cfg("tiny")
+    m = O.OracleTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
+    lang = IdLanguage()
+    n_resets = 0
+    for (seed, spec), (msgs, resets, unary) in zip(synth.SERVICER_STREAMS, gold):
+        pcm = synth.servicer_pcm(seed, spec)
+        got, got_resets = O.servicer_stream(m, pcm, lang.denumericalize)
+        assert got == msgs, (seed, spec)
+        assert got_resets == resets, (seed, spec)
+        assert lang.denumericalize(m.decode_greedy(O.features_offline(pcm))[0]) == unary
+        n_resets += len(resets)
+    assert n_resets >= 6
