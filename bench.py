@@ -138,6 +138,18 @@ def cell_flops(cfg, layer, rows):
     return 2.0 * rows * 4 * H * (I + H)
 
 
+def decode_weight_bytes(cfg, esz):
+    """Bytes of predictor / joint weights ONE greedy decode iteration streams (whatever the number of rows that emitted):
+    predictor layer 0 recurrent half (the input half is a per-token table), layers >= 1 both halves, the predictor half of
+    the joint (W1p) and the vocabulary projection (W2)."""
+    H, J, V = cfg["hidden"], cfg["joint"], cfg["vocab"]
+    G = 4 if str(cfg["pred_cell"]).upper() == "LSTM" else 3
+    b = G * H * H                                   # layer 0: R
+    b += (cfg["pred_layers"] - 1) * 2 * G * H * H   # layers >= 1: W and R
+    b += J * H + V * J
+    return float(b * esz)
+
+
 def flop_per_frame(cfg, n_tok):
     """algorithmic FLOP per stacked frame (80 ms of one stream), elementwise work excluded."""
     F, H, J, V, E = cfg["feat"], cfg["hidden"], cfg["joint"], cfg["vocab"], cfg["embed"]
@@ -284,11 +296,16 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=8,
                     help="steps of the extra PROFILED region behind the timed one (in-kernel clocks of the cell launches; the cells then "
                          "run as plain launches, not as the main-stream graph); used unless --cell-prof-in-timed is 1 or 2")
-    ap.add_argument("--cell-prof-in-timed", type=int, default=3,
-                    help="timers of the dominant kernel inside the timed region: 3 = one HIP-event pair per model step around the cell "
-                         "sequence on the cells' stream (the cells stay one hipGraph replay per model step); 1 = events + per-workgroup "
-                         "clock stores in the cell kernels (plain launches), 2 = clocks only, 0 = none")
-    ap.add_argument("--check-rows", type=int, default=8,
+    ap.add_argument("--cell-prof-in-timed", type=int, default=0,
+                    help="timers of the dominant kernel inside the timed region: 0 = none (default since round 5: the HIP-event pair of "
+                         "mode 3 showed as two 5.9 us gaps per model step on the main stream in the kernel trace and cost the job 2 %%: "
+                         "profiles/r05/r05_experiments.txt A; both timers then come from --prof-steps further steps of the same job); "
+                         "3 = one HIP-event pair per model step around the cell sequence on the cells' stream; 1 = events + "
+                         "per-workgroup clock stores in the cell kernels (plain launches), 2 = clocks only")
+    ap.add_argument("--sustained-s", type=float, default=5.0,
+                    help="N = 1 only: seconds of the same job run once more behind everything else (`sustained`: value, p50, cell us "
+                         "under sustained clocks); 0 = off")
+    ap.add_argument("--check-rows", type=int, default=64,
                     help="self-check: rows replayed through the synchronous protocol after the timed region (0 = off)")
     ap.add_argument("--split-push", action="store_true",
                     help="lasr_push_pcm + lasr_step_submit as two calls instead of lasr_push_submit (A/B)")
@@ -347,6 +364,12 @@ def main():
     eng = Engine(sd, cfg, max_streams=B, device=local, dtype=args.dtype, beam=args.beam)
     if args.lm != "none":
         eng.attach_lm(synth.synth_lm_state_dict("lm768"), int8=args.lm == "int8")
+    eng_cfg = {}
+    for key in ("enc_xg", "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "dec_min_rows", "cell_nw"):
+        try:
+            eng_cfg[key] = eng.config(key)
+        except Exception:
+            pass
     my_streams = shard_streams(B * world, world, rank)
     CPS = max(1, args.chunks_per_step)
     K, W = args.steps * CPS, args.warmup * CPS            # in chunks from here on
@@ -441,6 +464,8 @@ def main():
             ntok += collect(lat_out)[1]
         return ntok
 
+    region_cpu = [0.0]
+
     def timed_region(k0, n, lat_out, host=False, stats=None, barrier=True, before=None):
         """barrier + sync | n steps, every token on the host | sync + barrier.  Returns (elapsed, tokens).
         before: called behind the opening synchronisation (the --neighbour experiment starts its kernel there: started earlier, the
@@ -451,6 +476,7 @@ def main():
         if before is not None:
             before()
         tokens = 0
+        cpu0 = time.process_time()                 # CPU seconds of ALL threads of this process (API thread, pump, push helpers)
         t0 = time.perf_counter()
         for k in range(k0, k0 + n):
             ran, ntok = one_step(k, lat_out, host)
@@ -459,6 +485,7 @@ def main():
                 stats(eng.stats())
         tokens += drain(lat_out)
         torch.cuda.synchronize(device)
+        region_cpu[0] = time.process_time() - cpu0
         if dist is not None and barrier:
             host_barrier(dist)
         return time.perf_counter() - t0, tokens
@@ -504,6 +531,7 @@ def main():
         eng.bench_neighbour(1, 1, 1); eng.bench_neighbour(0)         # (stream, buffers, code: set up outside the timed region)
         nb_start = lambda: eng.bench_neighbour({"mfma": 1, "load": 2, "l2": 3, "mall": 4}[kind], int(wgs), int(ms))
     elapsed, tokens = timed_region(P + W, K, lat_model, host=args.host_pcm, stats=on_stats, before=nb_start)
+    cpu_timed = region_cpu[0]
     if nb is not None:
         nb["timed_region_ms"] = 1e3 * elapsed
         nb["achieved"] = eng.bench_neighbour(0)
@@ -528,10 +556,12 @@ def main():
         else:
             Kp = max(0, min(args.steps, args.prof_steps)) * CPS
             if Kp:                                # the kernels' own durations: a short region of the same job with the in-kernel clocks on
-                eng.cell_prof(2)
+                eng.cell_prof(1 if args.cell_prof_in_timed == 0 else 2)
                 prof_elapsed, _ = timed_region(k_next, Kp, None, host=args.host_pcm, barrier=False)
                 k_next += Kp
                 prof_value = Kp * B * CHUNK / SR / prof_elapsed
+                if args.cell_prof_in_timed == 0:
+                    cell_us_total, cell_launches = eng.cell_prof_read()
                 cell_kernel_us_total, cell_kernel_launches, cell_kernel_cells = eng.cell_prof_kernel()
     eng.cell_prof(False)
     eng.set_profiling(False)
@@ -542,7 +572,7 @@ def main():
     nms = max(1, host_timed["n_model_steps"])
     overlap_after = eng.overlap_probe(10000) if pipelined else float("nan")       # ... and after the job's RCCL collectives
     mine = [float(rank), audio_local / elapsed, elapsed, 1e6 * host_timed["push"] / nms, 1e6 * host_timed["submit"] / nms,
-            1e6 * host_timed["wait"] / nms, 1e6 * host_timed["fetch"] / nms, overlap_before, overlap_after]
+            1e6 * host_timed["wait"] / nms, 1e6 * host_timed["fetch"] / nms, overlap_before, overlap_after, cpu_timed / max(1e-9, elapsed)]
     per_rank = [mine]
     if dist is not None:
         t = torch.tensor(mine, dtype=torch.float64, device=device)
@@ -569,17 +599,32 @@ def main():
         cells_per_launch = cell_kernel_cells / cell_kernel_launches if cell_kernel_launches else 1.0
         flops_mean *= cells_per_launch
         wbytes_mean *= cells_per_launch
-        achieved = flops_mean / (cell_us * 1e-6) / 1e12
-        traffic = None                      # HBM bytes per launch from the committed PMC passes (profiles/)
+        if eng_cfg.get("enc_xg"):
+            # LASR_ENC_XG: per layer and model step one x-side GEMM (W_ih once) + n_buffer recurrent cells (W_hh each)
+            Tn = cfg.get("n_buffer", 2)
+            esz_w = 2.0 if bf else 4.0
+            wbytes_mean = float(np.mean([esz_w * 4 * H * ((cfg["feat"] if l == 0 else H) + Tn * H) for l in range(L)])) / (Tn + 1)
+        # the committed kernel trace of the same command (rocprofv3 --kernel-trace --stats, profiles/r05/): the tracer's in-job average
+        # of the same kernel.  It includes warm-up, the offline / PCIe legs and the tracer's own overhead (the job runs 10-15 %
+        # slower under it), so it is the upper end; `frac` is computed from the LARGER of the two durations
+        wkey = f"{args.model}_{args.dtype}_{B}_beam{args.beam}"
+        rocprof_us, rocprof_src, traffic, pmc_src = None, None, None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "cell_pmc.json")) as f:
-                pm = json.load(f)
-                if args.model == "cfg2" and B == 64:
-                    traffic = pm["hbm_bytes_per_launch"] if not bf else pm.get("bf16", {}).get("hbm_bytes_per_launch")
+            with open(os.path.join(ROOT, "profiles", "cell_rocprof.json")) as f:
+                rp = json.load(f).get(wkey)
+            if rp and not eng_cfg.get("enc_xg"):
+                rocprof_us, rocprof_src = float(rp["avg_us"]), rp.get("file")
         except Exception:
-            traffic = None
-        if traffic is not None:
-            traffic = int(traffic * cells_per_launch)        # the PMC passes measured a one-cell launch
+            pass
+        try:                                # HBM bytes per launch from the committed PMC passes
+            with open(os.path.join(ROOT, "profiles", "cell_pmc.json")) as f:
+                pm = json.load(f).get(wkey)
+            if pm and not eng_cfg.get("enc_xg"):
+                traffic, pmc_src = int(pm["hbm_bytes_per_launch"] * cells_per_launch), pm.get("file")      # (the passes measured a one-cell launch)
+        except Exception:
+            pass
+        dur_us = max(cell_us, rocprof_us) if rocprof_us else cell_us
+        achieved = flops_mean / (dur_us * 1e-6) / 1e12
         job_tflops = audio_total / elapsed_max * 12.5 * flop_per_frame(cfg, n_tok) / 1e12
         out = {
             "metric": METRIC,
@@ -603,7 +648,8 @@ def main():
                                     "one continuous greedy loop on a second stream") if pipelined else "synchronous",
                        "decode_groups": ("launched by the library's native pump thread (LASR_PUMP=0: by the API calls)"
                                          if os.environ.get("LASR_PUMP", "1") != "0" else "launched by the API calls (LASR_PUMP=0)") if pipelined else None,
-                       "priming_chunks": P},
+                       "priming_chunks": P,
+                       "engine": eng_cfg},        # lasr_debug_config: defaults + LASR_* switches as resolved at lasr_create
             "per_gpu_value": round(audio_total / elapsed_max / world, 1),
             **({"neighbour": nb, "data_note": "EXPERIMENT: a synthetic neighbour ran beside the timed region -- not a benchmark line"} if nb else {}),
             "per_rank": [{"rank": int(v[0]), "value": round(v[1], 1), "elapsed_s": round(v[2], 5),
@@ -611,7 +657,10 @@ def main():
                                                      "fetch": round(v[6], 1), "busy": round(v[3] + v[4] + v[6], 1)},
                           # two 10 ms delay kernels, one per engine stream, wall time / 10 ms: ~1 = concurrent, ~2 = one hardware queue
                           "overlap_probe": {"before_timed": round(v[7], 3), "after_collectives": round(v[8], 3)},
-                          "streams_overlap": bool(v[7] < 1.5) if v[7] == v[7] else None} for v in per_rank],
+                          "streams_overlap": bool(v[7] < 1.5) if v[7] == v[7] else None,
+                          # CPU seconds of the whole process (API thread + the library's pump and push-helper threads) per second of
+                          # the timed region: how many host cores this rank keeps busy (spinning included)
+                          "host_cores_busy": round(v[9], 2)} for v in per_rank],
             "latency_ms": {"definition": "host time from lasr_push_pcm of a model chunk to its tokens on the host"
                                          + (" (pipelined: includes the queueing behind the steps in flight)" if pipelined else ""),
                            "p50_model_chunk": round(1e3 * float(np.median(lat_model)), 4) if lat_model else None,
@@ -622,6 +671,11 @@ def main():
                                         "decode": round(float(np.mean(dec_ms)), 4) if dec_ms else None,
                                         "decode_iters": round(float(np.mean(iters)), 2) if iters else None},
             "tokens_per_frame": round(n_tok, 4) if args.beam == 1 else None,
+            # the decode stream in bytes: every iteration streams the same predictor / joint weights through the
+            # fabric beside the encoder cells, whatever the number of rows that emitted
+            "iterations_per_model_step": round(float(np.mean(iters)), 3) if iters else None,
+            "decode_fabric_MB_per_model_step": (round(float(np.mean(iters)) * decode_weight_bytes(cfg, 2.0 if bf else 4.0) / 1e6, 1)
+                                                if iters and args.beam == 1 else None),
             "roofline": {"bound": "mfma", "kernel": (f"k_gemm<EpiLSTM> (encoder LSTM cell, {B} rows, mean over the {L} layers)" if cells_per_launch <= 1.0 else
                                                     f"k_gemm_multi<EpiLSTM> (encoder LSTM cells of one layer-wavefront diagonal, {B} rows; "
                                                     f"{cells_per_launch:.2f} cells per launch on average, mean cell over the {L} layers)"),
@@ -629,6 +683,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(cell_us, 3), "launches_timed": int(cell_kernel_launches or cell_launches),
+                         "launch_us_rocprof": rocprof_us, "launch_us_rocprof_file": rocprof_src, "traffic_file": pmc_src,
+                         "frac_basis": ("launch_us_rocprof (the larger)" if rocprof_us and rocprof_us >= cell_us else "launch_us (in-kernel clocks"
+                                        + ("; the larger)" if rocprof_us else "; no committed kernel trace for this workload)")),
+                         "frac_launch_us": round(flops_mean / (cell_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if not bf else None,
                          "measured_in": ("launch_us and launch_us_events: the timed region itself" if args.cell_prof_in_timed in (1, 2) else
                                          f"launch_us_events: the timed region (one HIP-event pair per model step around the cell graph); "
                                          f"launch_us: {Kp // CPS} further steps of the same job right behind it, cells as plain launches "
@@ -647,9 +705,10 @@ def main():
         if bf:
             # 64 rows x 2 flop / 2 B = 64 flop/B is far below the bf16 ridge (2500 TFLOP/s / 8 TB/s = 312):
             # the bf16 cell is bound by streaming its weights, so it is priced against HBM bandwidth
-            gbs = wbytes_mean / (cell_us * 1e-6) / 1e9
+            gbs = wbytes_mean / (dur_us * 1e-6) / 1e9
             out["roofline"].update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                    "frac_launch_us": round(wbytes_mean / (cell_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
                                     "note": "algorithmic bytes = packed bf16 weights of one cell (W_ih + W_hh)"})
         try:                                                               # the kernel alone on the GPU (micro-benchmark)
             out["roofline"]["launch_us_isolated"] = round(eng.bench_cell(layer=1, iters=300), 3)
@@ -694,6 +753,25 @@ def main():
                                   "note": "lasr_transcribe_pcm: fresh state, max_iters 3, synchronous decode loop"}
             except Exception as e:                                            # never let the extra figure break the contract line
                 out["offline"] = {"error": str(e)[:200]}
+        if args.sustained_s > 0 and world == 1 and pipelined and not args.trace:
+            # the same job for >= sustained_s seconds (the headline's timed region is tens of milliseconds: nothing in it shows the
+            # clocks the chip sustains under this load): value, latency and the cell kernel's own duration (in-kernel clocks of the
+            # first 4096 cell launches of the leg)
+            try:
+                n_s = int(np.ceil(args.sustained_s / max(1e-6, elapsed / args.steps)))
+                eng.cell_prof(2)
+                lat_s = []
+                dt_s, _ = timed_region(k_next, n_s * CPS, lat_s, host=args.host_pcm, barrier=False)
+                k_next += n_s * CPS
+                cus, cl, _cc = eng.cell_prof_kernel()
+                eng.cell_prof(False)
+                out["sustained"] = {"seconds": round(dt_s, 3), "steps": n_s, "value": round(n_s * CPS * B * CHUNK / SR / dt_s, 1),
+                                    "p50_model_chunk_ms": round(1e3 * float(np.median(lat_s)), 4) if lat_s else None,
+                                    "p95_model_chunk_ms": round(1e3 * float(np.percentile(lat_s, 95)), 4) if lat_s else None,
+                                    "cell_launch_us": round(cus / cl, 3) if cl else None, "cell_launches_timed": int(cl),
+                                    "note": "the headline job again, back to back for this long, same process and engine"}
+            except Exception as e:
+                out["sustained"] = {"error": str(e)[:200]}
         if NCHK:
             # self-check: the first NCHK streams again, from their first chunk, on freshly reset slots through the SYNCHRONOUS
             # protocol (push -> step -> fetch per chunk); per model step the tokens must equal what the run above fetched

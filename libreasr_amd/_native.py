@@ -72,20 +72,25 @@ SYMBOLS = [
     ("lasr_get_stats", C.c_int, [_P, C.POINTER(StepStats)]),
     ("lasr_set_profiling", C.c_int, [_P, C.c_int]),
     ("lasr_sync", C.c_int, [_P]),
+    ("lasr_resample", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, C.POINTER(C.c_int64)]),
+    ("lasr_lm_weight_count", C.c_size_t, [_P]),
+    ("lasr_attach_lm", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("lasr_attach_lm_int8", C.c_int, [_P, _P, _P, C.c_size_t]),
+]
+
+# measurement / debug / experiment entry points: include/lasr_debug.h (not part of the drop-in surface)
+DEBUG_SYMBOLS = [
     ("lasr_debug_timing", C.c_int, [_P, _P]),
     ("lasr_debug_read", C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("lasr_bench_cell", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("lasr_overlap_probe", C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     ("lasr_bench_neighbour", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
-    ("lasr_resample", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, C.POINTER(C.c_int64)]),
     ("lasr_cell_prof", C.c_int, [_P, C.c_int]),
     ("lasr_cell_prof_kernel", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     ("lasr_trace", C.c_int, [_P, C.c_int]),
     ("lasr_trace_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     ("lasr_cell_prof_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
-    ("lasr_lm_weight_count", C.c_size_t, [_P]),
-    ("lasr_attach_lm", C.c_int, [_P, _P, _P, C.c_size_t]),
-    ("lasr_attach_lm_int8", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("lasr_debug_config", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int)]),
 ]
 
 
@@ -106,7 +111,7 @@ def lib():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  libreasr_amd has no CPU fallback.")
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, res, args in SYMBOLS:
+    for name, res, args in SYMBOLS + DEBUG_SYMBOLS:
         f = getattr(L, name)       # AttributeError here == the .so does not export the header's symbol
         f.restype = res
         f.argtypes = args

@@ -291,6 +291,9 @@ struct lasr_ctx {
     unsigned long long* cp_slots = nullptr;   // device [2][NCELLSLOT][PROF_W]: per launch and workgroup, entry clocks then exit clocks
     long long cp_slot_next = 0;
     std::vector<unsigned char> cp_slot_cells;  // cells computed by the launch of slot i (layer-wavefront launches: up to 8)
+    bool enc_xg = false;            // x side of a layer's frames as ONE GEMM per model step (k_gemm<EpiXG>), cells with K = H; LASR_ENC_XG
+    float* gx = nullptr;            // [H / U][4 U][gx_rows]: x-side gate pre-activations of the frames in flight in one layer
+    int gx_rows = 0, gx_frames = 0; // rows per column (= gx_frames x M)
     int enc_wave = 0;               // encoder pass as a layer wavefront (cells of an anti-diagonal share a launch): default on for bf16; LASR_ENC_WAVE
     double cp_clock_mhz = 100.0;
 
@@ -314,13 +317,17 @@ struct lasr_ctx {
 
 namespace {
 
+// c->err belongs to the API thread (lasr_last_error hands out its c_str()); the pump thread points this at its own buffer
+// (c->pump_err, read by the API thread under c->mu), so two threads never write one std::string
+thread_local std::string* tl_err_sink = nullptr;
 int fail(lasr_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (c) c->err = buf;
+    if (tl_err_sink) *tl_err_sink = buf;
+    else if (c) c->err = buf;
     return code;
 }
 

@@ -105,6 +105,23 @@ void run_encoder(lasr_ctx* c, int T_max) {
                 }
                 if (n) launch_enc_wave(c, cells, n, par0, mt_total);
             }
+        } else if (c->enc_xg && c->gx) {
+            // x side of a layer for up to gx_frames frames in ONE GEMM (W_ih crosses the fabric once per model step instead of
+            // once per frame -- custom_rnn.py:172 hands nn.LSTM the whole sequence), then the frames' recurrent cells with K = H
+            const int XT = std::min(c->gx_frames, XG_TMAX);
+            for (int l = 0; l < L; ++l) {
+                c->enc_par = par0;
+                const void* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
+                void* ydst = c->ybuf[l & 1];
+                for (int t0 = 0; t0 < T_max; t0 += XT) {
+                    const int Tn = std::min(XT, T_max - t0);
+                    launch_enc_xg(c, l, t0, Tn, xsrc, mt_total);
+                    for (int t = t0; t < t0 + Tn; ++t) {
+                        launch_enc_cell(c, l, t, xsrc, mt_total, ydst, mt_total, (t - t0) * c->M);
+                        c->enc_par ^= 1;
+                    }
+                }
+            }
         } else {
             for (int l = 0; l < L; ++l) {
                 c->enc_par = par0;
@@ -126,7 +143,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
     bool replayed = false;
     if (c->main_graph && c->use_graphs && c->pe == c->pe_ring && !(c->cell_prof && c->cp_slots) && !c->dbg && T_max <= 8) {
         std::vector<unsigned long long> key{(unsigned long long)T_max, (unsigned long long)par0, (unsigned long long)(uintptr_t)c->T_row_dev,
-                                            (unsigned long long)(uintptr_t)c->x0, (unsigned long long)mt_total, (unsigned long long)c->enc_wave};
+                                            (unsigned long long)(uintptr_t)c->x0, (unsigned long long)mt_total, (unsigned long long)(c->enc_wave + 2 * (int)c->enc_xg)};
         for (int t = 0; t < T_max; ++t) key.push_back(c->tile_masks.empty() ? ~0ull : c->tile_masks[t]);
         auto it = c->mgraphs.find(key);
         bool ok = true;

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/lasr.h"
+#include "../../include/lasr_debug.h"
 
 using namespace lasr;
 
@@ -164,6 +165,16 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         //  128 streams, greedy / beam 8: 46.8 / 14.6 k against 45.9 / 14.4 k as a wavefront, profiles/r04/r04_cell_tiling_d.txt)
         if (c->enc_u12) c->enc_wave = 0;
         if (getenv("LASR_ENC_WAVE")) c->enc_wave = atoi(getenv("LASR_ENC_WAVE"));
+        // x side of a layer's frames as one GEMM per model step (round 5): a mode of the plain (non-wavefront) order
+        if (getenv("LASR_ENC_XG")) c->enc_xg = atoi(getenv("LASR_ENC_XG")) != 0;
+        if (c->enc_xg) {
+            c->enc_wave = 0;
+            c->gx_frames = std::max(d.n_buffer, std::min(XG_TMAX, 1024 / M));
+            c->gx_frames = std::min(c->gx_frames, XG_TMAX);
+            c->gx_rows = c->gx_frames * M;
+            RC(dalloc(c, &c->gx, (size_t)4 * H * c->gx_rows));
+            HIPCHK(c, hipMemset(c->gx, 0, sizeof(float) * (size_t)4 * H * c->gx_rows));
+        }
         // decode-stream GEMMs (predictor cells, PPJ, logits): 4 waves per workgroup with f32 operands (next to the encoder cells
         // of the main stream fewer waves per CU interfere less: whole job +5 %), 8 with bf16 (4: -3 %)
         c->dec_nw_mask = c->bf ? 0 : 7;
@@ -1126,6 +1137,11 @@ static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fuse
     HIPCHK(c, hipSetDevice(c->device));
     // keep the decode stream busy while the host enqueues (and the GPU runs) this chunk's encoder (a no-op with the pump thread)
     RC(cont_pump(c, c->kick_n));
+    {   // the pump and every graph it can need BEFORE anything of this step is enqueued: a capture / instantiation failure then
+        // leaves the host frame targets and the device frame counters in agreement
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->pump_on || c->cgraphs.empty()) RC(pump_start(c));
+    }
     const int idx = (int)(c->model_steps % lasr_ctx::NFLY);
     float* pe_keep = c->pe;
     c->pe = c->pe_ring;                     // run_encoder writes the joint's encoder half into the ring
@@ -1154,7 +1170,6 @@ static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fuse
     bool kicked = false;
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        if (!c->pump_on || c->cgraphs.empty()) RC(pump_start(c));      // (first step, or the graphs were dropped while idle)
         c->pending.push_back(std::move(p));
         if (c->pump_on) { c->kick.fetch_add(1, std::memory_order_release); kicked = true; }     // (under c->mu: see pump_kick)
     }
@@ -1582,6 +1597,7 @@ static int cont_pump(lasr_ctx* c, int G) {
 // ---- the pump thread
 static void pump_main(lasr_ctx* c) {
     (void)hipSetDevice(c->device);
+    tl_err_sink = &c->pump_err;             // fail() on this thread writes the pump's own buffer (under c->mu), never c->err
     long long seen_kick = -1;
     for (;;) {
         bool inflight = false, idle = false;
@@ -1590,7 +1606,7 @@ static void pump_main(lasr_ctx* c) {
             if (c->pump_stop.load(std::memory_order_acquire)) return;
             if (c->pump_on && c->pump_rc == 0) {
                 const int rc = cont_pump_locked(c, c->pump_G, true);
-                if (rc < 0) { c->pump_rc = rc; c->pump_err = c->err; c->progress.fetch_add(1, std::memory_order_release); }
+                if (rc < 0) { c->pump_rc = rc; c->progress.fetch_add(1, std::memory_order_release); }
                 // (rc 1: the graph for this parity is missing -- the API thread captures it with its next call)
             }
             inflight = c->group_inflight;
@@ -1607,12 +1623,16 @@ static void pump_main(lasr_ctx* c) {
             continue;
         }
         if (idle) {
-            // nothing to launch: wait for the next submitted step (spin briefly -- steps come every ~200 us under load -- then sleep)
+            // nothing to launch: wait for the next submitted step.  Spin briefly (steps come every ~200 us under load), then PARK on
+            // the condition variable: the kick counter moves under c->mu, so a kick cannot fall between the check and the sleep, and
+            // an idle engine costs no CPU (the 2 ms timed wait of round 4 re-ran the 1-2 ms spin phase after every
+            // time-out -- 30-50 % of a core per idle context).  The 250 ms time-out is a backstop only (lasr_step_wait kicks too).
+            bool parked = false;
             for (int spins = 0; c->kick.load(std::memory_order_acquire) == seen_kick && !c->pump_stop.load(std::memory_order_relaxed); ++spins) {
-                if (spins < 40000) { __builtin_ia32_pause(); continue; }
+                if (!parked && spins < 40000) { __builtin_ia32_pause(); continue; }
                 std::unique_lock<std::mutex> lk(c->mu);
-                c->cv_pump.wait_for(lk, std::chrono::milliseconds(2), [&] { return c->kick.load() != seen_kick || c->pump_stop.load(); });
-                break;
+                c->cv_pump.wait_for(lk, std::chrono::milliseconds(250), [&] { return c->kick.load() != seen_kick || c->pump_stop.load(); });
+                parked = true;               // (a time-out goes straight back to sleep: no second spin phase)
             }
             seen_kick = c->kick.load(std::memory_order_acquire);
         }
@@ -2681,32 +2701,57 @@ int lasr_bench_neighbour(lasr_ctx* c, int kind, int n_wg, int ms, double* rate) 
     return LASR_OK;
 }
 
+// engine configuration as resolved at lasr_create (include/lasr_debug.h)
+int lasr_debug_config(lasr_ctx* c, const char* key, int* value) {
+    if (!c || !key || !value) return LASR_EINVAL;
+    const struct { const char* k; int v; } tab[] = {
+        {"enc_xg", (int)c->enc_xg}, {"enc_wave", c->enc_wave}, {"enc_u12", (int)c->enc_u12}, {"main_graph", (int)c->main_graph},
+        {"pump_G", c->pump_G}, {"la_stream", c->la_stream}, {"la_offline", c->la_offline}, {"dec_min_rows", c->dec_min_rows},
+        {"cell_nw", c->cell_nw ? c->cell_nw : (c->bf ? 8 : 4)}, {"use_graphs", (int)c->use_graphs}, {"fe_mode", c->fe_mode}, {"M", c->M},
+    };
+    for (const auto& e : tab)
+        if (!strcmp(e.k, key)) { *value = e.v; return LASR_OK; }
+    return fail(c, LASR_EINVAL, "lasr_debug_config: unknown key '%s'", key);
+}
+
 int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us) {
     if (!c || !us || layer < 0 || layer >= c->d.enc_layers || iters < 1) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    RC(ensure_T(c, 1));
+    // c->enc_xg: an iteration is the layer's share of a model step -- one x-side GEMM over n_buffer frames + n_buffer recurrent
+    // cells --, reported per cell (so the figure compares with the fused cell's)
+    const int Tn = (c->enc_xg && c->gx) ? std::min(c->d.n_buffer, c->gx_frames) : 1;
+    RC(ensure_T(c, Tn));
     const int H = c->d.hidden, I = c->enc[layer].I, M = c->M;
     // random (not zero) operands: zero-filled data inflates the clock (DVFS)
-    hipLaunchKernelGGL(k_fill_rand, dim3(grid1((size_t)M * I)), dim3(256), 0, c->stream, layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1], (size_t)M * I, 17u, c->bf);
+    hipLaunchKernelGGL(k_fill_rand, dim3(grid1((size_t)c->Tcap * M * I)), dim3(256), 0, c->stream, layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1],
+                       (size_t)c->Tcap * M * I, 17u, c->bf);
     for (int p = 0; p < 2; ++p)
         hipLaunchKernelGGL(k_fill_rand, dim3(grid1((size_t)M * H)), dim3(256), 0, c->stream, c->enc_h[p][layer], (size_t)M * H, 23u + p, c->bf);
     RC(cmd_begin(c));
-    for (int r = 0; r < c->d.max_streams; ++r) c->hc.T_row[r] = 1;
+    for (int r = 0; r < c->d.max_streams; ++r) c->hc.T_row[r] = Tn;
     RC(cmd_commit(c));
-    RC(commit_T_rows(c, 1));
+    RC(commit_T_rows(c, Tn));
     const void* xsrc = layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1];
     const int mt_total = c->Tcap * c->MT;
-    for (int i = 0; i < 3; ++i) { launch_enc_cell(c, layer, 0, xsrc, mt_total, c->ybuf[layer & 1], mt_total); c->enc_par ^= 1; }
+    auto one = [&]() {
+        if (c->enc_xg && c->gx) {
+            launch_enc_xg(c, layer, 0, Tn, xsrc, mt_total);
+            for (int t = 0; t < Tn; ++t) { launch_enc_cell(c, layer, t, xsrc, mt_total, c->ybuf[layer & 1], mt_total, t * M); c->enc_par ^= 1; }
+        } else {
+            launch_enc_cell(c, layer, 0, xsrc, mt_total, c->ybuf[layer & 1], mt_total); c->enc_par ^= 1;
+        }
+    };
+    for (int i = 0; i < 3; ++i) one();
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; ++i) { launch_enc_cell(c, layer, 0, xsrc, mt_total, c->ybuf[layer & 1], mt_total); c->enc_par ^= 1; }
+    for (int i = 0; i < iters; ++i) one();
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *us = (double)ms * 1000.0 / iters;
+    *us = (double)ms * 1000.0 / ((double)iters * Tn);
     c->cmd_inflight = 0;
     HIPCHK(c, hipGetLastError());
     return LASR_OK;

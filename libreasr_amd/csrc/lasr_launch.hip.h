@@ -64,12 +64,14 @@ void tr_mark(lasr_ctx* c, int tag, hipStream_t st) {
 }
 
 // encoder LSTM cell (layer l, step t): x from `xsrc` (fragment-major, K = I); tiling "C"
-template <class Ops>
-void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
+// gx_row0 >= 0 (c->enc_xg): the x side of this frame was computed by launch_enc_xg into c->gx (row gx_row0 + stream);
+// the cell's K loop is the recurrent half only
+template <class Ops, bool GX>
+void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total, int gx_row0) {
     const Cell& L = c->enc[l];
     const int H = c->d.hidden;
     GemmArgs g{};
-    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = L.I / Ops::KCH; g.W[0] = L.WxC;
+    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t * c->MT; g.KC[0] = GX ? 0 : L.I / Ops::KCH; g.W[0] = L.WxC;
     g.A[1] = c->enc_h[c->enc_par][l]; g.a_mt_total[1] = c->MT; g.a_mt_off[1] = 0; g.KC[1] = H / Ops::KCH; g.W[1] = L.WhC;
     g.M = c->M; g.dbg = c->dbg;
     if (c->cell_prof && c->cp_slots && c->cp_slot_next < lasr_ctx::NCELLSLOT) {
@@ -78,26 +80,73 @@ void launch_enc_cell_t(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_tot
         g.prof_x = g.prof + (size_t)PROF_W * lasr_ctx::NCELLSLOT;
         c->cp_slot_next++;
     }
-    using E = EpiLSTM<Ops, false, false, 8>;
+    using E = EpiLSTM<Ops, false, false, 8, GX>;
     typename E::Args ea{};
     ea.bias = L.bias; ea.flag = c->T_row_dev; ea.t = t; ea.tile_mask = c->tile_masks.empty() ? ~0ull : c->tile_masks[t];
     ea.c = c->enc_c[l]; ea.h_in = c->enc_h[c->enc_par][l]; ea.h_out = c->enc_h[c->enc_par ^ 1][l];
     ea.y = ydst; ea.y_mt_total = y_mt_total; ea.y_mt_off = t * c->MT;
     ea.bn_s = L.bn_s; ea.bn_t = L.bn_t; ea.H = H; ea.M = c->M; ea.MT = c->MT;
+    ea.gx = GX ? c->gx : nullptr; ea.gx_ld = c->gx_rows; ea.gx_row0 = gx_row0;
     // K split over 4 waves for f32 operands (12.8 us against 17.2 us with 8: fewer requests in flight, half the
     // LDS reduction), 8 waves for bf16 (5.4 us against 6.6 us); LASR_CELL_NW overrides
     const int nw = c->cell_nw ? c->cell_nw : (Ops::BF ? 8 : 4);
     if (c->enc_u12) {
-        if (c->cell_nw == 4) launch_gemm<Ops, EpiLSTMe<Ops, 12>, 4, false, 3, 4>(c, H / 12, c->M / 64, g, ea);
-        else launch_gemm<Ops, EpiLSTMe<Ops, 12>, 4, false, 3, NW>(c, H / 12, c->M / 64, g, ea);
+        using E12 = EpiLSTMe<Ops, 12, GX>;
+        typename E12::Args e12;
+        static_assert(sizeof(e12) == sizeof(ea), "same Args layout");
+        memcpy((void*)&e12, (const void*)&ea, sizeof(e12));
+        if (c->cell_nw == 4) launch_gemm<Ops, E12, 4, false, 3, 4>(c, H / 12, c->M / 64, g, e12);
+        else launch_gemm<Ops, E12, 4, false, 3, NW>(c, H / 12, c->M / 64, g, e12);
         return;
     }
     if (nw == 4) launch_gemm<Ops, E, 2, false, 3, 4>(c, H / 8, c->M / 32, g, ea);
     else launch_gemm<Ops, E, 2, false>(c, H / 8, c->M / 32, g, ea);
 }
-void launch_enc_cell(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total) {
-    if (c->bf) launch_enc_cell_t<OpsBF16>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
-    else launch_enc_cell_t<OpsF32>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total);
+// x side of layer l for frames t0 .. t0 + Tn - 1 (rows frame-major in c->gx): ONE GEMM with the cell tiling's packed W_ih
+template <class Ops>
+void launch_enc_xg_t(lasr_ctx* c, int l, int t0, int Tn, const void* xsrc, int x_mt_total) {
+    const Cell& L = c->enc[l];
+    const int H = c->d.hidden, R = Tn * c->M;
+    GemmArgs g{};
+    g.A[0] = xsrc; g.a_mt_total[0] = x_mt_total; g.a_mt_off[0] = t0 * c->MT; g.KC[0] = L.I / Ops::KCH; g.W[0] = L.WxC;
+    g.A[1] = nullptr; g.KC[1] = 0; g.W[1] = nullptr;
+    g.M = c->M; g.dbg = nullptr;
+    if (c->cell_prof && c->cp_slots && c->cp_slot_next < lasr_ctx::NCELLSLOT) {
+        c->cp_slot_cells[c->cp_slot_next] = 0;            // (no cell finished by this launch: its time is spread over the frames' cells)
+        g.prof = c->cp_slots + (size_t)PROF_W * c->cp_slot_next;
+        g.prof_x = g.prof + (size_t)PROF_W * lasr_ctx::NCELLSLOT;
+        c->cp_slot_next++;
+    }
+    const int nw = c->cell_nw ? c->cell_nw : (Ops::BF ? 8 : 4);
+    auto fill = [&](auto& ea) {
+        ea.gx = c->gx; ea.gx_ld = c->gx_rows; ea.R = R; ea.MTm = c->MT;
+        for (int i = 0; i < XG_TMAX; ++i)
+            ea.mask[i] = i < Tn ? (c->tile_masks.empty() ? ~0ull : c->tile_masks[t0 + i]) : 0ull;
+    };
+    const int mg = (R + 63) / 64;
+    if (c->enc_u12) {
+        typename EpiXG<12>::Args ea{};
+        fill(ea);
+        launch_gemm<Ops, EpiXG<12>, 4, false, 3, NW>(c, H / 12, mg, g, ea);
+        return;
+    }
+    typename EpiXG<8>::Args ea{};
+    fill(ea);
+    if (nw == 4) launch_gemm<Ops, EpiXG<8>, 4, false, 3, 4>(c, H / 8, mg, g, ea);
+    else launch_gemm<Ops, EpiXG<8>, 4, false, 3, NW>(c, H / 8, mg, g, ea);
+}
+void launch_enc_xg(lasr_ctx* c, int l, int t0, int Tn, const void* xsrc, int x_mt_total) {
+    if (c->bf) launch_enc_xg_t<OpsBF16>(c, l, t0, Tn, xsrc, x_mt_total);
+    else launch_enc_xg_t<OpsF32>(c, l, t0, Tn, xsrc, x_mt_total);
+}
+void launch_enc_cell(lasr_ctx* c, int l, int t, const void* xsrc, int x_mt_total, void* ydst, int y_mt_total, int gx_row0 = -1) {
+    if (gx_row0 >= 0) {
+        if (c->bf) launch_enc_cell_t<OpsBF16, true>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total, gx_row0);
+        else launch_enc_cell_t<OpsF32, true>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total, gx_row0);
+        return;
+    }
+    if (c->bf) launch_enc_cell_t<OpsBF16, false>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total, 0);
+    else launch_enc_cell_t<OpsF32, false>(c, l, t, xsrc, x_mt_total, ydst, y_mt_total, 0);
 }
 
 // One anti-diagonal of the encoder's (layer, time) grid in ONE launch: cells (l, d - l), independent of each other.

@@ -404,6 +404,12 @@ class Engine:
         self._chk(self.lib.lasr_debug_read(self.ctx, w, int(index), out.ctypes.data_as(C.c_void_p), out.size, C.byref(r), C.byref(k)))
         return out
 
+    def config(self, key):
+        """lasr_debug_config: the engine's resolved configuration (defaults + LASR_* switches), e.g. "enc_xg", "pump_G", "la_stream"."""
+        v = C.c_int(0)
+        self._chk(self.lib.lasr_debug_config(self.ctx, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def cell_prof(self, on=True):
         """In-job HIP-event timing of the encoder-cell launches (see lasr_cell_prof)."""
         self._chk(self.lib.lasr_cell_prof(self.ctx, int(on)))      # True / 1: events + in-kernel clocks; 2: clocks only

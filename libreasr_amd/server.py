@@ -140,6 +140,9 @@ class Scheduler(threading.Thread):
         self.held_depth = max(1, min(int(held_depth), self.depth))
         self.any_held = False
         self._beam_cap = 1024               # tokens per stream fetch_many makes room for with beam > 1 (grows on LASR_EFULL)
+        # early verdicts: every step in flight of a slot decoded = depth x n_buffer x max_iters_stream tokens (20 per step with
+        # the reference's front-end: 300 at depth 15)
+        self._peek_cap = max(256, 32 * (self.depth + 1))
         self.inflight = collections.deque() # per submitted model step: (slots of its streams, {slot: result cell} | None)
         self.batch_outq = queue.SimpleQueue()   # trunk interface (push_batch): one item per collected model step
         self.downsample = downsample or engine.desc.stride
@@ -414,7 +417,17 @@ class Scheduler(threading.Thread):
         cand = np.flatnonzero((unj > 0) & (self.stp + unj + 1 >= self.rat))
         if not len(cand):
             return
-        steps_of, n_dec, n_inflight = self.eng.peek_many(cand, self.judged[cand])      # ONE engine call for all of them
+        # worst case per slot: every step in flight decoded, n_buffer frames x max_iters_stream tokens each (the fixed
+        # cap of 256 tokens / 16 steps overflowed at depth 13-15 and the LASR_EFULL ended the scheduler for every stream)
+        from ._native import LASR_EFULL, LasrError
+        steps_cap = max(16, int(self.depth) + 1)
+        try:
+            steps_of, n_dec, n_inflight = self.eng.peek_many(cand, self.judged[cand], cap=self._peek_cap, cap_steps=steps_cap)
+        except LasrError as e:
+            if e.code != LASR_EFULL:
+                raise
+            self._peek_cap = max(256, 4 * self._peek_cap)      # (a model with a larger n_buffer x max_iters_stream than the reference's)
+            return                               # the verdicts of this tick fall back to collect time
         resets = []
         for q, i in enumerate(cand.tolist()):
             st = self.streams.get(i)

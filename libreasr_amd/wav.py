@@ -23,7 +23,11 @@ def decode(path):
                 tag = struct.unpack("<H", body[24:26])[0]
             fmt = (tag, nch, sr, align, bits)
         elif cid == b"data":
-            if size in (0, 0xFFFFFFFF):                             # written to a pipe (ffmpeg / sox): "to the end of the file"
+            # written to a pipe (ffmpeg / sox): the sizes could not be patched -- data size 0xFFFFFFFF, or 0 together with a RIFF
+            # size of 0 / 0xFFFFFFFF: "to the end of the file".  A size of 0 in a file whose RIFF size is real is an EMPTY data chunk
+            # (followed by LIST / id3 chunks that are not samples): honoured as declared
+            riff = struct.unpack("<I", data[4:8])[0]
+            if size == 0xFFFFFFFF or (size == 0 and riff in (0, 0xFFFFFFFF)):
                 body, size = data[pos + 8:], len(data) - pos - 8
             pcm = body
         pos += 8 + size + (size & 1)                                # chunks are word-aligned

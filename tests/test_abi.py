@@ -21,14 +21,28 @@ def lib():
     return N.lib()
 
 
-def test_every_header_symbol_is_exported_and_bound(lib):
-    hdr = open(os.path.join(ROOT, "include", "lasr.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(lasr_[a-z_0-9]+)\s*\(", hdr))
-    bound = {n for n, _, _ in N.SYMBOLS}
-    assert declared == bound, (declared - bound, bound - declared)
-    for name in declared:
+    return set(re.findall(r"\b(lasr_[a-z_0-9]+)\s*\(", hdr))
+
+
+def test_every_header_symbol_is_exported_and_bound(lib):
+    """include/lasr.h = the drop-in surface (every call maps to a reference interface in INTEGRATION.md), include/lasr_debug.h =
+    bench / debug / trace / experiment hooks.  Each header's declarations == the Python binding's list of the same name, nothing
+    is declared twice, and the library exports exactly the union."""
+    import subprocess
+    api, dbg = _declared("lasr.h"), _declared("lasr_debug.h")
+    assert api == {n for n, _, _ in N.SYMBOLS}, (api ^ {n for n, _, _ in N.SYMBOLS})
+    assert dbg == {n for n, _, _ in N.DEBUG_SYMBOLS}, (dbg ^ {n for n, _, _ in N.DEBUG_SYMBOLS})
+    assert not (api & dbg)
+    # no measurement / experiment hook leaks into the drop-in header
+    assert not [n for n in api if n.startswith(("lasr_bench", "lasr_debug", "lasr_trace", "lasr_cell_prof", "lasr_overlap"))]
+    for name in api | dbg:
         assert hasattr(lib, name)
+    out = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("lasr_")}
+    assert exported == api | dbg, (exported ^ (api | dbg))
 
 
 def test_default_desc_and_weight_count(lib):

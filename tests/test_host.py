@@ -340,10 +340,19 @@ def test_wav_reader_header_edge_cases(tmp_path):
         with pytest.raises(ValueError):
             wav.decode(p)
     v = np.arange(-50, 50, dtype=np.int16)
-    for size in (0, 0xFFFFFFFF):
-        open(p, "wb").write(riff(struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16), v.tobytes(), size=size))
+    for size, riff_size in ((0xFFFFFFFF, None), (0, 0), (0, 0xFFFFFFFF)):
+        raw = riff(struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16), v.tobytes(), size=size)
+        if riff_size is not None:
+            raw = raw[:4] + struct.pack("<I", riff_size) + raw[8:]
+        open(p, "wb").write(raw)
         y, sr, bits = wav.decode(p)
         assert (sr, bits) == (16000, 16) and np.array_equal(y, v.astype(np.float32) / 32768.0)
+    # an EMPTY data chunk (size 0, real RIFF size) followed by a LIST chunk is empty -- the trailing chunk is not PCM
+    body = b"WAVE" + b"fmt " + struct.pack("<I", 16) + struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16) + b"data" + struct.pack("<I", 0) \
+        + b"LIST" + struct.pack("<I", 8) + b"INFOabcd"
+    open(p, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    with pytest.raises(ValueError):
+        wav.decode(p)
     open(p, "wb").write(riff(struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16), b""))
     with pytest.raises(ValueError):
         wav.decode(p)

@@ -70,11 +70,17 @@ class FakeEngine:
             done.append(list(out[s]))
         return done, len(mine)
 
-    def peek_many(self, slots, skip):
+    def peek_many(self, slots, skip, cap=256, cap_steps=16):
         res, nd, nf = [], [], []
         for s, sk in zip(np.asarray(slots).tolist(), np.asarray(skip).tolist()):
             done, n_in = self.peek(s)
-            res.append(done[sk:])
+            new = done[sk:]
+            self.peek_caps_seen = (cap, cap_steps)
+            if len(new) > cap_steps or sum(len(t) for t in new) > cap:      # what lasr_peek_many answers when the caller's buffers are short
+                from libreasr_amd._native import LASR_EFULL, LasrError
+                self.peek_efull = getattr(self, "peek_efull", 0) + 1
+                raise LasrError(LASR_EFULL, "peek buffers too small")
+            res.append(new)
             nd.append(len(done))
             nf.append(n_in)
         return res, np.array(nd), np.array(nf)
@@ -742,3 +748,35 @@ def test_two_trunks_fed_at_different_paces_with_the_reset_rule(lag):
     finally:
         sched.shutdown()
         sched.join(timeout=10)
+
+
+def test_early_verdict_buffers_follow_the_depth_and_a_short_buffer_is_not_fatal():
+    """ADVICE r4: at depth 13-15 a held slot can have more decoded tokens than the fixed 256-token / 16-step peek buffers held;
+    the LASR_EFULL then ended the scheduler for every stream.  The buffers are sized from the depth now, and a short buffer
+    (forced here) costs the tick its early verdicts -- they fall back to collect time -- not the scheduler."""
+    eng = FakeEngine(max_streams=8, silent={1, 4})
+    eng.peek_lag = 0
+    sched = srv.Scheduler(eng, depth=15)
+    assert sched._peek_cap >= 15 * 20 and sched._peek_cap >= 256
+    sched._peek_cap = 0                      # force the overflow path on the first peek
+    sched.start()
+    try:
+        rng = np.random.default_rng(3)
+        B, n = 6, 120
+        chunks = rng.integers(0, 9, (n, B, 4)).astype(np.float32)
+        sts = [sched.open(text_of=lambda t: "x" if t else "") for _ in range(B)]
+        for k in range(n):
+            sched.push_batch(sts, chunks[k].copy())
+        got = {st.slot: [] for st in sts}
+        while sum(len(g) for g in got.values()) < B * ((n - 2) // 2):
+            item = sched.batch_outq.get(timeout=20)
+            assert not isinstance(item, Exception), item
+            for st, t in zip(*item):
+                got[st.slot].append(t)
+        for i, st in enumerate(sts):
+            exp = [t for t in expected([chunks[k, i] for k in range(n)], slot_silent=st.slot in eng.silent) if t is not None]
+            assert got[st.slot] == exp, i
+        assert sched.error is None
+        assert getattr(eng, "peek_efull", 0) >= 1 and sched._peek_cap > 0     # the overflow happened and the buffer grew
+    finally:
+        sched.shutdown()
