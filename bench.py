@@ -690,7 +690,10 @@ def main():
                          "measured_in": ("launch_us and launch_us_events: the timed region itself" if args.cell_prof_in_timed in (1, 2) else
                                          f"launch_us_events: the timed region (one HIP-event pair per model step around the cell graph); "
                                          f"launch_us: {Kp // CPS} further steps of the same job right behind it, cells as plain launches "
-                                         "with in-kernel clocks"),
+                                         "with in-kernel clocks" if args.cell_prof_in_timed == 3 else
+                                         f"both timers: {Kp // CPS} further steps of the same job right behind the timed region (`value_profiled` "
+                                         "= its rate): an event record in front of and behind the cell sequence costs the main stream ~6 us each "
+                                         "(profiles/r05/r05_experiments.txt A), so the timed region itself carries no timer"),
                          "value_profiled": round(prof_value, 1) if prof_value else None,
                          "timing": "in-job (next to the decode stream), every cell launch of the timed region: kernel duration = max exit - "
                                    "min entry of the device wall clock over the launch's workgroups (the quantity rocprofv3 --kernel-trace "

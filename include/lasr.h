@@ -282,6 +282,38 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
  * restated in oracle/rnnt_oracle.py and pinned there to the reference's own quantised LM).  embed, hidden <= 1024. */
 int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, size_t n_weights);
 
+/* ---- Native serving front.  Replaces the per-RPC worker threads of the reference servicer
+ * (api-server.py:82-115: the per-stream frame list and window; :139: ThreadPoolExecutor(max_workers=4), one batch-1 model call per
+ * stream and chunk) and the Python tick loop of libreasr_amd.server.Scheduler for the per-stream-producer form: every stream owns
+ * a single-producer ring of client chunks in host memory; ONE native thread owns the engine, batches one chunk of every stream
+ * that has one waiting into lasr_push_submit_rows (ring addresses, no gather), keeps up to `depth` model steps in flight
+ * (<= lasr_max_inflight) and delivers every collected step's tokens to the streams' result queues.  reset_steps > 0 applies the
+ * servicer's reset rule (api-server.py:44-50,131-134: after reset_steps model steps since the last reset -- 25 = 4000 ms / 160 ms
+ * for the reference geometry -- the first step that emits no token resets encoder, predictor and LM) between two model steps of
+ * the stream, as the reference does; 0 = no rule.  Greedy decode, 16 kHz chunks of lasr_model_desc.chunk samples (the fused
+ * streaming path); other client rates / frame lengths keep going through lasr_step_window.  While a front exists it is the only
+ * caller of the engine's streaming entry points; lasr_front_pause hands the engine to the caller (unary Transcribe).
+ * Thread-safety: one producer (push / eof) and one consumer (next) per stream, any number of streams, any threads. */
+typedef struct lasr_front lasr_front;
+int lasr_front_create(lasr_ctx* c, int depth, int reset_steps, lasr_front** out);
+void lasr_front_destroy(lasr_front* f);                 /* collects what is in flight, closes the front's streams */
+int lasr_front_open(lasr_front* f, int* stream);        /* stream id == engine slot; LASR_EFULL when no slot is free */
+/* n_chunks client chunks ([n_chunks][chunk] float32, host memory) appended to the stream; copied before the call returns; blocks
+ * while the stream's ring (64 chunks) is full. */
+int lasr_front_push(lasr_front* f, int stream, const float* pcm, int n_chunks);
+int lasr_front_eof(lasr_front* f, int stream);          /* no more chunks: an end-of-stream result follows the last step's */
+/* Next result of the stream, in model-step order.  *flags: 1 = a model step (n_tokens new ids, possibly none), 2 = the reset rule
+ * fired after this step, 4 = end of stream.  Blocks up to timeout_ms (< 0: until there is one); returns 1 on time-out,
+ * LASR_EFULL if cap is too small (nothing consumed). */
+int lasr_front_next(lasr_front* f, int stream, int32_t* tokens, int cap, int* n_tokens, int* flags, int timeout_ms);
+int lasr_front_close(lasr_front* f, int stream);        /* waits for the stream's steps in flight, then frees the slot */
+/* Collect every step in flight and keep the front thread out of the engine until lasr_front_resume (same thread; does not nest). */
+int lasr_front_pause(lasr_front* f);
+int lasr_front_resume(lasr_front* f);
+/* Counters since create: lasr_push_submit_rows calls, model steps submitted, rows of those steps, resets by the rule. */
+int lasr_front_stats(lasr_front* f, long long* ticks, long long* steps, long long* rows, long long* resets);
+const char* lasr_front_error(const lasr_front* f);      /* text of the engine error that stopped the front, if any */
+
 /* Bench / debug / trace entry points (lasr_bench_*, lasr_debug_*, lasr_trace*, lasr_cell_prof*, lasr_overlap_probe) are not part
  * of the drop-in surface: they are declared in include/lasr_debug.h. */
 

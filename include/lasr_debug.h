@@ -77,6 +77,13 @@ int lasr_cell_prof_read(lasr_ctx* c, double* us_total, long long* launches);
  * pass runs as a layer wavefront, a launch holds the independent cells (l, t) of one anti-diagonal.  Synchronises the device. */
 int lasr_cell_prof_kernel(lasr_ctx* c, double* us_total, long long* launches, long long* cells);
 
+/* Capacity of the native serving front (lasr_front_*) with NATIVE per-stream producers: one thread per stream pushes its
+ * n_chunks chunks (chunks_per_push per call) and reads its results to the end.  pcm [n_streams][n_chunks * chunk] float32 host;
+ * tokens [n_streams][cap] / n_tok [n_streams] receive every stream's token ids; *seconds = wall time from the common start to
+ * the last stream's end-of-stream; stats4 (optional) = lasr_front_stats.  Creates and destroys its own front on `c`. */
+int lasr_bench_front(lasr_ctx* c, int depth, int reset_steps, int n_streams, const float* pcm, int n_chunks, int chunks_per_push,
+                     int32_t* tokens, int cap, int* n_tok, double* seconds, long long* stats4);
+
 #ifdef __cplusplus
 }
 #endif

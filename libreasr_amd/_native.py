@@ -76,6 +76,17 @@ SYMBOLS = [
     ("lasr_lm_weight_count", C.c_size_t, [_P]),
     ("lasr_attach_lm", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("lasr_attach_lm_int8", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("lasr_front_create", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("lasr_front_destroy", None, [_P]),
+    ("lasr_front_open", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("lasr_front_push", C.c_int, [_P, C.c_int, _P, C.c_int]),
+    ("lasr_front_eof", C.c_int, [_P, C.c_int]),
+    ("lasr_front_next", C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    ("lasr_front_close", C.c_int, [_P, C.c_int]),
+    ("lasr_front_pause", C.c_int, [_P]),
+    ("lasr_front_resume", C.c_int, [_P]),
+    ("lasr_front_stats", C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    ("lasr_front_error", C.c_char_p, [_P]),
 ]
 
 # measurement / debug / experiment entry points: include/lasr_debug.h (not part of the drop-in surface)
@@ -91,6 +102,7 @@ DEBUG_SYMBOLS = [
     ("lasr_trace_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     ("lasr_cell_prof_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     ("lasr_debug_config", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int)]),
+    ("lasr_bench_front", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.POINTER(C.c_double), _P]),
 ]
 
 

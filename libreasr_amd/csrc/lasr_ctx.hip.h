@@ -59,9 +59,9 @@ struct lasr_ctx {
     int cell_nw = 0;                // waves per encoder-cell workgroup (0: 4 for f32, 8 for bf16); LASR_CELL_NW
     bool enc_u12 = false;           // encoder cell tiling D (12 units x 64 rows per workgroup, EpiLSTMe): bf16, H % 12 == 0, M % 64 == 0,
                                     // H / 12 * M / 64 >= 256 workgroups; LASR_ENC_U12 overrides
-    int dec_prio = 1, cell_prio = 0;   // s_setprio of the decode-stream GEMMs / of everything else (experiments)
-    int logits_mt = 2;              // m-tiles per workgroup of the logits GEMM (1 | 2 | 4); LASR_LOGITS_MT
-    int dec_nw_mask = 0;            // LASR_DEC_NW4: bit 1 predictor cells, bit 2 PPJ, bit 4 linear (logits, pe) run with 4 waves
+    int dec_prio = 1, cell_prio = 0;   // s_setprio of the decode-stream GEMMs (+4 % at 6 steps in flight, round 2) / of everything else
+    int logits_mt = 2;              // m-tiles per workgroup of the logits GEMM (la x 64 rows must not re-read W2 per 16-row tile)
+    int dec_nw_mask = 0;            // bit 1 predictor cells, bit 2 PPJ, bit 4 linear (logits, pe) run with 4 waves: 7 for f32, 0 for bf16
     // beam search: c, BN(h) and pp ping-pong like h (every slot may be re-parented each round):
     // parity 0 = pred_c / pred_y / pp, parity 1 = the *1 buffers; all follow pred_par
     std::vector<float*> pred_c1;
@@ -129,7 +129,6 @@ struct lasr_ctx {
     double lm_stream_ratio[2] = {0.0, 0.0};   // overlap probe of stream_lm against the main / the decode stream
     int dec_stream_attempts = 0;    // streams tried at creation until one ran concurrently with the ctx stream (see create_impl)
     double dec_stream_ratio = 0.0;  // the chosen stream's probe (wall / delay: ~1 concurrent, ~2 one hardware queue)
-    hipStream_t stream_main_own = nullptr;   // LASR_MAIN_CUS experiment: CU-masked stream used instead of the caller's
     static constexpr int NFLY = 16; // steps in flight (ring of encoder-done events)
     static constexpr int RING = 64; // pe ring, frames per row
     static constexpr int TOKRING = 512, ENDSLOTS = 32;
@@ -166,7 +165,7 @@ struct lasr_ctx {
                                     // next group waits (stream-side) for that encoder instead of iterating for the stragglers alone; LASR_DEC_MIN_ROWS
     std::atomic<long long> kick{0}, progress{0};   // steps handed over by the API thread / groups consumed by the pump
     int pump_rc = 0; std::string pump_err;
-    int kick_n = 3, wait_n = 1;     // iterations per group: kicked from submit / launched while waiting (swept on configs[1])
+    int kick_n = 3, wait_n = 1;     // iterations per group without the pump: kicked from submit / launched while waiting (swept on configs[1])
     // hipGraph cache of streaming decode groups: key = (first iteration, iterations, pe/T_row buffer,
     // predictor parity at group start, frames)
     std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;

@@ -85,10 +85,6 @@ void run_encoder(lasr_ctx* c, int T_max) {
         (void)hipEventRecord(c->cp_ev[cp_slot][0], c->stream);
     }
     tr_mark(c, 3, c->stream);
-    {   // experiment: extra latency on the main stream, once per model step
-        static const int dly = getenv("LASR_DELAY_MAIN_US") ? atoi(getenv("LASR_DELAY_MAIN_US")) : 0;
-        if (dly > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream, (unsigned long long)dly * 100ull);
-    }
     // layer wavefront: the cells (l, t) with l + t = d depend only on diagonal d - 1, so a diagonal is ONE launch
     // (k_gemm_multi, up to NPMAX cells): L + T - 1 launches instead of L * T, and the per-launch fixed costs of a cell
     // overlap its neighbours' K loops.  Cell (l, t) reads h parity par0 ^ (t & 1); all layers end on par0 ^ (T & 1).
@@ -234,8 +230,8 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
     // come back in the same round trip.  In streaming mode every group is a cached hipGraph: one
     // launch instead of 4 kernels per iteration, so the GPU is not fed at host launch speed.
     // (with lookahead a row consumes up to `la` blank frames per iteration: fewer iterations up front)
-    static const int sync_first = getenv("LASR_SYNC_FIRST") ? atoi(getenv("LASR_SYNC_FIRST")) : 4;   // extra iterations of the first group
-    static const int sync_next = getenv("LASR_SYNC_NEXT") ? atoi(getenv("LASR_SYNC_NEXT")) : 2;       // (swept: 4 + 2 best, +2 %)
+    constexpr int sync_first = 4;   // extra iterations of the first group
+    constexpr int sync_next = 2;    // (swept in round 2: 4 + 2 best, +2 %)
     int group = offline ? std::min(total_cap, ((T_max + c->la - 1) / c->la + 16) & ~1) : std::min(total_cap, (T_max + sync_first) & ~1);
     const int next_group = offline ? 32 : sync_next;
     int* res = c->res_host;

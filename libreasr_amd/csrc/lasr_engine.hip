@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <tuple>
@@ -111,7 +112,6 @@ void lasr_destroy(lasr_ctx* c) {
     if (c->stream_nb) { (void)hipStreamSynchronize(c->stream_nb); (void)hipStreamDestroy(c->stream_nb); }
     if (c->ev_lm_fork) (void)hipEventDestroy(c->ev_lm_fork);
     if (c->ev_lm_join) (void)hipEventDestroy(c->ev_lm_join);
-    if (c->stream_main_own) { (void)hipStreamSynchronize(c->stream_main_own); (void)hipStreamDestroy(c->stream_main_own); }
     delete c;
 }
 
@@ -133,12 +133,10 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         if (e) c->la_stream = c->la_offline = c->la_sync = std::min(lasr_ctx::LA_MAX, std::max(1, atoi(e)));
         if (c->W > 1) c->la_stream = c->la_offline = c->la_sync = 1;
         c->la = c->la_stream;
-        if (getenv("LASR_KICK")) c->kick_n = std::max(1, atoi(getenv("LASR_KICK")));
-        if (getenv("LASR_GROUP")) c->wait_n = std::max(1, atoi(getenv("LASR_GROUP")));
         // beam: a model step takes ~5 selection rounds per frame; with short rounds (configs[2]: 77 us) the host round trip per
         // group is worth amortising (4 rounds per group: 13.4-13.8 -> 14.3-14.5 k audio-s/s), with long ones (configs[4]: 1024
         // hypothesis rows x 1536) the rounds launched past the need cost more (10.3 -> 10.0 k): profiles/r03/r03_experiments.txt O
-        else if (c->W > 1 && (size_t)Md * H <= (size_t)256 * 1024) c->wait_n = 4;
+        if (c->W > 1 && (size_t)Md * H <= (size_t)256 * 1024) c->wait_n = 4;
     }
     // groups launched by the pump thread (see pump_main): greedy 2 iterations (f32 52.1-52.6 k at 2, 51.7-52.1 at 3, 51.8 at 4 against
     // 51.8-51.9 without the pump; bf16 96.0 / 93.4 / 93.1 against 92.6: profiles/r04/r04_pump_ab.txt); beam: the group size of
@@ -178,10 +176,6 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         // decode-stream GEMMs (predictor cells, PPJ, logits): 4 waves per workgroup with f32 operands (next to the encoder cells
         // of the main stream fewer waves per CU interfere less: whole job +5 %), 8 with bf16 (4: -3 %)
         c->dec_nw_mask = c->bf ? 0 : 7;
-        if (getenv("LASR_DEC_NW4")) c->dec_nw_mask = atoi(getenv("LASR_DEC_NW4"));
-        if (getenv("LASR_DEC_PRIO")) c->dec_prio = atoi(getenv("LASR_DEC_PRIO"));
-        if (getenv("LASR_CELL_PRIO")) c->cell_prio = atoi(getenv("LASR_CELL_PRIO"));
-        if (getenv("LASR_LOGITS_MT")) { const int v = atoi(getenv("LASR_LOGITS_MT")); c->logits_mt = (v == 2 || v == 4) ? v : 1; }
         if (getenv("LASR_DBG_TIMING")) {
             RC(dalloc(c, &c->dbg, (size_t)5 * 4096 * 16));
             HIPCHK(c, hipMemset(c->dbg, 0, sizeof(unsigned long long) * 5 * 4096 * 16));
@@ -347,37 +341,9 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         HIPCHK(c, hipMemset(c->T_row_ring[q], 0, sizeof(int) * M));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_enc[q], hipEventDisableTiming));
     }
-    // CU partition between the two streams of the pipelined protocol (experiment knobs; hipExtStreamCreateWithCUMask).  Mask
-    // bit i is CU (i / 8) of XCD (i % 8) (KFD interleaves the mask over the XCCs first, then the shader engines), so a
-    // contiguous bit range is spread evenly over the 8 XCDs.  LASR_DEC_CUS = n: the decode stream runs on mask bits [off, off + n)
-    // (LASR_DEC_CU_OFF, default 0); LASR_MAIN_CUS = m: the engine runs the main-stream work on its OWN stream restricted to bits
-    // [256 - m, 256) instead of the caller's stream (experiment only: the caller's stream order is not honoured).
-    auto cu_mask_stream = [&](hipStream_t* st, int first, int n) -> int {
-        int ncu = 0;
-        HIPCHK(c, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        for (int i = first; i < first + n && i < ncu; ++i)
-            if (i >= 0) mask[i >> 5] |= 1u << (i & 31);
-        HIPCHK(c, hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
-        return LASR_OK;
-    };
-    if (getenv("LASR_MAIN_CUS") && atoi(getenv("LASR_MAIN_CUS")) > 0) {
-        int ncu = 0;
-        HIPCHK(c, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
-        const int m = std::min(ncu, atoi(getenv("LASR_MAIN_CUS")));
-        RC(cu_mask_stream(&c->stream_main_own, ncu - m, m));
-        c->stream = c->stream_main_own;
-    }
-    if (getenv("LASR_DEC_CUS") && atoi(getenv("LASR_DEC_CUS")) > 0) {
-        RC(cu_mask_stream(&c->stream_dec, getenv("LASR_DEC_CU_OFF") ? atoi(getenv("LASR_DEC_CU_OFF")) : 0, atoi(getenv("LASR_DEC_CUS"))));
-    } else
-    if (getenv("LASR_DEC_STREAM_PRIO")) {      // experiment: the latency-critical decode chain on a high-priority HIP stream
-        int lo = 0, hi = 0;
-        HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(c, hipStreamCreateWithPriority(&c->stream_dec, hipStreamNonBlocking, atoi(getenv("LASR_DEC_STREAM_PRIO")) > 0 ? hi : lo));
-    } else {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
-    }
+    // (round 3 measured CU masks for either stream, a high-priority decode stream and per-stream delay probes: every one of them
+    //  lost or was a probe -- profiles/r03/r03_experiments.txt B, C; the switches are gone, the patch of the masks is in the history)
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_dec, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_misc, hipEventDisableTiming));
     {   // The pipelined protocol needs the decode stream and the ctx stream on DIFFERENT hardware queues.  The runtime multiplexes
         // the process's streams onto a few queues (GPU_MAX_HW_QUEUES, 4 by default); in a process that already owns several
@@ -386,10 +352,9 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         // stream is probed (two 0.3 ms delay kernels, one per stream) and replaced until it overlaps; the rejected ones are kept
         // alive until then, so that the next one is placed elsewhere.  LASR_DEC_STREAM_PICK=0 switches this off.
         static const int pick = getenv("LASR_DEC_STREAM_PICK") ? atoi(getenv("LASR_DEC_STREAM_PICK")) : 1;
-        const bool plain = !(getenv("LASR_DEC_CUS") && atoi(getenv("LASR_DEC_CUS")) > 0) && !getenv("LASR_DEC_STREAM_PRIO");
         std::vector<hipStream_t> rejected;
         c->dec_stream_attempts = 1;
-        for (int attempt = 0; pick && plain && attempt < 8; ++attempt) {
+        for (int attempt = 0; pick && attempt < 8; ++attempt) {
             double ratio = 0.0;
             if (overlap_probe_impl(c, 300, &ratio) != LASR_OK) { (void)hipGetLastError(); break; }
             c->dec_stream_ratio = ratio;
@@ -685,7 +650,7 @@ static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
 //   device           read by the ring-append (or front-end) kernel in stream order, like any stream-ordered copy;
 //   host (default)   pageable OR pinned: copied into the engine's own pinned staging ring before the call returns (the caller's
 //                    buffer is free on return), DMA'd from there into a device staging entry on a copy-only stream; the kernel
-//                    reads HBM (LASR_PUSH_ZEROCOPY=1: the kernel reads the pinned staging entry over PCIe itself, no DMA);
+//                    reads HBM;
 //   pinned, no copy  LASR_PUSH_PINNED_NOCOPY: the DMA (or, zero-copy, the kernel) reads the CALLER's pinned buffer after the call
 //                    has returned; the buffer must stay untouched until lasr_push_consumed(ticket) says so.
 struct PushSrc { const float* src = nullptr; int ev_i = -1; long long ticket = -1; bool dma = false; };
@@ -770,9 +735,8 @@ static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, 
     if (c->push_used[ps.ev_i]) HIPCHK(c, hipEventSynchronize(c->push_ev[ps.ev_i]));       // 64 pushes ago: long done
     // How the bytes cross PCIe: a DMA (hipMemcpyAsync on a copy-only stream) into a device staging entry, issued NOW -- the ctx
     // stream is usually a model step behind the host, so the copy is long done when the front-end / ring-append kernel gets
-    // there, and that kernel reads HBM.  (LASR_PUSH_ZEROCOPY=1: the kernel reads the pinned memory itself, 16 bytes per lane
-    // over PCIe: ~20 us of the critical stream per 328 KB chunk batch, measured 43 k against 51 k audio-s/s resident.)
-    static const bool zero_copy = getenv("LASR_PUSH_ZEROCOPY") && atoi(getenv("LASR_PUSH_ZEROCOPY")) != 0;
+    // there, and that kernel reads HBM.  (Round 2 let the kernel read the pinned memory itself, 16 bytes per lane over PCIe:
+    // ~20 us of the critical stream per 328 KB chunk batch, 43 k against 51 k audio-s/s resident.)
     const float* host_src = nullptr;
     if (flags & LASR_PUSH_PINNED_NOCOPY) {
         const void* pinned = pinned_host_dev_ptr(pcm);
@@ -790,7 +754,7 @@ static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, 
         ps.src = c->push_stage_host_dev + (size_t)ps.ev_i * c->M * CH;
         host_src = c->push_stage_host + (size_t)ps.ev_i * c->M * CH;
     }
-    if (!zero_copy) {
+    {
         if (!c->push_stage_dev) {
             RC(dalloc(c, &c->push_stage_dev, (size_t)lasr_ctx::NSTAGE * c->M * CH));
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
@@ -950,16 +914,15 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
             a.T_row = c->T_row_dev; a.ln_w = c->ln_w; a.ln_b = c->ln_b; a.x0 = c->x0; a.F = d.feat; a.n_mels = d.n_mels;
             a.n_stack = d.n_stack; a.M = c->M; a.MT = c->MT; a.mt_total = c->Tcap * c->MT; a.feats_out = nullptr; a.bf = c->bf; a.Tmax = Tm;
-            static const bool ln_tile = !(getenv("LASR_LN_TILE") && atoi(getenv("LASR_LN_TILE")) == 0);
-            if (ln_tile && d.feat == 1280 && d.n_stack == 10 && d.n_mels == 128) {
+            if (d.feat == 1280 && d.n_stack == 10 && d.n_mels == 128) {
                 LnTileArgs t{};
                 t.pend = c->pend; t.pend_frames = d.n_buffer * d.n_stack; t.T_row = c->T_row_dev; t.ln_w = c->ln_w; t.ln_b = c->ln_b;
                 t.x0 = c->x0; t.MT = c->MT; t.mt_total = c->Tcap * c->MT; t.bf = c->bf;
                 static bool attr = false;
                 if (!attr) { (void)hipFuncSetAttribute((const void*)k_ln_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1284 * 4); attr = true; }
                 // store phase of the tile kernel on 4 z-slices (8 -> 32 workgroups; bit-identical): f32 52.5-52.7 -> 52.6-53.3 k, bf16
-                // 92.8 -> 95.4 k (profiles/r04/r04_lnz_ab.txt); LASR_LN_Z overrides
-                static const int ln_z = getenv("LASR_LN_Z") ? std::max(1, std::min(8, atoi(getenv("LASR_LN_Z")))) : 4;
+                // 92.8 -> 95.4 k (profiles/r04/r04_lnz_ab.txt)
+                constexpr int ln_z = 4;
                 hipLaunchKernelGGL(k_ln_tile, dim3(c->MT, Tm, ln_z), dim3(1024), 16 * 1284 * 4, fe_st, t);
             } else {
                 LAUNCH_STACK_LN( dim3((Tm + 3) / 4, c->M), dim3(256), 0, fe_st, a);
@@ -1406,8 +1369,6 @@ static void cont_enqueue(lasr_ctx* c, int G) {
         launch_predictor(c);
         launch_ppj(c);
         if (!side) lm_step(false);
-        static const int dly = getenv("LASR_DELAY_DEC_US") ? atoi(getenv("LASR_DELAY_DEC_US")) : 0;    // experiment: see k_delay
-        if (dly > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, c->stream, (unsigned long long)dly * 100ull);
     }
     lm_join();
 }
@@ -2758,3 +2719,5 @@ int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us) {
 }
 
 }  // extern "C"
+
+#include "lasr_front.hip.h"

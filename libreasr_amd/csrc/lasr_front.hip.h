@@ -1,0 +1,455 @@
+// lasr_front.hip.h -- native serving front: the per-stream producer side of a server without
+// Python on the tick path.  Part of the single translation unit lasr_engine.hip, included LAST: it is written against the public
+// C ABI of include/lasr.h only (lasr_push_submit_rows, lasr_step_wait, lasr_fetch_many, lasr_stream_*), like an application.
+//
+// What it replaces: the reference servicer runs each TranscribeStream RPC on one of 4 Python worker threads, batch 1
+// (api-server.py:82-135,139); round 3-4's libreasr_amd.server.Scheduler batches the streams in ONE Python thread and reaches
+// 41 k audio-s/s through the trunk form but 9 k through per-stream producer threads (a queue operation per 80 ms chunk and stream
+// under the GIL).  Here every stream has a single-producer ring of client chunks in host memory; ONE native thread owns the
+// engine: every tick it takes one chunk of every stream that has one waiting, hands their ring addresses to
+// lasr_push_submit_rows, keeps up to `depth` model steps in flight and delivers the tokens of every collected step to the
+// streams' result queues.  A Python (or any other) producer pays one foreign call per push -- several chunks per call when it
+// has them -- and one blocking call per result, both outside the GIL.
+//
+// Reset rule of the servicer (api-server.py:44-50,131-134), applied between two model steps of the stream as the reference does:
+// after `reset_steps` model steps since the last reset, the first step that emits no token resets encoder / predictor / LM.
+// A stream whose step in flight may trigger a reset is not run ahead: the chunk that would start its next model step waits for
+// that verdict (chunks that only fill the window / Buffer go through); all other streams keep going.  Streams whose
+// step-completing chunk falls on a different tick than the majority's wait one tick, so the streams share their model steps.
+#pragma once
+
+struct lasr_front {
+    struct Stream {
+        int slot = -1;
+        std::atomic<bool> open{false};
+        bool closing = false;                 // (front thread reads it under em)
+        // input: single-producer / single-consumer ring of client chunks (host memory, `chunk` floats each)
+        std::vector<float> ring;
+        std::atomic<long long> head{0}, tail{0};     // chunks produced / consumed
+        std::atomic<bool> eof_in{false};
+        bool eof_out = false;
+        // mirrors of the engine's window / Buffer bookkeeping, and the rule's counters (front thread only)
+        long long n_chunks = 0; int n_pend = 0;
+        int infl = 0; long long stp = 0;
+        // results: one entry per collected model step
+        std::mutex rm; std::condition_variable rcv;
+        struct Res { std::vector<int32_t> tok; int flags; };
+        std::deque<Res> res;
+        std::condition_variable pcv;          // producer waiting for ring space / closer waiting for infl == 0 (under rm)
+    };
+    lasr_ctx* c = nullptr;
+    int depth = 12, reset_steps = 0, ring_chunks = 64, chunk = 0, n_window = 0, n_buffer = 0, max_tok = 0;
+    std::vector<std::unique_ptr<Stream>> st;  // by engine slot
+    std::mutex em;                            // the engine is single-caller: front thread vs open / close / pause
+    std::thread th;
+    std::atomic<bool> stop{false};
+    std::atomic<long long> work{0};           // bumped by every push / eof / close: the sleeping front thread re-checks
+    std::mutex fm; std::condition_variable fcv; std::atomic<bool> sleeping{false};
+    std::deque<std::vector<int>> inflight;    // rows (slots) of every submitted, uncollected model step
+    // results leave through a second thread: waking 64 blocked consumers (one futex wake each) costs the thread that does it
+    // 60-190 us per model step -- on the front thread that made the HOST the limit (33 k audio-s/s with full 64-row steps)
+    struct Out { std::vector<int> rows; std::vector<int32_t> tok; std::vector<int> cnt, flags; int cap = 0; };
+    std::deque<Out> outq; std::mutex om; std::condition_variable ocv; std::thread oth;
+    bool out_busy = false;                    // the delivery thread holds a record it has taken off outq (under om)
+    int rc = 0; std::string err;              // first engine error: the front stops, every call returns it
+    std::atomic<long long> n_ticks{0}, n_steps{0}, n_rows{0}, n_resets{0};
+    // scratch of the front thread
+    std::vector<int> slots, step_rows; std::vector<const float*> rows; std::vector<int32_t> tokbuf; std::vector<int> cnt;
+};
+
+namespace {
+
+constexpr int FRONT_RES_STEP = 1, FRONT_RES_RESET = 2, FRONT_RES_EOF = 4;
+
+int front_fail(lasr_front* f, int rc) {
+    if (!f->rc) { f->rc = rc; f->err = lasr_last_error(f->c); }
+    for (auto& s : f->st)                   // wake every waiter: they return the error
+        if (s) { std::lock_guard<std::mutex> lk(s->rm); s->rcv.notify_all(); s->pcv.notify_all(); }
+    return rc;
+}
+
+void front_deliver(lasr_front::Stream& s, const int32_t* tok, int n, int flags) {
+    std::lock_guard<std::mutex> lk(s.rm);
+    s.res.push_back({std::vector<int32_t>(tok, tok + n), flags});
+    s.rcv.notify_one();
+}
+
+void front_out(lasr_front* f, lasr_front::Out&& o) {
+    { std::lock_guard<std::mutex> lk(f->om); f->outq.push_back(std::move(o)); }
+    f->ocv.notify_one();
+}
+// delivery thread: the results of collected steps (and end-of-stream marks, in order behind them) -> the streams' queues
+void front_out_main(lasr_front* f) {
+    for (;;) {
+        lasr_front::Out o;
+        {
+            std::unique_lock<std::mutex> lk(f->om);
+            f->ocv.wait(lk, [&] { return !f->outq.empty() || f->stop.load(); });
+            if (f->outq.empty()) return;
+            o = std::move(f->outq.front());
+            f->outq.pop_front();
+            f->out_busy = true;
+        }
+        for (size_t i = 0; i < o.rows.size(); ++i)
+            front_deliver(*f->st[o.rows[i]], o.tok.data() + i * (size_t)o.cap, o.cnt[i], o.flags[i]);
+        { std::lock_guard<std::mutex> lk(f->om); f->out_busy = false; }
+    }
+}
+
+// tokens of the oldest model step in flight -> its streams; the reset rule.  em held.
+int front_collect(lasr_front* f) {
+    if (f->inflight.empty()) return LASR_OK;
+    int ran = 0;
+    int rc = lasr_step_wait(f->c, &ran);
+    if (rc) return front_fail(f, rc);
+    std::vector<int> rows = std::move(f->inflight.front());
+    f->inflight.pop_front();
+    if (ran != (int)rows.size()) {
+        fail(f->c, LASR_ESTATE, "front: expected a model step of %d streams, the engine ran %d", (int)rows.size(), ran);
+        return front_fail(f, LASR_ESTATE);
+    }
+    const int cap = f->max_tok;
+    f->tokbuf.resize((size_t)rows.size() * cap);
+    f->cnt.resize(rows.size());
+    rc = lasr_fetch_many(f->c, rows.data(), (int)rows.size(), f->tokbuf.data(), cap, f->cnt.data());
+    if (rc) return front_fail(f, rc);
+    lasr_front::Out o;
+    o.cap = cap; o.flags.assign(rows.size(), FRONT_RES_STEP);
+    for (size_t i = 0; i < rows.size(); ++i) {
+        lasr_front::Stream& s = *f->st[rows[i]];
+        s.infl--;
+        s.stp++;
+        if (f->reset_steps > 0 && s.stp >= f->reset_steps && f->cnt[i] == 0) {
+            // (the stream has nothing else in flight: see the hold rule in front_tick)
+            rc = lasr_stream_reset(f->c, s.slot, 1 | 2 | 4);            // models.py:494-497
+            if (rc) return front_fail(f, rc);
+            s.stp = 0;
+            o.flags[i] |= FRONT_RES_RESET;
+            f->n_resets.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+    o.rows = std::move(rows); o.tok.swap(f->tokbuf); o.cnt.swap(f->cnt);
+    front_out(f, std::move(o));
+    return LASR_OK;
+}
+
+// one tick: one chunk of every stream that has one waiting and may run.  Returns 1 when something was done.  em held.
+int front_tick(lasr_front* f, bool* did) {
+    *did = false;
+    lasr_ctx* c = f->c;
+    while ((int)f->inflight.size() >= f->depth) { int rc = front_collect(f); if (rc) return rc; *did = true; }
+    f->slots.clear(); f->rows.clear(); f->step_rows.clear();
+    int n_step = 0, n_fill = 0, n_absent = 0;
+    // pass 1: classify
+    struct Cand { int slot; bool stepper; };
+    static thread_local std::vector<Cand> cand;
+    cand.clear();
+    for (auto& sp : f->st) {
+        if (!sp || !sp->open.load(std::memory_order_acquire) || sp->closing) continue;
+        lasr_front::Stream& s = *sp;
+        if (s.head.load(std::memory_order_acquire) == s.tail.load(std::memory_order_relaxed)) {
+            if (!s.eof_in.load(std::memory_order_acquire)) { n_absent++; continue; }          // a live stream with nothing waiting
+            if (!s.eof_out && s.infl == 0) {                                                  // everything delivered
+                s.eof_out = true;
+                lasr_front::Out o;                 // (behind the stream's last step result, through the same queue)
+                o.rows = {s.slot}; o.cnt = {0}; o.flags = {FRONT_RES_EOF}; o.cap = 1; o.tok.assign(1, 0);
+                front_out(f, std::move(o));
+                *did = true;
+            }
+            continue;
+        }
+        const bool stepper = s.n_chunks + 1 >= f->n_window && s.n_pend + 1 == f->n_buffer;
+        // the step in flight may end in a reset (its ordinal since the last reset is >= reset_steps): its verdict first
+        if (stepper && f->reset_steps > 0 && s.infl > 0 && s.stp + s.infl >= f->reset_steps) continue;
+        cand.push_back({s.slot, stepper});
+        (stepper ? n_step : n_fill)++;
+    }
+    if (cand.empty()) {
+        if (!f->inflight.empty()) { int rc = front_collect(f); if (rc) return rc; *did = true; }   // nothing waiting: results at once
+        return LASR_OK;
+    }
+    // A model step costs the GPU the same for 1 row or 64.  While the GPU has work queued (>= 2 steps in flight) and some open
+    // stream has no chunk waiting yet, the tick collects the oldest step instead of submitting a thin batch: the front then runs
+    // at the GPU's pace and the producers that are behind (Python threads taking turns on the GIL) fill their rings meanwhile.
+    // With fewer than 2 steps in flight the batch goes out as it is (a lone real-time stream sees the synchronous latency).
+    if (n_absent > 0 && (int)f->inflight.size() >= 2) {
+        int rc = front_collect(f);
+        if (rc) return rc;
+        *did = true;
+        return LASR_OK;
+    }
+    // streams out of phase share their model steps from the second one on: a minority of step-completing chunks waits a tick
+    const bool hold_steppers = n_step > 0 && n_fill > 0 && n_step <= n_fill;
+    for (const Cand& k : cand) {
+        if (k.stepper && hold_steppers) continue;
+        lasr_front::Stream& s = *f->st[k.slot];
+        f->slots.push_back(k.slot);
+        f->rows.push_back(s.ring.data() + (size_t)(s.tail.load(std::memory_order_relaxed) % f->ring_chunks) * f->chunk);
+        if (k.stepper) f->step_rows.push_back(k.slot);
+    }
+    if (f->slots.empty()) return LASR_OK;
+    const int before = lasr_step_pending(c);
+    int rc = lasr_push_submit_rows(c, f->slots.data(), (int)f->slots.size(), f->rows.data(), nullptr);
+    if (rc) return front_fail(f, rc);
+    *did = true;
+    f->n_ticks.fetch_add(1, std::memory_order_relaxed);
+    for (int slot : f->slots) {                 // (the chunks have been copied into the engine's staging ring: the ring entries are free)
+        lasr_front::Stream& s = *f->st[slot];
+        s.n_chunks++;
+        if (s.n_chunks >= f->n_window && ++s.n_pend == f->n_buffer) s.n_pend = 0;
+        const long long t1 = s.tail.fetch_add(1, std::memory_order_release) + 1;
+        // a producer blocked on a full ring is woken when the ring is half empty, not after every chunk taken (a futex wake per
+        // stream and tick on this thread otherwise: 64 system calls per tick while a fast producer is throttled)
+        if (s.head.load(std::memory_order_acquire) - t1 == f->ring_chunks / 2) { std::lock_guard<std::mutex> lk(s.rm); s.pcv.notify_all(); }
+    }
+    const int after = lasr_step_pending(c);
+    if ((after > before) != !f->step_rows.empty()) {
+        fail(c, LASR_ESTATE, "front: the engine %s a model step where the front's window / Buffer mirror expected %s", after > before ? "ran" : "did not run",
+             f->step_rows.empty() ? "none" : "one");
+        return front_fail(f, LASR_ESTATE);
+    }
+    if (!f->step_rows.empty()) {
+        for (int slot : f->step_rows) f->st[slot]->infl++;
+        f->n_steps.fetch_add(1, std::memory_order_relaxed);
+        f->n_rows.fetch_add((long long)f->step_rows.size(), std::memory_order_relaxed);
+        f->inflight.push_back(f->step_rows);
+    }
+    return LASR_OK;
+}
+
+void front_main(lasr_front* f) {
+    (void)hipSetDevice(f->c->device);
+    long long seen = -1;
+    while (!f->stop.load(std::memory_order_acquire)) {
+        bool did = false;
+        if (!f->rc) {
+            std::lock_guard<std::mutex> lk(f->em);
+            (void)front_tick(f, &did);
+        }
+        if (did) continue;
+        // nothing to do: spin briefly (chunks of a saturated replay arrive every few microseconds), then sleep until the next push
+        const long long w = f->work.load(std::memory_order_acquire);
+        if (w != seen) { seen = w; continue; }
+        bool woke = false;
+        for (int i = 0; i < 2000; ++i) {
+            __builtin_ia32_pause();
+            if (f->work.load(std::memory_order_acquire) != seen || f->stop.load(std::memory_order_relaxed)) { woke = true; break; }
+        }
+        if (woke) continue;
+        std::unique_lock<std::mutex> lk(f->fm);
+        f->sleeping.store(true, std::memory_order_seq_cst);
+        f->fcv.wait_for(lk, std::chrono::milliseconds(50), [&] { return f->work.load() != seen || f->stop.load(); });
+        f->sleeping.store(false, std::memory_order_seq_cst);
+    }
+}
+
+void front_kick(lasr_front* f) {
+    f->work.fetch_add(1, std::memory_order_seq_cst);
+    if (f->sleeping.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(f->fm); f->fcv.notify_one(); }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lasr_front_create(lasr_ctx* c, int depth, int reset_steps, lasr_front** out) {
+    if (!c || !out) return LASR_EINVAL;
+    *out = nullptr;
+    if (c->W > 1) return fail(c, LASR_ESTATE, "lasr_front: greedy decode only (beam %d)", c->W);
+    if (!c->fe_fused) return fail(c, LASR_ESTATE, "lasr_front: needs the fused streaming front-end (<= 512 streams, the reference's frame geometry)");
+    lasr_front* f = new lasr_front();
+    f->c = c;
+    f->depth = std::max(1, std::min(depth > 0 ? depth : 12, lasr_max_inflight(c)));
+    f->reset_steps = std::max(0, reset_steps);
+    f->chunk = c->d.chunk; f->n_window = c->d.n_window; f->n_buffer = c->d.n_buffer;
+    f->max_tok = std::max(16, c->d.n_buffer * c->d.max_iters_stream + 4);
+    f->st.resize(c->d.max_streams);
+    f->th = std::thread(front_main, f);
+    f->oth = std::thread(front_out_main, f);
+    *out = f;
+    return LASR_OK;
+}
+
+void lasr_front_destroy(lasr_front* f) {
+    if (!f) return;
+    f->stop.store(true, std::memory_order_release);
+    front_kick(f);
+    { std::lock_guard<std::mutex> lk(f->fm); f->fcv.notify_all(); }
+    f->th.join();
+    { std::lock_guard<std::mutex> lk(f->om); }
+    f->ocv.notify_all();
+    f->oth.join();
+    {   // leave the engine idle: collect what is in flight, close the streams
+        std::lock_guard<std::mutex> lk(f->em);
+        while (!f->inflight.empty() && !f->rc) (void)front_collect(f);
+        for (auto& s : f->st)
+            if (s && s->open.load()) { (void)lasr_stream_close(f->c, s->slot); s->open.store(false); }
+    }
+    for (auto& s : f->st)
+        if (s) { std::lock_guard<std::mutex> lk(s->rm); s->rcv.notify_all(); s->pcv.notify_all(); }
+    delete f;
+}
+
+int lasr_front_open(lasr_front* f, int* stream) {
+    if (!f || !stream) return LASR_EINVAL;
+    if (f->rc) return f->rc;
+    std::lock_guard<std::mutex> lk(f->em);
+    int slot = -1;
+    int rc = lasr_stream_open(f->c, &slot);
+    if (rc) return rc;
+    if (!f->st[slot]) f->st[slot].reset(new lasr_front::Stream());
+    lasr_front::Stream& s = *f->st[slot];
+    s.slot = slot; s.closing = false; s.eof_out = false;
+    s.ring.assign((size_t)f->ring_chunks * f->chunk, 0.f);
+    s.head.store(0); s.tail.store(0); s.eof_in.store(false);
+    s.n_chunks = 0; s.n_pend = 0; s.infl = 0; s.stp = 0;
+    { std::lock_guard<std::mutex> rl(s.rm); s.res.clear(); }
+    s.open.store(true, std::memory_order_release);
+    *stream = slot;
+    return LASR_OK;
+}
+
+// n_chunks client chunks (chunk floats each, host memory) of `stream`, copied into its ring; blocks while the ring is full
+int lasr_front_push(lasr_front* f, int stream, const float* pcm, int n_chunks) {
+    if (!f || stream < 0 || stream >= (int)f->st.size() || !f->st[stream] || (n_chunks > 0 && !pcm)) return LASR_EINVAL;
+    lasr_front::Stream& s = *f->st[stream];
+    if (!s.open.load(std::memory_order_acquire) || s.eof_in.load()) return LASR_ESTATE;
+    for (int k = 0; k < n_chunks; ++k) {
+        if (f->rc) return f->rc;
+        const long long h = s.head.load(std::memory_order_relaxed);
+        if (h - s.tail.load(std::memory_order_acquire) >= f->ring_chunks) {          // back-pressure
+            std::unique_lock<std::mutex> lk(s.rm);
+            s.pcv.wait_for(lk, std::chrono::milliseconds(20), [&] { return h - s.tail.load(std::memory_order_acquire) < f->ring_chunks || f->rc || f->stop.load(); });
+            if (f->stop.load()) return LASR_ESTATE;
+            --k;
+            continue;
+        }
+        memcpy(s.ring.data() + (size_t)(h % f->ring_chunks) * f->chunk, pcm + (size_t)k * f->chunk, sizeof(float) * f->chunk);
+        s.head.store(h + 1, std::memory_order_release);
+        front_kick(f);
+    }
+    return LASR_OK;
+}
+
+int lasr_front_eof(lasr_front* f, int stream) {
+    if (!f || stream < 0 || stream >= (int)f->st.size() || !f->st[stream]) return LASR_EINVAL;
+    f->st[stream]->eof_in.store(true, std::memory_order_release);
+    front_kick(f);
+    return LASR_OK;
+}
+
+// Next result of `stream`, in model-step order: *flags bit 1 = a model step (n_tokens new token ids, possibly 0), bit 2 = the
+// reset rule fired after this step, bit 4 = end of stream (every step of the pushed chunks has been delivered; after
+// lasr_front_eof).  Blocks up to timeout_ms (< 0: for ever); returns 1 on time-out.
+int lasr_front_next(lasr_front* f, int stream, int32_t* tokens, int cap, int* n_tokens, int* flags, int timeout_ms) {
+    if (!f || stream < 0 || stream >= (int)f->st.size() || !f->st[stream] || !n_tokens || !flags) return LASR_EINVAL;
+    lasr_front::Stream& s = *f->st[stream];
+    std::unique_lock<std::mutex> lk(s.rm);
+    auto ready = [&] { return !s.res.empty() || f->rc != 0 || f->stop.load(); };
+    if (timeout_ms < 0) s.rcv.wait(lk, ready);
+    else if (!s.rcv.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready)) return 1;
+    if (s.res.empty()) return f->rc ? f->rc : LASR_ESTATE;
+    lasr_front::Stream::Res& r = s.res.front();
+    if ((int)r.tok.size() > cap) return LASR_EFULL;
+    if (!r.tok.empty()) memcpy(tokens, r.tok.data(), sizeof(int32_t) * r.tok.size());
+    *n_tokens = (int)r.tok.size();
+    *flags = r.flags;
+    s.res.pop_front();
+    return LASR_OK;
+}
+
+int lasr_front_close(lasr_front* f, int stream) {
+    if (!f || stream < 0 || stream >= (int)f->st.size() || !f->st[stream]) return LASR_EINVAL;
+    lasr_front::Stream& s = *f->st[stream];
+    if (!s.open.load()) return LASR_ESTATE;
+    for (;;) {      // its steps in flight are collected by the front thread; then the slot can be closed
+        std::lock_guard<std::mutex> lk(f->em);
+        s.closing = true;
+        if (f->rc) return f->rc;
+        if (s.infl == 0) {
+            for (;;) {              // its last results have left the delivery queue (a late one must not reach the slot's next stream)
+                { std::lock_guard<std::mutex> ol(f->om); if (f->outq.empty() && !f->out_busy) break; }
+                std::this_thread::yield();
+            }
+            int rc = lasr_stream_close(f->c, s.slot);
+            s.open.store(false, std::memory_order_release);
+            std::lock_guard<std::mutex> rl(s.rm);
+            s.res.clear();
+            return rc;
+        }
+        int rc = front_collect(f);
+        if (rc) return rc;
+    }
+}
+
+// The engine for the caller (a unary Transcribe RPC, an offline utterance): every step in flight is collected and the front
+// thread stays out until lasr_front_resume, which the SAME thread calls.  Does not nest.
+int lasr_front_pause(lasr_front* f) {
+    if (!f) return LASR_EINVAL;
+    f->em.lock();
+    while (!f->inflight.empty() && !f->rc) (void)front_collect(f);
+    if (f->rc) { f->em.unlock(); return f->rc; }
+    return LASR_OK;
+}
+int lasr_front_resume(lasr_front* f) {
+    if (!f) return LASR_EINVAL;
+    f->em.unlock();
+    front_kick(f);
+    return LASR_OK;
+}
+
+// counters: ticks (lasr_push_submit_rows calls), model steps submitted, rows of those steps, resets by the rule
+int lasr_front_stats(lasr_front* f, long long* ticks, long long* steps, long long* rows, long long* resets) {
+    if (!f) return LASR_EINVAL;
+    if (ticks) *ticks = f->n_ticks.load();
+    if (steps) *steps = f->n_steps.load();
+    if (rows) *rows = f->n_rows.load();
+    if (resets) *resets = f->n_resets.load();
+    return f->rc;
+}
+
+const char* lasr_front_error(const lasr_front* f) { return f ? f->err.c_str() : "null front"; }
+
+// include/lasr_debug.h: capacity of the front with NATIVE per-stream producers (one std::thread per stream pushing
+// chunks_per_push chunks per call, then reading its results to the end): what the per-stream form can carry when the producers
+// are not Python threads taking turns on the GIL.  pcm [n_streams][n_chunks * chunk] host; tokens [n_streams][cap], n_tok [n_streams].
+int lasr_bench_front(lasr_ctx* c, int depth, int reset_steps, int n_streams, const float* pcm, int n_chunks, int chunks_per_push,
+                     int32_t* tokens, int cap, int* n_tok, double* seconds, long long* stats4) {
+    if (!c || !pcm || !tokens || !n_tok || !seconds || n_streams < 1 || n_chunks < 1 || chunks_per_push < 1) return LASR_EINVAL;
+    lasr_front* f = nullptr;
+    RC(lasr_front_create(c, depth, reset_steps, &f));
+    std::vector<int> sid(n_streams, -1);
+    int rc = LASR_OK;
+    for (int i = 0; i < n_streams && !rc; ++i) rc = lasr_front_open(f, &sid[i]);
+    std::atomic<int> go{0}, bad{0};
+    std::vector<std::thread> th;
+    const size_t per = (size_t)n_chunks * c->d.chunk;
+    for (int i = 0; i < n_streams && !rc; ++i)
+        th.emplace_back([&, i] {
+            while (!go.load(std::memory_order_acquire)) __builtin_ia32_pause();
+            int n = 0;
+            for (int k = 0; k < n_chunks; k += chunks_per_push)
+                if (lasr_front_push(f, sid[i], pcm + i * per + (size_t)k * c->d.chunk, std::min(chunks_per_push, n_chunks - k))) { bad.fetch_add(1); break; }
+            (void)lasr_front_eof(f, sid[i]);
+            for (;;) {
+                int32_t buf[64]; int nt = 0, fl = 0;
+                const int r = lasr_front_next(f, sid[i], buf, 64, &nt, &fl, 20000);
+                if (r != LASR_OK) { bad.fetch_add(1); break; }
+                if (fl & FRONT_RES_EOF) break;
+                for (int q = 0; q < nt && n < cap; ++q) tokens[(size_t)i * cap + n++] = buf[q];
+            }
+            n_tok[i] = n;
+        });
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(1, std::memory_order_release);
+    for (auto& t : th) t.join();
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats4) (void)lasr_front_stats(f, &stats4[0], &stats4[1], &stats4[2], &stats4[3]);
+    if (!rc && bad.load()) rc = f->rc ? f->rc : LASR_ESTATE;
+    for (int i = 0; i < n_streams; ++i)
+        if (sid[i] >= 0) (void)lasr_front_close(f, sid[i]);
+    lasr_front_destroy(f);
+    return rc;
+}
+
+}  // extern "C"

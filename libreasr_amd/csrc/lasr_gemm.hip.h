@@ -96,7 +96,7 @@ struct GemmArgs {
     unsigned long long* dbg; // optional per-workgroup phase timestamps [blocks][16] (LASR_DBG_TIMING)
     unsigned long long* prof; // optional: per-workgroup entry (prof[wg % PROF_W]) and exit (prof_x[wg % PROF_W]) wall_clock64(), plain stores --
     unsigned long long* prof_x; //   max exit - min entry over the workgroups = the kernel's own duration (atomics on one word cost the job 7 %)
-    int prio;                // wave priority for the whole kernel (s_setprio 0..3); experiments: LASR_DEC_PRIO / LASR_CELL_PRIO
+    int prio;                // wave priority for the whole kernel (s_setprio 0..3): 1 for the decode-stream GEMMs, 0 otherwise
     int skip_idle;           // COMPACT: an m-group without a compacted row returns at once (its rows' carry is done by k_beam_carry)
 };
 

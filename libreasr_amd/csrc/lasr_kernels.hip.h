@@ -243,7 +243,7 @@ __device__ __forceinline__ float block_sum_256(float x, float* sh4, int lane, in
     return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
-// experiments (LASR_DELAY_MAIN_US / LASR_DELAY_DEC_US): one wave holds its stream for `ticks` of the 100 MHz wall clock without
+// lasr_overlap_probe (and round 3's stream-sensitivity probes): one wave holds its stream for `ticks` of the 100 MHz wall clock without
 // touching memory -- the marginal cost of a microsecond on either stream of the pipelined protocol
 __global__ void k_delay(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();

@@ -241,10 +241,8 @@ void launch_predictor_t(lasr_ctx* c, bool beam, int l0 = 0, int l1 = -1) {
     const int p = c->pred_par;
     // many decoder rows (beam 8 x 64+ streams, >= 512 streams): 16-unit workgroups, a quarter of the activation traffic
     // (configs[4], 1024 rows: predictor cells 135 -> ~50 us, whole job +60 %; at 256 rows: bf16 equal, f32 -22 %; at 64: -20 %)
-    static const int wide_env = getenv("LASR_PRED_WIDE") ? atoi(getenv("LASR_PRED_WIDE")) : -1;
-    const bool wide = wide_env >= 0 ? wide_env == 1 : c->Md >= 512;
-    const int w8_min = getenv("LASR_W8_MIN") ? atoi(getenv("LASR_W8_MIN")) : 256;
-    const bool wide8 = wide_env >= 0 ? wide_env == 2 : (c->bf && c->Md >= w8_min && c->Md < 512);   // 8 units per workgroup, 8 waves
+    const bool wide = c->Md >= 512;
+    const bool wide8 = c->bf && c->Md >= 256 && c->Md < 512;   // 8 units per workgroup, 8 waves (configs[2]: 6.4 -> 7.2 k in round 2)
     const bool split_carry = beam && beam_carry_on();
     if (split_carry && beam_carry_mode() == 1 && l0 == 0) {      // the slots that are not extended: whole-row copies by their own launch (see k_beam_carry)
         BeamCarryArgs a{};
@@ -326,15 +324,8 @@ void launch_ppj_t(lasr_ctx* c, bool beam) {
     ea.ja = c->ja; ea.J = J; ea.M = c->Md; ea.MT = c->MTj; ea.ring = c->pe_ring_R; ea.la = beam ? 1 : c->la;
     if (beam) { ea.parent = c->b_parent; ea.W = c->W; ea.M_enc = c->M; ea.pp_in = p ? c->pp1 : c->pp; }
     if (beam && beam_carry_on()) { ea.no_carry = 1; g.skip_idle = 1; }      // (k_beam_carry, launched with the predictor pass)
-    static const int ppj_wide_env = getenv("LASR_PPJ_WIDE") ? atoi(getenv("LASR_PPJ_WIDE")) : -1;
-    const bool ppj_wide = (ppj_wide_env >= 0 ? ppj_wide_env != 0 : c->Md >= 512) && c->MTd % 4 == 0;   // 64-row workgroups for many decoder rows
-    static const int ppj_nt4 = getenv("LASR_PPJ_NT4") ? atoi(getenv("LASR_PPJ_NT4")) : 0;      // 64-column workgroups: measured slower (19.9 against 14.3 us at 1024 rows)
-    if (ppj_wide && ppj_nt4 && J % 64 == 0 && !(beam && beam_carry_mode() == 2)) {
-        typename EpiPPJ<Ops, 4>::Args e4{};
-        static_assert(sizeof(e4) == sizeof(ea), "same Args layout");
-        memcpy((void*)&e4, (const void*)&ea, sizeof(e4));
-        launch_gemm<Ops, EpiPPJ<Ops, 4>, 4, true, -1, 4>(c, J / 64, c->MTd / 4, g, e4);
-    } else
+    const bool ppj_wide = c->Md >= 512 && c->MTd % 4 == 0;   // 64-row workgroups for many decoder rows (64-column ones measured slower:
+                                                             // 19.9 against 14.3 us at 1024 rows, round 4)
     if (beam && beam_carry_mode() == 2) {      // the round's carry as extra workgroups of this launch
         if (ppj_wide) launch_gemm_carry<Ops, EpiPPJ<Ops>, 4, true, -1, 4>(c, J / 16, c->MTd / 4, g, ea);
         else if (c->dec_nw_mask & 2) launch_gemm_carry<Ops, EpiPPJ<Ops>, 1, true, -1, 4>(c, J / 16, c->MTd, g, ea);
@@ -480,12 +471,11 @@ const int* cur_lm_valid(lasr_ctx* c) { return (c->W > 1 && c->lm.par) ? c->lm.va
 void launch_beam_select(lasr_ctx* c, BeamState& b, int iter_slot) {
     const int M = c->M;
     b.lm_on = c->lm.on ? 1 : 0; b.done2 = c->c_done2;
-    static const int nt_env = getenv("LASR_BEAM_NT") ? atoi(getenv("LASR_BEAM_NT")) : 0;      // experiment: 512 | 1024
-    const bool small = nt_env ? nt_env == 512 && c->d.vocab <= 2048 : c->d.vocab <= 2048;
+    const bool small = c->d.vocab <= 2048;      // 512 threads fill their register slots with real logits (1024: half padding; round 3, P)
     const float* lg = (const float*)c->logits;
     // one wave per hypothesis row (k_beam_select_rw; LASR_BEAM_SELECT_RW=0: every row spread over all waves, round 3's kernel)
     static const int rw_env = getenv("LASR_BEAM_SELECT_RW") ? atoi(getenv("LASR_BEAM_SELECT_RW")) : 1;
-    if (small && rw_env && !nt_env) {
+    if (small && rw_env) {
         if (c->W <= 2) hipLaunchKernelGGL((k_beam_select_rw<2>), dim3(M), dim3(128), 0, c->stream, lg, b, iter_slot);
         else if (c->W <= 4) hipLaunchKernelGGL((k_beam_select_rw<4>), dim3(M), dim3(256), 0, c->stream, lg, b, iter_slot);
         else hipLaunchKernelGGL((k_beam_select_rw<8>), dim3(M), dim3(512), 0, c->stream, lg, b, iter_slot);
@@ -541,8 +531,7 @@ void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
     EpiLinear::Args ea{};
     ea.bias = c->b2; ea.out = out; ea.ldo = V; ea.n_rows = n_rows;
     ea.t_idx = gated ? c->dec_t_idx : nullptr; ea.T_row = c->T_row_dec; ea.M = c->M; ea.W = c->W;
-    static const int lg_nt4 = getenv("LASR_LOGITS_NT4") ? atoi(getenv("LASR_LOGITS_NT4")) : 1;      // 64 x 64 workgroups for >= 512 rows (A/B)
-    if (lg_nt4 && n_rows >= 512 && V % 64 == 0) {
+    if (n_rows >= 512 && V % 64 == 0) {      // 64 x 64 workgroups for the beam's hundreds of hypothesis rows (round 4: logits 28 -> 20 us)
         GemmArgs g4 = g;
         g4.KC[0] = J / c->kch;
         EpiLinearT<4>::Args e4{};
@@ -552,27 +541,7 @@ void launch_logits(lasr_ctx* c, float* out, int n_rows, bool gated) {
         else launch_gemm<OpsF32, EpiLinearT<4>, 4, false, -1, 4>(c, V / 64, (n_rows + 63) / 64, g4, e4);
         return;
     }
-    // 32 x 32 workgroups for the greedy loop's 64-128 rows (experiment, LASR_LOGITS_NT2=1): half the workgroups of the 32 x 16
-    // tiling, each activation row fetched by 64 n-groups instead of 128 (same waves per workgroup, same K split: bit-identical)
-    static const int lg_nt2 = getenv("LASR_LOGITS_NT2") ? atoi(getenv("LASR_LOGITS_NT2")) : 0;
-    if (lg_nt2 && c->logits_mt == 2 && n_rows < 512 && V % 32 == 0) {
-        GemmArgs g2 = g;
-        g2.KC[0] = J / c->kch;
-        EpiLinearT<2>::Args e2{};
-        static_assert(sizeof(e2) == sizeof(ea), "same Args layout");
-        memcpy((void*)&e2, (const void*)&ea, sizeof(e2));
-        const int mg = (n_rows + 31) / 32;
-        if (c->dec_nw_mask & 4) {
-            if (c->bf) launch_gemm<OpsBF16, EpiLinearT<2>, 2, false, -1, 4>(c, V / 32, mg, g2, e2);
-            else launch_gemm<OpsF32, EpiLinearT<2>, 2, false, -1, 4>(c, V / 32, mg, g2, e2);
-        } else {
-            if (c->bf) launch_gemm<OpsBF16, EpiLinearT<2>, 2, false, -1>(c, V / 32, mg, g2, e2);
-            else launch_gemm<OpsF32, EpiLinearT<2>, 2, false, -1>(c, V / 32, mg, g2, e2);
-        }
-        return;
-    }
-    static const int lw_env = getenv("LASR_LOGITS_WIDE") ? atoi(getenv("LASR_LOGITS_WIDE")) : -1;
-    if (c->logits_mt == 4 || (c->logits_mt == 2 && (lw_env >= 0 ? lw_env != 0 : n_rows >= 512))) { launch_logits_t<4>(c, g, n_rows, J, ea); return; }
+    if (c->logits_mt == 4 || (c->logits_mt == 2 && n_rows >= 512)) { launch_logits_t<4>(c, g, n_rows, J, ea); return; }
     if (c->logits_mt == 2) { launch_logits_t<2>(c, g, n_rows, J, ea); return; }
     launch_linear<false, -1>(c, V / 16, (n_rows + 15) / 16, g, J, ea);
 }

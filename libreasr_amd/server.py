@@ -817,14 +817,164 @@ class ASRServicer(apg.ASRServicer):
             self.sched.close(st)
 
 
-def serve(lang="en", port=None, block=True, depth=12, **load_kw):
-    """Start the gRPC server (api-server.py:138-145).  Returns (server, scheduler, port)."""
+class NativeASRServicer(apg.ASRServicer):
+    """The same RPC surface on the NATIVE front (libreasr_amd/front.py, include/lasr.h lasr_front_*): the RPC threads push
+    frames into per-stream rings and block in C for their results; batching, steps in flight and the reset rule
+    (api-server.py:131-134) run in the library's front thread -- no Python on the tick path.  16 kHz / 80 ms clients take this
+    path; other rates / frame lengths run the servicer's per-window sequence (api-server.py:83-115 -> lasr_step_window) with the
+    front paused for the call, as the Python scheduler runs them synchronously."""
+
+    def __init__(self, lang, front, language, conf=None):
+        self.lang_name, self.front, self.lang = lang, front, language
+        eng = front.eng
+        self.eng = eng
+        self.downsample, self.n_buffer, self.chunk, self.n_window = eng.desc.stride, eng.desc.n_buffer, eng.desc.chunk, eng.desc.n_window
+        self.sr = eng.desc.sample_rate
+
+    _guard = staticmethod(ASRServicer._guard)
+
+    def Transcribe(self, request, context):                                # api-server.py:64-80
+        aud = tensorize(request.data)[0].numpy()
+        sr = request.sr or 16000
+
+        def run():
+            with self.front.paused() as eng:
+                slot = eng.open()
+                try:
+                    pcm = aud
+                    if sr != self.sr:
+                        import torch
+                        pcm = eng.resample(torch.as_tensor(aud[None]).to(eng.device), sr)[0]
+                    eng.transcribe_pcm([slot], [pcm])
+                    return eng.fetch(slot)[0]
+                finally:
+                    eng.close_slot(slot)
+
+        return ap.Transcript(data=self.lang.denumericalize(self._guard(context, run)))
+
+    def _diffs(self, results):
+        """api-server.py:116-130 over an iterator of per-model-step token lists: the servicer's diff + "same diff twice" rule."""
+        y, last, last_diff = [], "", ""
+        for res in results:
+            y = y + res
+            if self.lang.denumericalize(res) != "":
+                now = self.lang.denumericalize(y)
+                diff = "".join(b for a, b in it.zip_longest(last, now) if a != b)
+                last = now
+                if diff == last_diff:
+                    continue
+                last_diff = diff
+                yield ap.Transcript(data=diff)
+
+    def TranscribeStream(self, request_iterator, context):                 # api-server.py:82-134
+        from .front import RES_EOF
+        frames = iter(request_iterator)
+        try:
+            first = next(frames)
+        except StopIteration:
+            return
+        sr0 = first.sr or 16000
+        if sr0 != self.sr or len(first.data) != 4 * self.chunk:
+            yield from self._stream_generic(tensorize(first.data)[0].numpy(), sr0, frames, context)
+            return
+        fr = self.front
+        sid = self._guard(context, fr.open)
+        err = []
+
+        def reader():
+            try:
+                fr.push(sid, first.data)          # (the wire bytes go straight into the stream's ring: tensorize without the tensor)
+                for frame in frames:
+                    if (frame.sr or 16000) != self.sr or len(frame.data) != 4 * self.chunk:
+                        raise ValueError("a stream keeps the sample rate and frame length of its first frame")
+                    fr.push(sid, frame.data)
+            except Exception as e:          # client gone / front stopped / bad frame
+                err.append(e)
+            finally:
+                try:
+                    fr.eof(sid)
+                except Exception as e:
+                    err.append(e)
+
+        threading.Thread(target=reader, daemon=True, name=f"lasr-reader-{sid}").start()
+
+        def results():
+            while True:
+                r = fr.next(sid, timeout_ms=500)
+                if err and isinstance(err[0], ValueError):
+                    context.abort(grpc.StatusCode.INVALID_ARGUMENT, str(err[0]))
+                if r is None:
+                    continue
+                toks, flags = r
+                if flags & RES_EOF:
+                    if err:
+                        raise err[0]
+                    return
+                yield toks
+
+        try:
+            yield from self._diffs(results())
+        finally:
+            fr.close(sid)
+
+    def _stream_generic(self, pcm0, sr0, frames, context):
+        """Other client rates / frame lengths: the servicer's own sequence per window, synchronous, the front paused for the call."""
+        eng = self.eng
+        with self.front.paused():
+            slot = self._guard(context, eng.open)
+        buf, steps = [], [0]
+
+        def results():
+            for pcm, sr in it.chain([(pcm0, sr0)], ((tensorize(f.data)[0].numpy(), f.sr or 16000) for f in frames)):
+                if sr != sr0 or len(pcm) != len(pcm0):
+                    context.abort(grpc.StatusCode.INVALID_ARGUMENT, "a stream keeps the sample rate and frame length of its first frame")
+                buf.append(pcm)
+                if len(buf) != self.n_window:
+                    continue
+                win = np.concatenate(buf)
+                del buf[0]
+                try:
+                    with self.front.paused():
+                        ran = eng.step_window([slot], win[None], sr)       # (the engine keeps the stream's Buffer: ran = the model ran)
+                        toks = eng.fetch(slot)[0] if ran else []
+                except Exception as e:
+                    from ._native import LASR_EINVAL, LasrError
+                    if isinstance(e, ValueError) or (isinstance(e, LasrError) and e.code == LASR_EINVAL):
+                        context.abort(grpc.StatusCode.INVALID_ARGUMENT, str(e))    # (e.g. windows too short for n_stack frames)
+                    raise
+                if not ran:
+                    continue
+                steps[0] += 1
+                yield toks
+                if self.lang.denumericalize(toks) == "" and should_reset(steps[0], self.downsample, self.n_buffer):
+                    with self.front.paused():
+                        eng.reset(slot, 1 | 2 | 4)                         # api-server.py:131-134
+                    steps[0] = 0
+
+        try:
+            yield from self._diffs(results())
+        finally:
+            with self.front.paused():
+                eng.close_slot(slot)
+
+
+def serve(lang="en", port=None, block=True, depth=12, front="python", **load_kw):
+    """Start the gRPC server (api-server.py:138-145).  Returns (server, scheduler, port).  front="native": the library's front
+    thread instead of the Python scheduler (the returned object is the NativeFront; `shutdown()` works on both)."""
     from .lib.inference import load_stuff
     conf, language, model, _, _ = load_stuff(lang, **load_kw)
-    sched = Scheduler(model.engine, depth=depth)
-    sched.start()
     server = grpc.server(futures.ThreadPoolExecutor(max_workers=WORKERS))
-    apg.add_ASRServicer_to_server(ASRServicer(lang, sched, language, conf), server)
+    if front == "native":
+        from .front import NativeFront
+        k = 1
+        while not should_reset(k, model.engine.desc.stride, model.engine.desc.n_buffer) and k < (1 << 20):
+            k += 1
+        sched = NativeFront(model.engine, depth=depth, reset_steps=k)
+        apg.add_ASRServicer_to_server(NativeASRServicer(lang, sched, language, conf), server)
+    else:
+        sched = Scheduler(model.engine, depth=depth)
+        sched.start()
+        apg.add_ASRServicer_to_server(ASRServicer(lang, sched, language, conf), server)
     bound = server.add_insecure_port(port or PORTS[lang])
     server.start()
     print("[api-server] gRPC server running on", port or PORTS[lang], "language", lang)

@@ -199,3 +199,235 @@ def test_x_side_gemm_mode_matches_reference(name, n_sec, n_streams, golden_dir, 
             assert counts[s] == list(g[f"st_counts_{s}"])
     finally:
         eng.close()
+
+
+def _stream_tokens(eng, pcm, depth=6, host=False):
+    slots = [eng.open() for _ in range(len(pcm))]
+    chunks = [synth.stream_chunks(p, 1280, lead=1, tail=10) for p in pcm]
+    got = [[] for _ in slots]
+
+    def collect():
+        if eng.wait():
+            for s, t in enumerate(eng.fetch_many(slots, 8192)):
+                if eng.desc.beam > 1:
+                    got[s] = t                   # beam: every fetch hands out the whole current best hypothesis
+                else:
+                    got[s] += t
+
+    for k in range(len(chunks[0])):
+        batch = np.stack([c[k] for c in chunks])
+        eng.push_submit(slots, batch if host else dev(batch))
+        if eng.pending() >= depth:
+            collect()
+    while eng.pending():
+        collect()
+    for s in slots:
+        eng.close_slot(s)
+    return got
+
+
+# every LASR_* switch of the library that has no other owner test (docs/SWITCHES.md): the run must keep the contract of its
+# operand type -- f32: tokens == the reference's goldens; bf16 (bit-identical re-orderings only): tokens == the default engine's
+SWITCH_CASES = [
+    ("LASR_CELL_NW", "8", "f32"), ("LASR_ENC_WAVE", "1", "f32"), ("LASR_MAIN_GRAPH", "1", "f32"), ("LASR_NO_GRAPH", "1", "f32"),
+    ("LASR_PUMP_G", "1", "f32"), ("LASR_PUMP_G", "3", "f32"), ("LASR_DEC_MIN_ROWS", "16", "f32"), ("LASR_DEC_STREAM_PICK", "0", "f32"),
+    ("LASR_SYNC_MEMCPY", "1", "f32"), ("LASR_PUSH_THREADS", "0", "f32"), ("LASR_VERBOSE", "1", "f32"),
+    ("LASR_ENC_WAVE", "0", "bf16"), ("LASR_MAIN_GRAPH", "0", "bf16"),
+]
+
+
+@pytest.mark.parametrize("key,val,dtype", SWITCH_CASES)
+def test_switches_without_another_owner_keep_the_contract(key, val, dtype, golden_dir, monkeypatch):
+    import __graft_entry__ as graft
+    from libreasr_amd.engine import Engine
+    graft.build()
+    cfg = synth.model_cfg("tiny")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    pcm = synth.synth_pcm(3, 16000 * 3, seed=1234)
+    if dtype == "f32":
+        g = np.load(os.path.join(golden_dir, "model_tiny.npz"))
+        want = [list(g[f"st_tokens_{s}"]) for s in range(3)]
+    else:
+        base = Engine(sd, cfg, max_streams=16, dtype=dtype)
+        try:
+            want = _stream_tokens(base, pcm)
+        finally:
+            base.close()
+    monkeypatch.setenv(key, val)
+    eng = Engine(sd, cfg, max_streams=16, dtype=dtype)
+    try:
+        host = key == "LASR_PUSH_THREADS"
+        assert _stream_tokens(eng, pcm, host=host) == want
+        if key == "LASR_SYNC_MEMCPY":          # (the switch is the synchronous protocol's: run that one as well)
+            slots = [eng.open() for _ in range(3)]
+            chunks = [synth.stream_chunks(p, 1280, lead=1, tail=10) for p in pcm]
+            got = [[] for _ in slots]
+            for k in range(len(chunks[0])):
+                eng.push(slots, dev(np.stack([c[k] for c in chunks])))
+                eng.step(slots)
+                for s, slot in enumerate(slots):
+                    got[s] += eng.fetch(slot)[0]
+            assert got == want
+    finally:
+        eng.close()
+
+
+def test_beam_carry_modes_are_bit_identical(monkeypatch):
+    """LASR_BEAM_CARRY 0 (carry inside the cell epilogues) / 1 (its own launch) / 2 (default: extra workgroups of the joint-half
+    GEMM's launch): the same hypotheses and scores on the pipelined protocol."""
+    import __graft_entry__ as graft
+    from libreasr_amd.engine import Engine
+    graft.build()
+    cfg = synth.model_cfg("tiny")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    pcm = synth.synth_pcm(3, 16000 * 3, seed=1234)
+    res = {}
+    for mode in ("2", "1", "0"):
+        monkeypatch.setenv("LASR_BEAM_CARRY", mode)
+        eng = Engine(sd, cfg, max_streams=16, beam=4)
+        try:
+            res[mode] = _stream_tokens(eng, pcm, depth=3)
+        finally:
+            eng.close()
+    assert res["0"] == res["2"] and res["1"] == res["2"]
+    assert sum(len(t) for t in res["2"]) > 10
+
+
+def test_native_front_grpc_equals_the_reference_servicer(golden_dir):
+    """The gRPC servicer on the NATIVE front (lasr_front_*: per-stream rings, batching, steps in flight and the reset rule in the
+    library's own thread): the same seven concurrent streams, message for message what the reference's own
+    ASRServicer.TranscribeStream emitted (resets inside a > 4 s silence, before any token, three in one stream); the unary RPC
+    with the front paused; a 48 kHz client and a 100 ms client through the per-window path against the oracle's servicer."""
+    import grpc
+    import __graft_entry__ as graft
+    graft.build()
+    from libreasr_amd import server as srv
+    from libreasr_amd.interfaces import libreasr_pb2 as ap
+    from libreasr_amd.interfaces import libreasr_pb2_grpc as apg
+    from libreasr_amd.lib.language import IdLanguage
+    from oracle import rnnt_oracle as O
+
+    gold = servicer_golden(golden_dir)
+    pcm = [synth.servicer_pcm(seed, spec) for seed, spec in synth.SERVICER_STREAMS]
+    n = len(pcm)
+    server, front, port = srv.serve("en", port="127.0.0.1:0", block=False, config_path="/nonexistent.yaml",
+                                    synthetic="tiny", max_streams=16, front="native")
+    try:
+        got = [None] * n
+        barrier = threading.Barrier(n)
+
+        def client(i):
+            with grpc.insecure_channel(f"127.0.0.1:{port}") as ch:
+                stub = apg.ASRStub(ch)
+
+                def reqs():
+                    barrier.wait()
+                    for c in synth.stream_chunks(pcm[i], 1280, lead=1, tail=10):
+                        yield ap.Audio(data=c.tobytes(), sr=16000)
+
+                got[i] = [t.data for t in stub.TranscribeStream(reqs())]
+
+        ths = [threading.Thread(target=client, args=(i,)) for i in range(n)]
+        [t.start() for t in ths]
+        [t.join(timeout=180) for t in ths]
+        for i in range(n):
+            assert got[i] == gold[i][0], f"stream {i} {synth.SERVICER_STREAMS[i]}"
+        st = front.stats()
+        assert st["resets"] == sum(len(g[1]) for g in gold), st          # the rule fired exactly where the reference's did
+        assert st["rows"] > st["steps"], st                              # concurrent streams shared model steps
+        cfg = synth.model_cfg("tiny")
+        m = O.OracleTransducer(synth.synth_state_dict(cfg, seed=0), cfg)
+        lang = IdLanguage()
+        with grpc.insecure_channel(f"127.0.0.1:{port}") as ch:
+            stub = apg.ASRStub(ch)
+            for i in (0, 3):
+                assert stub.Transcribe(ap.Audio(data=pcm[i].tobytes(), sr=16000)).data == gold[i][2]
+            pcm48 = synth.synth_pcm(1, 48000 * 2, seed=9, sr=48000)[0]
+            got48 = [t.data for t in stub.TranscribeStream(
+                ap.Audio(data=c.tobytes(), sr=48000) for c in synth.stream_chunks(pcm48, 3840, lead=1, tail=10))]
+            assert got48 == O.servicer_stream(m, pcm48, lang.denumericalize, sr=48000, chunk=3840)[0] and got48
+            got100 = [t.data for t in stub.TranscribeStream(
+                ap.Audio(data=c.tobytes(), sr=16000) for c in synth.stream_chunks(pcm[1], 1600, lead=1, tail=8))]
+            assert got100 == O.servicer_stream(m, pcm[1], lang.denumericalize, chunk=1600, tail=8)[0]
+            with pytest.raises(grpc.RpcError):
+                list(stub.TranscribeStream(ap.Audio(data=np.zeros(100, np.float32).tobytes(), sr=16000) for _ in range(3)))
+    finally:
+        server.stop(0)
+        front.shutdown()
+
+
+def test_native_front_64_per_stream_producers_with_served_rate():
+    """64 streams of configs[1], one PRODUCER THREAD PER STREAM (the gRPC servicer's shape) on the native front --
+    every token against the reference's torch-CPU path; the served rate is recorded (gpurun_out/served_rate_native.json) for one
+    chunk per push (what an RPC thread does) and for runs of 8 chunks per push (a client that uploads faster than real time).
+    Round 4's Python scheduler served this shape at 8.9 k audio-s/s."""
+    import json
+    import time
+    import __graft_entry__ as graft
+    graft.build()
+    from libreasr_amd.engine import Engine
+    from libreasr_amd.front import RES_EOF, NativeFront, bench_native_producers
+    from oracle import torch_cpu as TC
+
+    cfg = synth.model_cfg("cfg2")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    B, n = 64, 64
+    pcm = np.stack([synth.synth_pcm(1, n * 1280, seed=1234 + s)[0] for s in range(B)])
+    _, ref = TC.time_stream_path_batched(sd, cfg, list(pcm), n, threads=8)
+    assert sum(len(r) for r in ref) > 500
+    eng = Engine(sd, cfg, max_streams=B)
+    rates = {}
+    try:
+        for run_len in (1, 8):
+            front = NativeFront(eng, depth=12, reset_steps=0)
+            try:
+                sids = [front.open() for _ in range(B)]
+                got = [[] for _ in range(B)]
+                start = threading.Barrier(B + 1)
+
+                def producer(i):
+                    start.wait()
+                    for k in range(0, n, run_len):
+                        front.push(sids[i], pcm[i, k * 1280:(k + run_len) * 1280])
+                    front.eof(sids[i])
+                    while True:
+                        toks, flags = front.next(sids[i])
+                        if flags & RES_EOF:
+                            break
+                        got[i] += toks
+
+                ths = [threading.Thread(target=producer, args=(i,)) for i in range(B)]
+                [t.start() for t in ths]
+                start.wait()
+                t0 = time.perf_counter()
+                [t.join(timeout=300) for t in ths]
+                dt = time.perf_counter() - t0
+                bad = [i for i in range(B) if got[i] != ref[i]]
+                assert not bad, f"run length {run_len}: streams {bad} differ from the reference path"
+                st = front.stats()
+                rates[f"chunks_per_push_{run_len}"] = {"audio_sec_per_sec": round(B * n * 0.08 / dt, 1), "seconds": round(dt, 4),
+                                                       "rows_per_model_step": round(st["rows"] / max(1, st["steps"]), 2), **st}
+                for s_ in sids:
+                    front.close(s_)
+            finally:
+                front.destroy()
+        # the front with NATIVE per-stream producers (lasr_bench_front: one std::thread per stream, one chunk per push): what the
+        # per-stream form carries when the producers are not Python threads taking turns on the GIL
+        long_pcm = np.concatenate([pcm] * 4, axis=1)                      # 256 chunks per stream for a steadier figure
+        _, ref_long = TC.time_stream_path_batched(sd, cfg, list(long_pcm), 4 * n, threads=8)
+        for run_len in (1, 4):
+            toks, sec, st = bench_native_producers(eng, long_pcm, depth=12, chunks_per_push=run_len)
+            bad = [i for i in range(B) if toks[i] != ref_long[i]]
+            assert not bad, f"native producers: streams {bad} differ from the reference path"
+            rates[f"native_producers_chunks_per_push_{run_len}"] = {"audio_sec_per_sec": round(B * 4 * n * 0.08 / sec, 1), "seconds": round(sec, 4),
+                                                                   "rows_per_model_step": round(st["rows"] / max(1, st["steps"]), 2), **st}
+        rates["note"] = ("64 streams of configs[1] (f32 greedy) on the native front: chunks_per_push_* = one PYTHON producer thread per stream, "
+                         "64 chunks each (GIL-bound); native_producers_* = one native thread per stream, 256 chunks each; "
+                         "tokens == the reference's torch-CPU path for every stream in every leg")
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "served_rate_native.json"), "w") as f:
+            json.dump(rates, f, indent=1)
+        print("served rates (native front):", rates)
+        assert rates["native_producers_chunks_per_push_1"]["rows_per_model_step"] > 48
+    finally:
+        eng.close()

@@ -356,3 +356,29 @@ def test_wav_reader_header_edge_cases(tmp_path):
     open(p, "wb").write(riff(struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16), b""))
     with pytest.raises(ValueError):
         wav.decode(p)
+
+
+def test_every_library_switch_is_documented_with_an_owner():
+    """docs/SWITCHES.md lists exactly the LASR_* variables the library reads (grep getenv in csrc/), each with an owner test
+    or tool that exists in the tree (no experiment toggles without an owner)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    for p in glob.glob(os.path.join(root, "libreasr_amd", "csrc", "*.h*")):
+        read |= set(re.findall(r'getenv\("(LASR_[A-Z0-9_]+)"\)', open(p).read()))
+    doc = open(os.path.join(root, "docs", "SWITCHES.md")).read()
+    rows = [ln for ln in doc.splitlines() if ln.startswith("| `LASR_")]
+    documented = set()
+    for ln in rows:
+        cells = [c.strip() for c in ln.strip("|").split("|")]
+        names = re.findall(r"`(LASR_[A-Z0-9_]+)`", cells[0])
+        documented |= set(names)
+        owner = cells[-1]
+        files = re.findall(r"`?((?:tests|tools)/[\w/]+\.py|test_\w+\.py)", owner)
+        assert files, f"no owner for {names}"
+        for f in files:
+            path = f if "/" in f else os.path.join("tests", f)
+            assert os.path.exists(os.path.join(root, path)), (names, path)
+    assert read == documented, (read - documented, documented - read)
+    assert len(read) <= 30
