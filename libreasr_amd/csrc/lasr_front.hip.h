@@ -31,6 +31,8 @@ struct lasr_front {
         // mirrors of the engine's window / Buffer bookkeeping, and the rule's counters (front thread only)
         long long n_chunks = 0; int n_pend = 0;
         int infl = 0; long long stp = 0;
+        int judged = 0;                       // steps in flight already judged (and counted in stp) through an early verdict
+        bool early_reset_pending = false;     // ... and the last of them ended in a reset (reported with that step's result)
         // results: one entry per collected model step
         std::mutex rm; std::condition_variable rcv;
         struct Res { std::vector<int32_t> tok; int flags; };
@@ -53,6 +55,8 @@ struct lasr_front {
     bool out_busy = false;                    // the delivery thread holds a record it has taken off outq (under om)
     int rc = 0; std::string err;              // first engine error: the front stops, every call returns it
     std::atomic<long long> n_ticks{0}, n_steps{0}, n_rows{0}, n_resets{0};
+    int held_last = 0;                        // streams the last tick found held at the reset threshold (early verdicts are tried for them)
+    std::vector<int> ev_slots, ev_skip, ev_cnt, ev_ndec, ev_nfl; std::vector<int32_t> ev_tok;
     // scratch of the front thread
     std::vector<int> slots, step_rows; std::vector<const float*> rows; std::vector<int32_t> tokbuf; std::vector<int> cnt;
 };
@@ -118,6 +122,11 @@ int front_collect(lasr_front* f) {
     for (size_t i = 0; i < rows.size(); ++i) {
         lasr_front::Stream& s = *f->st[rows[i]];
         s.infl--;
+        if (s.judged > 0) {                  // judged (and counted, and reset if the rule said so) when its row was decoded
+            s.judged--;
+            if (s.early_reset_pending && s.judged == 0) { o.flags[i] |= FRONT_RES_RESET; s.early_reset_pending = false; }
+            continue;
+        }
         s.stp++;
         if (f->reset_steps > 0 && s.stp >= f->reset_steps && f->cnt[i] == 0) {
             // (the stream has nothing else in flight: see the hold rule in front_tick)
@@ -133,13 +142,55 @@ int front_collect(lasr_front* f) {
     return LASR_OK;
 }
 
+// Early verdicts: a stream held at the reset threshold is judged as soon as its row is decoded (lasr_peek_many), not when its
+// step is collected `steps in flight` later; a reset the rule asks for is applied at once (LASR_RESET_IF_DECODED: the slot's
+// steps are decoded, not collected) and the stream's next step can start.  em held.
+int front_early_verdicts(lasr_front* f) {
+    f->ev_slots.clear(); f->ev_skip.clear();
+    for (auto& sp : f->st) {
+        if (!sp || !sp->open.load(std::memory_order_acquire) || sp->closing) continue;
+        const int unj = sp->infl - sp->judged;
+        if (unj > 0 && sp->stp + unj >= f->reset_steps) { f->ev_slots.push_back(sp->slot); f->ev_skip.push_back(sp->judged); }
+    }
+    const int n = (int)f->ev_slots.size();
+    if (!n) return LASR_OK;
+    const int cap = f->max_tok * (f->depth + 1), cap_steps = f->depth + 1;
+    f->ev_tok.resize((size_t)n * cap); f->ev_cnt.assign((size_t)n * cap_steps, 0); f->ev_ndec.assign(n, 0); f->ev_nfl.assign(n, 0);
+    int rc = lasr_peek_many(f->c, f->ev_slots.data(), n, f->ev_skip.data(), f->ev_tok.data(), cap, f->ev_cnt.data(), cap_steps,
+                            f->ev_ndec.data(), f->ev_nfl.data());
+    if (rc == LASR_EFULL) return LASR_OK;                 // (verdicts fall back to collect time)
+    if (rc) return front_fail(f, rc);
+    for (int q = 0; q < n; ++q) {
+        lasr_front::Stream& s = *f->st[f->ev_slots[q]];
+        const int k_new = f->ev_ndec[q] - f->ev_skip[q];
+        for (int k = 0; k < k_new; ++k) {
+            s.judged++;
+            s.stp++;
+            if (s.stp >= f->reset_steps && f->ev_cnt[(size_t)q * cap_steps + k] == 0) {
+                // past the threshold a stream has ONE unjudged step in flight at a time: this was its last, and it is decoded
+                if (s.judged != f->ev_nfl[q]) {
+                    fail(f->c, LASR_ESTATE, "front: slot %d ran ahead of the reset threshold (%d steps in flight, %d judged)", s.slot, f->ev_nfl[q], s.judged);
+                    return front_fail(f, LASR_ESTATE);
+                }
+                rc = lasr_stream_reset(f->c, s.slot, 1 | 2 | 4 | LASR_RESET_IF_DECODED);
+                if (rc) return front_fail(f, rc);
+                s.stp = 0;
+                s.early_reset_pending = true;
+                f->n_resets.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
+    }
+    return LASR_OK;
+}
+
 // one tick: one chunk of every stream that has one waiting and may run.  Returns 1 when something was done.  em held.
 int front_tick(lasr_front* f, bool* did) {
     *did = false;
     lasr_ctx* c = f->c;
     while ((int)f->inflight.size() >= f->depth) { int rc = front_collect(f); if (rc) return rc; *did = true; }
     f->slots.clear(); f->rows.clear(); f->step_rows.clear();
-    int n_step = 0, n_fill = 0, n_absent = 0;
+    int n_step = 0, n_fill = 0, n_absent = 0, n_held = 0;
+    if (f->reset_steps > 0 && f->held_last > 0) { int rc = front_early_verdicts(f); if (rc) return rc; }
     // pass 1: classify
     struct Cand { int slot; bool stepper; };
     static thread_local std::vector<Cand> cand;
@@ -160,10 +211,11 @@ int front_tick(lasr_front* f, bool* did) {
         }
         const bool stepper = s.n_chunks + 1 >= f->n_window && s.n_pend + 1 == f->n_buffer;
         // the step in flight may end in a reset (its ordinal since the last reset is >= reset_steps): its verdict first
-        if (stepper && f->reset_steps > 0 && s.infl > 0 && s.stp + s.infl >= f->reset_steps) continue;
+        if (stepper && f->reset_steps > 0 && s.infl - s.judged > 0 && s.stp + (s.infl - s.judged) >= f->reset_steps) { n_held++; continue; }
         cand.push_back({s.slot, stepper});
         (stepper ? n_step : n_fill)++;
     }
+    f->held_last = n_held;
     if (cand.empty()) {
         if (!f->inflight.empty()) { int rc = front_collect(f); if (rc) return rc; *did = true; }   // nothing waiting: results at once
         return LASR_OK;
@@ -302,7 +354,7 @@ int lasr_front_open(lasr_front* f, int* stream) {
     s.slot = slot; s.closing = false; s.eof_out = false;
     s.ring.assign((size_t)f->ring_chunks * f->chunk, 0.f);
     s.head.store(0); s.tail.store(0); s.eof_in.store(false);
-    s.n_chunks = 0; s.n_pend = 0; s.infl = 0; s.stp = 0;
+    s.n_chunks = 0; s.n_pend = 0; s.infl = 0; s.stp = 0; s.judged = 0; s.early_reset_pending = false;
     { std::lock_guard<std::mutex> rl(s.rm); s.res.clear(); }
     s.open.store(true, std::memory_order_release);
     *stream = slot;

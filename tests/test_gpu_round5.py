@@ -421,6 +421,13 @@ def test_native_front_64_per_stream_producers_with_served_rate():
             assert not bad, f"native producers: streams {bad} differ from the reference path"
             rates[f"native_producers_chunks_per_push_{run_len}"] = {"audio_sec_per_sec": round(B * 4 * n * 0.08 / sec, 1), "seconds": round(sec, 4),
                                                                    "rows_per_model_step": round(st["rows"] / max(1, st["steps"]), 2), **st}
+        # the servicer's reset rule on every stream (25 steps = 4 s): the tokens with 12 steps in flight + early verdicts must be
+        # those of ONE step in flight (every verdict known before the stream's next step: the reference's order of events)
+        t12, sec12, st12 = bench_native_producers(eng, long_pcm, depth=12, reset_steps=25, cap=8192)
+        t1, _, st1 = bench_native_producers(eng, long_pcm, depth=1, reset_steps=25, cap=8192)
+        assert t12 == t1 and st12["resets"] == st1["resets"] and st12["resets"] > 100
+        rates["native_producers_reset_rule"] = {"audio_sec_per_sec": round(B * 4 * n * 0.08 / sec12, 1), "seconds": round(sec12, 4),
+                                                "rows_per_model_step": round(st12["rows"] / max(1, st12["steps"]), 2), **st12}
         rates["note"] = ("64 streams of configs[1] (f32 greedy) on the native front: chunks_per_push_* = one PYTHON producer thread per stream, "
                          "64 chunks each (GIL-bound); native_producers_* = one native thread per stream, 256 chunks each; "
                          "tokens == the reference's torch-CPU path for every stream in every leg")
