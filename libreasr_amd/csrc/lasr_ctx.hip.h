@@ -152,6 +152,13 @@ struct lasr_ctx {
     int work_left = 0;              // rows that still had encoded frames to decode when the last consumed group ended
     long long model_steps = 0, cont_iters = 0, iters_reported = 0;
     bool group_inflight = false;    // a decode group has been launched and its flag not yet consumed
+    // The flag of a group is published by its LAST SELECTION kernel; the predictor cells and the joint half of that iteration run
+    // behind it on the decode stream and write the rows' predictor state (emitting rows: the cell; the others: the carry into the
+    // other parity).  Work that touches the decode state from the ctx stream once the pipeline has drained (a reset of an idle
+    // context, the synchronous protocol) first makes the ctx stream wait for the decode stream (order_after_decode_tail).  Round 5:
+    // a reset right behind lasr_step_wait at ONE step in flight raced with that tail -- 1 reset of 303 lost in the first run of a
+    // fresh context, found by the native front's depth-12 == depth-1 check against the numpy oracle.
+    bool dec_tail_open = false;
     // native pump thread of the pipelined protocol (lasr_engine.hip, pump_main): owns the group launches while steps are in flight.
     // mu guards the decode-side host state: pending, h_avail, h_cur_seen, work_left, group_inflight, cont_iters, pred_par / lm.par,
     // the beam's host trees and results

@@ -451,6 +451,15 @@ int check_slots(lasr_ctx* c, const int* slots, int n, bool need_open) {
     return LASR_OK;
 }
 
+// c->mu held.  The ctx stream waits (on the GPU, the host does not block) for whatever the last decode group still has queued
+// behind its published flag: see lasr_ctx::dec_tail_open
+int order_after_decode_tail(lasr_ctx* c) {
+    if (!c->dec_tail_open || !c->stream_dec || !c->ev_misc) return LASR_OK;
+    HIPCHK(c, hipEventRecord(c->ev_misc, c->stream_dec));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_misc, 0));
+    c->dec_tail_open = false;
+    return LASR_OK;
+}
 int require_idle(lasr_ctx* c) {
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->pending.empty()) return fail(c, LASR_ESTATE, "%d submitted step(s) not collected: call lasr_step_wait first", (int)c->pending.size());
@@ -458,8 +467,9 @@ int require_idle(lasr_ctx* c) {
         HIPCHK(c, hipStreamSynchronize(c->stream_dec));      // use the same decode state on the ctx stream
         cont_poll(c);                                        // (its flag and cursors are there now)
         c->group_inflight = false;
+        c->dec_tail_open = false;
     }
-    return LASR_OK;
+    return order_after_decode_tail(c);
 }
 
 bool is_device_ptr(const void* p) {

@@ -556,6 +556,7 @@ static int reset_impl(lasr_ctx* c, const int* slots, int n, int what) {
         RC(cmd_commit(c));
         std::lock_guard<std::mutex> lk(c->mu);            // (decode-side launches: the pump thread stays out)
         if (c->pending.empty() && !c->group_inflight) {
+            RC(order_after_decode_tail(c));          // (the last group's predictor cells may still be running on the decode stream)
             RC(apply_reset(c, (what & 2) != 0));
         } else {
             // other streams have steps in flight: the encoder side of the reset is ordered on the main
@@ -1477,6 +1478,7 @@ static int cont_launch_group(lasr_ctx* c, int G, bool from_pump = false) {
     c->tr_last_G = G;
     c->cont_iters += G;
     c->group_inflight = true;
+    c->dec_tail_open = true;
     HIPCHK(c, hipGetLastError());
     return LASR_OK;
 }

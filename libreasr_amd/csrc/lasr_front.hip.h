@@ -55,6 +55,7 @@ struct lasr_front {
     bool out_busy = false;                    // the delivery thread holds a record it has taken off outq (under om)
     int rc = 0; std::string err;              // first engine error: the front stops, every call returns it
     std::atomic<long long> n_ticks{0}, n_steps{0}, n_rows{0}, n_resets{0};
+    bool early = true;
     int held_last = 0;                        // streams the last tick found held at the reset threshold (early verdicts are tried for them)
     std::vector<int> ev_slots, ev_skip, ev_cnt, ev_ndec, ev_nfl; std::vector<int32_t> ev_tok;
     // scratch of the front thread
@@ -190,7 +191,7 @@ int front_tick(lasr_front* f, bool* did) {
     while ((int)f->inflight.size() >= f->depth) { int rc = front_collect(f); if (rc) return rc; *did = true; }
     f->slots.clear(); f->rows.clear(); f->step_rows.clear();
     int n_step = 0, n_fill = 0, n_absent = 0, n_held = 0;
-    if (f->reset_steps > 0 && f->held_last > 0) { int rc = front_early_verdicts(f); if (rc) return rc; }
+    if (f->reset_steps > 0 && f->early && f->held_last > 0) { int rc = front_early_verdicts(f); if (rc) return rc; }
     // pass 1: classify
     struct Cand { int slot; bool stepper; };
     static thread_local std::vector<Cand> cand;
@@ -312,7 +313,8 @@ int lasr_front_create(lasr_ctx* c, int depth, int reset_steps, lasr_front** out)
     lasr_front* f = new lasr_front();
     f->c = c;
     f->depth = std::max(1, std::min(depth > 0 ? depth : 12, lasr_max_inflight(c)));
-    f->reset_steps = std::max(0, reset_steps);
+    f->reset_steps = std::abs(reset_steps);
+    f->early = reset_steps > 0;               // (reset_steps < 0: the same rule without early verdicts -- every verdict at collect time: A/B aid)
     f->chunk = c->d.chunk; f->n_window = c->d.n_window; f->n_buffer = c->d.n_buffer;
     f->max_tok = std::max(16, c->d.n_buffer * c->d.max_iters_stream + 4);
     f->st.resize(c->d.max_streams);

@@ -438,3 +438,44 @@ def test_native_front_64_per_stream_producers_with_served_rate():
         assert rates["native_producers_chunks_per_push_1"]["rows_per_model_step"] > 48
     finally:
         eng.close()
+
+
+def test_reset_right_behind_step_wait_waits_for_the_decode_tail():
+    """Regression (round 5): with ONE step in flight a reset the rule asks for is issued the moment lasr_step_wait returns -- the
+    decode group's flag is published by its last selection kernel while that iteration's predictor cells (incl. the carry of the
+    non-emitting rows into the other parity) are still running on the decode stream; the reset's kernels on the ctx stream raced
+    with them and a reset was lost (1 of 303, streams 2 and 25, only in the FIRST run of a fresh context).  The scenario, on a
+    fresh context, against the numpy oracle with the servicer's rule for the two streams that showed it and two more."""
+    import __graft_entry__ as graft
+    graft.build()
+    from libreasr_amd.engine import Engine
+    from libreasr_amd.front import bench_native_producers
+    from oracle import rnnt_oracle as O
+
+    cfg = synth.model_cfg("cfg2")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    B, n = 64, 256
+    base = np.stack([synth.synth_pcm(1, 64 * 1280, seed=1234 + s)[0] for s in range(B)])
+    pcm = np.concatenate([base] * 4, axis=1)
+    eng = Engine(sd, cfg, max_streams=B)
+    try:
+        first, _, st = bench_native_producers(eng, pcm, depth=1, reset_steps=25, cap=8192)        # the first run of this context
+        m = O.OracleTransducer(sd, cfg)
+        for i in (2, 25, 7, 40):
+            fe, dec = O.StreamFrontend(), m.stream_decoder()
+            y, steps = [], 0
+            for k in range(n):
+                o = fe.push(pcm[i, k * 1280:(k + 1) * 1280])
+                if o is None:
+                    continue
+                ys = dec.step(o)
+                steps += 1
+                y += ys
+                if not ys and O.should_reset(steps):
+                    dec.reset()
+                    steps = 0
+            assert first[i] == y, f"stream {i}"
+        again, _, st2 = bench_native_producers(eng, pcm, depth=12, reset_steps=25, cap=8192)
+        assert again == first and st2["resets"] == st["resets"]
+    finally:
+        eng.close()
