@@ -153,7 +153,7 @@ int lasr_step_window(lasr_ctx* c, const int* slots, int n, const float* pcm, int
  * 0 if no model step was pending); rows that finish a step early continue with the frames of the later,
  * already encoded steps.  Issue submit(k+1) ... before wait(k): the encoders of the next chunks then
  * overlap the latency-bound decode loop.  Up to lasr_max_inflight() model steps may be submitted and not
- * yet collected: 15 with the reference front-end (n_buffer 2, max_iters_stream 10); fewer when n_buffer *
+ * yet collected: 25 with the reference front-end (n_buffer 2, max_iters_stream 10; 15 until round 5); fewer when n_buffer *
  * max_iters_stream is large (the limit keeps the per-row rings of encoder frames (64) and tokens (512) from
  * wrapping).  A deep pipeline is what absorbs bursty streams: a row that emits many tokens on a few frames falls
  * behind while the others run ahead on the frames of later steps.  At the limit lasr_step_submit returns LASR_ESTATE and changes nothing (the pushed chunk stays

@@ -129,7 +129,7 @@ struct lasr_ctx {
     double lm_stream_ratio[2] = {0.0, 0.0};   // overlap probe of stream_lm against the main / the decode stream
     int dec_stream_attempts = 0;    // streams tried at creation until one ran concurrently with the ctx stream (see create_impl)
     double dec_stream_ratio = 0.0;  // the chosen stream's probe (wall / delay: ~1 concurrent, ~2 one hardware queue)
-    static constexpr int NFLY = 16; // steps in flight (ring of encoder-done events)
+    static constexpr int NFLY = 32; // ring of encoder-done events: up to NFLY - 1 steps in flight (round 5: 16 -> 32; the token ring binds first: 25)
     static constexpr int RING = 64; // pe ring, frames per row
     static constexpr int TOKRING = 512, ENDSLOTS = 32;
     hipEvent_t ev_enc[NFLY] = {};
@@ -164,6 +164,7 @@ struct lasr_ctx {
     // the beam's host trees and results
     std::mutex mu;
     std::condition_variable cv_pump;
+    std::condition_variable cv_prog;          // lasr_step_wait sleeping on the pump's progress counter (under mu)
     std::thread pump_th;
     bool pump_started = false, pump_on = false;
     std::atomic<bool> pump_stop{false};

@@ -1538,6 +1538,7 @@ static void cont_poll(lasr_ctx* c) {
         tr_note(c, 20, need * 1000.0 + c->tr_last_G * 100.0 + v + rows / 1000.0);
     }
     c->progress.fetch_add(1, std::memory_order_release);
+    c->cv_prog.notify_all();           // (c->mu held: a lasr_step_wait that sleeps on the counter checks it under the same mutex)
 }
 
 // non-blocking: launch the next group of G iterations if none is in flight and frames are waiting (or the encoder
@@ -1569,7 +1570,7 @@ static void pump_main(lasr_ctx* c) {
             if (c->pump_stop.load(std::memory_order_acquire)) return;
             if (c->pump_on && c->pump_rc == 0) {
                 const int rc = cont_pump_locked(c, c->pump_G, true);
-                if (rc < 0) { c->pump_rc = rc; c->progress.fetch_add(1, std::memory_order_release); }
+                if (rc < 0) { c->pump_rc = rc; c->progress.fetch_add(1, std::memory_order_release); c->cv_prog.notify_all(); }
                 // (rc 1: the graph for this parity is missing -- the API thread captures it with its next call)
             }
             inflight = c->group_inflight;
@@ -1649,10 +1650,19 @@ int lasr_step_wait(lasr_ctx* c, int* n_ran) {
                 if (c->pump_rc) return fail(c, c->pump_rc, "decode pump: %s", c->pump_err.c_str());
                 if (cont_step_done(c, c->pending.front())) break;
             }
+            // a short spin (a group that is about to publish), then the thread sleeps until the pump has consumed the next group's
+            // flag (cont_poll notifies): with 20 steps in flight a collect has slack, and a rank no longer burns a core waiting
+            // (round 5: 2.65 -> see profiles/r05 host cores per rank).  The time-out kicks a sleeping pump (backstop).
             unsigned long long spins = 0;
             while (c->progress.load(std::memory_order_acquire) == seen) {
                 __builtin_ia32_pause();
-                if (++spins > (1ull << 22)) { pump_kick(c); break; }      // (~10 ms: re-check; wakes a sleeping pump)
+                if (++spins > 3000) {
+                    std::unique_lock<std::mutex> lk(c->mu);
+                    const bool moved = c->cv_prog.wait_for(lk, std::chrono::milliseconds(10), [&] { return c->progress.load(std::memory_order_acquire) != seen || c->pump_rc != 0; });
+                    lk.unlock();
+                    if (!moved) pump_kick(c);
+                    break;
+                }
             }
             if (guard > (1u << 16)) return fail(c, LASR_EHIP, "decode loop did not converge");
         }

@@ -79,9 +79,9 @@ def test_inflight_limit_is_what_the_header_says():
     from libreasr_amd._native import LASR_ESTATE, LasrError
     eng, sd, cfg = make("tiny", max_streams=16)
     try:
-        assert eng.lib.lasr_max_inflight(eng.ctx) == 15
+        assert eng.lib.lasr_max_inflight(eng.ctx) == 25
         m = O.OracleTransducer(sd, cfg)
-        n = 60
+        n = 80
         pcm = synth.synth_pcm(2, n * 1280, seed=5)
         slots = [eng.open() for _ in range(2)]
         got = [[], []]
@@ -90,14 +90,14 @@ def test_inflight_limit_is_what_the_header_says():
             eng.push(slots, np.stack([p[k * 1280:(k + 1) * 1280] for p in pcm]))
             try:
                 eng.submit(slots)
-            except LasrError as e:                  # the 16th model step in flight
-                assert e.code == LASR_ESTATE and eng.pending() == 15
+            except LasrError as e:                  # the 26th model step in flight
+                assert e.code == LASR_ESTATE and eng.pending() == 25
                 refused += 1
                 assert eng.wait() == 2              # collect the oldest, then the same submit goes through
                 for i, t in enumerate(eng.fetch_many(slots, 64)):
                     got[i] += t
                 eng.submit(slots)
-        assert refused > 0 and eng.pending() == 15
+        assert refused > 0 and eng.pending() == 25
         while eng.pending():
             eng.wait()
             for i, t in enumerate(eng.fetch_many(slots, 64)):

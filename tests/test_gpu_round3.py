@@ -38,11 +38,12 @@ def oracle_stream(m, pcm_row, n_chunks, n_buffer=2):
     return dec.y
 
 
-def test_config1_64_rows_depth_12_push_submit_against_the_reference_path():
+@pytest.mark.parametrize("depth", [12, 20, 25])        # round 3-4's bench depth, round 5's default, the engine's limit
+def test_config1_64_rows_depth_12_push_submit_against_the_reference_path(depth):
     from oracle import torch_cpu as TC
     eng, sd, cfg = make("cfg2", max_streams=64)
     try:
-        B, n, depth = 64, 72, 12
+        B, n = 64, 72
         pcm = np.stack([synth.synth_pcm(1, n * 1280, seed=1234 + s)[0] for s in range(B)])
         dev = torch.as_tensor(pcm.reshape(B, n, 1280).transpose(1, 0, 2).copy()).cuda()
         slots = [eng.open() for _ in range(B)]
