@@ -138,6 +138,59 @@ def cell_flops(cfg, layer, rows):
     return 2.0 * rows * 4 * H * (I + H)
 
 
+def timeline_breakdown(marks):
+    """Per-model-step budget of the two streams from lasr_trace marks (tools/stream_timeline.py, condensed).  Main stream: 1 push,
+    3 first cell, 4 cells done, 5 model step enqueued; decode stream: 10 group reached, 11 + 100 G (+ 1000: steps admitted)
+    admission done, 12 group done.  Microseconds; None when the region is too short."""
+    m = [(t, us) for t, us in marks if us >= 0 and t != 20]
+    steps, cur = [], {}
+    for t, us in m:
+        if t >= 10:
+            continue
+        if t == 1:
+            cur.setdefault("push", []).append(us)
+        elif t == 3:
+            cur["c0"] = us
+        elif t == 4:
+            cur["c1"] = us
+        elif t == 5:
+            cur["end"] = us
+            if "c0" in cur and "c1" in cur and len(cur.get("push", [])) >= 2:
+                steps.append(cur)
+            cur = {}
+    steps = steps[len(steps) // 3:]
+    if len(steps) < 8:
+        return None
+    period = float(np.mean(np.diff([q["end"] for q in steps])))
+    out = {"main_period_us": round(period, 1),
+           "frontend_us": round(float(np.mean([q["c0"] - q["push"][-2] for q in steps])), 1),
+           "encoder_cells_us": round(float(np.mean([q["c1"] - q["c0"] for q in steps])), 1),
+           "joint_half_us": round(float(np.mean([q["end"] - q["c1"] for q in steps])), 1),
+           "main_idle_us": round(float(np.mean([b["push"][-2] - a["end"] for a, b in zip(steps[:-1], steps[1:])])), 1)}
+    groups, g = [], {}
+    for t, us in m:
+        if t < 10:
+            continue
+        if t == 10:
+            g = {"reach": us}
+        elif t % 100 == 11:
+            g["adm"], g["G"] = us, (t % 1000) // 100
+        elif t == 12:
+            g["end"] = us
+            if "adm" in g and "reach" in g:
+                groups.append(g)
+            g = {}
+    groups = [q for q in groups if q["reach"] >= steps[0]["push"][0]]
+    if len(groups) >= 4:
+        span = groups[-1]["end"] - groups[0]["reach"]
+        busy = sum(q["end"] - q["adm"] for q in groups)
+        it = sum(q["G"] for q in groups)
+        out.update({"decode_us_per_iteration": round(busy / max(1, it), 1), "decode_iterations_per_step": round(it / (span / period), 2),
+                    "decode_stream_busy_frac": round(busy / span, 3),
+                    "decode_waiting_for_an_encoder_frac": round(sum(q["adm"] - q["reach"] for q in groups) / span, 3)})
+    return out
+
+
 def decode_weight_bytes(cfg, esz):
     """Bytes of predictor / joint weights ONE greedy decode iteration streams (whatever the number of rows that emitted):
     predictor layer 0 recurrent half (the input half is a per-token table), layers >= 1 both halves, the predictor half of
@@ -781,6 +834,24 @@ def main():
                                     "note": "the headline job again, back to back for this long, same process and engine"}
             except Exception as e:
                 out["sustained"] = {"error": str(e)[:200]}
+        if world == 1 and pipelined and not args.trace and extras:
+            # where a model step's time goes on each stream: 40 further steps of the same job with the library's trace marks on
+            # (event records on both streams: they cost a few microseconds each, which is why the timed region carries none)
+            try:
+                eng.trace(True)
+                try:
+                    timed_region(k_next, 40 * CPS, None, host=args.host_pcm, barrier=False)
+                    k_next += 40 * CPS
+                    tl = timeline_breakdown(eng.trace_read())
+                finally:
+                    eng.trace(False)
+                if tl:
+                    out["stream_timeline_us_per_model_step"] = {**tl, "measured_in": "the last two thirds of 40 further steps of the same job with lasr_trace marks on both streams (event records: the marks slow the job by a few percent)"}
+                    out["stage_ms_per_model_step"].update({"frontend": round(tl["frontend_us"] / 1e3, 4), "encoder": round(tl["encoder_cells_us"] / 1e3, 4),
+                                                           "decode": round(tl.get("decode_us_per_iteration", 0.0) * tl.get("decode_iterations_per_step", 0.0) / 1e3, 4) or None,
+                                                           "note": "pipelined protocol: from the traced steps (stream_timeline_us_per_model_step); the two stages overlap on two streams"})
+            except Exception as e:
+                out["stream_timeline_us_per_model_step"] = {"error": str(e)[:200]}
         if NCHK:
             # self-check: the first NCHK streams again, from their first chunk, on freshly reset slots through the SYNCHRONOUS
             # protocol (push -> step -> fetch per chunk); per model step the tokens must equal what the run above fetched

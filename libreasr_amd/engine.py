@@ -94,6 +94,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "ctx", None):
+            for fr in list(getattr(self, "_fronts", ())):      # a native front's threads use the context: they go first
+                fr.destroy()
             self.lib.lasr_destroy(self.ctx)
             self.ctx = None
 

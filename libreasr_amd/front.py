@@ -22,6 +22,9 @@ class NativeFront:
         engine._chk(self.lib.lasr_front_create(engine.ctx, int(depth), int(reset_steps), C.byref(h)))
         self.h = h
         self._cap = max(64, int(engine.desc.n_buffer) * int(engine.desc.max_iters_stream) + 4)
+        if not hasattr(engine, "_fronts"):
+            engine._fronts = []
+        engine._fronts.append(self)          # Engine.close() destroys the front before the context its threads use
 
     def _chk(self, rc):
         if rc < 0:
@@ -78,9 +81,18 @@ class NativeFront:
         return dict(zip(("ticks", "steps", "rows", "resets"), (int(x.value) for x in v)))
 
     def destroy(self):
+        """Stops the front's threads (join the producers / consumers of its streams first: they must not be inside push / next)."""
         if self.h:
             self.lib.lasr_front_destroy(self.h)
             self.h = None
+            if self in getattr(self.eng, "_fronts", ()):
+                self.eng._fronts.remove(self)
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
     shutdown = destroy                      # (same name as the Python scheduler's)
 
