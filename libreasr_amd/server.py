@@ -728,8 +728,10 @@ class Scheduler(threading.Thread):
                     if s.n_pend == d.n_buffer:
                         s.n_pend = 0
                         self.stp[s.slot] += 1
-                        if s.text_of is not None:
-                            self._judge(s, t)
+                        # (the servicer's reset rule for these streams too -- api-server.py:131-134 does not look at the client's
+                        #  rate; round 5: the verdict used to be computed and dropped.  Nothing of the slot is in flight here.)
+                        if s.text_of is not None and self._judge(s, t):
+                            self._reset(s.slot)
                         cell.append(t)
                     else:
                         cell.append(None)

@@ -159,6 +159,19 @@ def golden_servicer(name="tiny"):
         out[f"resets_{i}"] = np.array(resets, dtype=np.int32)      # value of `steps` at each reset (>= 25 = 4 s / 160 ms)
         out[f"unary_{i}"] = np.str_(text)
         print(f"  servicer {name} stream {i}: {len(pcm) / 16000:.2f} s, {len(msgs)} messages, resets at steps {list(resets)}")
+    # the same servicer code on a client that sends 100 ms frames (1600 samples): the per-window path of the engine
+    # (lasr_step_window) and the servers' generic-client form are checked against this, resets included
+    i = 4
+    pcm = servicer_pcm(*SERVICER_STREAMS[i])
+    s_tfm.fs[-1].saved.clear()
+    del resets[:]
+    reqs = [mod.ap.Audio(data=c.tobytes(), sr=16000) for c in synth.stream_chunks(pcm, 1600, lead=1, tail=8)]
+    with torch.no_grad():
+        msgs = [t_.data for t_ in sv.TranscribeStream(iter(reqs), None)]
+    out["msgs100_4"] = np.array(msgs if msgs else [""], dtype=np.str_)
+    out["n_msgs100_4"] = np.int32(len(msgs))
+    out["resets100_4"] = np.array(resets, dtype=np.int32)
+    print(f"  servicer {name} stream {i} in 100 ms frames: {len(msgs)} messages, resets at steps {list(resets)}")
     np.savez_compressed(os.path.join(OUT, f"servicer_{name}.npz"), **out)
 
 

@@ -346,6 +346,15 @@ def test_native_front_grpc_equals_the_reference_servicer(golden_dir):
             got48 = [t.data for t in stub.TranscribeStream(
                 ap.Audio(data=c.tobytes(), sr=48000) for c in synth.stream_chunks(pcm48, 3840, lead=1, tail=10))]
             assert got48 == O.servicer_stream(m, pcm48, lang.denumericalize, sr=48000, chunk=3840)[0] and got48
+            # ... and a 100 ms client with a > 4 s silent stretch: the reset rule applies on the per-window path too (api-server.py:131-134)
+            sil = synth.servicer_pcm(*synth.SERVICER_STREAMS[4])
+            want, resets = O.servicer_stream(m, sil, lang.denumericalize, chunk=1600, tail=8)
+            assert len(resets) >= 2, "the stream was meant to cross the reset threshold"
+            got = [t.data for t in stub.TranscribeStream(
+                ap.Audio(data=c.tobytes(), sr=16000) for c in synth.stream_chunks(sil, 1600, lead=1, tail=8))]
+            assert got == want
+            gs = np.load(os.path.join(golden_dir, "servicer_tiny.npz"))
+            assert got == [str(v) for v in gs["msgs100_4"][:int(gs["n_msgs100_4"])]]        # ... and == the reference's own servicer
             got100 = [t.data for t in stub.TranscribeStream(
                 ap.Audio(data=c.tobytes(), sr=16000) for c in synth.stream_chunks(pcm[1], 1600, lead=1, tail=8))]
             assert got100 == O.servicer_stream(m, pcm[1], lang.denumericalize, chunk=1600, tail=8)[0]

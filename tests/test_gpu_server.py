@@ -2,6 +2,7 @@
 batching scheduler: concurrent TranscribeStream clients + a unary Transcribe, against transcripts
 derived from the oracle with the servicer's own diff / reset rules."""
 import itertools as it
+import os
 import threading
 
 import numpy as np
@@ -91,6 +92,15 @@ def test_grpc_server_batched_streams_and_unary():
                 ap.Audio(data=c.tobytes(), sr=48000) for c in synth.stream_chunks(pcm48, 3840, lead=1, tail=10))]
             assert got48 == expected_stream_transcripts(m, pcm48, lang, sr=48000, chunk=3840)
             assert len(got48) > 0
+            # ... and a 100 ms client with a > 4 s silent stretch: the reset rule applies on the per-window path too (api-server.py:131-134)
+            sil = synth.servicer_pcm(*synth.SERVICER_STREAMS[4])
+            want, resets = O.servicer_stream(m, sil, lang.denumericalize, chunk=1600, tail=8)
+            assert len(resets) >= 2, "the stream was meant to cross the reset threshold"
+            got = [t.data for t in stub.TranscribeStream(
+                ap.Audio(data=c.tobytes(), sr=16000) for c in synth.stream_chunks(sil, 1600, lead=1, tail=8))]
+            assert got == want
+            gs = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "servicer_tiny.npz"))
+            assert got == [str(v) for v in gs["msgs100_4"][:int(gs["n_msgs100_4"])]]        # ... and == the reference's own servicer
             # 16 kHz frames of another length (100 ms) go the same way
             got100 = [t.data for t in stub.TranscribeStream(
                 ap.Audio(data=c.tobytes(), sr=16000) for c in synth.stream_chunks(pcm[1], 1600, lead=1, tail=8))]

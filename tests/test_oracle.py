@@ -323,3 +323,9 @@ def test_servicer_restatement_matches_the_reference_servicer(golden_dir):
         assert lang.denumericalize(m.decode_greedy(O.features_offline(pcm))[0]) == unary
         n_resets += len(resets)
     assert n_resets >= 6
+    # the same streams' servicer on 100 ms frames (the generic-client / per-window form), from the reference's own servicer too
+    g = load(golden_dir, "servicer_tiny.npz")
+    pcm = synth.servicer_pcm(*synth.SERVICER_STREAMS[4])
+    got, got_resets = O.servicer_stream(m, pcm, lang.denumericalize, chunk=1600, tail=8)
+    assert got == [str(v) for v in g["msgs100_4"][:int(g["n_msgs100_4"])]] and got_resets == [int(v) for v in g["resets100_4"]]
+    assert len(got_resets) == 2
