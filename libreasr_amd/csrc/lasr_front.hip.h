@@ -43,6 +43,7 @@ struct lasr_front {
     int depth = 12, reset_steps = 0, ring_chunks = 64, chunk = 0, n_window = 0, n_buffer = 0, max_tok = 0;
     std::vector<std::unique_ptr<Stream>> st;  // by engine slot
     std::mutex em;                            // the engine is single-caller: front thread vs open / close / pause
+    std::atomic<int> em_waiters{0};           // callers waiting for em: the front thread, which re-takes em every tick, lets them in
     std::thread th;
     std::atomic<bool> stop{false};
     std::atomic<long long> work{0};           // bumped by every push / eof / close: the sleeping front thread re-checks
@@ -63,6 +64,15 @@ struct lasr_front {
 };
 
 namespace {
+
+// em for a caller thread (open / close / pause).  A plain std::mutex is not fair: the front thread unlocks and re-locks it within
+// nanoseconds while it has work, and a sleeping waiter could starve for as long as the replay lasts; the waiter announces itself
+// and the front thread stays out until it has been served (front_main).
+struct FrontCallerLock {
+    lasr_front* f;
+    explicit FrontCallerLock(lasr_front* f_) : f(f_) { f->em_waiters.fetch_add(1, std::memory_order_acq_rel); f->em.lock(); f->em_waiters.fetch_sub(1, std::memory_order_acq_rel); }
+    ~FrontCallerLock() { f->em.unlock(); }
+};
 
 constexpr int FRONT_RES_STEP = 1, FRONT_RES_RESET = 2, FRONT_RES_EOF = 4;
 
@@ -275,6 +285,7 @@ void front_main(lasr_front* f) {
     long long seen = -1;
     while (!f->stop.load(std::memory_order_acquire)) {
         bool did = false;
+        for (int spins = 0; f->em_waiters.load(std::memory_order_acquire) > 0 && spins < 100000; ++spins) std::this_thread::yield();
         if (!f->rc) {
             std::lock_guard<std::mutex> lk(f->em);
             (void)front_tick(f, &did);
@@ -347,7 +358,7 @@ void lasr_front_destroy(lasr_front* f) {
 int lasr_front_open(lasr_front* f, int* stream) {
     if (!f || !stream) return LASR_EINVAL;
     if (f->rc) return f->rc;
-    std::lock_guard<std::mutex> lk(f->em);
+    FrontCallerLock lk(f);
     int slot = -1;
     int rc = lasr_stream_open(f->c, &slot);
     if (rc) return rc;
@@ -417,7 +428,7 @@ int lasr_front_close(lasr_front* f, int stream) {
     lasr_front::Stream& s = *f->st[stream];
     if (!s.open.load()) return LASR_ESTATE;
     for (;;) {      // its steps in flight are collected by the front thread; then the slot can be closed
-        std::lock_guard<std::mutex> lk(f->em);
+        FrontCallerLock lk(f);
         s.closing = true;
         if (f->rc) return f->rc;
         if (s.infl == 0) {
@@ -440,7 +451,9 @@ int lasr_front_close(lasr_front* f, int stream) {
 // thread stays out until lasr_front_resume, which the SAME thread calls.  Does not nest.
 int lasr_front_pause(lasr_front* f) {
     if (!f) return LASR_EINVAL;
+    f->em_waiters.fetch_add(1, std::memory_order_acq_rel);
     f->em.lock();
+    f->em_waiters.fetch_sub(1, std::memory_order_acq_rel);
     while (!f->inflight.empty() && !f->rc) (void)front_collect(f);
     if (f->rc) { f->em.unlock(); return f->rc; }
     return LASR_OK;
