@@ -362,6 +362,9 @@ def main():
                     help="self-check: rows replayed through the synchronous protocol after the timed region (0 = off)")
     ap.add_argument("--split-push", action="store_true",
                     help="lasr_push_pcm + lasr_step_submit as two calls instead of lasr_push_submit (A/B)")
+    ap.add_argument("--device-stable", type=int, default=1,
+                    help="1: device pushes carry LASR_PUSH_DEVICE_STABLE (the resident PCM is never rewritten), so the chunk that "
+                         "completes no model step is appended by the next call's front-end launch; 0: plain append launch (A/B)")
     ap.add_argument("--lm", choices=["none", "fp32", "int8"], default="none",
                     help="extra line: LM shallow fusion in the greedy loop (the reference's served configuration, config/testing.yaml: "
                          "lm.enable) with a synthetic 4 x 768 LM: fp32 / bf16 operands like the model, or int8-served as load_lm does")
@@ -424,7 +427,7 @@ def main():
     if args.lm != "none":
         eng.attach_lm(synth.synth_lm_state_dict("lm768"), int8=args.lm == "int8")
     eng_cfg = {}
-    for key in ("enc_xg", "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "dec_min_rows", "cell_nw"):
+    for key in ("enc_xg", "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "dec_min_rows", "cell_nw", "push_lazy"):
         try:
             eng_cfg[key] = eng.config(key)
         except Exception:
@@ -468,7 +471,8 @@ def main():
         if pipelined and not args.split_push:
             # push + submit in one call: the front-end launch of a model step appends the newest chunk itself
             before = eng.pending()
-            eng.push_submit(slots, src[k % n_chunks], pinned_nocopy=nocopy)
+            # (the resident PCM is never rewritten: LASR_PUSH_DEVICE_STABLE holds trivially)
+            eng.push_submit(slots, src[k % n_chunks], pinned_nocopy=nocopy, device_stable=(not host) and bool(args.device_stable))
             host_us["push"] += time.perf_counter() - t_push
             ntok, done = 0, 0
             if eng.pending() > before:

@@ -125,12 +125,19 @@ int lasr_stream_close(lasr_ctx* c, int slot);
  *     has returned -- also after lasr_step_submit / lasr_push_submit have returned.  *ticket identifies the push: the buffer
  *     must stay untouched until lasr_push_consumed(ctx, ticket) returns 1 (0 = not yet; an event query, no blocking).
  *     Every host push gets a ticket (ticket may be NULL); device pushes report -1.
+ *   - lasr_push_submit with LASR_PUSH_DEVICE_STABLE (opt-in, DEVICE memory): the caller promises that the buffer stays
+ *     unchanged until the model step this chunk belongs to has been collected (lasr_step_wait) or lasr_sync has returned.  The
+ *     chunk of a call that completes no model step is then not appended to the PCM ring by a launch of its own: the next
+ *     lasr_push_submit of the same slots appends both chunks in its front-end launch (one launch less per model step on the
+ *     stream that binds the job).  Host pushes get this without a flag -- their source is the engine's own staging entry.
+ *     Results are the same either way; any other call that touches the ring appends the waiting chunk first.
  * lasr_step_stream: for every listed slot whose window is full, computes the log-mel frames of
  * the window's middle (TransformTime + StreamPostprocess + StackDownsample, transforms.py:
  * 306-342,436-441), buffers them (Buffer), and for slots whose buffer reached n_buffer runs
  * encoder + greedy decode with carried state (models.py:506-575).  Blocks until the tokens of
  * this step are on the host.  n_ran (optional) = number of slots the model ran for. */
 #define LASR_PUSH_PINNED_NOCOPY 1
+#define LASR_PUSH_DEVICE_STABLE 2
 int lasr_push_pcm_ex(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket);
 int lasr_push_consumed(lasr_ctx* c, long long ticket);
 int lasr_push_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm);

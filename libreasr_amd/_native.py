@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("LASR_LIB") or os.path.join(_HERE, "csrc", "liblasr_hi
 
 LASR_OK, LASR_EINVAL, LASR_ENOMEM, LASR_EHIP, LASR_ESTATE, LASR_EFULL = 0, -1, -2, -3, -4, -5
 LASR_PUSH_PINNED_NOCOPY = 1
+LASR_PUSH_DEVICE_STABLE = 2
 LASR_RESET_IF_DECODED = 16
 
 

@@ -257,6 +257,14 @@ struct lasr_ctx {
         std::atomic<bool> stop{false};
     } pool;
     std::vector<int> h_ring_pos;          // host mirror of ring_pos (every append goes through the host: +1 per pushed chunk)
+    // Deferred append (round 5): the chunk of a lasr_push_submit that completes no model step is not appended by a launch of its
+    // own when its source stays readable (the engine's device staging entry of a host push; a device buffer pushed with
+    // LASR_PUSH_DEVICE_STABLE): the NEXT lasr_push_submit of the same slots appends both chunks in its front-end launch
+    // (k_fe_mel src2) -- one launch and one kernel boundary less per model step on the stream that binds the job.  Every other
+    // entry point that touches the PCM ring flushes it first (flush_lazy: the plain append launch).
+    struct LazyPush { bool on = false; const float* src = nullptr; std::vector<int> slots; int ev_i = -1; bool dma = false; } lazy;
+    int lazy_taken = 0, lazy_flushed = 0; // deferred chunks appended by a front-end launch / by the plain launch after all (lasr_debug_config)
+    bool lazy_on = true;                  // LASR_PUSH_LAZY=0 turns the deferred append off (A/B switch)
     int fe_mode = 1;                      // fused front-end: 1 = k_fe_mel (+ ring append) -> k_stack_ln, 0 = k_frontend; LASR_FE_MODE
     float* lm_buf = nullptr; size_t lm_floats = 0;       // offline log-mel
     float* feat_stage = nullptr; size_t feat_stage_floats = 0;

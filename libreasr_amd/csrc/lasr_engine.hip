@@ -28,6 +28,7 @@ using namespace lasr;
 
 #include "lasr_ctx.hip.h"
 static void cont_poll(lasr_ctx* c);       // (pipelined protocol, below; require_idle consumes a group that was still running)
+static int flush_lazy(lasr_ctx* c);       // (deferred ring append of lasr_push_submit, below)
 #include "lasr_launch.hip.h"
 #include "lasr_decode.hip.h"
 #include "lasr_weights.hip.h"
@@ -143,6 +144,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     // round 3's wait path
     c->pump_G = c->W > 1 ? c->wait_n : 2;
     if (getenv("LASR_PUMP_G")) c->pump_G = std::max(1, std::min(8, atoi(getenv("LASR_PUMP_G"))));
+    if (getenv("LASR_PUSH_LAZY")) c->lazy_on = atoi(getenv("LASR_PUSH_LAZY")) != 0;
     if (getenv("LASR_DEC_MIN_ROWS")) c->dec_min_rows = std::max(0, atoi(getenv("LASR_DEC_MIN_ROWS")));
     const size_t Mj = (size_t)c->MTj * 16;
     c->G_pred = d.pred_cell ? 4 : 3;
@@ -545,6 +547,7 @@ static int reset_impl(lasr_ctx* c, const int* slots, int n, int what) {
         }
     }
     HIPCHK(c, hipSetDevice(c->device));
+    if (what & 8) RC(flush_lazy(c));         // (the PCM ring of these slots starts over)
     for (int i = 0; i < n; ++i) {
         const int slot = slots[i];
         if (what & 8) { c->n_chunks[slot] = 0; c->n_pend[slot] = 0; c->queue[slot].clear(); c->neg_logp[slot] = 0.0; }
@@ -637,6 +640,7 @@ static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
             c->pend_mat[(size_t)s * d.n_buffer + j] = 1;
         }
         if (!any) continue;
+        RC(flush_lazy(c));                                       // (the kernel below reads the ring)
         fill_mel_args(c, m);
         m.pcm = c->win; m.N = (long long)d.n_window * d.chunk; m.stream = 1; m.ring_head = c->ring_pos; m.chunk = d.chunk;
         m.n_window = d.n_window; m.ring_chunks = c->ring_chunks; m.frame0 = stream_frame0(c, nullptr);
@@ -789,16 +793,39 @@ static int push_append_launch(lasr_ctx* c, const int* slots, int n, const PushSr
     }
     return LASR_OK;
 }
-// after the launch that reads ps.src: the host mirrors and the "source consumed" event
-static int push_finish(lasr_ctx* c, const int* slots, int n, const PushSrc& ps, long long* ticket, bool counted = false) {
+// the "source consumed" event of a host push whose append was deferred: recorded behind the launch that finally read it
+static int lazy_consumed(lasr_ctx* c) {
+    if (c->lazy.ev_i >= 0) {
+        HIPCHK(c, hipEventRecord(c->push_ev[c->lazy.ev_i], c->stream));
+        c->push_used[c->lazy.ev_i] = true;
+        c->push_dma[c->lazy.ev_i] = c->lazy.dma;
+    }
+    c->lazy = lasr_ctx::LazyPush{};
+    return LASR_OK;
+}
+// a deferred append that the next call cannot take along: the plain append launch, now (see lasr_ctx::LazyPush)
+static int flush_lazy(lasr_ctx* c) {
+    if (!c->lazy.on) return LASR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    PushSrc ps;
+    ps.src = c->lazy.src;
+    const std::vector<int> slots = c->lazy.slots;
+    RC(push_append_launch(c, slots.data(), (int)slots.size(), ps));
+    c->lazy_flushed++;
+    return lazy_consumed(c);
+}
+// after the launch that reads ps.src: the host mirrors and the "source consumed" event (defer_event: the append was deferred)
+static int push_finish(lasr_ctx* c, const int* slots, int n, const PushSrc& ps, long long* ticket, bool counted = false, bool defer_event = false) {
     for (int i = 0; i < n; ++i) {
         if (!counted) c->n_chunks[slots[i]]++;
         c->h_ring_pos[slots[i]] = (c->h_ring_pos[slots[i]] + 1) % c->ring_chunks;
     }
     if (ps.ev_i >= 0) {
-        HIPCHK(c, hipEventRecord(c->push_ev[ps.ev_i], c->stream));
-        c->push_used[ps.ev_i] = true;
         c->push_dma[ps.ev_i] = ps.dma;
+        if (!defer_event) {
+            HIPCHK(c, hipEventRecord(c->push_ev[ps.ev_i], c->stream));
+            c->push_used[ps.ev_i] = true;
+        }
     }
     if (ticket) *ticket = ps.ticket;
     return LASR_OK;
@@ -811,6 +838,7 @@ int lasr_push_pcm_ex(lasr_ctx* c, const int* slots, int n, const float* pcm, int
     if (n == 0) return LASR_OK;
     if (!pcm) return fail(c, LASR_EINVAL, "pcm is null");
     HIPCHK(c, hipSetDevice(c->device));
+    RC(flush_lazy(c));
     if (!c->pending.empty()) RC(cont_pump(c, c->kick_n));      // steps in flight: keep the decode loop fed
     PushSrc ps;
     RC(push_prepare(c, slots, n, pcm, flags, ps));
@@ -897,10 +925,16 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             int* trow_home = (c->pe == c->pe_ring) ? c->T_row_main : nullptr;      // pipelined: one fixed buffer (see commit_T_rows)
             m.trow_out = trow_home ? trow_home : c->dc.T_row; m.enc_frames = f.enc_frames; m.enc_base = f.enc_base;
             m.src = fused ? fused->src : nullptr;
+            const bool with_lazy = fused && c->lazy.on;          // (push_submit_impl: the deferred chunk belongs to exactly `slots`)
+            m.src2 = with_lazy ? c->lazy.src : nullptr;
             for (int r = 0; r < 512; ++r) { m.idx[r] = -1; m.tp_pk[r] = 0; m.age_pk[r] = 0; }
             for (int r = 0; r < c->M; ++r) m.tp_pk[r] = (unsigned char)(c->h_ring_pos[r] << 4);
             if (fused)
-                for (int i = 0; i < n; ++i) m.idx[slots[i]] = (short)i;
+                for (int i = 0; i < n; ++i) {
+                    m.idx[slots[i]] = (short)i;
+                    // (the host mirror already counts the deferred chunk; the ring on the device does not hold it yet)
+                    if (with_lazy) m.tp_pk[slots[i]] = (unsigned char)(((c->h_ring_pos[slots[i]] - 1 + c->ring_chunks) % c->ring_chunks) << 4);
+                }
             for (int s : model_rows) {
                 m.tp_pk[s] |= (unsigned char)d.n_buffer;
                 unsigned pk = 0;
@@ -910,6 +944,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             hipStream_t fe_st = c->stream;
             hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * d.n_buffer, c->M), dim3(320), 0, fe_st, m);
             if (fused_done) *fused_done = fused != nullptr;
+            if (with_lazy) { c->lazy_taken++; RC(lazy_consumed(c)); }
             RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring, trow_home));    // the continuous loop reads its own frame counters
             StackLnArgs a{};
             a.src = c->pend; a.mode = 0; a.src_frames = d.n_buffer * d.n_stack; a.frame_step = d.n_stack; a.row_off = nullptr;
@@ -991,6 +1026,7 @@ int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
     if (!c) return LASR_EINVAL;
     if (n_ran) *n_ran = 0;
     RC(check_slots(c, slots, n, true));
+    RC(flush_lazy(c));
     RC(require_idle(c));
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<int> model_rows;
@@ -1030,6 +1066,7 @@ static int submit_impl(lasr_ctx* c, const int* slots, int n, const PushSrc* fuse
 int lasr_step_submit(lasr_ctx* c, const int* slots, int n) {
     if (!c) return LASR_EINVAL;
     RC(check_slots(c, slots, n, true));
+    RC(flush_lazy(c));
     return submit_impl(c, slots, n, nullptr, nullptr);
 }
 
@@ -1075,16 +1112,30 @@ static int push_submit_impl(lasr_ctx* c, const int* slots, int n, const float* p
     tr_mark(c, 1, c->stream);
     if (c->fe_fused) RC(materialize_pending(c, slots, n));
     const bool can_fuse = c->fe_fused && c->fe_mode == 1;
+    // a deferred chunk rides in this call's front-end launch only when it belongs to exactly these slots, in this order
+    if (c->lazy.on && !(can_fuse && (int)c->lazy.slots.size() == n && std::equal(slots, slots + n, c->lazy.slots.begin()))) RC(flush_lazy(c));
     if (!can_fuse) RC(push_append_launch(c, slots, n, ps));
     for (int i = 0; i < n; ++i) c->n_chunks[slots[i]]++;
     bool fused_done = false;
     int rc = submit_impl(c, slots, n, can_fuse ? &ps : nullptr, &fused_done);
     if (rc) {       // (argument errors were caught above: what can fail here is the runtime)
+        (void)flush_lazy(c);
         if (can_fuse && !fused_done) (void)push_append_launch(c, slots, n, ps);
         (void)push_finish(c, slots, n, ps, ticket, true);
         return rc;
     }
-    if (can_fuse && !fused_done) RC(push_append_launch(c, slots, n, ps));      // no model step from this chunk: plain append
+    if (can_fuse && !fused_done) {
+        // no model step from this chunk.  Its append waits for the next call's front-end launch when the source stays readable
+        // until then (the engine's own device staging entry of a host push; a device buffer the caller declared stable);
+        // otherwise the plain append launch, now.
+        RC(flush_lazy(c));                       // (an older deferred chunk goes first: ring order)
+        const bool stable = c->lazy_on && (ps.dma || (!rows && (flags & LASR_PUSH_DEVICE_STABLE) && ps.ev_i < 0));
+        if (stable) {
+            c->lazy.on = true; c->lazy.src = ps.src; c->lazy.slots.assign(slots, slots + n); c->lazy.ev_i = ps.ev_i; c->lazy.dma = ps.dma;
+            return push_finish(c, slots, n, ps, ticket, true, /*defer_event=*/true);
+        }
+        RC(push_append_launch(c, slots, n, ps));
+    }
     return push_finish(c, slots, n, ps, ticket, true);
 }
 
@@ -1728,6 +1779,7 @@ static int transcribe_common(lasr_ctx* c, const int* slots, int n, int T_max) {
 
 int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, const int64_t* n_samples) {
     if (!c) return LASR_EINVAL;
+    RC(flush_lazy(c));
     RC(require_idle(c));
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
@@ -1784,6 +1836,7 @@ int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, 
 
 int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* feats, const int32_t* n_frames) {
     if (!c) return LASR_EINVAL;
+    RC(flush_lazy(c));
     RC(require_idle(c));
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
@@ -1827,6 +1880,7 @@ int lasr_transcribe_feats(lasr_ctx* c, const int* slots, int n, const float* fea
 // state, max_iters_stream.  feats [n, T, feat] (host or device), the same T for every listed slot.
 int lasr_step_feats(lasr_ctx* c, const int* slots, int n, const float* feats, int T) {
     if (!c) return LASR_EINVAL;
+    RC(flush_lazy(c));
     RC(require_idle(c));
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
@@ -2036,6 +2090,7 @@ int lasr_step_window(lasr_ctx* c, const int* slots, int n, const float* pcm, int
     if (!c) return LASR_EINVAL;
     if (n_ran) *n_ran = 0;
     RC(check_slots(c, slots, n, true));
+    RC(flush_lazy(c));
     RC(require_idle(c));
     if (n == 0) return LASR_OK;
     if (!pcm || N < 1) return fail(c, LASR_EINVAL, "bad window");
@@ -2215,6 +2270,7 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
     if (d->vocab != c->d.vocab) return fail(c, LASR_EINVAL, "LM vocabulary %d != model vocabulary %d", d->vocab, c->d.vocab);
     if (d->vocab > 4096) return fail(c, LASR_EINVAL, "LM fusion keeps a row's log-probs in registers: vocab <= 4096");
     if (d->embed % 16 || d->hidden % (c->bf ? 32 : 16)) return fail(c, LASR_EINVAL, "LM dims must be multiples of 16 (hidden: 32 for bf16)");
+    RC(flush_lazy(c));
     RC(require_idle(c));
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2299,6 +2355,7 @@ int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights
     if (d->vocab > 4096 || d->vocab % 16) return fail(c, LASR_EINVAL, "LM fusion keeps a row's log-probs in registers: vocab <= 4096, multiple of 16");
     if (d->hidden % 4 || d->hidden > 1024 || d->embed > 1024 || d->embed < 1 || d->layers < 1 || d->layers > 8)
         return fail(c, LASR_EINVAL, "int8 LM: hidden a multiple of 4, embed / hidden <= 1024 (exact integer accumulation), 1..8 layers");
+    RC(flush_lazy(c));
     RC(require_idle(c));
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2521,6 +2578,7 @@ int lasr_trace_read(lasr_ctx* c, double* us, int* tags, int cap, int* n) {
 int lasr_debug_read(lasr_ctx* c, int what, int index, float* out, size_t cap, int* rows, int* cols) {
     if (!c || !out) return LASR_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
+    RC(flush_lazy(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->stream_dec) HIPCHK(c, hipStreamSynchronize(c->stream_dec));
     const lasr_model_desc& d = c->d;
@@ -2583,6 +2641,7 @@ int lasr_debug_read(lasr_ctx* c, int what, int index, float* out, size_t cap, in
 int lasr_sync(lasr_ctx* c) {
     if (!c) return LASR_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
+    RC(flush_lazy(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cmd_inflight = 0;
     return LASR_OK;
@@ -2594,6 +2653,7 @@ int lasr_sync(lasr_ctx* c) {
 // the job then runs at 0.74 of its rate, profiles/r03/r03_experiments.txt M).  bench.py reports it per rank.
 int lasr_overlap_probe(lasr_ctx* c, int delay_us, double* ratio) {
     if (!c || !ratio || delay_us < 1 || delay_us > 1000000) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
+    RC(flush_lazy(c));
     RC(require_idle(c));
     HIPCHK(c, hipSetDevice(c->device));
     return overlap_probe_impl(c, delay_us, ratio);
@@ -2681,6 +2741,7 @@ int lasr_debug_config(lasr_ctx* c, const char* key, int* value) {
         {"enc_xg", (int)c->enc_xg}, {"enc_wave", c->enc_wave}, {"enc_u12", (int)c->enc_u12}, {"main_graph", (int)c->main_graph},
         {"pump_G", c->pump_G}, {"la_stream", c->la_stream}, {"la_offline", c->la_offline}, {"dec_min_rows", c->dec_min_rows},
         {"cell_nw", c->cell_nw ? c->cell_nw : (c->bf ? 8 : 4)}, {"use_graphs", (int)c->use_graphs}, {"fe_mode", c->fe_mode}, {"M", c->M},
+        {"push_lazy", (int)c->lazy_on}, {"lazy_taken", c->lazy_taken}, {"lazy_flushed", c->lazy_flushed},
     };
     for (const auto& e : tab)
         if (!strcmp(e.k, key)) { *value = e.v; return LASR_OK; }

@@ -2070,6 +2070,8 @@ struct FeMelArgs {
     int* enc_frames;         // pipelined protocol (else nullptr): see FrontArgs
     int* enc_base;
     const float* src;        // fused ring append (else nullptr): [n][chunk], row r takes chunk idx[r]
+    const float* src2;       // deferred append of the PREVIOUS chunk of the same rows (else nullptr): the chunk of the last lasr_push_submit
+                             // that completed no model step was not appended by a launch of its own -- this launch appends both (src2 first)
     short idx[512];          // -1: the row is not pushed by this launch
     unsigned char tp_pk[512];    // frames of this step (low nibble) | ring position BEFORE this launch's append (high nibble)
     unsigned short age_pk[512];  // 4 bits per t': chunks pushed since the window of stacked frame t' was current; 15: already in pend
@@ -2087,19 +2089,23 @@ __global__ __launch_bounds__(32 * NSTACK) void k_fe_mel(const FeMelArgs a) {
     const int Tr = a.tp_pk[row] & 15, pos = a.tp_pk[row] >> 4;
     const int si = a.src ? (int)a.idx[row] : -1;
     const int NR = a.ring_chunks;
+    const bool two = si >= 0 && a.src2 != nullptr;       // this row's previous chunk is still waiting in src2
+    const int pos_new = two ? (pos + 1) % NR : pos;      // ring slot of the newest chunk
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             a.trow_out[row] = Tr;
             if (a.enc_frames) { const int e = a.enc_frames[row]; a.enc_base[row] = e; a.enc_frames[row] = e + Tr; }
-            if (si >= 0) a.ring_pos[row] = (pos + 1) % NR;
+            if (si >= 0) a.ring_pos[row] = (pos_new + 1) % NR;
         }
-        if (si >= 0) {                                   // the ring append of this row's newest chunk
-            float* d = a.pcm + ((size_t)row * NR + pos) * a.chunk;
-            const float* s = a.src + (size_t)si * a.chunk;
-            if ((a.chunk & 3) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
-                for (int i = threadIdx.x; i < a.chunk / 4; i += blockDim.x) ((float4*)d)[i] = ((const float4*)s)[i];
-            } else {
-                for (int i = threadIdx.x; i < a.chunk; i += blockDim.x) d[i] = s[i];
+        if (si >= 0) {                                   // the ring append of this row's newest chunk (and of the deferred one)
+            for (int q = two ? 0 : 1; q < 2; ++q) {
+                float* d = a.pcm + ((size_t)row * NR + (q ? pos_new : pos)) * a.chunk;
+                const float* s = (q ? a.src : a.src2) + (size_t)si * a.chunk;
+                if ((a.chunk & 3) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+                    for (int i = threadIdx.x; i < a.chunk / 4; i += blockDim.x) ((float4*)d)[i] = ((const float4*)s)[i];
+                } else {
+                    for (int i = threadIdx.x; i < a.chunk; i += blockDim.x) d[i] = s[i];
+                }
             }
         }
     }
@@ -2109,10 +2115,11 @@ __global__ __launch_bounds__(32 * NSTACK) void k_fe_mel(const FeMelArgs a) {
     const MelTables tab{s_fbw, s_fbs, s_fbo, s_tw512, s_tw1024};
     stage_mel_tables(tab, a.tw512, a.tw1024, a.fb_w, a.fb_start, a.fb_off, a.fb_nnz, a.n_mels);
     const int f = half * NWV + w;                        // log-mel frame of the stacked frame
-    const int pos_after = si >= 0 ? (pos + 1) % NR : pos;
+    const int pos_after = si >= 0 ? (pos_new + 1) % NR : pos;
     const int head = (pos_after - age - a.n_window + 2 * NR) % NR;
     const float* ring = a.pcm + (size_t)row * NR * a.chunk;
     const float* fresh = si >= 0 ? a.src + (size_t)si * a.chunk : nullptr;
+    const float* fresh2 = two ? a.src2 + (size_t)si * a.chunk : nullptr;
     const int N = a.n_window * a.chunk;
     const int base = (a.frame0 + f) * a.hop - 512;
     auto sample = [&](int n) -> float {
@@ -2125,7 +2132,7 @@ __global__ __launch_bounds__(32 * NSTACK) void k_fe_mel(const FeMelArgs a) {
         while (wi >= a.chunk) { wi -= a.chunk; ++ck; }
         int slot = head + ck;
         if (slot >= NR) slot -= NR;
-        const float x = (fresh && slot == pos) ? fresh[wi] : ring[(size_t)slot * a.chunk + wi];
+        const float x = (fresh && slot == pos_new) ? fresh[wi] : (fresh2 && slot == pos) ? fresh2[wi] : ring[(size_t)slot * a.chunk + wi];
         return x * wv;
     };
     cf v[8];

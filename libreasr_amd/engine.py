@@ -151,13 +151,16 @@ class Engine:
         self._chk(self.lib.lasr_push_pcm_ex(self.ctx, p, n, _ptr(pcm), N.LASR_PUSH_PINNED_NOCOPY if pinned_nocopy else 0, C.byref(t)))
         return t.value
 
-    def push_submit(self, slots, pcm, pinned_nocopy=False):
+    def push_submit(self, slots, pcm, pinned_nocopy=False, device_stable=False):
         """push(slots, pcm) + submit(slots) in one call (lasr_push_submit): the front-end launch of a model step takes the newest
-        chunk from `pcm` itself.  Same memory rules and results as push + submit.  Returns the push ticket."""
+        chunk from `pcm` itself.  Same memory rules and results as push + submit.  device_stable=True (a cuda tensor): the caller
+        keeps the tensor unchanged until the model step the chunk belongs to is collected (LASR_PUSH_DEVICE_STABLE: a chunk that
+        completes no model step is appended by the next call's launch).  Returns the push ticket."""
         a, p, n = self._slots(slots)
         pcm = self._pcm(pcm, n)
         t = C.c_longlong(-1)
-        self._chk(self.lib.lasr_push_submit(self.ctx, p, n, _ptr(pcm), N.LASR_PUSH_PINNED_NOCOPY if pinned_nocopy else 0, C.byref(t)))
+        flags = (N.LASR_PUSH_PINNED_NOCOPY if pinned_nocopy else 0) | (N.LASR_PUSH_DEVICE_STABLE if device_stable else 0)
+        self._chk(self.lib.lasr_push_submit(self.ctx, p, n, _ptr(pcm), flags, C.byref(t)))
         return t.value
 
     def push_submit_rows(self, slots, addrs):

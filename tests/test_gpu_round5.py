@@ -572,3 +572,90 @@ def test_native_front_irregular_arrivals_against_the_synchronous_protocol():
         assert total_resets > 5
     finally:
         eng.close()
+
+
+def test_deferred_ring_append_is_invisible(golden_dir, monkeypatch):
+    """lasr_push_submit defers the ring append of a chunk that completes no model step to the NEXT call's front-end launch
+    (host pushes always; device pushes with LASR_PUSH_DEVICE_STABLE): the tokens are the reference's goldens whether the
+    deferred chunk rides along (same slots next call), is flushed by a call with other slots, by lasr_sync, by a plain push +
+    submit pair, by a stream opening in between -- and with LASR_PUSH_LAZY=0."""
+    import __graft_entry__ as graft
+    from libreasr_amd.engine import Engine
+    graft.build()
+    cfg = synth.model_cfg("tiny")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    pcm = synth.synth_pcm(3, 16000 * 3, seed=1234)
+    g = np.load(os.path.join(golden_dir, "model_tiny.npz"))
+    want = [list(g[f"st_tokens_{s}"]) for s in range(3)]
+    chunks = [synth.stream_chunks(p, 1280, lead=1, tail=10) for p in pcm]
+    n = len(chunks[0])
+    all_dev = dev(np.stack([np.stack([c[k] for c in chunks]) for k in range(n)]))       # [n, 3, 1280], kept for the whole test
+
+    def run(eng, mode):
+        slots = [eng.open() for _ in range(3)]
+        got = [[] for _ in slots]
+
+        def collect():
+            if eng.wait():
+                for s, t in enumerate(eng.fetch_many(slots, 8192)):
+                    got[s] += t
+
+        extra = None
+        for k in range(n):
+            if mode == "device":
+                eng.push_submit(slots, all_dev[k], device_stable=True)
+            elif mode == "host":
+                eng.push_submit(slots, all_dev[k].cpu().numpy())
+            elif mode == "other_slots":         # the three streams arrive in two calls: slot lists differ from call to call
+                eng.push_submit(slots[:2], all_dev[k, :2], device_stable=True)
+                eng.push_submit(slots[2:], all_dev[k, 2:].cpu().numpy())
+            elif mode == "interleaved":         # every other entry point that touches the ring, between deferred and next chunk
+                what = k % 5
+                if what == 0:
+                    eng.push_submit(slots, all_dev[k], device_stable=True)
+                    eng.sync()
+                elif what == 1:
+                    eng.push(slots, all_dev[k])
+                    eng.submit(slots)
+                elif what == 2:
+                    eng.push_submit(slots, all_dev[k].cpu().numpy())
+                    if extra is None:
+                        extra = eng.open()     # (lasr_stream_reset with the ring bit)
+                    else:
+                        eng.close_slot(extra)
+                        extra = None
+                elif what == 3:
+                    eng.push_submit(slots, all_dev[k], device_stable=True)
+                else:
+                    eng.push_submit(slots, all_dev[k].cpu().numpy())
+                    eng.debug_read("ring")
+            if eng.pending() >= 4:
+                collect()
+        while eng.pending():
+            collect()
+        for s in slots:
+            eng.close_slot(s)
+        return got
+
+    eng = Engine(sd, cfg, max_streams=16)
+    try:
+        assert eng.config("push_lazy") == 1
+        for mode in ("device", "host"):
+            t0, f0 = eng.config("lazy_taken"), eng.config("lazy_flushed")
+            assert run(eng, mode) == want, mode
+            # tiny: 2 chunks per model step, all streams in phase: every other chunk rides in the next call's launch
+            assert eng.config("lazy_taken") - t0 >= n // 2 - 4 and eng.config("lazy_flushed") - f0 <= 2, mode
+        f0 = eng.config("lazy_flushed")
+        assert run(eng, "other_slots") == want
+        assert eng.config("lazy_flushed") - f0 >= n // 2 - 4
+        assert run(eng, "interleaved") == want
+    finally:
+        eng.close()
+    monkeypatch.setenv("LASR_PUSH_LAZY", "0")
+    eng = Engine(sd, cfg, max_streams=16)
+    try:
+        assert eng.config("push_lazy") == 0
+        assert run(eng, "device") == want and run(eng, "host") == want
+        assert eng.config("lazy_taken") == 0 and eng.config("lazy_flushed") == 0
+    finally:
+        eng.close()
