@@ -34,6 +34,8 @@ done
 python3 tools/rocpd_gaps.py $O/kt_driver/kt_results.db > $O/kernel_gaps_driver.txt 2>&1
 rm -rf $O/kt_driver $O/kt_steady $O/kt_bf16 $O/kt_beam $O/kt_cfg5 $O/kt_cfg5g $O/trace_f32.json
 # PMC passes on the isolated cells, one counter group per pass (gpurun refuses --pmc with the hip / hsa trace domains)
+# (SKIP_PMC=1: the cell kernels are unchanged since the committed passes -- profiles/cell_pmc.json, profiles/r05/r05_cell_pmc.txt)
+if [ -z "$SKIP_PMC" ]; then
 cd /tmp
 rocprofv3 -L 2>/dev/null | grep -o "TCC_[A-Z0-9_]*\|TCP_TCC_[A-Z0-9_]*\|SQ_VALU_MFMA[A-Z0-9_]*\|SQ_BUSY[A-Z0-9_]*" | sort -u | head -80 > $O/pmc_counter_names.txt
 n=0
@@ -46,5 +48,6 @@ done
 cd $R
 for f in $O/pmc_*/pmc_results.db; do echo "== $f"; python3 tools/rocpd_pmc.py $f --filter EpiLSTM; done > $O/cell_pmc.txt 2>&1
 rm -rf $O/pmc_f32_* $O/pmc_bf16_* $O/pmc_cfg5_*
+fi
 python3 tools/r05/summ.py $O/bench_*.json $O/kt_*.json
-cat $O/timeline_f32.txt; head -14 $O/kernel_stats_driver.txt | cut -c1-190; head -60 $O/cell_pmc.txt
+cat $O/timeline_f32.txt; head -14 $O/kernel_stats_driver.txt | cut -c1-190; [ -f $O/cell_pmc.txt ] && head -60 $O/cell_pmc.txt; true

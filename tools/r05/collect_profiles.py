@@ -107,7 +107,8 @@ for k, v in vals.items():
         pmc["cfg2_bf16_64_beam4"] = e
     if k == "cfg5":
         pmc["cfg5_bf16_128_beam8"] = e
-json.dump(pmc, open(os.path.join(ROOT, "profiles", "cell_pmc.json"), "w"), indent=1)
+if pmc:          # (a run with SKIP_PMC=1 keeps the committed passes: the cell kernels have not changed since)
+    json.dump(pmc, open(os.path.join(ROOT, "profiles", "cell_pmc.json"), "w"), indent=1)
 print(json.dumps({k: {q: v[q] for q in ("hbm_bytes_per_launch", "hbm_over_weights", "tcc_hit_rate", "l2_bytes_at_128B_per_request", "mfma_busy_frac_of_isolated_launch_at_2p4GHz")} for k, v in pmc.items()}, indent=1))
 for extra in ("parity_counts.json", "served_rate.json", "pytest_gpu.txt"):
     p = os.path.join(ROOT, "gpurun_out", "r5d", extra)
