@@ -303,9 +303,12 @@ int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights
  * Thread-safety: one producer (push / eof) and one consumer (next) per stream, any number of streams, any threads. */
 typedef struct lasr_front lasr_front;
 int lasr_front_create(lasr_ctx* c, int depth, int reset_steps, lasr_front** out);
-/* Collects what is in flight, closes the front's streams, joins its threads.  No other thread may be inside a lasr_front_* call
- * (a producer blocked on a full ring or a consumer blocked in lasr_front_next is released with LASR_ESTATE first: join them, then
- * destroy); the front must go before lasr_destroy of its context. */
+/* Shutdown in two steps.  lasr_front_stop: the front thread stops submitting; every producer blocked on a full ring and every
+ * consumer blocked in lasr_front_next returns LASR_ESTATE (results already queued are still handed out); the handle stays valid,
+ * so the application can join those threads.  lasr_front_destroy: collects what is in flight, closes the front's streams, joins
+ * its threads, frees the handle -- no other thread may be inside a lasr_front_* call any more; the front must go before
+ * lasr_destroy of its context.  (destroy without stop is fine when nothing can be blocked.) */
+int lasr_front_stop(lasr_front* f);
 void lasr_front_destroy(lasr_front* f);
 int lasr_front_open(lasr_front* f, int* stream);        /* stream id == engine slot; LASR_EFULL when no slot is free */
 /* n_chunks client chunks ([n_chunks][chunk] float32, host memory) appended to the stream; copied before the call returns; blocks

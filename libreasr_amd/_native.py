@@ -78,6 +78,7 @@ SYMBOLS = [
     ("lasr_attach_lm", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("lasr_attach_lm_int8", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("lasr_front_create", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("lasr_front_stop", C.c_int, [_P]),
     ("lasr_front_destroy", None, [_P]),
     ("lasr_front_open", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("lasr_front_push", C.c_int, [_P, C.c_int, _P, C.c_int]),

@@ -54,7 +54,7 @@ struct lasr_front {
     struct Out { std::vector<int> rows; std::vector<int32_t> tok; std::vector<int> cnt, flags; int cap = 0; };
     std::deque<Out> outq; std::mutex om; std::condition_variable ocv; std::thread oth;
     bool out_busy = false;                    // the delivery thread holds a record it has taken off outq (under om)
-    int rc = 0; std::string err;              // first engine error: the front stops, every call returns it
+    std::atomic<int> rc{0}; std::string err;  // first engine error: the front stops, every call returns it (err is written before rc: under em)
     std::atomic<long long> n_ticks{0}, n_steps{0}, n_rows{0}, n_resets{0};
     bool early = true;
     int held_last = 0;                        // streams the last tick found held at the reset threshold (early verdicts are tried for them)
@@ -77,7 +77,7 @@ struct FrontCallerLock {
 constexpr int FRONT_RES_STEP = 1, FRONT_RES_RESET = 2, FRONT_RES_EOF = 4;
 
 int front_fail(lasr_front* f, int rc) {
-    if (!f->rc) { f->rc = rc; f->err = lasr_last_error(f->c); }
+    if (!f->rc.load(std::memory_order_acquire)) { f->err = lasr_last_error(f->c); f->rc.store(rc, std::memory_order_release); }
     for (auto& s : f->st)                   // wake every waiter: they return the error
         if (s) { std::lock_guard<std::mutex> lk(s->rm); s->rcv.notify_all(); s->pcv.notify_all(); }
     return rc;
@@ -335,11 +335,21 @@ int lasr_front_create(lasr_ctx* c, int depth, int reset_steps, lasr_front** out)
     return LASR_OK;
 }
 
-void lasr_front_destroy(lasr_front* f) {
-    if (!f) return;
+// Stops the front thread and releases every producer blocked on a full ring and every consumer blocked in lasr_front_next (they
+// return LASR_ESTATE).  The handle stays valid: join those threads, then lasr_front_destroy.  Idempotent.
+int lasr_front_stop(lasr_front* f) {
+    if (!f) return LASR_EINVAL;
     f->stop.store(true, std::memory_order_release);
     front_kick(f);
     { std::lock_guard<std::mutex> lk(f->fm); f->fcv.notify_all(); }
+    for (auto& s : f->st)
+        if (s) { std::lock_guard<std::mutex> lk(s->rm); s->rcv.notify_all(); s->pcv.notify_all(); }
+    return LASR_OK;
+}
+
+void lasr_front_destroy(lasr_front* f) {
+    if (!f) return;
+    (void)lasr_front_stop(f);
     f->th.join();
     { std::lock_guard<std::mutex> lk(f->om); }
     f->ocv.notify_all();
@@ -413,7 +423,7 @@ int lasr_front_next(lasr_front* f, int stream, int32_t* tokens, int cap, int* n_
     auto ready = [&] { return !s.res.empty() || f->rc != 0 || f->stop.load(); };
     if (timeout_ms < 0) s.rcv.wait(lk, ready);
     else if (!s.rcv.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready)) return 1;
-    if (s.res.empty()) return f->rc ? f->rc : LASR_ESTATE;
+    if (s.res.empty()) return f->rc.load() ? f->rc.load() : LASR_ESTATE;
     lasr_front::Stream::Res& r = s.res.front();
     if ((int)r.tok.size() > cap) return LASR_EFULL;
     if (!r.tok.empty()) memcpy(tokens, r.tok.data(), sizeof(int32_t) * r.tok.size());
@@ -475,7 +485,10 @@ int lasr_front_stats(lasr_front* f, long long* ticks, long long* steps, long lon
     return f->rc;
 }
 
-const char* lasr_front_error(const lasr_front* f) { return f ? f->err.c_str() : "null front"; }
+const char* lasr_front_error(const lasr_front* f) {
+    if (!f) return "null front";
+    return f->rc.load(std::memory_order_acquire) ? f->err.c_str() : "";
+}
 
 // include/lasr_debug.h: capacity of the front with NATIVE per-stream producers (one std::thread per stream pushing
 // chunks_per_push chunks per call, then reading its results to the end): what the per-stream form can carry when the producers
@@ -512,7 +525,7 @@ int lasr_bench_front(lasr_ctx* c, int depth, int reset_steps, int n_streams, con
     for (auto& t : th) t.join();
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (stats4) (void)lasr_front_stats(f, &stats4[0], &stats4[1], &stats4[2], &stats4[3]);
-    if (!rc && bad.load()) rc = f->rc ? f->rc : LASR_ESTATE;
+    if (!rc && bad.load()) rc = f->rc.load() ? f->rc.load() : LASR_ESTATE;
     for (int i = 0; i < n_streams; ++i)
         if (sid[i] >= 0) (void)lasr_front_close(f, sid[i]);
     lasr_front_destroy(f);

@@ -6,6 +6,7 @@ decoded); one native thread batches the streams, keeps model steps in flight and
 (api-server.py:44-50,131-134).  `libreasr_amd.server.serve(front="native")` puts it behind the gRPC servicer."""
 import contextlib
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -25,6 +26,24 @@ class NativeFront:
         if not hasattr(engine, "_fronts"):
             engine._fronts = []
         engine._fronts.append(self)          # Engine.close() destroys the front before the context its threads use
+        # calls in progress on other threads: destroy() frees the handle only when none is left (see shutdown)
+        self._lk = threading.Condition()
+        self._inside = 0
+        self._stopped = False
+
+    @contextlib.contextmanager
+    def _call(self):
+        with self._lk:
+            if self.h is None or self._stopped:
+                raise N.LasrError(N.LASR_ESTATE, "the front has been stopped")
+            self._inside += 1
+        try:
+            yield self.h
+        finally:
+            with self._lk:
+                self._inside -= 1
+                if self._inside == 0:
+                    self._lk.notify_all()
 
     def _chk(self, rc):
         if rc < 0:
@@ -34,7 +53,8 @@ class NativeFront:
 
     def open(self):
         s = C.c_int(-1)
-        self._chk(self.lib.lasr_front_open(self.h, C.byref(s)))
+        with self._call() as h:
+            self._chk(self.lib.lasr_front_open(h, C.byref(s)))
         return int(s.value)
 
     def push(self, stream, pcm):
@@ -44,49 +64,71 @@ class NativeFront:
             n = len(pcm) // 4
             if n == 0 or len(pcm) % 4 or n % self.chunk:
                 raise ValueError(f"push takes whole chunks of {self.chunk} float32 samples")
-            self._chk(self.lib.lasr_front_push(self.h, int(stream), bytes(pcm) if not isinstance(pcm, bytes) else pcm, n // self.chunk))
+            with self._call() as h:
+                self._chk(self.lib.lasr_front_push(h, int(stream), bytes(pcm) if not isinstance(pcm, bytes) else pcm, n // self.chunk))
             return
         a = np.ascontiguousarray(pcm, dtype=np.float32).reshape(-1)
         if a.size == 0 or a.size % self.chunk:
             raise ValueError(f"push takes whole chunks of {self.chunk} samples")
-        self._chk(self.lib.lasr_front_push(self.h, int(stream), a.ctypes.data, a.size // self.chunk))
+        with self._call() as h:
+            self._chk(self.lib.lasr_front_push(h, int(stream), a.ctypes.data, a.size // self.chunk))
 
     def eof(self, stream):
-        self._chk(self.lib.lasr_front_eof(self.h, int(stream)))
+        with self._call() as h:
+            self._chk(self.lib.lasr_front_eof(h, int(stream)))
 
     def next(self, stream, timeout_ms=-1):
         """-> (tokens, flags) of the stream's next model step, or None on time-out.  flags: RES_STEP | RES_RESET | RES_EOF."""
         buf = (C.c_int32 * self._cap)()
         n, fl = C.c_int(0), C.c_int(0)
-        rc = self._chk(self.lib.lasr_front_next(self.h, int(stream), buf, self._cap, C.byref(n), C.byref(fl), int(timeout_ms)))
+        with self._call() as h:
+            rc = self._chk(self.lib.lasr_front_next(h, int(stream), buf, self._cap, C.byref(n), C.byref(fl), int(timeout_ms)))
         if rc == 1:
             return None
         return list(buf[:n.value]), int(fl.value)
 
     def close(self, stream):
-        self._chk(self.lib.lasr_front_close(self.h, int(stream)))
+        with self._call() as h:
+            self._chk(self.lib.lasr_front_close(h, int(stream)))
 
     @contextlib.contextmanager
     def paused(self):
         """The engine for the caller (unary Transcribe): every step in flight is collected first, the front thread stays out."""
-        self._chk(self.lib.lasr_front_pause(self.h))
-        try:
-            yield self.eng
-        finally:
-            self.lib.lasr_front_resume(self.h)
+        with self._call() as h:
+            self._chk(self.lib.lasr_front_pause(h))
+            try:
+                yield self.eng
+            finally:
+                self.lib.lasr_front_resume(h)
 
     def stats(self):
         v = [C.c_longlong(0) for _ in range(4)]
-        self._chk(self.lib.lasr_front_stats(self.h, *[C.byref(x) for x in v]))
+        with self._call() as h:
+            self._chk(self.lib.lasr_front_stats(h, *[C.byref(x) for x in v]))
         return dict(zip(("ticks", "steps", "rows", "resets"), (int(x.value) for x in v)))
 
-    def destroy(self):
-        """Stops the front's threads (join the producers / consumers of its streams first: they must not be inside push / next)."""
-        if self.h:
-            self.lib.lasr_front_destroy(self.h)
-            self.h = None
-            if self in getattr(self.eng, "_fronts", ()):
-                self.eng._fronts.remove(self)
+    def stop(self):
+        """Releases every thread blocked in push / next (they raise) and stops the front thread; the handle stays valid: join
+        those threads, then destroy()."""
+        with self._lk:
+            if self.h is None or self._stopped:
+                return
+            self._stopped = True              # (no new call gets in; the ones inside return LASR_ESTATE)
+        self.lib.lasr_front_stop(self.h)
+
+    def destroy(self, timeout=10.0):
+        """stop(), wait until no other thread is inside a call any more, then free the front (lasr_front_destroy: collects what
+        is in flight, closes its streams, joins its threads)."""
+        self.stop()
+        with self._lk:
+            if self.h is None:
+                return
+            if not self._lk.wait_for(lambda: self._inside == 0, timeout):
+                raise RuntimeError(f"NativeFront.destroy: {self._inside} call(s) still inside the front after {timeout} s")
+            h, self.h = self.h, None
+        self.lib.lasr_front_destroy(h)
+        if self in getattr(self.eng, "_fronts", ()):
+            self.eng._fronts.remove(self)
 
     def __del__(self):
         try:

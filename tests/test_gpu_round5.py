@@ -659,3 +659,64 @@ def test_deferred_ring_append_is_invisible(golden_dir, monkeypatch):
         assert eng.config("lazy_taken") == 0 and eng.config("lazy_flushed") == 0
     finally:
         eng.close()
+
+
+def test_native_front_stop_releases_blocked_threads(golden_dir):
+    """Shutdown with threads inside the front: a consumer blocked in next() (no time-out) and a producer blocked on a full ring
+    (the front is paused, nothing drains it) are released by stop() with LASR_ESTATE; destroy() waits for them to be out before
+    it frees the handle; the engine serves the reference's goldens afterwards."""
+    import time
+    import __graft_entry__ as graft
+    graft.build()
+    from libreasr_amd import _native as N
+    from libreasr_amd.engine import Engine
+    from libreasr_amd.front import NativeFront
+
+    cfg = synth.model_cfg("tiny")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    eng = Engine(sd, cfg, max_streams=16)
+    try:
+        front = NativeFront(eng, depth=4, reset_steps=0)
+        a, b = front.open(), front.open()
+        out = {}
+
+        def consumer():
+            try:
+                front.next(a)                      # nothing was pushed: blocks
+                out["consumer"] = "returned"
+            except N.LasrError as e:
+                out["consumer"] = e.code
+
+        def producer():
+            chunk = np.zeros(1280, np.float32)
+            try:
+                for _ in range(200):               # the ring holds 64 chunks and the front is paused: blocks at the 65th
+                    front.push(b, chunk)
+                out["producer"] = "returned"
+            except N.LasrError as e:
+                out["producer"] = e.code
+
+        tc = threading.Thread(target=consumer)
+        tc.start()
+        pause = front.paused()
+        pause.__enter__()
+        tp = threading.Thread(target=producer)
+        tp.start()
+        time.sleep(0.3)
+        assert tc.is_alive() and tp.is_alive()
+        front.stop()
+        tc.join(timeout=5)
+        tp.join(timeout=5)
+        assert not tc.is_alive() and not tp.is_alive()
+        pause.__exit__(None, None, None)
+        assert out["consumer"] == N.LASR_ESTATE and out["producer"] == N.LASR_ESTATE
+        with pytest.raises(N.LasrError):
+            front.open()                           # stopped: no new call gets in
+        front.destroy()
+        assert front.h is None
+        # the engine is idle and intact
+        pcm = synth.synth_pcm(3, 16000 * 3, seed=1234)
+        g = np.load(os.path.join(golden_dir, "model_tiny.npz"))
+        assert _stream_tokens(eng, pcm) == [list(g[f"st_tokens_{s}"]) for s in range(3)]
+    finally:
+        eng.close()
