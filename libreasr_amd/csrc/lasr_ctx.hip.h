@@ -263,6 +263,7 @@ struct lasr_ctx {
     // (k_fe_mel src2) -- one launch and one kernel boundary less per model step on the stream that binds the job.  Every other
     // entry point that touches the PCM ring flushes it first (flush_lazy: the plain append launch).
     struct LazyPush { bool on = false; const float* src = nullptr; std::vector<int> slots; int ev_i = -1; bool dma = false; } lazy;
+    int pump_nap_pct = 0;                 // LASR_PUMP_NAP_PCT (see pump_main)
     int lazy_taken = 0, lazy_flushed = 0; // deferred chunks appended by a front-end launch / by the plain launch after all (lasr_debug_config)
     bool lazy_on = true;                  // LASR_PUSH_LAZY=0 turns the deferred append off (A/B switch)
     int fe_mode = 1;                      // fused front-end: 1 = k_fe_mel (+ ring append) -> k_stack_ln, 0 = k_frontend; LASR_FE_MODE

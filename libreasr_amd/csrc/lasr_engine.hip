@@ -20,6 +20,8 @@
 #include <tuple>
 #include <string>
 #include <vector>
+#include <sys/prctl.h>
+#include <time.h>
 
 #include "../../include/lasr.h"
 #include "../../include/lasr_debug.h"
@@ -144,6 +146,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     // round 3's wait path
     c->pump_G = c->W > 1 ? c->wait_n : 2;
     if (getenv("LASR_PUMP_G")) c->pump_G = std::max(1, std::min(8, atoi(getenv("LASR_PUMP_G"))));
+    if (getenv("LASR_PUMP_NAP_PCT")) c->pump_nap_pct = std::max(0, std::min(90, atoi(getenv("LASR_PUMP_NAP_PCT"))));
     if (getenv("LASR_PUSH_LAZY")) c->lazy_on = atoi(getenv("LASR_PUSH_LAZY")) != 0;
     if (getenv("LASR_DEC_MIN_ROWS")) c->dec_min_rows = std::max(0, atoi(getenv("LASR_DEC_MIN_ROWS")));
     const size_t Mj = (size_t)c->MTj * 16;
@@ -1614,6 +1617,11 @@ static void pump_main(lasr_ctx* c) {
     (void)hipSetDevice(c->device);
     tl_err_sink = &c->pump_err;             // fail() on this thread writes the pump's own buffer (under c->mu), never c->err
     long long seen_kick = -1;
+    // LASR_PUMP_NAP_PCT > 0: the pump sleeps through that share of a group's expected duration (moving average of the last groups)
+    // before it starts to spin on the group's flag -- a group of 2 iterations runs ~170 us, and polling it from the first
+    // microsecond keeps one host core per context at 100 %.  The timer slack of this thread goes down to 1 us for that.
+    double ema_us = 0.0;
+    if (c->pump_nap_pct > 0) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
     for (;;) {
         bool inflight = false, idle = false;
         {
@@ -1630,10 +1638,23 @@ static void pump_main(lasr_ctx* c) {
         if (inflight) {
             // the group's flag: a plain spin (the pump is the only thing this thread does); a submit in the meantime changes nothing
             // before the group has finished
+            const auto t_launch = std::chrono::steady_clock::now();
+            if (c->pump_nap_pct > 0 && ema_us > 20.0) {
+                const long ns = (long)(ema_us * 10.0 * c->pump_nap_pct);        // us * 1000 * pct / 100
+                struct timespec ts{0, std::min(ns, 2000000L)};
+                (void)nanosleep(&ts, nullptr);
+            }
             unsigned long long spins = 0;
             while (__atomic_load_n((volatile int*)c->cont_host, __ATOMIC_ACQUIRE) == -1 && !c->pump_stop.load(std::memory_order_relaxed)) {
                 __builtin_ia32_pause();
                 if (++spins > (1ull << 31)) break;
+            }
+            if (c->pump_nap_pct > 0) {
+                // (a group found finished right after the nap may have overslept: its duration is an upper bound, and the
+                //  average then shrinks the next nap only through the shorter groups -- so count such a group at 80 %)
+                double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count();
+                if (spins < 4) us *= 0.8;
+                ema_us = ema_us == 0.0 ? us : 0.875 * ema_us + 0.125 * us;
             }
             continue;
         }
@@ -2741,7 +2762,7 @@ int lasr_debug_config(lasr_ctx* c, const char* key, int* value) {
         {"enc_xg", (int)c->enc_xg}, {"enc_wave", c->enc_wave}, {"enc_u12", (int)c->enc_u12}, {"main_graph", (int)c->main_graph},
         {"pump_G", c->pump_G}, {"la_stream", c->la_stream}, {"la_offline", c->la_offline}, {"dec_min_rows", c->dec_min_rows},
         {"cell_nw", c->cell_nw ? c->cell_nw : (c->bf ? 8 : 4)}, {"use_graphs", (int)c->use_graphs}, {"fe_mode", c->fe_mode}, {"M", c->M},
-        {"push_lazy", (int)c->lazy_on}, {"lazy_taken", c->lazy_taken}, {"lazy_flushed", c->lazy_flushed},
+        {"push_lazy", (int)c->lazy_on}, {"pump_nap_pct", c->pump_nap_pct}, {"lazy_taken", c->lazy_taken}, {"lazy_flushed", c->lazy_flushed},
     };
     for (const auto& e : tab)
         if (!strcmp(e.k, key)) { *value = e.v; return LASR_OK; }

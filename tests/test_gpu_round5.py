@@ -231,7 +231,7 @@ def _stream_tokens(eng, pcm, depth=6, host=False):
 SWITCH_CASES = [
     ("LASR_CELL_NW", "8", "f32"), ("LASR_ENC_WAVE", "1", "f32"), ("LASR_MAIN_GRAPH", "1", "f32"), ("LASR_NO_GRAPH", "1", "f32"),
     ("LASR_PUMP_G", "1", "f32"), ("LASR_PUMP_G", "3", "f32"), ("LASR_DEC_MIN_ROWS", "16", "f32"), ("LASR_DEC_STREAM_PICK", "0", "f32"),
-    ("LASR_SYNC_MEMCPY", "1", "f32"), ("LASR_PUSH_THREADS", "0", "f32"), ("LASR_VERBOSE", "1", "f32"),
+    ("LASR_SYNC_MEMCPY", "1", "f32"), ("LASR_PUSH_THREADS", "0", "f32"), ("LASR_VERBOSE", "1", "f32"), ("LASR_PUMP_NAP_PCT", "60", "f32"),
     ("LASR_ENC_WAVE", "0", "bf16"), ("LASR_MAIN_GRAPH", "0", "bf16"),
 ]
 
