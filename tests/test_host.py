@@ -382,3 +382,70 @@ def test_every_library_switch_is_documented_with_an_owner():
             assert os.path.exists(os.path.join(root, path)), (names, path)
     assert read == documented, (read - documented, documented - read)
     assert len(read) <= 30
+
+
+def test_native_front_wrapper_frees_the_handle_only_when_no_call_is_inside():
+    """libreasr_amd.front.NativeFront on a stand-in library (no GPU): stop() lets no new call in and calls lasr_front_stop;
+    destroy() waits until the call that was blocked inside has returned before lasr_front_destroy runs; a second destroy is a no-op."""
+    import threading
+    import time
+    import types
+    from libreasr_amd import _native as N
+    from libreasr_amd.front import NativeFront
+
+    log = []
+    release = threading.Event()
+
+    class Lib:
+        def lasr_front_create(self, ctx, depth, reset_steps, out):
+            log.append("create")
+            return 0
+
+        def lasr_front_next(self, h, stream, buf, cap, n, fl, timeout):
+            log.append("next-in")
+            release.wait(5)                       # (the native call blocks until lasr_front_stop releases it)
+            log.append("next-out")
+            return N.LASR_ESTATE
+
+        def lasr_front_stop(self, h):
+            log.append("stop")
+            release.set()
+            return 0
+
+        def lasr_front_destroy(self, h):
+            log.append("destroy")
+
+        def lasr_front_open(self, h, s):
+            log.append("open")
+            return 0
+
+        def lasr_front_error(self, h):
+            return b"stopped"
+
+        def lasr_last_error(self, ctx):
+            return b""
+
+    eng = types.SimpleNamespace(lib=Lib(), ctx=None, desc=types.SimpleNamespace(chunk=1280, n_buffer=2, max_iters_stream=10),
+                                _chk=lambda rc: rc)
+    front = NativeFront(eng, depth=4)
+    assert front in eng._fronts
+    err = []
+
+    def consumer():
+        try:
+            front.next(0)
+        except N.LasrError as e:
+            err.append(e.code)
+
+    t = threading.Thread(target=consumer)
+    t.start()
+    while "next-in" not in log:
+        time.sleep(0.001)
+    front.destroy()                               # stop -> the consumer leaves -> destroy
+    t.join(5)
+    assert log == ["create", "next-in", "stop", "next-out", "destroy"]
+    assert err == [N.LASR_ESTATE] and front.h is None and front not in eng._fronts
+    with pytest.raises(N.LasrError):
+        front.open()
+    front.destroy()
+    assert log[-1] == "destroy" and log.count("destroy") == 1
