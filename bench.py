@@ -427,7 +427,7 @@ def main():
     if args.lm != "none":
         eng.attach_lm(synth.synth_lm_state_dict("lm768"), int8=args.lm == "int8")
     eng_cfg = {}
-    for key in ("enc_xg", "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "dec_min_rows", "cell_nw", "push_lazy"):
+    for key in ("enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "cell_nw", "push_lazy"):
         try:
             eng_cfg[key] = eng.config(key)
         except Exception:
@@ -662,31 +662,27 @@ def main():
         cells_per_launch = cell_kernel_cells / cell_kernel_launches if cell_kernel_launches else 1.0
         flops_mean *= cells_per_launch
         wbytes_mean *= cells_per_launch
-        if eng_cfg.get("enc_xg"):
-            # LASR_ENC_XG: per layer and model step one x-side GEMM (W_ih once) + n_buffer recurrent cells (W_hh each)
-            Tn = cfg.get("n_buffer", 2)
-            esz_w = 2.0 if bf else 4.0
-            wbytes_mean = float(np.mean([esz_w * 4 * H * ((cfg["feat"] if l == 0 else H) + Tn * H) for l in range(L)])) / (Tn + 1)
-        # the committed kernel trace of the same command (rocprofv3 --kernel-trace --stats, profiles/r05/): the tracer's in-job average
-        # of the same kernel.  It includes warm-up, the offline / PCIe legs and the tracer's own overhead (the job runs 10-15 %
-        # slower under it), so it is the upper end; `frac` is computed from the LARGER of the two durations
+        # `frac` comes from THIS run's own measurement (launch_us: in-kernel clocks over the launches of the profiled steps).  The
+        # committed kernel trace of the same command (rocprofv3 --kernel-trace --stats under profiles/) is reported BESIDE it
+        # (launch_us_rocprof, frac_rocprof) and never substituted: it averages warm-up, the offline / PCIe legs and the tracer's
+        # own overhead
         wkey = f"{args.model}_{args.dtype}_{B}_beam{args.beam}"
         rocprof_us, rocprof_src, traffic, pmc_src = None, None, None, None
         try:
             with open(os.path.join(ROOT, "profiles", "cell_rocprof.json")) as f:
                 rp = json.load(f).get(wkey)
-            if rp and not eng_cfg.get("enc_xg"):
+            if rp:
                 rocprof_us, rocprof_src = float(rp["avg_us"]), rp.get("file")
         except Exception:
             pass
         try:                                # HBM bytes per launch from the committed PMC passes
             with open(os.path.join(ROOT, "profiles", "cell_pmc.json")) as f:
                 pm = json.load(f).get(wkey)
-            if pm and not eng_cfg.get("enc_xg"):
+            if pm:
                 traffic, pmc_src = int(pm["hbm_bytes_per_launch"] * cells_per_launch), pm.get("file")      # (the passes measured a one-cell launch)
         except Exception:
             pass
-        dur_us = max(cell_us, rocprof_us) if rocprof_us else cell_us
+        dur_us = cell_us
         achieved = flops_mean / (dur_us * 1e-6) / 1e12
         job_tflops = audio_total / elapsed_max * 12.5 * flop_per_frame(cfg, n_tok) / 1e12
         out = {
@@ -747,9 +743,8 @@ def main():
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launch_us": round(cell_us, 3), "launches_timed": int(cell_kernel_launches or cell_launches),
                          "launch_us_rocprof": rocprof_us, "launch_us_rocprof_file": rocprof_src, "traffic_file": pmc_src,
-                         "frac_basis": ("launch_us_rocprof (the larger)" if rocprof_us and rocprof_us >= cell_us else "launch_us (in-kernel clocks"
-                                        + ("; the larger)" if rocprof_us else "; no committed kernel trace for this workload)")),
-                         "frac_launch_us": round(flops_mean / (cell_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if not bf else None,
+                         "frac_basis": "launch_us: in-kernel clocks of this run (the committed trace's figure is frac_rocprof, beside it)",
+                         "frac_rocprof": (round(flops_mean / (rocprof_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if rocprof_us and not bf else None),
                          "measured_in": ("launch_us and launch_us_events: the timed region itself" if args.cell_prof_in_timed in (1, 2) else
                                          f"launch_us_events: the timed region (one HIP-event pair per model step around the cell graph); "
                                          f"launch_us: {Kp // CPS} further steps of the same job right behind it, cells as plain launches "
@@ -774,7 +769,7 @@ def main():
             gbs = wbytes_mean / (dur_us * 1e-6) / 1e9
             out["roofline"].update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                    "frac_launch_us": round(wbytes_mean / (cell_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                                    "frac_rocprof": round(wbytes_mean / (rocprof_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if rocprof_us else None,
                                     "note": "algorithmic bytes = packed bf16 weights of one cell (W_ih + W_hh)"})
         try:                                                               # the kernel alone on the GPU (micro-benchmark)
             out["roofline"]["launch_us_isolated"] = round(eng.bench_cell(layer=1, iters=300), 3)

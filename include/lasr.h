@@ -66,7 +66,8 @@ typedef struct {
     int32_t max_iters_stream;  /* 10 (transcribe_stream default, models.py:458)         */
     int32_t beam;        /* 1 = greedy (the only decode the reference has); 2..8 = beam  */
                          /* search width W (spec: oracle _beam_frame):     */
-                         /* W hypothesis slots per stream, streams x W <= 1024 rows.     */
+                         /* W hypothesis slots per stream, streams x W <= 1024 rows,     */
+                         /* vocab <= 2048 (a hypothesis row's logits live in one wave).  */
                          /* lasr_fetch then returns the WHOLE current best hypothesis    */
                          /* after every model step (it may change retroactively),        */
                          /* neg_logp = -its score, align = 0.  Both protocols (the        */

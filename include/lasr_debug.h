@@ -35,8 +35,7 @@ int lasr_debug_timing(lasr_ctx* c, unsigned long long* out);
 int lasr_debug_read(lasr_ctx* c, int what, int index, float* out, size_t cap, int* rows, int* cols);
 
 /* Engine configuration as resolved at lasr_create (defaults + LASR_* environment switches): *value = the integer behind `key`.
- * Keys: "enc_xg", "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "la_offline", "dec_min_rows", "cell_nw",
- * "use_graphs", "fe_mode", "M".  LASR_EINVAL for an unknown key.  bench.py records these beside every line. */
+ * Keys: "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "la_offline", "cell_nw", "use_graphs", "M".  LASR_EINVAL for an unknown key.  bench.py records these beside every line. */
 int lasr_debug_config(lasr_ctx* c, const char* key, int* value);
 
 /* Roofline micro-benchmark of the dominant kernel (one encoder LSTM-cell launch: all rows active,

@@ -1,9 +1,6 @@
 // lasr_ctx.hip.h -- the engine context (lasr_ctx), error / allocation helpers, operand packing, description checks
-// Part of the single translation unit lasr_engine.hip (textual include, in this order:
-// lasr_ctx, lasr_launch, lasr_decode, lasr_weights); not a stand-alone header.
+// Included through lasr_host.hip.h by every translation unit of the library.
 #pragma once
-
-namespace {
 
 constexpr int NW = 8;          // waves per GEMM workgroup (K split)
 constexpr int NCMD = 64;       // ring of host->device command blocks
@@ -18,8 +15,6 @@ struct Cell {                  // one recurrent layer (+ its BatchNorm fold and 
     float *h0 = nullptr, *c0 = nullptr;
     float *tab = nullptr;      // predictor layer 0: per-token input projection table
 };
-
-}  // namespace
 
 struct lasr_ctx {
     lasr_model_desc d;
@@ -169,8 +164,6 @@ struct lasr_ctx {
     bool pump_started = false, pump_on = false;
     std::atomic<bool> pump_stop{false};
     int pump_G = 3;                 // iterations per group launched by the pump; LASR_PUMP_G
-    int dec_min_rows = 0;           // decode throttle: with <= this many rows still holding frames and an encoder step not yet admitted, the
-                                    // next group waits (stream-side) for that encoder instead of iterating for the stragglers alone; LASR_DEC_MIN_ROWS
     std::atomic<long long> kick{0}, progress{0};   // steps handed over by the API thread / groups consumed by the pump
     int pump_rc = 0; std::string pump_err;
     int kick_n = 3, wait_n = 1;     // iterations per group without the pump: kicked from submit / launched while waiting (swept on configs[1])
@@ -224,7 +217,7 @@ struct lasr_ctx {
     int tok_cap_alloc = 0;
 
     // front-end buffers
-    // fused streaming front-end (k_frontend): nothing is computed on a client chunk that does not complete a model
+    // fused streaming front-end (k_fe_mel + k_ln_tile): nothing is computed on a client chunk that does not complete a model
     // step; the step's launch works through the row's last n_buffer windows, which the PCM ring (ring_chunks =
     // n_window + n_buffer - 1 chunks) still holds.  pend_serial[s * n_buffer + j] = chunk count of slot s when its
     // pending frame j was taken; pend_mat = that frame had to be computed early into `pend` (the client pushed more
@@ -266,7 +259,6 @@ struct lasr_ctx {
     int pump_nap_pct = 0;                 // LASR_PUMP_NAP_PCT (see pump_main)
     int lazy_taken = 0, lazy_flushed = 0; // deferred chunks appended by a front-end launch / by the plain launch after all (lasr_debug_config)
     bool lazy_on = true;                  // LASR_PUSH_LAZY=0 turns the deferred append off (A/B switch)
-    int fe_mode = 1;                      // fused front-end: 1 = k_fe_mel (+ ring append) -> k_stack_ln, 0 = k_frontend; LASR_FE_MODE
     float* lm_buf = nullptr; size_t lm_floats = 0;       // offline log-mel
     float* feat_stage = nullptr; size_t feat_stage_floats = 0;
 
@@ -307,9 +299,6 @@ struct lasr_ctx {
     unsigned long long* cp_slots = nullptr;   // device [2][NCELLSLOT][PROF_W]: per launch and workgroup, entry clocks then exit clocks
     long long cp_slot_next = 0;
     std::vector<unsigned char> cp_slot_cells;  // cells computed by the launch of slot i (layer-wavefront launches: up to 8)
-    bool enc_xg = false;            // x side of a layer's frames as ONE GEMM per model step (k_gemm<EpiXG>), cells with K = H; LASR_ENC_XG
-    float* gx = nullptr;            // [H / U][4 U][gx_rows]: x-side gate pre-activations of the frames in flight in one layer
-    int gx_rows = 0, gx_frames = 0; // rows per column (= gx_frames x M)
     int enc_wave = 0;               // encoder pass as a layer wavefront (cells of an anti-diagonal share a launch): default on for bf16; LASR_ENC_WAVE
     double cp_clock_mhz = 100.0;
 
@@ -453,7 +442,7 @@ bool valid_desc(const lasr_model_desc* d) {
     if (d->blank < 0 || d->blank >= d->vocab || d->bos < 0 || d->bos >= d->vocab) return false;
     if ((d->dtype != 0 && d->dtype != 1) || d->beam < 1 || d->beam > 8) return false;
     if ((d->max_streams + 63) / 64 * 64 * d->beam > 1024) return false;      // decoder rows (streams x beam slots)
-    if (d->beam > 1 && d->vocab > 4096) return false;                         // k_beam_select keeps a stream's logits in registers
+    if (d->beam > 1 && d->vocab > 2048) return false;                         // k_beam_select_rw keeps a hypothesis row's logits in one wave's registers
     if (d->dtype == 1) {   // bf16 operands: 32-wide K chunks
         auto m32 = [](int v) { return v % 32 == 0; };
         if (!m32(d->feat) || !m32(d->hidden) || !m32(d->joint)) return false;

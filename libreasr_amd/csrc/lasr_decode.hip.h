@@ -1,6 +1,5 @@
 // lasr_decode.hip.h -- state reset, encoder pass, greedy and beam decode loops of the synchronous protocol
-// Part of the single translation unit lasr_engine.hip (textual include, in this order:
-// lasr_ctx, lasr_launch, lasr_decode, lasr_weights); not a stand-alone header.
+// Engine unit only (lasr_engine.hip), included after lasr_host.hip.h and lasr_cmd.hip.h.
 #pragma once
 
 namespace {
@@ -101,23 +100,6 @@ void run_encoder(lasr_ctx* c, int T_max) {
                 }
                 if (n) launch_enc_wave(c, cells, n, par0, mt_total);
             }
-        } else if (c->enc_xg && c->gx) {
-            // x side of a layer for up to gx_frames frames in ONE GEMM (W_ih crosses the fabric once per model step instead of
-            // once per frame -- custom_rnn.py:172 hands nn.LSTM the whole sequence), then the frames' recurrent cells with K = H
-            const int XT = std::min(c->gx_frames, XG_TMAX);
-            for (int l = 0; l < L; ++l) {
-                c->enc_par = par0;
-                const void* xsrc = (l == 0) ? c->x0 : c->ybuf[(l - 1) & 1];
-                void* ydst = c->ybuf[l & 1];
-                for (int t0 = 0; t0 < T_max; t0 += XT) {
-                    const int Tn = std::min(XT, T_max - t0);
-                    launch_enc_xg(c, l, t0, Tn, xsrc, mt_total);
-                    for (int t = t0; t < t0 + Tn; ++t) {
-                        launch_enc_cell(c, l, t, xsrc, mt_total, ydst, mt_total, (t - t0) * c->M);
-                        c->enc_par ^= 1;
-                    }
-                }
-            }
         } else {
             for (int l = 0; l < L; ++l) {
                 c->enc_par = par0;
@@ -139,7 +121,7 @@ void run_encoder(lasr_ctx* c, int T_max) {
     bool replayed = false;
     if (c->main_graph && c->use_graphs && c->pe == c->pe_ring && !(c->cell_prof && c->cp_slots) && !c->dbg && T_max <= 8) {
         std::vector<unsigned long long> key{(unsigned long long)T_max, (unsigned long long)par0, (unsigned long long)(uintptr_t)c->T_row_dev,
-                                            (unsigned long long)(uintptr_t)c->x0, (unsigned long long)mt_total, (unsigned long long)(c->enc_wave + 2 * (int)c->enc_xg)};
+                                            (unsigned long long)(uintptr_t)c->x0, (unsigned long long)mt_total, (unsigned long long)c->enc_wave};
         for (int t = 0; t < T_max; ++t) key.push_back(c->tile_masks.empty() ? ~0ull : c->tile_masks[t]);
         auto it = c->mgraphs.find(key);
         bool ok = true;
@@ -264,22 +246,13 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
         // k_publish stores them into the pinned block and releases the word last (system scope).  Offline (whole utterances,
         // large token blocks): only the word comes back per group; the results are copied once at the end, behind a real
         // synchronisation.  A word that arrives by hipMemcpyAsync carries nothing but itself: no ordering against any other
-        // copy is assumed anywhere (LASR_SYNC_MEMCPY=1 restores the round-3 "payload copy, then flag copy" for A/B runs).
-        static const bool legacy = getenv("LASR_SYNC_MEMCPY") && atoi(getenv("LASR_SYNC_MEMCPY")) != 0;
+        // copy is assumed anywhere (round 3's "payload copy, then flag copy" let the flag overtake the payload: tests/soak.py).
         const int n_pay = M + M * s.tok_cap;
-        if (!offline && !legacy) {
+        if (!offline) {
             const int nb = std::max(1, std::min(64, (n_pay + 1023) / 1024));
             hipLaunchKernelGGL(k_publish, dim3(nb), dim3(256), 0, c->stream, (const int*)c->ds.step_ntok, c->res_dev + 4, n_pay,
                                (const int*)(c->ds.unfinished + (first + n - 1)), c->res_dev, c->pub_arrivals);
             return LASR_OK;
-        }
-        if (legacy) {
-            HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * (size_t)n_pay, hipMemcpyDeviceToHost, c->stream));
-            if (offline) {
-                HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipMemcpyAsync(n_ones, c->ds.n_ones, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipMemcpyAsync(logp, c->ds.logp_sum, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
-            }
         }
         HIPCHK(c, hipMemcpyAsync(res, c->ds.unfinished + (first + n - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
         return LASR_OK;
@@ -325,7 +298,7 @@ int run_decode(lasr_ctx* c, int T_max, int max_iters, bool offline, const std::v
         group = next_group;
     }
     c->stats.decode_iters = iter;
-    if (offline && !(getenv("LASR_SYNC_MEMCPY") && atoi(getenv("LASR_SYNC_MEMCPY")) != 0)) {
+    if (offline) {
         // offline results: one copy each, read only after the stream has been synchronised
         HIPCHK(c, hipMemcpyAsync(ntok, c->ds.step_ntok, sizeof(int) * ((size_t)M + (size_t)M * s.tok_cap), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(sum_iters, c->ds.sum_iters, sizeof(int) * M, hipMemcpyDeviceToHost, c->stream));

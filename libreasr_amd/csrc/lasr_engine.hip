@@ -1,37 +1,13 @@
 // lasr_engine.hip -- host side of liblasr_hip.so: weight packing, per-stream device state, the
 // per-chunk step (front-end -> encoder -> greedy decode loop) and the C ABI of include/lasr.h.
 // gfx950 only.  No CPU fallback: every numeric result comes from the kernels in lasr_kernels.hip.h.
-#include "lasr_kernels.hip.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <deque>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <thread>
-#include <tuple>
-#include <string>
-#include <vector>
+#include "lasr_host.hip.h"
 #include <sys/prctl.h>
 #include <time.h>
 
-#include "../../include/lasr.h"
-#include "../../include/lasr_debug.h"
-
-using namespace lasr;
-
-#include "lasr_ctx.hip.h"
 static void cont_poll(lasr_ctx* c);       // (pipelined protocol, below; require_idle consumes a group that was still running)
 static int flush_lazy(lasr_ctx* c);       // (deferred ring append of lasr_push_submit, below)
-#include "lasr_launch.hip.h"
+#include "lasr_cmd.hip.h"
 #include "lasr_decode.hip.h"
 #include "lasr_weights.hip.h"
 
@@ -148,7 +124,6 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     if (getenv("LASR_PUMP_G")) c->pump_G = std::max(1, std::min(8, atoi(getenv("LASR_PUMP_G"))));
     if (getenv("LASR_PUMP_NAP_PCT")) c->pump_nap_pct = std::max(0, std::min(90, atoi(getenv("LASR_PUMP_NAP_PCT"))));
     if (getenv("LASR_PUSH_LAZY")) c->lazy_on = atoi(getenv("LASR_PUSH_LAZY")) != 0;
-    if (getenv("LASR_DEC_MIN_ROWS")) c->dec_min_rows = std::max(0, atoi(getenv("LASR_DEC_MIN_ROWS")));
     const size_t Mj = (size_t)c->MTj * 16;
     c->G_pred = d.pred_cell ? 4 : 3;
     c->bf = d.dtype == 1; c->kch = c->bf ? 32 : 16; c->esz = c->bf ? 2 : 4;
@@ -168,16 +143,6 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         //  128 streams, greedy / beam 8: 46.8 / 14.6 k against 45.9 / 14.4 k as a wavefront, profiles/r04/r04_cell_tiling_d.txt)
         if (c->enc_u12) c->enc_wave = 0;
         if (getenv("LASR_ENC_WAVE")) c->enc_wave = atoi(getenv("LASR_ENC_WAVE"));
-        // x side of a layer's frames as one GEMM per model step (round 5): a mode of the plain (non-wavefront) order
-        if (getenv("LASR_ENC_XG")) c->enc_xg = atoi(getenv("LASR_ENC_XG")) != 0;
-        if (c->enc_xg) {
-            c->enc_wave = 0;
-            c->gx_frames = std::max(d.n_buffer, std::min(XG_TMAX, 1024 / M));
-            c->gx_frames = std::min(c->gx_frames, XG_TMAX);
-            c->gx_rows = c->gx_frames * M;
-            RC(dalloc(c, &c->gx, (size_t)4 * H * c->gx_rows));
-            HIPCHK(c, hipMemset(c->gx, 0, sizeof(float) * (size_t)4 * H * c->gx_rows));
-        }
         // decode-stream GEMMs (predictor cells, PPJ, logits): 4 waves per workgroup with f32 operands (next to the encoder cells
         // of the main stream fewer waves per CU interfere less: whole job +5 %), 8 with bf16 (4: -3 %)
         c->dec_nw_mask = c->bf ? 0 : 7;
@@ -406,7 +371,6 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     HIPCHK(c, hipMemset(c->ds.logp_sum, 0, sizeof(double) * M));
     // (the reference front-end: 10 frames of 128 mels per stacked frame; other shapes take the per-chunk kernels)
     c->fe_fused = M <= 512 && d.n_buffer <= 4 && d.n_stack == 10 && d.n_mels <= 128 && d.feat == 1280 && !getenv("LASR_FE_LEGACY");
-    if (getenv("LASR_FE_MODE")) c->fe_mode = atoi(getenv("LASR_FE_MODE")) ? 1 : 0;
     c->h_ring_pos.assign(M, 0);
     c->ring_chunks = c->fe_fused ? d.n_window + d.n_buffer - 1 : d.n_window;
     c->pend_serial.assign((size_t)M * d.n_buffer, 0); c->pend_mat.assign((size_t)M * d.n_buffer, 0);
@@ -433,7 +397,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
             RC(dalloc(c, &EF, (size_t)V * H));
             GemmArgs g{}; g.A[0] = emb_dev; g.a_mt_total[0] = E; g.a_mt_off[0] = 0; g.KC[0] = E / 16; g.W[0] = wf; g.a_rows = V;
             EpiLinear::Args ea{}; ea.bias = bfn; ea.out = EF; ea.ldo = H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
-            launch_gemm<OpsF32, EpiLinear, 1, true>(c, H / 16, V / 16, g, ea);
+            launch_table_gemm_f32(c, H / 16, V / 16, g, ea);
             HIPCHK(c, hipStreamSynchronize(c->stream));
             dfree(c, wf); dfree(c, bfn);
         } else {
@@ -446,7 +410,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         RC(dalloc(c, &c->pred[0].tab, (size_t)V * G * H));
         GemmArgs g{}; g.A[0] = EF; g.a_mt_total[0] = H; g.a_mt_off[0] = 0; g.KC[0] = H / 16; g.W[0] = wt; g.a_rows = V;
         EpiLinear::Args ea{}; ea.bias = bt; ea.out = c->pred[0].tab; ea.ldo = G * H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
-        launch_gemm<OpsF32, EpiLinear, 1, true>(c, G * H / 16, V / 16, g, ea);
+        launch_table_gemm_f32(c, G * H / 16, V / 16, g, ea);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
         dfree(c, wt); dfree(c, bt); dfree(c, EF); dfree(c, emb_dev);
@@ -625,7 +589,7 @@ static int stream_frame0(lasr_ctx* c, int* nf_out) {
 
 // Fused front-end, irregular clients: a slot that is about to be pushed again although it still has a pending frame whose
 // window the ring would lose (more than one chunk pushed per lasr_step_* call) gets that frame computed NOW into `pend`
-// (the per-chunk log-mel kernel, window selected by its age); the step's k_frontend launch then takes it from there.
+// (the per-chunk log-mel kernel, window selected by its age); the step's k_fe_mel launch then skips it (age 15).
 static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
     const lasr_model_desc& d = c->d;
     const int slack = c->ring_chunks - d.n_window;
@@ -900,25 +864,20 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
         rec(c, 0);
         if (model_rows.empty()) return LASR_OK;
         RC(ensure_T(c, Tm));
-        FrontArgs f{};
-        f.window = c->window; f.tw512 = c->tw512; f.tw1024 = c->tw1024; f.fb_start = c->fb_start; f.fb_off = c->fb_off; f.fb_w = c->fb_w;
-        f.n_mels = d.n_mels; f.hop = d.hop; f.fb_nnz = c->fb_nnz; f.win_off = (d.n_fft - d.win) / 2; f.win_len = d.win;
-        f.pcm = c->win; f.ring_pos = c->ring_pos; f.chunk = d.chunk; f.n_window = d.n_window; f.ring_chunks = c->ring_chunks; f.frame0 = a0;
-        f.pend = c->pend; f.pend_frames = d.n_buffer * d.n_stack;
-        f.ln_w = c->ln_w; f.ln_b = c->ln_b; f.x0 = c->x0; f.F = d.feat; f.M = c->M; f.MT = c->MT; f.mt_total = c->Tcap * c->MT; f.bf = c->bf;
-        f.trow_out = c->dc.T_row;
-        if (c->pe == c->pe_ring) { f.enc_frames = c->c_enc_frames; f.enc_base = c->c_enc_base; }
+        int* enc_frames = nullptr; int* enc_base = nullptr;
+        if (c->pe == c->pe_ring) { enc_frames = c->c_enc_frames; enc_base = c->c_enc_base; }
+        // per (t', row): chunks pushed since the window of stacked frame t' was current; 255: the frame is already in pend
+        std::vector<unsigned char> age_v((size_t)d.n_buffer * c->M, 0);
         for (int s : model_rows) {
-            f.trow_v[s] = (unsigned char)d.n_buffer;
             for (int j = 0; j < d.n_buffer; ++j) {
                 const size_t q = (size_t)s * d.n_buffer + j;
                 const int age = c->n_chunks[s] - c->pend_serial[q];
                 if (!c->pend_mat[q] && age > c->ring_chunks - d.n_window)
                     return fail(c, LASR_ESTATE, "slot %d: the PCM ring no longer holds the window of pending frame %d", s, j);
-                f.age_v[j][s] = c->pend_mat[q] ? 255 : (unsigned char)age;
+                age_v[(size_t)j * c->M + s] = c->pend_mat[q] ? 255 : (unsigned char)age;
             }
         }
-        if (c->fe_mode == 1) {
+        {
             // log-mel halves (+ the ring append of the newest chunk when fused) on 2 x n_buffer x rows workgroups, then stack + LayerNorm
             FeMelArgs m{};
             m.window = c->window; m.tw512 = c->tw512; m.tw1024 = c->tw1024; m.fb_start = c->fb_start; m.fb_off = c->fb_off; m.fb_w = c->fb_w;
@@ -926,7 +885,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             m.pcm = c->win; m.ring_pos = c->ring_pos; m.chunk = d.chunk; m.n_window = d.n_window; m.ring_chunks = c->ring_chunks; m.frame0 = a0;
             m.pend = c->pend; m.pend_frames = d.n_buffer * d.n_stack;
             int* trow_home = (c->pe == c->pe_ring) ? c->T_row_main : nullptr;      // pipelined: one fixed buffer (see commit_T_rows)
-            m.trow_out = trow_home ? trow_home : c->dc.T_row; m.enc_frames = f.enc_frames; m.enc_base = f.enc_base;
+            m.trow_out = trow_home ? trow_home : c->dc.T_row; m.enc_frames = enc_frames; m.enc_base = enc_base;
             m.src = fused ? fused->src : nullptr;
             const bool with_lazy = fused && c->lazy.on;          // (push_submit_impl: the deferred chunk belongs to exactly `slots`)
             m.src2 = with_lazy ? c->lazy.src : nullptr;
@@ -941,7 +900,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             for (int s : model_rows) {
                 m.tp_pk[s] |= (unsigned char)d.n_buffer;
                 unsigned pk = 0;
-                for (int j = 0; j < d.n_buffer; ++j) pk |= (unsigned)(f.age_v[j][s] == 255 ? 15 : f.age_v[j][s]) << (4 * j);
+                for (int j = 0; j < d.n_buffer; ++j) { const unsigned a8 = age_v[(size_t)j * c->M + s]; pk |= (a8 == 255 ? 15u : a8) << (4 * j); }
                 m.age_pk[s] = (unsigned short)pk;
             }
             hipStream_t fe_st = c->stream;
@@ -966,11 +925,6 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             } else {
                 LAUNCH_STACK_LN( dim3((Tm + 3) / 4, c->M), dim3(256), 0, fe_st, a);
             }
-        } else {
-        const dim3 grid(d.n_buffer, c->M);
-        hipLaunchKernelGGL((k_frontend<10, 20>), grid, dim3(640), 0, c->stream, f);
-        // (after the launch that stores T_row: the synchronous protocol copies it to a fixed buffer on the stream)
-        RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring));    // the continuous loop reads its own frame counters
         }
         rec(c, 1);
         run_encoder(c, Tm);
@@ -1114,7 +1068,7 @@ static int push_submit_impl(lasr_ctx* c, const int* slots, int n, const float* p
     RC(push_prepare(c, slots, n, pcm, flags, ps, rows));
     tr_mark(c, 1, c->stream);
     if (c->fe_fused) RC(materialize_pending(c, slots, n));
-    const bool can_fuse = c->fe_fused && c->fe_mode == 1;
+    const bool can_fuse = c->fe_fused;
     // a deferred chunk rides in this call's front-end launch only when it belongs to exactly these slots, in this order
     if (c->lazy.on && !(can_fuse && (int)c->lazy.slots.size() == n && std::equal(slots, slots + n, c->lazy.slots.begin()))) RC(flush_lazy(c));
     if (!can_fuse) RC(push_append_launch(c, slots, n, ps));
@@ -1491,9 +1445,7 @@ static int cont_launch_group(lasr_ctx* c, int G, bool from_pump = false) {
     const bool by_value = M <= 512;
     for (auto& q : c->pending) {
         if (q.admitted) continue;
-        // (decode throttle, dec_min_rows > 0: an iteration streams the same ~50 MB of predictor / joint weights for 3 straggler rows
-        //  as for 64 -- with few rows left and an encoder on its way the group waits for that encoder and then runs on full rows)
-        const bool must = c->work_left <= c->dec_min_rows && !admitted_any;
+        const bool must = c->work_left == 0 && !admitted_any;
         if (!must && hipEventQuery(c->ev_enc[q.idx]) != hipSuccess) { (void)hipGetLastError(); break; }
         HIPCHK(c, hipStreamWaitEvent(sd, c->ev_enc[q.idx], 0));
         if (by_value) { for (int r : q.rows) c->h_avail[r] = q.target[r]; }
@@ -2323,7 +2275,7 @@ int lasr_attach_lm(lasr_ctx* c, const lasr_lm_desc* d, const float* weights, siz
         RC(dalloc(c, &m.cells[0].tab, (size_t)V * 4 * H));
         GemmArgs g{}; g.A[0] = emb_dev; g.a_mt_total[0] = E; g.a_mt_off[0] = 0; g.KC[0] = E / 16; g.W[0] = wt; g.a_rows = V;
         EpiLinear::Args ea{}; ea.bias = bt; ea.out = m.cells[0].tab; ea.ldo = 4 * H; ea.n_rows = V; ea.t_idx = nullptr; ea.T_row = nullptr; ea.M = M;
-        launch_gemm<OpsF32, EpiLinear, 1, true>(c, 4 * H / 16, V / 16, g, ea);
+        launch_table_gemm_f32(c, 4 * H / 16, V / 16, g, ea);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
         dfree(c, emb_dev); dfree(c, wt); dfree(c, bt);
@@ -2759,9 +2711,9 @@ int lasr_bench_neighbour(lasr_ctx* c, int kind, int n_wg, int ms, double* rate) 
 int lasr_debug_config(lasr_ctx* c, const char* key, int* value) {
     if (!c || !key || !value) return LASR_EINVAL;
     const struct { const char* k; int v; } tab[] = {
-        {"enc_xg", (int)c->enc_xg}, {"enc_wave", c->enc_wave}, {"enc_u12", (int)c->enc_u12}, {"main_graph", (int)c->main_graph},
-        {"pump_G", c->pump_G}, {"la_stream", c->la_stream}, {"la_offline", c->la_offline}, {"dec_min_rows", c->dec_min_rows},
-        {"cell_nw", c->cell_nw ? c->cell_nw : (c->bf ? 8 : 4)}, {"use_graphs", (int)c->use_graphs}, {"fe_mode", c->fe_mode}, {"M", c->M},
+        {"enc_wave", c->enc_wave}, {"enc_u12", (int)c->enc_u12}, {"main_graph", (int)c->main_graph},
+        {"pump_G", c->pump_G}, {"la_stream", c->la_stream}, {"la_offline", c->la_offline},
+        {"cell_nw", c->cell_nw ? c->cell_nw : (c->bf ? 8 : 4)}, {"use_graphs", (int)c->use_graphs}, {"M", c->M},
         {"push_lazy", (int)c->lazy_on}, {"pump_nap_pct", c->pump_nap_pct}, {"lazy_taken", c->lazy_taken}, {"lazy_flushed", c->lazy_flushed},
     };
     for (const auto& e : tab)
@@ -2772,9 +2724,7 @@ int lasr_debug_config(lasr_ctx* c, const char* key, int* value) {
 int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us) {
     if (!c || !us || layer < 0 || layer >= c->d.enc_layers || iters < 1) return c ? fail(c, LASR_EINVAL, "bad argument") : LASR_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    // c->enc_xg: an iteration is the layer's share of a model step -- one x-side GEMM over n_buffer frames + n_buffer recurrent
-    // cells --, reported per cell (so the figure compares with the fused cell's)
-    const int Tn = (c->enc_xg && c->gx) ? std::min(c->d.n_buffer, c->gx_frames) : 1;
+    const int Tn = 1;
     RC(ensure_T(c, Tn));
     const int H = c->d.hidden, I = c->enc[layer].I, M = c->M;
     // random (not zero) operands: zero-filled data inflates the clock (DVFS)
@@ -2788,14 +2738,7 @@ int lasr_bench_cell(lasr_ctx* c, int layer, int iters, double* us) {
     RC(commit_T_rows(c, Tn));
     const void* xsrc = layer == 0 ? c->x0 : c->ybuf[(layer - 1) & 1];
     const int mt_total = c->Tcap * c->MT;
-    auto one = [&]() {
-        if (c->enc_xg && c->gx) {
-            launch_enc_xg(c, layer, 0, Tn, xsrc, mt_total);
-            for (int t = 0; t < Tn; ++t) { launch_enc_cell(c, layer, t, xsrc, mt_total, c->ybuf[layer & 1], mt_total, t * M); c->enc_par ^= 1; }
-        } else {
-            launch_enc_cell(c, layer, 0, xsrc, mt_total, c->ybuf[layer & 1], mt_total); c->enc_par ^= 1;
-        }
-    };
+    auto one = [&]() { launch_enc_cell(c, layer, 0, xsrc, mt_total, c->ybuf[layer & 1], mt_total); c->enc_par ^= 1; };
     for (int i = 0; i < 3; ++i) one();
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));

@@ -1,5 +1,5 @@
 // lasr_front.hip.h -- native serving front: the per-stream producer side of a server without
-// Python on the tick path.  Part of the single translation unit lasr_engine.hip, included LAST: it is written against the public
+// Python on the tick path.  Part of the engine unit lasr_engine.hip, included LAST: it is written against the public
 // C ABI of include/lasr.h only (lasr_push_submit_rows, lasr_step_wait, lasr_fetch_many, lasr_stream_*), like an application.
 //
 // What it replaces: the reference servicer runs each TranscribeStream RPC on one of 4 Python worker threads, batch 1

@@ -501,13 +501,10 @@ __device__ __forceinline__ bool any16(bool flag, int lane) {
 // PRED (COMPACT): row-major state [M][H]; the rows that emitted advance; phase X is the per-token
 // table tab[token][4H] when TABLE.
 // Each workgroup tile has exactly ROWS*U = 256 (row, unit) items: one per thread.
-// GX (encoder, round 5): the x-side products of the step's frames come from ONE GEMM per layer and model step (k_gemm<EpiXG>:
-// W_ih crosses the fabric once per model step instead of once per frame); the cell's K loop is the recurrent half only and
-// the epilogue adds gx[(jb * 4U + gate * U + unit) * gx_ld + gx_row0 + row] to the bias.
-template <class Ops, bool PRED, bool TABLE, int U, bool GX = false>
+template <class Ops, bool PRED, bool TABLE, int U>
 struct EpiLSTM {
     static constexpr int NT = U / 4;                       // 4 gates x U units = NT 16-column tiles
-    static constexpr int PH0_TILES = (TABLE || GX) ? 0 : ((1 << NT) - 1);
+    static constexpr int PH0_TILES = TABLE ? 0 : ((1 << NT) - 1);
     static constexpr int PH1_TILES = (1 << NT) - 1;
     static constexpr int PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = PRED;
@@ -535,8 +532,6 @@ struct EpiLSTM {
         const float* c_in;
         const void* y_in;
         int no_carry;          // beam: the rows that are not extended have been carried by k_beam_carry
-        const float* gx;       // GX: x-side gate pre-activations [H/U][4U][gx_ld] (column-major per n-group: rows contiguous)
-        int gx_ld, gx_row0;    //     rows per column of gx; row of (frame t, stream 0) inside it
     };
     struct Pre {
         int r;                 // row this thread finishes (-1: none)
@@ -576,11 +571,6 @@ struct EpiLSTM {
             p.x[0] = tb[0]; p.x[1] = tb[H]; p.x[2] = tb[2 * H]; p.x[3] = tb[3 * H];
         } else {
             p.x[0] = a.bias[u]; p.x[1] = a.bias[H + u]; p.x[2] = a.bias[2 * H + u]; p.x[3] = a.bias[3 * H + u];
-            if constexpr (GX) {      // (consecutive lanes = consecutive rows of one column: coalesced)
-                const float* gp = a.gx + ((size_t)jb * 4 * U + uu) * a.gx_ld + a.gx_row0 + p.r;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) p.x[g] += gp[(size_t)g * U * a.gx_ld];
-            }
         }
         p.c_old = beam ? a.c_in[(size_t)u * a.M + beam_prow(a.parent, a.W, p.r)] : a.c[(size_t)u * a.M + p.r];
         p.s = a.bn_s[u]; p.t = a.bn_t[u];
@@ -618,10 +608,10 @@ struct EpiLSTM {
 // workgroups, exactly one per CU, 7 fragment loads per 12 MFMAs (tiling C: 4 per 4, three 32 x 32 workgroups per CU): the
 // operand bytes a CU pulls through L2 per launch drop from 1.18 MB to 0.69 MB.  64 x 12 = 768 (row, unit) items per workgroup:
 // an item loop, operands loaded in the epilogue.  Same arithmetic per item as EpiLSTM<enc>.
-template <class Ops, int U_, bool GX = false>
+template <class Ops, int U_>
 struct EpiLSTMe {
     static constexpr int U = U_, NT = U_ / 4;
-    static constexpr int PH0_TILES = GX ? 0 : (1 << NT) - 1, PH1_TILES = (1 << NT) - 1;
+    static constexpr int PH0_TILES = (1 << NT) - 1, PH1_TILES = (1 << NT) - 1;
     static constexpr int PH0_DEAD = -1, PH1_DEAD = -1;
     static constexpr bool COMPACT = false;
     using Args = typename EpiLSTM<Ops, false, false, 8>::Args;
@@ -640,12 +630,7 @@ struct EpiLSTMe {
                 Ops::st(a.h_out, ho, Ops::ld(a.h_in, ho));
                 continue;
             }
-            float x[4] = {a.bias[u], a.bias[H + u], a.bias[2 * H + u], a.bias[3 * H + u]};
-            if constexpr (GX) {
-                const float* gp = a.gx + ((size_t)jb * 4 * U + uu) * a.gx_ld + a.gx_row0 + vr;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) x[g] += gp[(size_t)g * U * a.gx_ld];
-            }
+            const float x[4] = {a.bias[u], a.bias[H + u], a.bias[2 * H + u], a.bias[3 * H + u]};
             const float gi = red.sum(row, 0 * U + uu) + x[0], gf = red.sum(row, 1 * U + uu) + x[1];
             const float gg = red.sum(row, 2 * U + uu) + x[2], go = red.sum(row, 3 * U + uu) + x[3];
             const float c2 = sigmoid_(gf) * a.c[(size_t)u * a.M + vr] + sigmoid_(gi) * tanhf(gg);
@@ -653,42 +638,6 @@ struct EpiLSTMe {
             a.c[(size_t)u * a.M + vr] = c2;
             Ops::st(a.h_out, ho, h2);
             if (a.y) Ops::st(a.y, Ops::aoff(vr + 16 * a.y_mt_off, u, a.y_mt_total), h2 * a.bn_s[u] + a.bn_t[u]);
-        }
-    }
-};
-
-// ---- x side of the encoder cells of ONE layer for several frames at once (round 5; what nn.LSTM does with the whole
-// sequence it is handed, custom_rnn.py:172): gx[rows = frame-major (tt * M + r)][4H] = X W_ih^T with the cell tiling's packed
-// W_ih (n-group jb = U units x 4 gates, column = gate * U + unit), stored column-major per n-group so that the cell epilogue
-// of (frame, 32 or 64 rows) reads contiguous runs.  64 rows (MT = 4) per workgroup: 4 A + NT W fragment loads per 4 NT MFMA groups.
-constexpr int XG_TMAX = 16;        // frames per launch (the masks of their active m-tiles travel by value)
-template <int U_>
-struct EpiXG {
-    static constexpr int U = U_, NT = U_ / 4;
-    static constexpr int PH0_TILES = (1 << NT) - 1, PH1_TILES = 0, PH0_DEAD = -1, PH1_DEAD = -1;
-    static constexpr bool COMPACT = false;
-    struct Args {
-        float* gx;
-        int gx_ld;             // rows per column (capacity of the buffer)
-        int R;                 // rows of this launch (frames x M)
-        int MTm;               // m-tiles per frame (M / 16)
-        unsigned long long mask[XG_TMAX];    // per frame: m-tiles with a row that advances
-    };
-    __device__ static bool tile_active(const Args& a, int mt, int lane) {
-        const int f = mt / a.MTm;
-        return f < XG_TMAX && mt * 16 < a.R && ((a.mask[f] >> (mt - f * a.MTm)) & 1ull);
-    }
-    struct Pre {};
-    template <int MTB>
-    __device__ static __forceinline__ Pre prefetch(const Args&, int, int, int, int, const int*) { return Pre{}; }
-    template <int MTB, class Red>
-    __device__ static __forceinline__ void run(const Args& a, const Red red, int tid, int jb, int mg, int, const int*, const Pre&, int nthr) {
-        constexpr int ROWS = MTB * 16, CW = 4 * U;
-        for (int it = tid; it < ROWS * CW; it += nthr) {
-            const int row = it % ROWS, col = it / ROWS;          // consecutive threads -> consecutive rows of one column
-            const int r = mg * ROWS + row;
-            if (r >= a.R) continue;
-            a.gx[((size_t)jb * CW + col) * a.gx_ld + r] = red.sum(row, col);
         }
     }
 };

@@ -40,7 +40,7 @@ __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(
 // ------------------------------------------------------------------------------------------------
 // joint activation for all rows (start of a step): ja = tanh(pe[t_idx] + pp).
 // W > 1 (beam search): rows are hypothesis slots, W per stream; t_idx / T_row / pe are per stream (M_enc rows)
-__global__ void k_ja(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
+inline __global__ void k_ja(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
                      const int* __restrict__ T_row, void* __restrict__ ja, int J, int M, int MT, int ring, int bf,
                      int W, int M_enc, int la) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,7 +59,7 @@ __global__ void k_ja(const float* __restrict__ pe, const float* __restrict__ pp,
 // VALUE (the host knows every row's cumulative frame count), are stored for the kernels behind this one and used here for
 // the joint activation of the rows that were idle -- one launch instead of a counter-advance kernel per admitted step + k_ja
 struct AvailV { int v[512]; };
-__global__ void k_ja_admit(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
+inline __global__ void k_ja_admit(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
                            const AvailV av, int* __restrict__ avail_out, void* __restrict__ ja, int J, int M, int MT, int ring,
                            int bf, int la) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -76,7 +76,7 @@ __global__ void k_ja_admit(const float* __restrict__ pe, const float* __restrict
 }
 
 // fragment-major -> row-major [rows][K] f32
-__global__ void k_from_frag(const void* __restrict__ src, int mt_total, int mt_off, float* __restrict__ dst, int ldd,
+inline __global__ void k_from_frag(const void* __restrict__ src, int mt_total, int mt_off, float* __restrict__ dst, int ldd,
                             int rows, int K, int bf) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * K) return;
@@ -84,16 +84,16 @@ __global__ void k_from_frag(const void* __restrict__ src, int mt_total, int mt_o
     dst[(size_t)r * ldd + k] = act_ld(bf, src, act_off(bf, r + 16 * mt_off, k, mt_total));
 }
 // flat f32 <-> element-typed copies (op-level entry points in bf16 mode)
-__global__ void k_to_elem(const float* __restrict__ src, void* __restrict__ dst, size_t n, int bf) {
+inline __global__ void k_to_elem(const float* __restrict__ src, void* __restrict__ dst, size_t n, int bf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) act_st(bf, dst, i, src[i]);
 }
-__global__ void k_from_elem(const void* __restrict__ src, float* __restrict__ dst, size_t n, int bf) {
+inline __global__ void k_from_elem(const void* __restrict__ src, float* __restrict__ dst, size_t n, int bf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = act_ld(bf, src, i);
 }
 // [H][M] -> [rows][H]
-__global__ void k_c_to_rows(const float* __restrict__ c, int M, float* __restrict__ dst, int rows, int H) {
+inline __global__ void k_c_to_rows(const float* __restrict__ c, int M, float* __restrict__ dst, int rows, int H) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * H) return;
     const int r = idx / H, u = idx - r * H;
@@ -101,7 +101,7 @@ __global__ void k_c_to_rows(const float* __restrict__ c, int M, float* __restric
 }
 
 // encoder output of the last layer: fragment-major rows (t*M + b) -> out[b][t][H]
-__global__ void k_enc_out(const void* __restrict__ y, int mt_total, int M, float* __restrict__ out, int B, int T, int H, int bf) {
+inline __global__ void k_enc_out(const void* __restrict__ y, int mt_total, int M, float* __restrict__ out, int B, int T, int H, int bf) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * T * H) return;
     const int u = (int)(idx % H);
@@ -111,7 +111,7 @@ __global__ void k_enc_out(const void* __restrict__ y, int mt_total, int M, float
 }
 
 // deterministic pseudo-random fill in [-1, 1) (micro-benchmark operands)
-__global__ void k_fill_rand(void* __restrict__ p, size_t n, unsigned seed, int bf) {
+inline __global__ void k_fill_rand(void* __restrict__ p, size_t n, unsigned seed, int bf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned x = (unsigned)i * 2654435761u ^ (seed * 40503u + 0x9e3779b9u);
@@ -154,7 +154,7 @@ struct BosArgs {
     int H, J, Lp, M, lstm, bf;
 };
 // row 0 of the predictor state / pp (just refreshed by a BOS pass) -> the constants of ResetArgs
-__global__ void k_bos_capture(const BosArgs a) {
+inline __global__ void k_bos_capture(const BosArgs a) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u < a.H)
         for (int l = 0; l < a.Lp; ++l) {
@@ -163,7 +163,7 @@ __global__ void k_bos_capture(const BosArgs a) {
         }
     if (u < a.J) a.bos_pp[u] = a.pp[u];
 }
-__global__ void k_reset_rows(const ResetArgs a) {
+inline __global__ void k_reset_rows(const ResetArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.M * a.H) return;
     const int r = idx / a.H, u = idx - r * a.H;
@@ -245,7 +245,7 @@ __device__ __forceinline__ float block_sum_256(float x, float* sh4, int lane, in
 
 // lasr_overlap_probe (and round 3's stream-sensitivity probes): one wave holds its stream for `ticks` of the 100 MHz wall clock without
 // touching memory -- the marginal cost of a microsecond on either stream of the pipelined protocol
-__global__ void k_delay(unsigned long long ticks) {
+inline __global__ void k_delay(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
@@ -254,7 +254,7 @@ __global__ void k_delay(unsigned long long ticks) {
 // 100 MHz wall clock on a stream of its own.  k_nb_mfma issues f32 MFMAs back to back from registers (no memory traffic: it takes
 // matrix-pipe cycles of the SIMD it sits on and nothing else); k_nb_load streams a large buffer with 8 x 1 KB loads in flight per
 // wave (no MFMA: it takes L2 / fabric / HBM bandwidth).  Each writes its iteration count to done[blockIdx.x].
-__global__ __launch_bounds__(64) void k_nb_mfma(unsigned long long ticks, unsigned long long* __restrict__ done, float* __restrict__ sink) {
+inline __global__ __launch_bounds__(64) void k_nb_mfma(unsigned long long ticks, unsigned long long* __restrict__ done, float* __restrict__ sink) {
     f32x4 acc0{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     const float a = 1e-3f * (float)threadIdx.x, b = 1.0f - 1e-4f * (float)threadIdx.x;
     const unsigned long long t0 = wall_clock64();
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void k_nb_mfma(unsigned long long ticks, unsign
 // larger than the CU's L1, and 32 CUs x 96 KB stay inside an XCD's 4 MB L2 -- the L2 -> CU path and nothing behind it); region_vec
 // == 0: all waves stream the whole buffer (temporal != 0: ordinary loads -- a 128 MB buffer then lives in the Infinity Cache;
 // temporal == 0: non-temporal loads of a 512 MB buffer -- HBM).
-__global__ __launch_bounds__(64) void k_nb_load(unsigned long long ticks, const f32x4* __restrict__ buf, size_t n_vec, size_t region_vec,
+inline __global__ __launch_bounds__(64) void k_nb_load(unsigned long long ticks, const f32x4* __restrict__ buf, size_t n_vec, size_t region_vec,
                                                 int temporal, unsigned long long* __restrict__ done, float* __restrict__ sink) {
     const size_t span = region_vec ? region_vec : n_vec;
     const size_t base = region_vec ? (size_t)blockIdx.x * region_vec : 0;
@@ -369,7 +369,7 @@ __device__ __forceinline__ void wave_argmax_f32(float& best, int& arg) {
 // store of the last workgroup to arrive -- the host spins on that word.  (Two hipMemcpyAsync calls "payload, then flag" are
 // NOT such a protocol: HIP orders the copies on the stream, not their visibility to a host that has not synchronised; a
 // fresh flag over a stale payload was observed at a rate of 3e-3 per stream, tests/soak.py.)
-__global__ __launch_bounds__(256) void k_publish(const int* __restrict__ src, int* __restrict__ dst_host, int n,
+inline __global__ __launch_bounds__(256) void k_publish(const int* __restrict__ src, int* __restrict__ dst_host, int n,
                                                  const int* __restrict__ flag_src, int* __restrict__ flag_host, int* __restrict__ arrivals) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst_host[i] = src[i];
     __threadfence_system();                          // this thread's stores are visible system-wide ...
@@ -383,12 +383,12 @@ __global__ __launch_bounds__(256) void k_publish(const int* __restrict__ src, in
 }
 
 // frames of newly encoded steps become visible to the decode loop (continuous mode)
-__global__ void k_advance(int* __restrict__ counter, const int* __restrict__ add, int M) {
+inline __global__ void k_advance(int* __restrict__ counter, const int* __restrict__ add, int M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) counter[i] += add[i];
 }
 
-__global__ void k_step_begin(DecState s, int M, int n_iter_slots, int reset_metrics) {
+inline __global__ void k_step_begin(DecState s, int M, int n_iter_slots, int reset_metrics) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) {
         s.t_idx[i] = 0;
@@ -751,7 +751,7 @@ struct LmResetArgs {
     // int8-served LM: the quantised image of every layer's h kept beside it (see k_lm_cell_q): zeros with scale 0.1 for h = 0
     unsigned short* qh[8]; float* sxh[8]; int Kp;
 };
-__global__ void k_lm_reset(const LmResetArgs a) {
+inline __global__ void k_lm_reset(const LmResetArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.M * a.H) return;
     const int r = idx / a.H, u = idx - r * a.H;
@@ -795,7 +795,7 @@ __device__ __forceinline__ void lm_qparams(float mn, float mx, float* smn, float
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(256) void k_lm_quant(const float* __restrict__ src, int lds, int K, unsigned short* __restrict__ dst,
+inline __global__ __launch_bounds__(256) void k_lm_quant(const float* __restrict__ src, int lds, int K, unsigned short* __restrict__ dst,
                                                   int ldd, float* __restrict__ scale_out) {
     const int r = blockIdx.x, tid = threadIdx.x;
     const float* x = src + (size_t)r * lds;
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void k_lm_quant(const float* __restrict__ src,
 // compute for itself -- the x side of the layer above in this step, the h side of this layer in the next one; the parameters
 // depend on the vector alone, so one image serves both and equals what k_lm_quant makes of the stored h bit for bit): the LM
 // step needs no quantisation launch (21 -> 13 launches per decode iteration).  H <= 1024.
-__global__ __launch_bounds__(256) void k_lm_cell_q(const float* __restrict__ gx, const float* __restrict__ tab, const int* __restrict__ token,
+inline __global__ __launch_bounds__(256) void k_lm_cell_q(const float* __restrict__ gx, const float* __restrict__ tab, const int* __restrict__ token,
                                                    const float* __restrict__ gh, const int* __restrict__ emit, float* __restrict__ h,
                                                    float* __restrict__ c, int H, int M, unsigned short* __restrict__ qh,
                                                    float* __restrict__ sxh, int Kp) {
@@ -900,314 +900,6 @@ struct BeamState {
     int lm_on;
     int* done2;          // [64] second arrival counter (k_beam_fuse)
 };
-
-// WT: compile-time bound of W (2, 4, 8).  One workgroup of NT threads per stream: its W x V logits
-// are read ONCE into registers (KEEP = 4 per thread and row: V <= 4 NT, issued before anything else);
-// the statistics of all rows are reduced together and the W ordered argmax passes scan 4 W register
-// values per thread, so the kernel is a handful of block reductions deep.
-// NT: threads per workgroup = 512 for V <= 2048 (all KEEP register slots of a row hold real logits: half the waves, half the
-// wave winners to merge, the same instructions per thread), 1024 up to V = 4096.
-template <int WT, int NT>
-__global__ __launch_bounds__(NT) void k_beam_select(const float* __restrict__ logits, BeamState s, int iter_slot) {
-    constexpr int KEEP = 4, NWV = NT / 64;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int W = s.W, V = s.V, r0 = q * W;
-    // ---- the stream's logits -> registers (in flight while the state below is fetched)
-    float zv[WT][KEEP];
-#pragma unroll
-    for (int b = 0; b < WT; ++b) {
-        const float* z = logits + (size_t)(r0 + (b < W ? b : 0)) * V;
-#pragma unroll
-        for (int k = 0; k < KEEP; ++k) {
-            const int v = tid + NT * k;
-            zv[b][k] = v < V ? z[v] : -INFINITY;
-        }
-    }
-    const int iter_no = s.cont ? (int)(*(const unsigned*)s.iter_ctr & 0x3fffffffu) : iter_slot;     // same value in every workgroup
-    const int uslot = s.cont ? (iter_no & 63) : iter_slot;                                          // slot of the flag rings
-    int* tre = s.trellis + (size_t)(s.cont ? iter_no % s.tring : iter_slot) * s.Md + r0;
-    if (s.cont && q == 0 && tid == 0) {                                                             // recycle the flag rings
-        s.unfinished[(uslot + 32) & 63] = 0;
-        s.done_blocks[(uslot + 32) & 63] = 0;
-    }
-    auto publish = [&]() {           // thread 0 of every workgroup, after its last store of this launch (continuous mode)
-        if (!s.cont) return;
-        if (s.host_flag && !s.lm_on) __threadfence_system();     // this stream's records (pinned memory) before the count
-        if (atomicAdd(&s.done_blocks[uslot], 1) == (int)gridDim.x - 1) {      // last workgroup of the launch
-            if (s.host_flag && !s.lm_on) {
-                const int v = atomicAdd(&s.unfinished[uslot], 0);
-                __hip_atomic_store(s.host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            *s.iter_ctr = iter_no + 1;
-        }
-    };
-    const bool dbg = s.dbg && q == 0 && tid == 0;
-    const unsigned long long t_entry = dbg ? wall_clock64() : 0ull;
-    const int t = s.t_idx[q], Tr = s.T_row[q];
-    if (dbg && t < Tr) s.dbg[0] = t_entry;           // (stamps of the last round in which stream 0 was decoding: one consistent set)
-    if (t >= Tr) {                                   // stream has nothing to decode: identity round
-        if (tid < W) { s.emit[r0 + tid] = 0; s.parent[r0 + tid] = tid; tre[tid] = -1; }
-        if (tid == 0 && s.cont) {
-            s.frame_done[(size_t)(iter_no % s.tring) * gridDim.x + q] = 0;
-            if (s.host_flag) s.host_cur[q] = t;
-            publish();
-        }
-        return;
-    }
-    __shared__ double sc[WT];
-    __shared__ int al[WT], ib[WT];
-    __shared__ float redf[NWV][WT];
-    __shared__ double redd[NWV];
-    __shared__ int redi[NWV];
-    __shared__ double sel_sc[WT];
-    __shared__ int sel_ord[WT];
-    if (tid < WT) {
-        const bool in = tid < W;
-        sc[tid] = in ? s.score[r0 + tid] : -INFINITY; al[tid] = in ? s.alive[r0 + tid] : 0; ib[tid] = in ? s.inB[r0 + tid] : 0;
-    }
-    __syncthreads();
-    if (dbg) s.dbg[1] = wall_clock64();
-    bool inA[WT];
-#pragma unroll
-    for (int b = 0; b < WT; ++b) {
-        inA[b] = al[b] && !ib[b];                    // uniform over the workgroup
-        if (!inA[b]) {
-#pragma unroll
-            for (int k = 0; k < KEEP; ++k) zv[b][k] = -INFINITY;
-        }
-    }
-    // ---- log-softmax statistics: max, then log(sum exp(z - max)), all rows at once
-    float m[WT], lg[WT];
-#pragma unroll
-    for (int b = 0; b < WT; ++b) {
-        float x = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < KEEP; ++k) x = fmaxf(x, zv[b][k]);
-        x = wave_max_f32(x);
-        if (lane == 0) redf[w][b] = x;
-    }
-    __syncthreads();
-    __shared__ float bc[2][WT];                      // broadcast of the per-row results computed by wave 0
-    if (w == 0) {
-#pragma unroll
-        for (int b = 0; b < WT; ++b) {
-            float x = lane < NWV ? redf[lane][b] : -INFINITY;
-            x = wave_max_f32(x);
-            if (lane == 0) bc[0][b] = x;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < WT; ++b) m[b] = bc[0][b];
-#pragma unroll
-    for (int b = 0; b < WT; ++b) {
-        float sum = 0.f;
-        if (inA[b]) {
-#pragma unroll
-            for (int k = 0; k < KEEP; ++k) sum += expf(zv[b][k] - m[b]);      // exp(-inf) = 0 for the padding
-        }
-        sum = wave_sum_f32(sum);                     // (same association as the xor butterfly: bit-identical)
-        if (lane == 0) redf[w][b] = sum;
-    }
-    __syncthreads();
-    if (w == 0) {
-#pragma unroll
-        for (int b = 0; b < WT; ++b) {
-            float x = 0.f;
-            if (lane == 0) {                          // fixed summation order over the 16 wave partials
-#pragma unroll
-                for (int k = 0; k < NWV; ++k) x += redf[k][b];
-                bc[1][b] = logf(x);
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < WT; ++b) lg[b] = bc[1][b];
-    int nb_arg[WT];
-#pragma unroll
-    for (int b = 0; b < WT; ++b) nb_arg[b] = -1;
-    if (s.lm_on) {                                   // per row: argmax of z over the non-blank tokens (first maximum)
-        __shared__ float nbv[NWV][WT];
-        __shared__ int nba[NWV][WT];
-        __shared__ int nbr[WT];
-#pragma unroll
-        for (int b = 0; b < WT; ++b) {
-            float x = -INFINITY;
-            int a = 0x7fffffff;
-#pragma unroll
-            for (int k = 0; k < KEEP; ++k) {
-                const int v = tid + NT * k;
-                if (v != s.blank && v < V && zv[b][k] > x) { x = zv[b][k]; a = v; }
-            }
-            wave_argmax_f32(x, a);
-            if (lane == 0) { nbv[w][b] = x; nba[w][b] = a; }
-        }
-        __syncthreads();
-        if (w == 0) {
-#pragma unroll
-            for (int b = 0; b < WT; ++b) {
-                float x = lane < NWV ? nbv[lane][b] : -INFINITY;
-                int a = lane < NWV ? nba[lane][b] : 0x7fffffff;
-                wave_argmax_f32(x, a);
-                if (lane == 0) nbr[b] = a;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < WT; ++b) nb_arg[b] = nbr[b];
-    }
-    if (dbg) s.dbg[2] = wall_clock64();
-    // ---- the ordered top-W of all candidates, in two wave-level stages (no block-wide reduction per winner):
-    //   (1) every wave finds the ordered top-W of ITS candidates: pass j admits only candidates strictly after the wave's winner
-    //       j-1 in the total order (score desc, ord asc), so no "taken" set is needed; every lane caches its local best, which
-    //       stays valid until it wins -- only the winning lane rescans;
-    //   (2) wave 0 selects the ordered top-W among the NWV x W wave winners the same way.
-    // The global top-W is contained in the union of the waves' top-W, and both stages use the same total order, so the result
-    // is the one a single ordered scan gives.
-    __shared__ double cand_sc[NWV][WT];
-    __shared__ int cand_ord[NWV][WT];
-    {
-        // Per lane and row the (up to) KEEP extension candidates are sorted once (log p descending, token ascending: the total
-        // order restricted to a row, where the score is monotonic in log p); the lane's best remaining candidate is then the best
-        // of its rows' heads -- W values to compare per pass instead of W x KEEP -- and a lane that wins pops that row's head.
-        static_assert(KEEP == 4, "4-element sorting network");
-        int kp[WT];                                  // original k of the sorted positions, 2 bits each, head in the low bits
-#pragma unroll
-        for (int b = 0; b < WT; ++b) {
-            kp[b] = 0 | (1 << 2) | (2 << 4) | (3 << 6);
-            if (!al[b]) {
-#pragma unroll
-                for (int k = 0; k < KEEP; ++k) zv[b][k] = -INFINITY;
-                continue;
-            }
-            if (ib[b]) {                             // carried unchanged: ONE candidate (thread 0), score sc[b] (+ 0), ord b (V + 1)
-                zv[b][0] = tid == 0 ? 0.f : -INFINITY;
-#pragma unroll
-                for (int k = 1; k < KEEP; ++k) zv[b][k] = -INFINITY;
-                continue;
-            }
-#pragma unroll
-            for (int k = 0; k < KEEP; ++k) zv[b][k] = (zv[b][k] - m[b]) - lg[b];      // log p (padding stays -inf)
-            if (s.lm_on) {                           // LM fusion: only the blank and the row's best non-blank token are candidates
-#pragma unroll
-                for (int k = 0; k < KEEP; ++k) {
-                    const int v = tid + NT * k;
-                    if (v != s.blank && v != nb_arg[b]) zv[b][k] = -INFINITY;
-                }
-            }
-            int k0 = 0, k1 = 1, k2 = 2, k3 = 3;
-            auto cx = [&](float& a, int& ka, float& c, int& kc) {                       // a before c unless c is strictly better
-                if (c > a || (c == a && kc < ka)) { const float t = a; a = c; c = t; const int tk = ka; ka = kc; kc = tk; }
-            };
-            cx(zv[b][0], k0, zv[b][1], k1); cx(zv[b][2], k2, zv[b][3], k3);
-            cx(zv[b][0], k0, zv[b][2], k2); cx(zv[b][1], k1, zv[b][3], k3);
-            cx(zv[b][1], k1, zv[b][2], k2);
-            kp[b] = k0 | (k1 << 2) | (k2 << 4) | (k3 << 6);
-        }
-        for (int j = 0; j < W; ++j) {
-            double best = -INFINITY;
-            int bord = 0x7fffffff;
-#pragma unroll
-            for (int b = 0; b < WT; ++b) {
-                const float h = zv[b][0];
-                if (!(h > -INFINITY)) continue;
-                const double val = sc[b] + (double)h;
-                const int ord = b * (V + 1) + (ib[b] ? 0 : 1 + tid + NT * (kp[b] & 3));
-                if (val > best || (val == best && ord < bord)) { best = val; bord = ord; }
-            }
-            const int mine = bord;
-            wave_argmax_f64(best, bord);
-            if (lane == 0) { cand_sc[w][j] = best; cand_ord[w][j] = bord; }
-            if (!(best > -INFINITY)) {               // this wave's candidates are exhausted (wave-uniform)
-                if (lane == 0)
-                    for (int k = j + 1; k < W; ++k) { cand_sc[w][k] = -INFINITY; cand_ord[w][k] = 0x7fffffff; }
-                break;
-            }
-            if (mine == bord) {                      // this lane's candidate won: pop the head of its row
-                const int bw = bord / (V + 1);
-#pragma unroll
-                for (int b = 0; b < WT; ++b)
-                    if (b == bw) { zv[b][0] = zv[b][1]; zv[b][1] = zv[b][2]; zv[b][2] = zv[b][3]; zv[b][3] = -INFINITY; kp[b] >>= 2; }
-            }
-        }
-    }
-    __syncthreads();
-    if (dbg) s.dbg[9] = wall_clock64();
-    if (w == 0) {
-        // NWV x W <= 128 wave winners: two per lane
-        double c0 = -INFINITY, c1 = -INFINITY;
-        int o0 = 0x7fffffff, o1 = 0x7fffffff;
-        if (lane < NWV * W) { c0 = cand_sc[lane / W][lane % W]; o0 = cand_ord[lane / W][lane % W]; }
-        if (lane + 64 < NWV * W) { c1 = cand_sc[(lane + 64) / W][(lane + 64) % W]; o1 = cand_ord[(lane + 64) / W][(lane + 64) % W]; }
-        double last_sc = INFINITY;
-        int last_ord = -1;
-        for (int j = 0; j < W; ++j) {
-            double best = -INFINITY;
-            int bord = 0x7fffffff;
-            auto offer = [&](double val, int ord) {
-                const bool after = val < last_sc || (val == last_sc && ord > last_ord);
-                const bool better = val > best || (val == best && ord < bord);
-                if ((val > -INFINITY) && after && better) { best = val; bord = ord; }
-            };
-            offer(c0, o0); offer(c1, o1);
-            wave_argmax_f64(best, bord);
-            if (lane == 0) { sel_sc[j] = best; sel_ord[j] = bord; }
-            if (!(best > -INFINITY)) {               // candidates exhausted: the remaining slots are dead
-                if (lane == 0)
-                    for (int k = j + 1; k < W; ++k) { sel_sc[k] = -INFINITY; sel_ord[k] = 0x7fffffff; }
-                break;
-            }
-            last_sc = best; last_ord = bord;
-        }
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    if (dbg) s.dbg[3] = wall_clock64();
-    const int round = s.iters[q] + 1;
-    bool all_b = true;
-    int nib[WT];
-    for (int j = 0; j < W; ++j) {
-        const int r = r0 + j;
-        nib[j] = 1;
-        if (!(sel_sc[j] > -INFINITY)) {
-            s.alive[r] = 0; s.emit[r] = 0; s.parent[r] = j; s.score[r] = -INFINITY; tre[j] = -2;
-            continue;
-        }
-        const int b = sel_ord[j] / (V + 1), k = sel_ord[j] - b * (V + 1);
-        s.alive[r] = 1; s.parent[r] = b; s.score[r] = sel_sc[j];
-        int em = 0, inb = 1;
-        if (k > 0 && k - 1 != s.blank) {
-            em = 1;
-            s.token[r] = k - 1;
-            inb = round >= s.max_iters ? 1 : 0;
-        }
-        s.emit[r] = em;
-        nib[j] = inb;
-        tre[j] = (b << 16) | (em ? k : 0);
-        all_b = all_b && inb;
-    }
-    int tn = t, rn = round;
-    if (all_b) { tn = t + 1; rn = 0; }
-    for (int j = 0; j < W; ++j) s.inB[r0 + j] = all_b ? 0 : (sel_sc[j] > -INFINITY ? nib[j] : 0);
-    s.t_idx[q] = tn; s.iters[q] = rn;
-    if (s.cont) {
-        s.frame_done[(size_t)(iter_no % s.tring) * gridDim.x + q] = all_b ? 1 : 0;
-        if (all_b && tn % s.step_T == 0) {           // the stream just finished one of its model steps: scores for the host
-            const int es = (tn / s.step_T - 1) % s.end_slots;
-            int am = 0;
-            for (int j = 0; j < W; ++j) {
-                s.end_score[((size_t)q * s.end_slots + es) * W + j] = sel_sc[j];
-                if (sel_sc[j] > -INFINITY) am |= 1 << j;
-            }
-            s.end_alive[(size_t)q * s.end_slots + es] = am;
-        }
-        if (s.host_flag) s.host_cur[q] = tn;
-    }
-    if (tn < Tr) atomicAdd(&s.unfinished[uslot], 1);
-    if (dbg) s.dbg[4] = wall_clock64();
-    publish();
-}
 
 // k_beam_select with ONE WAVE PER HYPOTHESIS ROW (V <= 2048, the 512-thread form's arithmetic): wave b keeps row b's logits in
 // registers (32 per lane), so the row's statistics and its ordered top-W by log p are wave-local -- DPP reductions on floats, no
@@ -1461,7 +1153,7 @@ __global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restr
 
 // continuous beam loop, admission of newly encoded steps (<= 512 streams): frames-available counts by value (as k_ja_admit) and
 // the joint activation of every hypothesis slot of the streams that have a frame to decode (rows = stream * W + slot)
-__global__ void k_ja_admit_beam(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
+inline __global__ void k_ja_admit_beam(const float* __restrict__ pe, const float* __restrict__ pp, const int* __restrict__ t_idx,
                                 const AvailV av, int* __restrict__ avail_out, void* __restrict__ ja, int J, int Md, int W, int M_enc,
                                 int MT, int ring, int bf) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1561,7 +1253,7 @@ __device__ __forceinline__ void beam_carry_body(const BeamCarryArgs& a, const in
         }
     }
 }
-__global__ __launch_bounds__(256) void k_beam_carry(const BeamCarryArgs a) { beam_carry_body(a, blockIdx.x, blockIdx.y); }
+inline __global__ __launch_bounds__(256) void k_beam_carry(const BeamCarryArgs a) { beam_carry_body(a, blockIdx.x, blockIdx.y); }
 // The carry as extra workgroups of a GEMM launch of the same round (the joint-half GEMM, the last of the predictor chain): rows
 // blockIdx.y >= m_groups of the grid are carry blocks -- Md slot blocks, then the cell-state blocks.  The carry depends on the
 // selection kernel only and touches no row the chain's GEMMs touch, so it needs no launch (and no launch boundary) of its own:
@@ -1582,7 +1274,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_carry(const GemmArgs g, const 
 }
 
 // start of a beam decode step: per-stream cursors and the iteration flags
-__global__ void k_beam_begin(BeamState s, int M, int n_iter_slots) {
+inline __global__ void k_beam_begin(BeamState s, int M, int n_iter_slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) { s.t_idx[i] = 0; s.iters[i] = 0; }
     if (i < s.Md) { s.emit[i] = 0; s.parent[i] = i % s.W; s.inB[i] = 0; }
@@ -1864,7 +1556,7 @@ __device__ __forceinline__ void mel_log(const float* P, const MelTables& t, int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
+inline __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     __shared__ float2 sz[4][512 + 8];
     __shared__ float sp[4][520];
     __shared__ float s_fbw[1536];
@@ -1943,120 +1635,13 @@ __global__ __launch_bounds__(256) void k_logmel(const MelArgs a) {
     mel_log(sp[w], tab, a.n_mels, j, a.out + ((size_t)out_row * a.out_frames + out_frame) * a.n_mels);
 }
 
-// Streaming front-end of one model step in ONE launch (<= 512 rows, n_buffer <= 4): for every row that runs the model,
-// the n_buffer x n_stack log-mel frames of its last n_buffer client chunks (StreamPostprocess picks n_stack frames of the
-// 3-chunk window that was current when that chunk arrived: the PCM ring keeps n_window + n_buffer - 1 chunks, so the
-// older windows are still there), StackDownsample and LayerNorm -> fragment-major x0.  Workgroup (t', row) = one stacked
-// frame, one wave per log-mel frame.  Replaces log-mel (per client chunk) + stack/LayerNorm (per model step) = 3 launches
-// and the command-block copies: the per-row command (frames of this step, window ages) is passed by value.
-struct FrontArgs {
-    const float* window; const float2* tw512; const float2* tw1024;
-    const int* fb_start; const int* fb_off; const float* fb_w;
-    int n_mels, hop, fb_nnz, win_off, win_len;
-    const float* pcm;        // [M][ring_chunks][chunk]
-    const int* ring_pos;     // [M] next write slot
-    int chunk, n_window, ring_chunks, frame0;
-    const float* pend;       // [M][n_buffer * n_stack][n_mels]: frames that had to be computed early (age 255)
-    int pend_frames;
-    const float* ln_w; const float* ln_b;
-    void* x0;
-    int F, M, MT, mt_total, bf;
-    int* trow_out;           // [M]: the row's frame count of this step, for the kernels behind this one
-    int* enc_frames;         // pipelined protocol (else nullptr): [M] frames encoded so far; this launch snapshots it into
-    int* enc_base;           //   enc_base (the ring base of this step's joint GEMM) and advances it by the step's frames
-    unsigned char trow_v[512];
-    unsigned char age_v[4][512];   // [t'][row]: chunks pushed since the window of stacked frame t' was current; 255: in pend
-};
-template <int NSTACK, int VPL>
-__global__ __launch_bounds__(64 * NSTACK) void k_frontend(const FrontArgs a) {
-    __shared__ float2 sz[NSTACK][512 + 8];
-    __shared__ float sp[NSTACK][520];
-    __shared__ float smel[NSTACK][128];
-    __shared__ float s_fbw[1536];
-    __shared__ int s_fbs[128], s_fbo[129];
-    __shared__ float2 s_tw512[512], s_tw1024[513];
-    const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
-    const int tp = blockIdx.x, row = blockIdx.y;
-    const int Tr = a.trow_v[row];
-    if (tp == 0 && threadIdx.x == 0) {
-        a.trow_out[row] = Tr;
-        if (a.enc_frames) { const int e = a.enc_frames[row]; a.enc_base[row] = e; a.enc_frames[row] = e + Tr; }
-    }
-    if (tp >= Tr) return;                                // uniform over the workgroup
-    const MelTables tab{s_fbw, s_fbs, s_fbo, s_tw512, s_tw1024};
-    stage_mel_tables(tab, a.tw512, a.tw1024, a.fb_w, a.fb_start, a.fb_off, a.fb_nnz, a.n_mels);
-    const int age = a.age_v[tp][row];
-    if (age == 255) {                                    // uniform: this stacked frame's log-mel frames are in pend
-        const float* src = a.pend + ((size_t)row * a.pend_frames + (size_t)tp * NSTACK + w) * a.n_mels;
-        for (int m = j; m < a.n_mels; m += 64) smel[w][m] = src[m];
-        __syncthreads();
-    } else {
-        const int NR = a.ring_chunks;
-        const int head = (a.ring_pos[row] - age - a.n_window + 2 * NR) % NR;
-        const float* src = a.pcm + (size_t)row * NR * a.chunk;
-        const int N = a.n_window * a.chunk;
-        const int base = (a.frame0 + w) * a.hop - 512;
-        auto sample = [&](int n) -> float {
-            if (n < a.win_off || n >= a.win_off + a.win_len) return 0.f;
-            const float wv = a.window[n];
-            int q = base + n;
-            if (q < 0) q = -q;                           // reflect (torch.stft center=True, pad_mode="reflect")
-            if (q >= N) q = 2 * (N - 1) - q;
-            const int ck = q / a.chunk, wi = q - ck * a.chunk;
-            int slot = head + ck;
-            if (slot >= NR) slot -= NR;
-            return src[(size_t)slot * a.chunk + wi] * wv;
-        };
-        cf v[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int n = j + 64 * m;
-            v[m] = cf{sample(2 * n), sample(2 * n + 1)};
-        }
-        fft1024_power(v, sz[w], sp[w], s_tw512, s_tw1024, j);
-        mel_log(sp[w], tab, a.n_mels, j, smel[w]);
-        __syncthreads();
-    }
-    // StackDownsample (feat[m * n_stack + k] = mel[k][m]) + LayerNorm by wave 0, in the arithmetic order of k_stack_ln
-    if (w != 0) return;
-    float x[VPL];
-    float sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < VPL; ++q) {
-        const int f = j + 64 * q;
-        const int m = f / NSTACK, k = f - m * NSTACK;
-        const float val = f < a.F ? smel[k][m] : 0.f;
-        x[q] = val;
-        sum += val;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mu = sum / (float)a.F;
-    float var = 0.f;
-#pragma unroll
-    for (int q = 0; q < VPL; ++q) {
-        const float d = (j + 64 * q < a.F) ? x[q] - mu : 0.f;
-        var += d * d;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
-    const float rstd = 1.0f / sqrtf(var / (float)a.F + 1e-5f);
-#pragma unroll
-    for (int q = 0; q < VPL; ++q) {
-        const int f = j + 64 * q;
-        if (f >= a.F) continue;
-        const float y = (x[q] - mu) * rstd * a.ln_w[f] + a.ln_b[f];
-        act_st(a.bf, a.x0, act_off(a.bf, tp * a.MT * 16 + row, f, a.mt_total), y);
-    }
-}
-
 // Streaming front-end of one model step, log-mel half (<= 512 rows): workgroup (2 t' + half, row) computes five of the ten
 // log-mel frames of stacked frame t' (one wave per frame) into the row's pending-frame buffer; k_stack_ln then stacks +
 // LayerNorms from there.  n_buffer x 2 x rows workgroups of 5 waves: 256 for the reference shape at 64 streams, one per CU
-// (k_frontend: 128 workgroups of 10 waves, half the CUs idle).  The ring append of the NEWEST client chunk is part of this
+// (round 2's one-launch form had 128 workgroups of 10 waves: half the CUs idle).  The ring append of the NEWEST client chunk is part of this
 // launch (lasr_push_submit): rows with idx >= 0 take the chunk from the caller's buffer `src` -- every wave that needs samples of
 // the slot being written reads them from `src`, workgroup (0, row) copies the chunk into the ring and publishes the new ring
-// position -- so a model step costs one ring-append launch less.  Same arithmetic per frame as k_logmel / k_frontend.
+// position -- so a model step costs one ring-append launch less.  Same arithmetic per frame as k_logmel.
 struct FeMelArgs {
     const float* window; const float2* tw512; const float2* tw1024;
     const int* fb_start; const int* fb_off; const float* fb_w;
@@ -2067,8 +1652,8 @@ struct FeMelArgs {
     float* pend;             // [M][n_buffer * n_stack][n_mels]
     int pend_frames;
     int* trow_out;           // [M]: the row's frame count of this step, for the kernels behind this one
-    int* enc_frames;         // pipelined protocol (else nullptr): see FrontArgs
-    int* enc_base;
+    int* enc_frames;         // pipelined protocol (else nullptr): [M] frames encoded so far; this launch snapshots it into
+    int* enc_base;           //   enc_base (the ring base of this step's joint GEMM) and advances it by the step's frames
     const float* src;        // fused ring append (else nullptr): [n][chunk], row r takes chunk idx[r]
     const float* src2;       // deferred append of the PREVIOUS chunk of the same rows (else nullptr): the chunk of the last lasr_push_submit
                              // that completed no model step was not appended by a launch of its own -- this launch appends both (src2 first)
@@ -2149,7 +1734,7 @@ __global__ __launch_bounds__(32 * NSTACK) void k_fe_mel(const FeMelArgs a) {
 // polyphase windowed-sinc, one filter per output phase (U = sr_out / gcd phases, `taps` taps):
 //   out[n] = sum_j w[n % U][j] * x[first[n % U] + (n / U) * in_unit + j]     (x = 0 outside [0, N_in))
 // HBM-bound: every input sample is read ~taps * sr_out / sr_in times through L1/L2, written once.
-__global__ void k_resample(const float* __restrict__ x, long long N_in, const int* __restrict__ first,
+inline __global__ void k_resample(const float* __restrict__ x, long long N_in, const int* __restrict__ first,
                            const float* __restrict__ w, int U, int taps, int in_unit, float* __restrict__ out,
                            long long N_out) {
     const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2167,7 +1752,7 @@ __global__ void k_resample(const float* __restrict__ x, long long N_in, const in
 }
 
 // StackDownsample (transforms.py:436-441): feats[row][t'][m*n_stack + k] = logmel[row][f0 + stride*t' + k][m]
-__global__ void k_stack(const float* __restrict__ logmel, int T_frames, int n_mels, int n_stack, int stride,
+inline __global__ void k_stack(const float* __restrict__ logmel, int T_frames, int n_mels, int n_stack, int stride,
                         float* __restrict__ feats, int Tp, int F) {
     const int tp = blockIdx.x, row = blockIdx.y;
     const float* lm = logmel + (size_t)row * T_frames * n_mels;
@@ -2256,7 +1841,7 @@ struct LnTileArgs {
     void* x0;
     int MT, mt_total, bf;
 };
-__global__ __launch_bounds__(1024) void k_ln_tile(const LnTileArgs a) {
+inline __global__ __launch_bounds__(1024) void k_ln_tile(const LnTileArgs a) {
     constexpr int F = 1280, NS = 10, NM = 128, LD = F + 4;
     extern __shared__ float xs[];                    // [16][LD]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2322,7 +1907,7 @@ __global__ __launch_bounds__(1024) void k_ln_tile(const LnTileArgs a) {
 
 // streaming: append one client chunk per flagged row to its ring window
 struct PushIdx { short idx[512]; };   // staging row of slot r (-1: slot not pushed), passed by value
-__global__ void k_push_pcm(const float* __restrict__ src, const int* __restrict__ src_idx, const PushIdx pidx,
+inline __global__ void k_push_pcm(const float* __restrict__ src, const int* __restrict__ src_idx, const PushIdx pidx,
                            float* __restrict__ win, int* __restrict__ ring_pos, int chunk, int n_window) {
     const int row = blockIdx.x;
     const int si = src_idx ? src_idx[row] : (int)pidx.idx[row];

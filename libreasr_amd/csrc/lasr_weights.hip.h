@@ -1,6 +1,5 @@
 // lasr_weights.hip.h -- weight blob reader: BatchNorm fold, LSTM layer packing
-// Part of the single translation unit lasr_engine.hip (textual include, in this order:
-// lasr_ctx, lasr_launch, lasr_decode, lasr_weights); not a stand-alone header.
+// Engine unit only (lasr_engine.hip), included after lasr_decode.hip.h.
 #pragma once
 
 namespace {

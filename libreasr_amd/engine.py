@@ -410,7 +410,7 @@ class Engine:
         return out
 
     def config(self, key):
-        """lasr_debug_config: the engine's resolved configuration (defaults + LASR_* switches), e.g. "enc_xg", "pump_G", "la_stream"."""
+        """lasr_debug_config: the engine's resolved configuration (defaults + LASR_* switches), e.g. "enc_wave", "pump_G", "la_stream"."""
         v = C.c_int(0)
         self._chk(self.lib.lasr_debug_config(self.ctx, key.encode(), C.byref(v)))
         return int(v.value)

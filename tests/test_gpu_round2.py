@@ -325,7 +325,7 @@ def test_fused_frontend_irregular_pushes_equal_the_per_chunk_kernels():
 
 @pytest.mark.parametrize("n_buffer", [1, 3, 4])
 def test_fused_frontend_other_buffer_depths(n_buffer):
-    """The fused front-end (k_frontend) with Buffer(n_buffer) != 2: the PCM ring holds n_window + n_buffer - 1 chunks and the
+    """The fused front-end (k_fe_mel + k_ln_tile) with Buffer(n_buffer) != 2: the PCM ring holds n_window + n_buffer - 1 chunks and the
     step's launch works through the last n_buffer windows.  Three streams, one chunk out of phase with the others (their
     model steps fall on different calls), synchronous and pipelined protocol, against the oracle."""
     eng, sd, cfg = make("tiny", max_streams=16, n_buffer=n_buffer)

@@ -7,7 +7,7 @@
     chunks that do not in the same call)
   * host-memory lifetime rules of include/lasr.h: default pushes COPY (a pinned buffer may be overwritten as soon as the
     call returns); LASR_PUSH_PINNED_NOCOPY + lasr_push_consumed(ticket) for the zero-copy form
-  * the split front-end (k_fe_mel + k_stack_ln) against the one-launch k_frontend and the per-chunk kernels: same tokens"""
+  * the split front-end (k_fe_mel + k_stack_ln) against the per-chunk kernels: same tokens"""
 import os
 
 import numpy as np
@@ -178,11 +178,11 @@ def test_host_buffer_lifetime_rules():
 
 
 @pytest.mark.parametrize("n_buffer", [2, 3])
-def test_split_frontend_equals_one_launch_frontend_and_per_chunk_kernels(n_buffer):
+def test_split_frontend_equals_per_chunk_kernels(n_buffer):
     n, n_chunks = 3, 36
     pcm = synth.synth_pcm(n, n_chunks * 1280, seed=33)
     out = {}
-    for name, env in (("split", {}), ("one_launch", {"LASR_FE_MODE": "0"}), ("per_chunk", {"LASR_FE_LEGACY": "1"})):
+    for name, env in (("split", {}), ("per_chunk", {"LASR_FE_LEGACY": "1"})):
         os.environ.update(env)
         try:
             eng, sd, cfg = make("tiny", max_streams=16, n_buffer=n_buffer)

@@ -393,51 +393,6 @@ print("RESULT" + json.dumps(out))
     assert res["pair"].count(",") > 100
 
 
-def test_beam_selection_one_wave_per_row_equals_the_spread_kernel():
-    """k_beam_select_rw (one wave per hypothesis row, wave-local statistics and top-W) against LASR_BEAM_SELECT_RW=0 (round 3's
-    kernel: every row spread over all waves): the same hypotheses AND the same score bits -- beam 2 / 3 / 4 / 8, with and without
-    the LM inside the beam, offline and on the pipelined protocol, a vocabulary that does not fill the register slots (V = 64)
-    and one that does (cfg2: V = 2048)."""
-    code = r'''
-import json, sys, numpy as np, torch
-sys.path.insert(0, %r)
-from libreasr_amd import synth
-from libreasr_amd.engine import Engine
-out = {}
-lsd = synth.synth_lm_state_dict("tiny_lm")
-for name, beams in (("tiny_soft", (2, 3, 4, 8)), ("cfg2", (4, 8))):
-    cfg = synth.model_cfg(name); sd = synth.synth_state_dict(cfg, seed=0)
-    for beam in beams:
-        for lm in ((False, True) if name == "tiny_soft" else (False,)):
-            eng = Engine(sd, cfg, max_streams=4, beam=beam, dtype="f32" if name == "tiny_soft" else "bf16")
-            if lm: eng.attach_lm(lsd)
-            pcm = synth.synth_pcm(3, 16000 * 3, seed=17 + beam)
-            slots = [eng.open() for _ in range(3)]
-            eng.transcribe_pcm(slots, [pcm[i] for i in range(3)])
-            off = [[t, float(lp).hex()] for t, lp, _ in (eng.fetch(s) for s in slots)]
-            for s in slots: eng.reset(s, 15)
-            got = [[] for _ in slots]
-            def collect():
-                if eng.wait():
-                    for i, t in enumerate(eng.fetch_many(slots, 512)): got[i].append(t)
-            for k in range(pcm.shape[1] // 1280):
-                eng.push_submit(slots, torch.as_tensor(np.ascontiguousarray(pcm[:, k * 1280:(k + 1) * 1280])).cuda())
-                while eng.pending() >= 3: collect()
-            while eng.pending(): collect()
-            out["%%s_b%%d_lm%%d" %% (name, beam, lm)] = [off, got]
-            eng.close()
-print("RESULT" + json.dumps(out))
-''' % ROOT
-    res = {}
-    for tag, env in (("rw", {}), ("spread", {"LASR_BEAM_SELECT_RW": "0"})):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
-        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-        assert line, r.stdout[-2000:] + r.stderr[-2000:]
-        res[tag] = line[0]
-    assert res["rw"] == res["spread"]
-    assert res["rw"].count(",") > 300
-
-
 def test_bench_neighbour_runs_and_reports():
     """lasr_bench_neighbour (experiment hook): a neighbour of every kind runs on its own stream for a few milliseconds and reports a
     positive rate; a second start before the first was collected is refused; the engine works afterwards."""
