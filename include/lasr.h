@@ -297,8 +297,9 @@ int lasr_attach_lm_int8(lasr_ctx* c, const lasr_lm_desc* d, const float* weights
  * that has one waiting into lasr_push_submit_rows (ring addresses, no gather), keeps up to `depth` model steps in flight
  * (<= lasr_max_inflight) and delivers every collected step's tokens to the streams' result queues.  reset_steps > 0 applies the
  * servicer's reset rule (api-server.py:44-50,131-134: after reset_steps model steps since the last reset -- 25 = 4000 ms / 160 ms
- * for the reference geometry -- the first step that emits no token resets encoder, predictor and LM) between two model steps of
- * the stream, as the reference does; 0 = no rule.  Greedy decode, 16 kHz chunks of lasr_model_desc.chunk samples (the fused
+ * for the reference geometry -- the first step whose text is empty resets encoder, predictor and LM) between two model steps of
+ * the stream, as the reference does; 0 = no rule.  "Text is empty" = the step emitted no token, or only tokens named by
+ * lasr_front_set_empty_tokens (pieces the servicer's tokenizer decodes to "": the reference tests `y_one != ""`, :124).  Greedy decode, 16 kHz chunks of lasr_model_desc.chunk samples (the fused
  * streaming path); other client rates / frame lengths keep going through lasr_step_window.  While a front exists it is the only
  * caller of the engine's streaming entry points; lasr_front_pause hands the engine to the caller (unary Transcribe).
  * Thread-safety: one producer (push / eof) and one consumer (next) per stream, any number of streams, any threads. */
@@ -311,16 +312,25 @@ int lasr_front_create(lasr_ctx* c, int depth, int reset_steps, lasr_front** out)
  * lasr_destroy of its context.  (destroy without stop is fine when nothing can be blocked.) */
 int lasr_front_stop(lasr_front* f);
 void lasr_front_destroy(lasr_front* f);
-int lasr_front_open(lasr_front* f, int* stream);        /* stream id == engine slot; LASR_EFULL when no slot is free */
+/* Stream id = engine slot | generation << 16: an id that outlives its stream (a reader thread still holding it after close, while
+ * the slot already serves the next client) names nothing -- push / eof / next / close on it return LASR_ESTATE and touch no state.
+ * LASR_EFULL when no slot is free. */
+int lasr_front_open(lasr_front* f, int* stream);
 /* n_chunks client chunks ([n_chunks][chunk] float32, host memory) appended to the stream; copied before the call returns; blocks
- * while the stream's ring (64 chunks) is full. */
+ * while the stream's ring (64 chunks) is full -- until there is room, or the stream is closed / the front stopped (LASR_ESTATE). */
 int lasr_front_push(lasr_front* f, int stream, const float* pcm, int n_chunks);
 int lasr_front_eof(lasr_front* f, int stream);          /* no more chunks: an end-of-stream result follows the last step's */
 /* Next result of the stream, in model-step order.  *flags: 1 = a model step (n_tokens new ids, possibly none), 2 = the reset rule
  * fired after this step, 4 = end of stream.  Blocks up to timeout_ms (< 0: until there is one); returns 1 on time-out,
  * LASR_EFULL if cap is too small (nothing consumed). */
 int lasr_front_next(lasr_front* f, int stream, int32_t* tokens, int cap, int* n_tokens, int* flags, int timeout_ms);
-int lasr_front_close(lasr_front* f, int stream);        /* waits for the stream's steps in flight, then frees the slot */
+/* Takes no more input (a producer blocked in lasr_front_push returns LASR_ESTATE, and close waits until it has), waits for the
+ * stream's steps in flight, then frees the slot; a consumer blocked in lasr_front_next returns LASR_ESTATE. */
+int lasr_front_close(lasr_front* f, int stream);
+/* The reset rule's emptiness test on TEXT: ids[0..n) decode to the empty string in the servicer's tokenizer (a lone word-boundary
+ * piece); a step whose tokens are all among them counts as empty, like a step without tokens.  Default (never called / n = 0):
+ * only "no token".  Call before streams are opened. */
+int lasr_front_set_empty_tokens(lasr_front* f, const int32_t* ids, int n);
 /* Collect every step in flight and keep the front thread out of the engine until lasr_front_resume (same thread; does not nest). */
 int lasr_front_pause(lasr_front* f);
 int lasr_front_resume(lasr_front* f);

@@ -85,6 +85,7 @@ SYMBOLS = [
     ("lasr_front_eof", C.c_int, [_P, C.c_int]),
     ("lasr_front_next", C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     ("lasr_front_close", C.c_int, [_P, C.c_int]),
+    ("lasr_front_set_empty_tokens", C.c_int, [_P, _P, C.c_int]),
     ("lasr_front_pause", C.c_int, [_P]),
     ("lasr_front_resume", C.c_int, [_P]),
     ("lasr_front_stats", C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),

@@ -22,7 +22,11 @@ struct lasr_front {
     struct Stream {
         int slot = -1;
         std::atomic<bool> open{false};
-        bool closing = false;                 // (front thread reads it under em)
+        std::atomic<bool> closing{false};     // set by lasr_front_close: the front thread takes nothing more, a blocked producer leaves
+        // stream id = slot | generation << 16: a stale id (a reader thread of the slot's PREVIOUS stream) matches no open stream
+        std::atomic<int> gen{0};
+        std::atomic<int> inside{0};           // producer calls (push / eof) between their id check and their return: close waits for 0
+        std::atomic<long long> last_push_ns{0};   // steady clock of the last chunk pushed (thin-batch rule: who counts as "about to push")
         // input: single-producer / single-consumer ring of client chunks (host memory, `chunk` floats each)
         std::vector<float> ring;
         std::atomic<long long> head{0}, tail{0};     // chunks produced / consumed
@@ -32,7 +36,7 @@ struct lasr_front {
         long long n_chunks = 0; int n_pend = 0;
         int infl = 0; long long stp = 0;
         int judged = 0;                       // steps in flight already judged (and counted in stp) through an early verdict
-        bool early_reset_pending = false;     // ... and the last of them ended in a reset (reported with that step's result)
+        std::deque<char> judged_reset;        // ... one flag per judged step, oldest first: that step ended in a reset (reported with its result)
         // results: one entry per collected model step
         std::mutex rm; std::condition_variable rcv;
         struct Res { std::vector<int32_t> tok; int flags; };
@@ -57,6 +61,9 @@ struct lasr_front {
     std::atomic<int> rc{0}; std::string err;  // first engine error: the front stops, every call returns it (err is written before rc: under em)
     std::atomic<long long> n_ticks{0}, n_steps{0}, n_rows{0}, n_resets{0};
     bool early = true;
+    // reset rule on TEXT (api-server.py:124-133: `y_one != ""`): ids whose pieces decode to the empty string (a lone word-boundary
+    // piece of a BPE vocabulary); a step whose tokens are all in the set counts as empty.  Empty set = "no token" (IdLanguage)
+    std::vector<unsigned char> empty_tok;
     int held_last = 0;                        // streams the last tick found held at the reset threshold (early verdicts are tried for them)
     std::vector<int> ev_slots, ev_skip, ev_cnt, ev_ndec, ev_nfl; std::vector<int32_t> ev_tok;
     // scratch of the front thread
@@ -75,6 +82,24 @@ struct FrontCallerLock {
 };
 
 constexpr int FRONT_RES_STEP = 1, FRONT_RES_RESET = 2, FRONT_RES_EOF = 4;
+
+inline long long front_now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline int front_id(const lasr_front::Stream& s) { return s.slot | (s.gen.load(std::memory_order_relaxed) << 16); }
+// the open stream an id names, or nullptr (unknown slot, closed, or the id of an earlier stream of the slot)
+lasr_front::Stream* front_stream(lasr_front* f, int id) {
+    if (!f || id < 0) return nullptr;
+    const int slot = id & 0xffff, gen = id >> 16;
+    if (slot >= (int)f->st.size() || !f->st[slot]) return nullptr;
+    lasr_front::Stream* s = f->st[slot].get();
+    if (s->gen.load(std::memory_order_acquire) != gen || !s->open.load(std::memory_order_acquire)) return nullptr;
+    return s;
+}
+// does the step's text decode to ""?  (no token, or only pieces of the tokenizer's empty set)
+inline bool front_step_empty(const lasr_front* f, const int32_t* tok, int n) {
+    for (int i = 0; i < n; ++i)
+        if (tok[i] < 0 || tok[i] >= (int)f->empty_tok.size() || !f->empty_tok[tok[i]]) return false;
+    return true;
+}
 
 int front_fail(lasr_front* f, int rc) {
     if (!f->rc.load(std::memory_order_acquire)) { f->err = lasr_last_error(f->c); f->rc.store(rc, std::memory_order_release); }
@@ -135,11 +160,11 @@ int front_collect(lasr_front* f) {
         s.infl--;
         if (s.judged > 0) {                  // judged (and counted, and reset if the rule said so) when its row was decoded
             s.judged--;
-            if (s.early_reset_pending && s.judged == 0) { o.flags[i] |= FRONT_RES_RESET; s.early_reset_pending = false; }
+            if (!s.judged_reset.empty()) { if (s.judged_reset.front()) o.flags[i] |= FRONT_RES_RESET; s.judged_reset.pop_front(); }
             continue;
         }
         s.stp++;
-        if (f->reset_steps > 0 && s.stp >= f->reset_steps && f->cnt[i] == 0) {
+        if (f->reset_steps > 0 && s.stp >= f->reset_steps && front_step_empty(f, f->tokbuf.data() + i * (size_t)cap, f->cnt[i])) {
             // (the stream has nothing else in flight: see the hold rule in front_tick)
             rc = lasr_stream_reset(f->c, s.slot, 1 | 2 | 4);            // models.py:494-497
             if (rc) return front_fail(f, rc);
@@ -159,7 +184,7 @@ int front_collect(lasr_front* f) {
 int front_early_verdicts(lasr_front* f) {
     f->ev_slots.clear(); f->ev_skip.clear();
     for (auto& sp : f->st) {
-        if (!sp || !sp->open.load(std::memory_order_acquire) || sp->closing) continue;
+        if (!sp || !sp->open.load(std::memory_order_acquire) || sp->closing.load(std::memory_order_acquire)) continue;
         const int unj = sp->infl - sp->judged;
         if (unj > 0 && sp->stp + unj >= f->reset_steps) { f->ev_slots.push_back(sp->slot); f->ev_skip.push_back(sp->judged); }
     }
@@ -174,10 +199,15 @@ int front_early_verdicts(lasr_front* f) {
     for (int q = 0; q < n; ++q) {
         lasr_front::Stream& s = *f->st[f->ev_slots[q]];
         const int k_new = f->ev_ndec[q] - f->ev_skip[q];
+        const int32_t* tq = f->ev_tok.data() + (size_t)q * cap;      // the decoded steps' tokens, step after step
         for (int k = 0; k < k_new; ++k) {
+            const int nk = f->ev_cnt[(size_t)q * cap_steps + k];
             s.judged++;
             s.stp++;
-            if (s.stp >= f->reset_steps && f->ev_cnt[(size_t)q * cap_steps + k] == 0) {
+            s.judged_reset.push_back(0);
+            const bool empty = front_step_empty(f, tq, nk);
+            tq += nk;
+            if (s.stp >= f->reset_steps && empty) {
                 // past the threshold a stream has ONE unjudged step in flight at a time: this was its last, and it is decoded
                 if (s.judged != f->ev_nfl[q]) {
                     fail(f->c, LASR_ESTATE, "front: slot %d ran ahead of the reset threshold (%d steps in flight, %d judged)", s.slot, f->ev_nfl[q], s.judged);
@@ -186,7 +216,7 @@ int front_early_verdicts(lasr_front* f) {
                 rc = lasr_stream_reset(f->c, s.slot, 1 | 2 | 4 | LASR_RESET_IF_DECODED);
                 if (rc) return front_fail(f, rc);
                 s.stp = 0;
-                s.early_reset_pending = true;
+                s.judged_reset.back() = 1;
                 f->n_resets.fetch_add(1, std::memory_order_relaxed);
             }
         }
@@ -201,16 +231,22 @@ int front_tick(lasr_front* f, bool* did) {
     while ((int)f->inflight.size() >= f->depth) { int rc = front_collect(f); if (rc) return rc; *did = true; }
     f->slots.clear(); f->rows.clear(); f->step_rows.clear();
     int n_step = 0, n_fill = 0, n_absent = 0, n_held = 0;
+    const long long now_ns = front_now_ns();
     if (f->reset_steps > 0 && f->early && f->held_last > 0) { int rc = front_early_verdicts(f); if (rc) return rc; }
     // pass 1: classify
     struct Cand { int slot; bool stepper; };
     static thread_local std::vector<Cand> cand;
     cand.clear();
     for (auto& sp : f->st) {
-        if (!sp || !sp->open.load(std::memory_order_acquire) || sp->closing) continue;
+        if (!sp || !sp->open.load(std::memory_order_acquire) || sp->closing.load(std::memory_order_acquire)) continue;
         lasr_front::Stream& s = *sp;
         if (s.head.load(std::memory_order_acquire) == s.tail.load(std::memory_order_relaxed)) {
-            if (!s.eof_in.load(std::memory_order_acquire)) { n_absent++; continue; }          // a live stream with nothing waiting
+            if (!s.eof_in.load(std::memory_order_acquire)) {
+                // a live stream with nothing waiting counts as "about to push" only if it pushed within the last 2 ms (a producer that
+                // is behind by a turn on the GIL): an idle or real-time client must not hold the others at 2 steps in flight
+                if (now_ns - s.last_push_ns.load(std::memory_order_relaxed) < 2000000LL) n_absent++;
+                continue;
+            }
             if (!s.eof_out && s.infl == 0) {                                                  // everything delivered
                 s.eof_out = true;
                 lasr_front::Out o;                 // (behind the stream's last step result, through the same queue)
@@ -374,32 +410,59 @@ int lasr_front_open(lasr_front* f, int* stream) {
     if (rc) return rc;
     if (!f->st[slot]) f->st[slot].reset(new lasr_front::Stream());
     lasr_front::Stream& s = *f->st[slot];
-    s.slot = slot; s.closing = false; s.eof_out = false;
+    // (no producer of the slot's previous stream is inside a call any more: lasr_front_close waited for that)
+    s.slot = slot; s.closing.store(false); s.eof_out = false;
+    s.gen.store((s.gen.load() % 0x7fff) + 1, std::memory_order_release);          // 1 .. 32767: a stale id never matches
     s.ring.assign((size_t)f->ring_chunks * f->chunk, 0.f);
-    s.head.store(0); s.tail.store(0); s.eof_in.store(false);
-    s.n_chunks = 0; s.n_pend = 0; s.infl = 0; s.stp = 0; s.judged = 0; s.early_reset_pending = false;
+    s.head.store(0); s.tail.store(0); s.eof_in.store(false); s.last_push_ns.store(0);
+    s.n_chunks = 0; s.n_pend = 0; s.infl = 0; s.stp = 0; s.judged = 0; s.judged_reset.clear();
     { std::lock_guard<std::mutex> rl(s.rm); s.res.clear(); }
     s.open.store(true, std::memory_order_release);
-    *stream = slot;
+    *stream = front_id(s);
     return LASR_OK;
 }
 
-// n_chunks client chunks (chunk floats each, host memory) of `stream`, copied into its ring; blocks while the ring is full
+// a producer call on stream `id`: counted in s.inside BEFORE the id is checked, so lasr_front_close (closing = true, then wait for
+// inside == 0) either sees the call or the call sees `closing` -- nobody writes a ring that close has handed to the next stream
+struct FrontProducer {
+    lasr_front::Stream* s = nullptr;
+    FrontProducer(lasr_front* f, int id) {
+        if (!f || id < 0) return;
+        const int slot = id & 0xffff;
+        if (slot >= (int)f->st.size() || !f->st[slot]) return;
+        lasr_front::Stream* q = f->st[slot].get();
+        q->inside.fetch_add(1, std::memory_order_seq_cst);
+        if (q->gen.load(std::memory_order_seq_cst) != (id >> 16) || !q->open.load(std::memory_order_seq_cst) || q->closing.load(std::memory_order_seq_cst)) {
+            q->inside.fetch_sub(1, std::memory_order_seq_cst);
+            return;
+        }
+        s = q;
+    }
+    ~FrontProducer() { if (s) s->inside.fetch_sub(1, std::memory_order_seq_cst); }
+};
+
+// n_chunks client chunks (chunk floats each, host memory) of `stream`, copied into its ring; blocks while the ring is full.
+// LASR_ESTATE: the id names no open stream (closed meanwhile, or an earlier stream of the slot), or the stream is being closed.
 int lasr_front_push(lasr_front* f, int stream, const float* pcm, int n_chunks) {
-    if (!f || stream < 0 || stream >= (int)f->st.size() || !f->st[stream] || (n_chunks > 0 && !pcm)) return LASR_EINVAL;
-    lasr_front::Stream& s = *f->st[stream];
-    if (!s.open.load(std::memory_order_acquire) || s.eof_in.load()) return LASR_ESTATE;
+    if (!f || stream < 0 || (n_chunks > 0 && !pcm)) return LASR_EINVAL;
+    FrontProducer P(f, stream);
+    if (!P.s) return LASR_ESTATE;
+    lasr_front::Stream& s = *P.s;
+    if (s.eof_in.load()) return LASR_ESTATE;
     for (int k = 0; k < n_chunks; ++k) {
         if (f->rc) return f->rc;
+        if (s.closing.load(std::memory_order_acquire)) return LASR_ESTATE;
         const long long h = s.head.load(std::memory_order_relaxed);
         if (h - s.tail.load(std::memory_order_acquire) >= f->ring_chunks) {          // back-pressure
             std::unique_lock<std::mutex> lk(s.rm);
-            s.pcv.wait_for(lk, std::chrono::milliseconds(20), [&] { return h - s.tail.load(std::memory_order_acquire) < f->ring_chunks || f->rc || f->stop.load(); });
+            s.pcv.wait_for(lk, std::chrono::milliseconds(20), [&] {
+                return h - s.tail.load(std::memory_order_acquire) < f->ring_chunks || f->rc || f->stop.load() || s.closing.load(std::memory_order_acquire); });
             if (f->stop.load()) return LASR_ESTATE;
             --k;
             continue;
         }
         memcpy(s.ring.data() + (size_t)(h % f->ring_chunks) * f->chunk, pcm + (size_t)k * f->chunk, sizeof(float) * f->chunk);
+        s.last_push_ns.store(front_now_ns(), std::memory_order_relaxed);
         s.head.store(h + 1, std::memory_order_release);
         front_kick(f);
     }
@@ -407,8 +470,10 @@ int lasr_front_push(lasr_front* f, int stream, const float* pcm, int n_chunks) {
 }
 
 int lasr_front_eof(lasr_front* f, int stream) {
-    if (!f || stream < 0 || stream >= (int)f->st.size() || !f->st[stream]) return LASR_EINVAL;
-    f->st[stream]->eof_in.store(true, std::memory_order_release);
+    if (!f || stream < 0) return LASR_EINVAL;
+    FrontProducer P(f, stream);
+    if (!P.s) return LASR_ESTATE;
+    P.s->eof_in.store(true, std::memory_order_release);
     front_kick(f);
     return LASR_OK;
 }
@@ -417,12 +482,16 @@ int lasr_front_eof(lasr_front* f, int stream) {
 // reset rule fired after this step, bit 4 = end of stream (every step of the pushed chunks has been delivered; after
 // lasr_front_eof).  Blocks up to timeout_ms (< 0: for ever); returns 1 on time-out.
 int lasr_front_next(lasr_front* f, int stream, int32_t* tokens, int cap, int* n_tokens, int* flags, int timeout_ms) {
-    if (!f || stream < 0 || stream >= (int)f->st.size() || !f->st[stream] || !n_tokens || !flags) return LASR_EINVAL;
-    lasr_front::Stream& s = *f->st[stream];
+    if (!f || stream < 0 || !n_tokens || !flags) return LASR_EINVAL;
+    lasr_front::Stream* sp = front_stream(f, stream);
+    if (!sp) return LASR_ESTATE;
+    lasr_front::Stream& s = *sp;
+    const int gen = stream >> 16;
     std::unique_lock<std::mutex> lk(s.rm);
-    auto ready = [&] { return !s.res.empty() || f->rc != 0 || f->stop.load(); };
+    auto ready = [&] { return !s.res.empty() || f->rc != 0 || f->stop.load() || s.gen.load() != gen || !s.open.load(); };
     if (timeout_ms < 0) s.rcv.wait(lk, ready);
     else if (!s.rcv.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready)) return 1;
+    if (s.gen.load() != gen || !s.open.load()) return LASR_ESTATE;           // closed under the consumer
     if (s.res.empty()) return f->rc.load() ? f->rc.load() : LASR_ESTATE;
     lasr_front::Stream::Res& r = s.res.front();
     if ((int)r.tok.size() > cap) return LASR_EFULL;
@@ -434,27 +503,52 @@ int lasr_front_next(lasr_front* f, int stream, int32_t* tokens, int cap, int* n_
 }
 
 int lasr_front_close(lasr_front* f, int stream) {
-    if (!f || stream < 0 || stream >= (int)f->st.size() || !f->st[stream]) return LASR_EINVAL;
-    lasr_front::Stream& s = *f->st[stream];
-    if (!s.open.load()) return LASR_ESTATE;
+    if (!f || stream < 0) return LASR_EINVAL;
+    lasr_front::Stream* sp = front_stream(f, stream);
+    if (!sp) return LASR_ESTATE;
+    lasr_front::Stream& s = *sp;
+    // no more input: the front thread takes nothing more from the ring, a producer blocked on it (or about to write it) leaves
+    s.closing.store(true, std::memory_order_seq_cst);
+    { std::lock_guard<std::mutex> rl(s.rm); s.pcv.notify_all(); }
+    while (s.inside.load(std::memory_order_seq_cst) > 0) std::this_thread::yield();
     for (;;) {      // its steps in flight are collected by the front thread; then the slot can be closed
         FrontCallerLock lk(f);
-        s.closing = true;
         if (f->rc) return f->rc;
         if (s.infl == 0) {
             for (;;) {              // its last results have left the delivery queue (a late one must not reach the slot's next stream)
                 { std::lock_guard<std::mutex> ol(f->om); if (f->outq.empty() && !f->out_busy) break; }
+                // (after lasr_front_stop the delivery thread exits once its queue is empty: a record queued behind that stays --
+                //  nothing will deliver it, and the stream is going away: drop the queue instead of spinning for ever)
+                if (f->stop.load(std::memory_order_acquire) || f->rc.load()) {
+                    std::lock_guard<std::mutex> ol(f->om);
+                    if (!f->out_busy) { f->outq.clear(); break; }
+                }
                 std::this_thread::yield();
             }
             int rc = lasr_stream_close(f->c, s.slot);
             s.open.store(false, std::memory_order_release);
             std::lock_guard<std::mutex> rl(s.rm);
             s.res.clear();
+            s.rcv.notify_all();
             return rc;
         }
         int rc = front_collect(f);
         if (rc) return rc;
     }
+}
+
+// Reset rule on text (api-server.py:124-133 resets on `y_one == ""`, the DECODED step): ids[0..n) are the token ids whose piece
+// decodes to the empty string in the servicer's tokenizer; a step whose tokens are all among them counts as empty.  n = 0: only
+// "no token" is empty (what the rule is with an id-per-character vocabulary).  Call before streams are opened.
+int lasr_front_set_empty_tokens(lasr_front* f, const int32_t* ids, int n) {
+    if (!f || n < 0 || (n > 0 && !ids)) return LASR_EINVAL;
+    FrontCallerLock lk(f);
+    f->empty_tok.assign((size_t)f->c->d.vocab, 0);
+    for (int i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] >= f->c->d.vocab) return fail(f->c, LASR_EINVAL, "lasr_front_set_empty_tokens: id %d outside the vocabulary", ids[i]);
+        f->empty_tok[ids[i]] = 1;
+    }
+    return LASR_OK;
 }
 
 // The engine for the caller (a unary Transcribe RPC, an offline utterance): every step in flight is collected and the front

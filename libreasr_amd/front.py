@@ -16,7 +16,7 @@ RES_STEP, RES_RESET, RES_EOF = 1, 2, 4
 
 
 class NativeFront:
-    def __init__(self, engine, depth=12, reset_steps=0):
+    def __init__(self, engine, depth=12, reset_steps=0, empty_tokens=None):
         self.eng, self.lib = engine, engine.lib
         self.chunk = int(engine.desc.chunk)
         h = C.c_void_p()
@@ -30,6 +30,8 @@ class NativeFront:
         self._lk = threading.Condition()
         self._inside = 0
         self._stopped = False
+        if empty_tokens:
+            self.set_empty_tokens(empty_tokens)
 
     @contextlib.contextmanager
     def _call(self):
@@ -50,6 +52,25 @@ class NativeFront:
             msg = self.lib.lasr_front_error(self.h) or self.lib.lasr_last_error(self.eng.ctx) or b""
             raise N.LasrError(rc, msg.decode(errors="replace"))
         return rc
+
+    def set_empty_tokens(self, ids):
+        """Token ids whose piece decodes to "" in the servicer's tokenizer: the reset rule then judges a step by its TEXT
+        (api-server.py:124 `y_one != ""`), not by its token count.  Call before streams are opened."""
+        a = np.ascontiguousarray(sorted(set(int(i) for i in ids)), dtype=np.int32)
+        with self._call() as h:
+            self._chk(self.lib.lasr_front_set_empty_tokens(h, a.ctypes.data if a.size else None, int(a.size)))
+
+    @staticmethod
+    def empty_token_ids(language, vocab):
+        """ids of `language` (denumericalize: list[int] -> str) that decode to the empty string on their own."""
+        out = []
+        for i in range(int(vocab)):
+            try:
+                if language.denumericalize([i]) == "":
+                    out.append(i)
+            except Exception:
+                pass
+        return out
 
     def open(self):
         s = C.c_int(-1)

@@ -898,7 +898,8 @@ class NativeASRServicer(apg.ASRServicer):
                 except Exception as e:
                     err.append(e)
 
-        threading.Thread(target=reader, daemon=True, name=f"lasr-reader-{sid}").start()
+        rt = threading.Thread(target=reader, daemon=True, name=f"lasr-reader-{sid}")
+        rt.start()
 
         def results():
             while True:
@@ -917,7 +918,11 @@ class NativeASRServicer(apg.ASRServicer):
         try:
             yield from self._diffs(results())
         finally:
+            # close releases a reader blocked on a full ring (LASR_ESTATE) and waits until it is out of the library; the id carries
+            # the stream's generation, so a reader that wakes up later (client gone, iterator raising) touches nothing of the slot's
+            # next stream
             fr.close(sid)
+            rt.join(timeout=2.0)
 
     def _stream_generic(self, pcm0, sr0, frames, context):
         """Other client rates / frame lengths: the servicer's own sequence per window, synchronous, the front paused for the call."""
@@ -971,7 +976,9 @@ def serve(lang="en", port=None, block=True, depth=12, front="python", **load_kw)
         k = 1
         while not should_reset(k, model.engine.desc.stride, model.engine.desc.n_buffer) and k < (1 << 20):
             k += 1
-        sched = NativeFront(model.engine, depth=depth, reset_steps=k)
+        # the rule tests the step's TEXT (api-server.py:124): the ids this tokenizer decodes to "" go to the front at start-up
+        sched = NativeFront(model.engine, depth=depth, reset_steps=k,
+                            empty_tokens=NativeFront.empty_token_ids(language, model.engine.desc.vocab))
         apg.add_ASRServicer_to_server(NativeASRServicer(lang, sched, language, conf), server)
     else:
         sched = Scheduler(model.engine, depth=depth)

@@ -192,11 +192,77 @@ def golden_flac():
     print("flac:", len(pcm), sr, md5_ok, feats.shape)
 
 
+def golden_speech(names=("cfg2", "ref6")):
+    """configs[0]'s utterance -- the reference's demo FLAC, real speech, 330 400 samples = 20.65 s -- through the reference's OWN
+    pipeline and decode on the synthetic weights: the PCM itself (int16: exactly what the FLAC holds, the
+    reference's test data; STREAMINFO MD5 verified), its log-mel (TransformTime), offline + streaming tokens (api-client.py:32-59
+    chunking) and the message sequence of the reference's own servicer for the same frames.  Every GPU input before round 6 was
+    chirp + noise from synth.synth_pcm: low-energy / silent stretches of real audio never reached k_logmel."""
+    p = os.path.join(rf.REF_ROOT, "demo", "3729-6852-0035.flac")
+    from libreasr_amd import flac
+    pcm, sr, md5_ok = flac.decode(p)
+    assert md5_ok and sr == 16000
+    i16 = np.round(pcm * 32768.0).astype(np.int16)
+    assert np.array_equal(i16.astype(np.float32) / 32768.0, pcm.astype(np.float32)), "the FLAC holds 16-bit PCM"
+    x_tfm, s_tfm, AT = rf.ref_transforms()
+    import libreasr.lib.transforms as T
+    tt = [f for f in x_tfm.fs if isinstance(f, T.TransformTime)][0]
+    out = {"pcm_i16": i16, "sr": np.int32(sr), "names": np.array(names, dtype=np.str_)}
+    out["logmel"] = tt(AT(t(pcm[None]), sr))[0].numpy().astype(np.float32)            # [2066, 128]
+    feats_t = x_tfm(AT(t(pcm[None]), sr))[0]                                          # [258, 1280, 1]
+    feats = feats_t[:, :, 0].numpy()
+    out["feats_first"] = feats[:4].astype(np.float32); out["feats_last"] = feats[-2:].astype(np.float32)
+    out["n_frames"] = np.int32(feats.shape[0])
+    chunks = synth.stream_chunks(pcm, 1280, lead=1, tail=10)
+    for name in names:
+        cfg = synth.model_cfg(name)
+        sd = synth.synth_state_dict(cfg, seed=0)
+        m = rf.ref_transducer(cfg, sd)
+        with torch.no_grad():
+            txt, neg_logp, metrics, extra = m.decode_greedy(feats_t)
+            toks = [int(v) for v in txt.split()] if txt else []
+            out[f"{name}_off_tokens"] = np.array(toks, dtype=np.int32)
+            out[f"{name}_off_neglogp"] = np.float64(neg_logp)
+            out[f"{name}_off_align"] = np.float64(metrics["alignment_score"])
+            s_tfm.fs[-1].saved.clear()
+
+            def gen():
+                frames = []
+                for c in chunks:
+                    frames.append(t(c[None]))
+                    if len(frames) != 3:
+                        continue
+                    aud = torch.cat(frames, dim=1)
+                    del frames[0]
+                    yield s_tfm(AT(aud, 16000))
+
+            per_chunk, y_all = [], []
+            for y, y_one, reset_fn in m.transcribe_stream(gen(), m.lang.denumericalize):
+                per_chunk.append(len(y) - len(y_all))
+                y_all = [int(v) for v in y]
+            out[f"{name}_st_tokens"] = np.array(y_all, dtype=np.int32)
+            out[f"{name}_st_counts"] = np.array(per_chunk, dtype=np.int32)
+            # the reference's own servicer on the same frames (api-server.py:82-135) and its unary Transcribe (:64-80)
+            sv, mod, resets = rf.ref_servicer(m, s_tfm, x_tfm)
+            s_tfm.fs[-1].saved.clear()
+            reqs = [mod.ap.Audio(data=c.tobytes(), sr=16000) for c in chunks]
+            msgs = [t_.data for t_ in sv.TranscribeStream(iter(reqs), None)]
+            text = sv.Transcribe(mod.ap.Audio(data=pcm.astype(np.float32).tobytes(), sr=16000), None).data
+            out[f"{name}_msgs"] = np.array(msgs if msgs else [""], dtype=np.str_)
+            out[f"{name}_n_msgs"] = np.int32(len(msgs))
+            out[f"{name}_resets"] = np.array(resets, dtype=np.int32)
+            out[f"{name}_unary"] = np.str_(text)
+        print(f"  speech {name}: offline {len(toks)} tokens, stream {len(y_all)} tokens in {len(per_chunk)} calls, "
+              f"{len(msgs)} messages, resets {list(resets)}")
+    np.savez_compressed(os.path.join(OUT, "speech_demo.npz"), **out)
+    print("speech:", len(pcm), out["logmel"].shape, feats.shape)
+
+
 if __name__ == "__main__":
     assert rf.available(), "/root/reference is required to generate goldens"
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["frontend", "tiny", "tiny_lstm", "cfg2", "cfg2_lstm", "ref6", "cfg5", "flac", "lm", "lm_int8", "long", "servicer"]
+    which = sys.argv[1:] or ["frontend", "tiny", "tiny_lstm", "cfg2", "cfg2_lstm", "ref6", "cfg5", "flac", "lm", "lm_int8", "long", "servicer", "speech"]
     if "frontend" in which:
         golden_frontend()
     if "tiny" in which:
@@ -230,3 +296,5 @@ if __name__ == "__main__":
             golden_flac()
         except ImportError as e:
             print("flac golden skipped:", e)
+    if "speech" in which:
+        golden_speech()
