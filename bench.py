@@ -319,6 +319,110 @@ def cpu_numpy_port(cfg, sd, n_streams, n_chunks):
             "seconds": round(dt, 2)}
 
 
+def pin_to_gpu_numa_node(local):
+    """Multi-rank runs: this process (and every thread the library creates later: pump, push helpers) onto the CPUs of the NUMA node
+    the rank's GPU hangs off (sysfs: /sys/bus/pci/devices/<bdf>/numa_node -> /sys/devices/system/node/nodeN/cpulist).  Returns
+    (node, n_cpus) or (None, 0) when the topology does not say (single-socket hosts report -1)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None, 0
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return node, 0
+        os.sched_setaffinity(0, cpus)
+        return node, len(cpus)
+    except Exception:
+        return None, 0
+
+
+def emulation_parity(eng, args, slots, pcm_host, n_rows, n_chunks):
+    """bench.py --emu-parity: the first n_rows streams of the rank, reset and replayed from chunk 0 through the SYNCHRONOUS protocol,
+    against the numpy oracle's emulation of the same operand type and search (the checker: oracle/parity.py).  Greedy: token lists;
+    beam: the best hypothesis after every model step and the final score."""
+    from oracle import parity as PR          # checker leg only; never on the product path
+    rows = list(range(min(n_rows, len(slots))))
+    sl = [slots[r] for r in rows]
+    for s_ in sl:
+        eng.reset(s_, 15)
+    hist = {r: [] for r in rows}
+    toks = {r: [] for r in rows}
+    score = {r: 0.0 for r in rows}
+    for k in range(n_chunks):
+        eng.push(sl, np.ascontiguousarray(pcm_host[rows, k * CHUNK:(k + 1) * CHUNK]))
+        if not eng.step(sl):
+            continue
+        for r, s_ in zip(rows, sl):
+            t, nl, _ = eng.fetch(s_, cap=8192 if args.beam > 1 else 256)
+            if args.beam > 1:
+                hist[r].append(t if t else (hist[r][-1] if hist[r] else []))
+                score[r] = -nl
+            else:
+                toks[r].append(t)
+    eps = 0.03
+    operand = "bf16" if args.dtype == "bf16" else "f32"
+    if args.beam > 1:
+        res = PR.beam_rows_vs_emulation(args.model, args.beam, pcm_host, rows, n_chunks, hist, score, eps, operand=operand)
+    else:
+        res = PR.greedy_rows_vs_emulation(args.model, pcm_host, rows, n_chunks, toks, eps, operand=operand)
+    return {"rows": len(rows), "chunks": n_chunks, "exact": res["exact"], "tie": res["tie"], "near": res["near"], "failed": len(res["failures"]),
+            "tie_margins": res["margins"] + res["near_margins"], "eps": eps, "eps_wide": res["eps_wide"],
+            "against": f"numpy oracle, operand={operand}" + (f", _beam_frame spec, width {args.beam}" if args.beam > 1 else ", greedy")
+                       + " (bf16 operands / beam search have no reference implementation: parity unpinned, SURVEY 8a D4 / 8c)",
+            "criterion": "exact = identical at every model step; tie / near = the emulation had a decision with a margin below eps / "
+                         "eps_wide at or before the first step that differs; failed = a difference no such decision explains",
+            "full_size": "all rows x 48 chunks and 4 rows x 128 chunks: tests/test_gpu_round2.py, counts in profiles/r06/parity_counts.json"}
+
+
+OTHER_CONFIGS = [
+    ("configs[2]", ["--model", "cfg2", "--dtype", "bf16", "--beam", "4", "--streams", "64", "--steps", "10", "--warmup", "3"]),
+    ("configs[4] per-GPU shape", ["--model", "cfg5", "--dtype", "bf16", "--beam", "8", "--streams", "128", "--steps", "8", "--warmup", "2"]),
+]
+
+
+def other_config_legs():
+    """The BASELINE configs the headline line does not run (bf16 + beam search), each as a CHILD run of this script on the same GPU
+    behind the headline's own legs (the parent is idle meanwhile): same measurement code, same line; the fields a reader needs are
+    copied into `other_configs`.  ~20-40 s each (import, synthetic weights, engine, 8-10 steps, the checker)."""
+    legs = []
+    for tag, argv in OTHER_CONFIGS:
+        t0 = time.perf_counter()
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1"] + argv + ["--no-cpu-baseline", "--no-extras", "--sustained-s", "0",
+                                                                                  "--other-configs", "0", "--emu-parity", "4:24"]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if not lines:
+                legs.append({"config": tag, "error": f"rc {r.returncode}: no line", "stderr_tail": r.stderr[-300:]})
+                continue
+            c = json.loads(lines[-1])
+            rf = c.get("roofline", {})
+            legs.append({"config": tag, "workload": c["config"]["workload"], "value": c["value"], "unit": c["unit"], "dtype": c["dtype"],
+                         "steps": c["steps"], "warmup": c["warmup"], "ms_per_step": c["ms_per_step"],
+                         "pipeline": c["config"].get("pipeline"),
+                         "p50_model_chunk_ms": c["latency_ms"]["p50_model_chunk"], "p95_model_chunk_ms": c["latency_ms"]["p95_model_chunk"],
+                         "selection_rounds_per_model_step": c.get("iterations_per_model_step"),
+                         "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_us", "launches_timed",
+                                                              "launch_us_rocprof", "launch_us_rocprof_file", "frac_rocprof", "traffic_file",
+                                                              "launch_us_isolated", "weight_bytes_per_launch")},
+                         "parity": c.get("parity"), "rc": r.returncode, "leg_seconds": round(time.perf_counter() - t0, 1),
+                         "command": "python bench.py " + " ".join(cmd[2:])})
+        except Exception as e:
+            legs.append({"config": tag, "error": str(e)[:300]})
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -372,6 +476,13 @@ def main():
                     help="experiment: a synthetic neighbour beside the timed region (lasr_bench_neighbour) -- KIND mfma | load (HBM) | l2 | mall, WGS one-wave "
                          "workgroups, MS milliseconds from the start of the timed region (shorter than the region: its closing synchronisation would wait for the rest); the line then carries what the neighbour achieved")
     ap.add_argument("--trace", default=None, help="diagnostics: dump the two-stream mark timeline (lasr_trace) of the timed region to this file")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="1 (default): when this run is the headline workload at N = 1 with its extras, short legs of BASELINE configs[2] "
+                         "(cfg2 bf16 beam 4, 64 streams) and configs[4]'s per-GPU shape (cfg5 bf16 beam 8, 128 streams) run behind it, each "
+                         "as a child run of this script, and go into the line as `other_configs` (value, p50, roofline, parity); 0 = off")
+    ap.add_argument("--emu-parity", default=None, metavar="ROWS:CHUNKS",
+                    help="checker leg (bf16 / beam have no reference): the first ROWS streams replayed from chunk 0 for CHUNKS chunks "
+                         "through the synchronous protocol against the numpy oracle's emulation (oracle/parity.py): `parity` in the line")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU-only: exercise sharding + aggregation over gloo (no GPU work)")
     args = ap.parse_args()
@@ -418,6 +529,8 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    # several ranks on one host: each onto the CPUs next to its GPU, before the library creates its threads (LASR_BENCH_NUMA_PIN=0: off)
+    numa_node, numa_cpus = (pin_to_gpu_numa_node(local) if world > 1 and os.environ.get("LASR_BENCH_NUMA_PIN", "1") != "0" else (None, 0))
     dist = dist_init(world, use_cuda=True)
 
     cfg = synth.model_cfg(args.model)
@@ -427,7 +540,7 @@ def main():
     if args.lm != "none":
         eng.attach_lm(synth.synth_lm_state_dict("lm768"), int8=args.lm == "int8")
     eng_cfg = {}
-    for key in ("enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "cell_nw", "push_lazy"):
+    for key in ("enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "cell_nw", "push_lazy", "pump_nap_pct"):
         try:
             eng_cfg[key] = eng.config(key)
         except Exception:
@@ -635,7 +748,9 @@ def main():
     nms = max(1, host_timed["n_model_steps"])
     overlap_after = eng.overlap_probe(10000) if pipelined else float("nan")       # ... and after the job's RCCL collectives
     mine = [float(rank), audio_local / elapsed, elapsed, 1e6 * host_timed["push"] / nms, 1e6 * host_timed["submit"] / nms,
-            1e6 * host_timed["wait"] / nms, 1e6 * host_timed["fetch"] / nms, overlap_before, overlap_after, cpu_timed / max(1e-9, elapsed)]
+            1e6 * host_timed["wait"] / nms, 1e6 * host_timed["fetch"] / nms, overlap_before, overlap_after, cpu_timed / max(1e-9, elapsed),
+            float(-1 if numa_node is None else numa_node), float(numa_cpus), float(eng_cfg.get("pump_nap_pct", 0)),
+            float(np.median(lat_model)) * 1e3 if lat_model else float("nan")]
     per_rank = [mine]
     if dist is not None:
         t = torch.tensor(mine, dtype=torch.float64, device=device)
@@ -719,7 +834,11 @@ def main():
                           "streams_overlap": bool(v[7] < 1.5) if v[7] == v[7] else None,
                           # CPU seconds of the whole process (API thread + the library's pump and push-helper threads) per second of
                           # the timed region: how many host cores this rank keeps busy (spinning included)
-                          "host_cores_busy": round(v[9], 2)} for v in per_rank],
+                          "host_cores_busy": round(v[9], 2),
+                          # multi-rank runs: the NUMA node of the rank's GPU the process was pinned to (null: single rank / unknown
+                          # topology), the CPUs it may run on, the pump thread's nap share (LASR_PUMP_NAP_PCT; 75 by default there)
+                          "numa_node": (int(v[10]) if v[10] >= 0 else None), "cpus_pinned": int(v[11]), "pump_nap_pct": int(v[12]),
+                          "p50_model_chunk_ms": round(v[13], 4) if v[13] == v[13] else None} for v in per_rank],
             "latency_ms": {"definition": "host time from lasr_push_pcm of a model chunk to its tokens on the host"
                                          + (" (pipelined: includes the queueing behind the steps in flight)" if pipelined else ""),
                            "p50_model_chunk": round(1e3 * float(np.median(lat_model)), 4) if lat_model else None,
@@ -879,6 +998,15 @@ def main():
                 out["tokens_checked"] = 0
                 out["tokens_equal"] = False
                 out["self_check"] = {"error": str(e)[:300]}
+        if args.emu_parity and world == 1:
+            # checker leg: engine (sync protocol) against the oracle's emulation of the same operand type / search
+            try:
+                out["parity"] = emulation_parity(eng, args, slots, pcm_host, *[int(v) for v in args.emu_parity.split(":")])
+            except Exception as e:
+                out["parity"] = {"error": str(e)[:300]}
+        if (args.other_configs and world == 1 and extras and args.model == "cfg2" and args.dtype == "f32" and args.beam == 1
+                and B == STREAMS_PER_GPU and args.lm == "none" and not args.trace and not args.neighbour):
+            out["other_configs"] = other_config_legs()
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would stall the other ranks' teardown)
             gc.enable()
             try:

@@ -256,7 +256,7 @@ struct lasr_ctx {
     // (k_fe_mel src2) -- one launch and one kernel boundary less per model step on the stream that binds the job.  Every other
     // entry point that touches the PCM ring flushes it first (flush_lazy: the plain append launch).
     struct LazyPush { bool on = false; const float* src = nullptr; std::vector<int> slots; int ev_i = -1; bool dma = false; } lazy;
-    int pump_nap_pct = 0;                 // LASR_PUMP_NAP_PCT (see pump_main)
+    int pump_nap_pct = 0;                 // LASR_PUMP_NAP_PCT (see pump_main); default 75 when several ranks share the host, else 0
     int lazy_taken = 0, lazy_flushed = 0; // deferred chunks appended by a front-end launch / by the plain launch after all (lasr_debug_config)
     bool lazy_on = true;                  // LASR_PUSH_LAZY=0 turns the deferred append off (A/B switch)
     float* lm_buf = nullptr; size_t lm_floats = 0;       // offline log-mel

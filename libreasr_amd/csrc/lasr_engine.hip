@@ -122,7 +122,14 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     // round 3's wait path
     c->pump_G = c->W > 1 ? c->wait_n : 2;
     if (getenv("LASR_PUMP_G")) c->pump_G = std::max(1, std::min(8, atoi(getenv("LASR_PUMP_G"))));
-    if (getenv("LASR_PUMP_NAP_PCT")) c->pump_nap_pct = std::max(0, std::min(90, atoi(getenv("LASR_PUMP_NAP_PCT"))));
+    {   // The pump thread spins on its group's flag by design (one host core per context).  When several engine processes share the
+        // host (one rank per GPU: the launcher's LOCAL_WORLD_SIZE / WORLD_SIZE say so) it instead sleeps through 75 % of a group's
+        // expected duration (moving average) before it polls: 2.04 -> 1.32 host cores per rank in the 8-rank dry run at -1.7 %
+        // aggregate, -0.4 % at one rank (profiles/r05/pump_nap).  A single process keeps the spin: the headline takes the rate.
+        const char* lw = getenv("LOCAL_WORLD_SIZE") ? getenv("LOCAL_WORLD_SIZE") : getenv("WORLD_SIZE");
+        c->pump_nap_pct = (lw && atoi(lw) > 1) ? 75 : 0;
+        if (getenv("LASR_PUMP_NAP_PCT")) c->pump_nap_pct = std::max(0, std::min(90, atoi(getenv("LASR_PUMP_NAP_PCT"))));
+    }
     if (getenv("LASR_PUSH_LAZY")) c->lazy_on = atoi(getenv("LASR_PUSH_LAZY")) != 0;
     const size_t Mj = (size_t)c->MTj * 16;
     c->G_pred = d.pred_cell ? 4 : 3;

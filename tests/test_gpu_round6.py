@@ -294,3 +294,61 @@ def test_real_speech_through_the_grpc_servers(front, golden_dir):
     finally:
         server.stop(0)
         sched.shutdown()
+
+
+# ------------------------------------------------------------------------------- bf16 operands against the fp32 REFERENCE
+@pytest.mark.parametrize("name,n_streams", [("cfg2", 3), ("ref6", 1), ("cfg5", 1)])
+def test_bf16_token_error_rate_against_the_fp32_reference_long_goldens(name, n_streams, golden_dir):
+    """What bf16 operands cost in tokens: the reference's own fp32 decode of 20.65 s (cfg2) / 10 s utterances
+    (tests/golden/model_*_long.npz) against the engine with bf16 operands, greedy, offline and streaming -- token error rate =
+    edit distance / reference length, recorded in gpurun_out/parity_counts.json (committed under profiles/).  "Token-for-token"
+    is the fp32 contract and only fp32 meets it; the bf16 number is stated, not bounded (see the assertion's comment).  Beam 4
+    (cfg2) is recorded against the same greedy reference for information (a wider search is a different decode)."""
+    from oracle import parity as PR
+    record_parity = PR.record
+    g = np.load(os.path.join(golden_dir, f"model_{name}_long.npz"))
+    pcm = synth.synth_pcm(n_streams, int(g["n_samples"]), seed=1234)
+    eng, _, _ = make_engine(name, dtype="bf16")
+    rec = {}
+    try:
+        slots = [eng.open() for _ in range(n_streams)]
+        eng.transcribe_pcm(slots, [dev(p) for p in pcm])
+        off = [eng.fetch(s, cap=4096)[0] for s in slots]
+        for s in slots:
+            eng.reset(s, 15)
+        chunks = [synth.stream_chunks(p, 1280, lead=1, tail=10) for p in pcm]
+        st = [[] for _ in slots]
+        for k in range(len(chunks[0])):
+            eng.push(slots, dev(np.stack([c[k] for c in chunks])))
+            if eng.step(slots):
+                for i, t in enumerate(eng.fetch_many(slots, 64)):
+                    st[i] += t
+        for kind, got in (("offline", off), ("streaming", st)):
+            key = "off_tokens_" if kind == "offline" else "st_tokens_"
+            ref = [list(g[f"{key}{s}"]) for s in range(n_streams)]
+            d = sum(PR.edit_distance(got[s], ref[s]) for s in range(n_streams))
+            n = sum(len(r) for r in ref)
+            first = [next((q for q in range(min(len(a), len(b))) if a[q] != b[q]), min(len(a), len(b))) for a, b in zip(got, ref)]
+            rec[kind] = dict(ter=round(d / max(1, n), 5), edits=int(d), reference_tokens=int(n), streams_identical=int(sum(a == b for a, b in zip(got, ref))),
+                             first_difference_at_token=[int(f) for f in first])
+            print(f"{name} bf16 greedy {kind} vs the fp32 reference: TER {d}/{n} = {d / max(1, n):.4f}; identical streams "
+                  f"{rec[kind]['streams_identical']}/{n_streams}; first differences at token {first}")
+            # A RECORD, not a bound: with these synthetic (random) weights the decode is chaotic -- the first decision a bf16 rounding
+            # flips changes the predictor state, and the rest of the utterance follows another path (round 6: TER 0.4-0.6 on 20 s,
+            # first differences at tokens 3..85).  What is asserted is that the paths START together.
+            assert max(first) >= 3 or n < 8, rec[kind]
+    finally:
+        eng.close()
+    if name == "cfg2":
+        engb, _, _ = make_engine(name, dtype="bf16", beam=4)
+        try:
+            slots = [engb.open() for _ in range(n_streams)]
+            engb.transcribe_pcm(slots, [dev(p) for p in pcm])
+            offb = [engb.fetch(s, cap=4096)[0] for s in slots]
+            ref = [list(g[f"off_tokens_{s}"]) for s in range(n_streams)]
+            d = sum(PR.edit_distance(offb[s], ref[s]) for s in range(n_streams))
+            rec["beam4_offline_vs_fp32_greedy"] = dict(distance=int(d), reference_tokens=int(sum(len(r) for r in ref)),
+                                                      note="a wider search, not an error rate")
+        finally:
+            engb.close()
+    record_parity(f"{name}_bf16_vs_fp32_reference_long", **rec)
