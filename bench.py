@@ -446,8 +446,8 @@ def main():
                     help="chunks per stream of the best-effort CPU leg (all host cores, encoder batched over the streams)")
     ap.add_argument("--beam", type=int, default=1, help="beam width (1 = greedy, the headline config)")
     ap.add_argument("--depth", type=int, default=None,
-                    help="pipelined mode: model steps in flight before the oldest is collected (1..25); default 20 greedy, beam 6 (<= 64 "
-                         "streams) / 5 (more): what keeps the p50 push->tokens latency under 5 ms")
+                    help="pipelined mode: model steps in flight before the oldest is collected (1..25); default 18 greedy (the deepest whose "
+                         "p95 push->tokens stays under 5 ms over a 5 s run), beam 6 (<= 64 streams) / 5 (more)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
     ap.add_argument("--prof-steps", type=int, default=8,
@@ -492,9 +492,11 @@ def main():
         # so a decode iteration (which streams the same weights for 3 rows as for 64) serves more rows -- greedy, f32 / bf16 (round 5,
         # profiles/r05/r05_experiments.txt I): 12 -> 54.0 / 93.8 k at p50 2.2 / 1.25 ms, 15 -> 55.7 / 97.5 k, 20 -> 56.6 / 100.5 k at
         # 3.5 / 1.95 ms, 25 -> 56.9 / 100.8 k at 4.35 / 2.4 ms.  Default: the deepest whose p50 AND p95 push->tokens stay under the
-        # north star's 5 ms.  Beam: a model step of selection rounds is long (configs[4]: 3 -> 20.3 k at 2.8 ms, 5 -> 23.9 k at 4.0 ms,
-        # 6 -> 25.8 k at 4.3-4.9 ms).
-        args.depth = 20 if args.beam == 1 else (6 if args.streams <= 64 else 5)
+        # north star's 5 ms IN THE SUSTAINED LEG (round 6, VERDICT r5 item 5: 20 sat on the line -- p95 4.66 ms in the timed region,
+        # 5.12 ms over 4 s; 18: 4.29 / 4.57 ms at 56.46 against 56.66 k sustained, -0.35 %; 16: 4.05 ms, -1.2 %;
+        # profiles/r06/depth_sweep.txt).  Beam: a model step of selection rounds is long (configs[4]: 3 -> 20.3 k at 2.8 ms,
+        # 5 -> 23.9 k at 4.0 ms, 6 -> 25.8 k at 4.3-4.9 ms).
+        args.depth = 18 if args.beam == 1 else (6 if args.streams <= 64 else 5)
     rank, world, local = dist_env()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
