@@ -8,11 +8,13 @@ reference-faithful streaming call pattern: 80 ms client chunks, 3-chunk sliding 
 Buffer => the model runs every second chunk on 2 stacked frames (api-server.py:83-115,
 transforms.py:326-342,455-471, models.py:457-577).
 
-A "step" = one pass of the hot path over one batch of synthetic input: one 1.28 s SEGMENT (16 chunks of 80 ms,
---chunks-per-step) of every stream of the rank = 81.92 audio-seconds at 64 streams; each chunk is pushed for all
-streams (lasr_push_pcm + lasr_step_submit / _wait) and its tokens are fetched to the host.  (A single 80 ms chunk
-is 0.13 ms of GPU time: 20 of them cannot be timed against a 6-deep software pipeline.)  `value` does not depend
-on the segment length.  Synthetic PCM is resident in HBM before the timed region.
+A "step" = one pass of the hot path over one batch of synthetic input: one 5.12 s SEGMENT (64 chunks of 80 ms,
+--chunks-per-step) of every stream of the rank = 327.68 audio-seconds at 64 streams; each chunk is pushed for all
+streams (lasr_push_submit / lasr_step_wait) and its tokens are fetched to the host.  A segment must be longer than
+the software pipeline: 18 model steps (36 chunks) are in flight, and the timed region starts and ends on an idle
+GPU -- with rounds 3-5's 16-chunk segment (8 model steps) the fill and drain of the pipeline were 4 % of the
+driver's 20-step region (54.4 k against 56.5 k sustained); at 64 chunks they are 1 %.  `value` does not otherwise
+depend on the segment length.  Synthetic PCM is resident in HBM before the timed region.
 Streams are independent: rank r owns streams [64 r, 64 r + 64), there is no data-path collective
 ("scaling": "weak"); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks.
 
@@ -41,7 +43,7 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PRIME_CHUNKS = 24             # untimed chunks before the W warm-up steps: window fill + hipGraph instantiation
-CHUNKS_PER_STEP = 16          # one step = a 1.28 s segment of every stream
+CHUNKS_PER_STEP = 64          # one step = a 5.12 s segment of every stream (longer than the 18-deep pipeline: see the docstring)
 PCM_PERIOD = 320              # distinct synthetic chunks per stream (25.6 s); longer runs cycle through them
 METRIC = "audio-sec/sec/GPU (16 kHz streaming RNN-T) + p50 per-chunk latency"
 
@@ -385,8 +387,8 @@ def emulation_parity(eng, args, slots, pcm_host, n_rows, n_chunks):
 
 
 OTHER_CONFIGS = [
-    ("configs[2]", ["--model", "cfg2", "--dtype", "bf16", "--beam", "4", "--streams", "64", "--steps", "10", "--warmup", "3"]),
-    ("configs[4] per-GPU shape", ["--model", "cfg5", "--dtype", "bf16", "--beam", "8", "--streams", "128", "--steps", "8", "--warmup", "2"]),
+    ("configs[2]", ["--model", "cfg2", "--dtype", "bf16", "--beam", "4", "--streams", "64", "--steps", "4", "--warmup", "1"]),
+    ("configs[4] per-GPU shape", ["--model", "cfg5", "--dtype", "bf16", "--beam", "8", "--streams", "128", "--steps", "4", "--warmup", "1"]),
 ]
 
 
@@ -429,7 +431,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chunks-per-step", type=int, default=CHUNKS_PER_STEP,
-                    help="80 ms chunks per stream in one step (default 16 = a 1.28 s segment)")
+                    help="80 ms chunks per stream in one step (default 64 = a 5.12 s segment)")
     ap.add_argument("--model", default="cfg2")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -450,7 +452,7 @@ def main():
                          "p95 push->tokens stays under 5 ms over a 5 s run), beam 6 (<= 64 streams) / 5 (more)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
-    ap.add_argument("--prof-steps", type=int, default=8,
+    ap.add_argument("--prof-steps", type=int, default=2,
                     help="steps of the extra PROFILED region behind the timed one (in-kernel clocks of the cell launches; the cells then "
                          "run as plain launches, not as the main-stream graph); used unless --cell-prof-in-timed is 1 or 2")
     ap.add_argument("--cell-prof-in-timed", type=int, default=0,
@@ -552,7 +554,7 @@ def main():
     K, W = args.steps * CPS, args.warmup * CPS            # in chunks from here on
     P = max(0, PRIME_CHUNKS - W)
     extras = rank == 0 and not args.no_extras and args.beam == 1 and not args.no_pipeline
-    n_chunks = min(PCM_PERIOD, P + W + K + (2 * K + 32 if extras else 0) + max(0, min(args.steps, args.prof_steps)) * CPS + 4)
+    n_chunks = min(PCM_PERIOD, P + W + K + (2 * min(K, 640) + 192 if extras else 0) + max(0, min(args.steps, args.prof_steps)) * CPS + 4)
     # synthetic PCM for this rank's streams (seeded per global stream id), resident in HBM,
     # laid out [chunk][stream][1280] so that one step reads one contiguous block
     pcm_host = np.stack([synth.synth_pcm(1, n_chunks * CHUNK, seed=1234 + s)[0] for s in my_streams])
@@ -900,21 +902,26 @@ def main():
             # PCIe-inclusive leg (SURVEY 8d "from first PCM byte available on host"): the same K steps again with every
             # chunk handed to lasr_push_pcm as a host array; reported beside the headline, never as `value`
             try:
-                # (one-time costs of the host paths -- the engine's pinned + device staging rings (2 x 21 MB), the helper threads,
-                # first-touch page faults -- stay out of the timed legs: 16 untimed chunks per mode first)
-                timed_region(k_next, 16, None, host="pinned_nocopy", barrier=False)
-                timed_region(k_next + 16, 16, None, host=True, barrier=False)
-                k_next += 32
-                lat2 = []
-                dt2, _ = timed_region(k_next, K, lat2, host="pinned_nocopy", barrier=False)
+                # (one-time costs of the host paths stay out of the timed legs: the engine's pinned + device staging rings have 64
+                #  entries each (2 x 21 MB), first touched by the first 64 host pushes; the helper threads start with the first push.
+                #  Round 5 warmed 16 chunks per mode, so the leg that ran FIRST -- the no-copy one -- paid the rest inside its timed
+                #  region: its 39 k against 52 k was that, not the mode (tools/r06/nocopy_probe.py: 49-53 k no-copy against 47-51 k
+                #  copied, either order).  Now: 96 untimed chunks per mode, the copied mode timed first.)
+                timed_region(k_next, 96, None, host=True, barrier=False)
+                timed_region(k_next + 96, 96, None, host="pinned_nocopy", barrier=False)
+                k_next += 192
+                Kh = min(K, 640)
                 lat3 = []
-                dt3, _ = timed_region(k_next + K, K, lat3, host=True, barrier=False)
-                out["pcie_inclusive"] = {"value": round(K * B * CHUNK / SR / dt3, 1), "unit": "audio-sec/sec",
+                dt3, _ = timed_region(k_next, Kh, lat3, host=True, barrier=False)
+                lat2 = []
+                dt2, _ = timed_region(k_next + Kh, Kh, lat2, host="pinned_nocopy", barrier=False)
+                k_next += 2 * Kh
+                out["pcie_inclusive"] = {"value": round(Kh * B * CHUNK / SR / dt3, 1), "unit": "audio-sec/sec", "chunks": Kh,
                                          "p50_model_chunk_ms": round(1e3 * float(np.median(lat3)), 4) if lat3 else None,
                                          "note": "same steps, every chunk handed over as a PAGEABLE host array (what a server's receive path has): "
                                                  "copied into the engine's pinned staging ring before the call returns (helper threads), DMA'd "
                                                  "from there into a device staging entry on a copy-only stream: 328 KB per chunk",
-                                         "pinned_nocopy": {"value": round(K * B * CHUNK / SR / dt2, 1),
+                                         "pinned_nocopy": {"value": round(Kh * B * CHUNK / SR / dt2, 1),
                                                            "p50_model_chunk_ms": round(1e3 * float(np.median(lat2)), 4) if lat2 else None,
                                                            "note": "opt-in LASR_PUSH_PINNED_NOCOPY: the DMA reads the caller's pinned buffer, "
                                                                    "no host copy (buffer lifetime: lasr_push_consumed)"}}
@@ -960,13 +967,13 @@ def main():
             try:
                 eng.trace(True)
                 try:
-                    timed_region(k_next, 40 * CPS, None, host=args.host_pcm, barrier=False)
-                    k_next += 40 * CPS
+                    timed_region(k_next, 640, None, host=args.host_pcm, barrier=False)
+                    k_next += 640
                     tl = timeline_breakdown(eng.trace_read())
                 finally:
                     eng.trace(False)
                 if tl:
-                    out["stream_timeline_us_per_model_step"] = {**tl, "measured_in": "the last two thirds of 40 further steps of the same job with lasr_trace marks on both streams (event records: the marks slow the job by a few percent)"}
+                    out["stream_timeline_us_per_model_step"] = {**tl, "measured_in": "the last two thirds of 640 further chunks of the same job with lasr_trace marks on both streams (event records: the marks slow the job by a few percent)"}
                     out["stage_ms_per_model_step"].update({"frontend": round(tl["frontend_us"] / 1e3, 4), "encoder": round(tl["encoder_cells_us"] / 1e3, 4),
                                                            "decode": round(tl.get("decode_us_per_iteration", 0.0) * tl.get("decode_iterations_per_step", 0.0) / 1e3, 4) or None,
                                                            "note": "pipelined protocol: from the traced steps (stream_timeline_us_per_model_step); the two stages overlap on two streams"})
