@@ -262,7 +262,21 @@ def cpu_reference_path(cfg, sd, n_streams, n_chunks, threads=2, rows=None, gpu_s
                     "torch.stft front-end), batch 1 per stream, streams one after the other, torch.set_num_threads(2) "
                     "as libreasr/lib/inference.py:21; tokens pinned to the reference's goldens in tests/test_oracle.py",
             "sample": f"{n_streams} streams x {n_chunks} chunks of 80 ms ({n_streams * n_chunks * CHUNK / SR:.0f} audio-s)",
-            "seconds": round(dt, 2), "tokens": int(sum(len(t) for t in toks)), "host_cores_available": os.cpu_count()}
+            "seconds": round(dt, 2), "tokens": int(sum(len(t) for t in toks)), "host_cores_available": os.cpu_count(),
+            "reference_speed_pin": _reference_speed_pin()}
+
+
+def _reference_speed_pin():
+    """The port's SPEED against the reference's own transcribe_stream, measured where the reference exists (authoring container,
+    oracle/time_reference.py -> profiles/r06/reference_cpu_path.json): read from the committed file, not measured here."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06", "reference_cpu_path.json")) as f:
+            d = json.load(f)
+        return {"port_over_reference": d["port_over_reference_mean"], "runs": d["runs"], "file": "profiles/r06/reference_cpu_path.json",
+                "note": "measured in the authoring container (8 cores), where /root/reference can be imported: the reference's own "
+                        "Transducer.transcribe_stream + stream Pipeline against this port, same streams / torch / threads, tokens identical"}
+    except Exception:
+        return None
 
 
 def cpu_best_effort(cfg, sd, n_streams, n_chunks):
