@@ -463,7 +463,7 @@ def main():
     ap.add_argument("--beam", type=int, default=1, help="beam width (1 = greedy, the headline config)")
     ap.add_argument("--depth", type=int, default=None,
                     help="pipelined mode: model steps in flight before the oldest is collected (1..25); default 18 greedy (the deepest whose "
-                         "p95 push->tokens stays under 5 ms over a 5 s run), beam 6 (<= 64 streams) / 5 (more)")
+                         "p95 push->tokens stays under 5 ms over a 5 s run), beam 6")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous lasr_step_stream per chunk instead of the submit/wait software pipeline")
     ap.add_argument("--prof-steps", type=int, default=2,
@@ -511,8 +511,8 @@ def main():
         # north star's 5 ms IN THE SUSTAINED LEG (round 6, VERDICT r5 item 5: 20 sat on the line -- p95 4.66 ms in the timed region,
         # 5.12 ms over 4 s; 18: 4.29 / 4.57 ms at 56.46 against 56.66 k sustained, -0.35 %; 16: 4.05 ms, -1.2 %;
         # profiles/r06/depth_sweep.txt).  Beam: a model step of selection rounds is long (configs[4]: 3 -> 20.3 k at 2.8 ms,
-        # 5 -> 23.9 k at 4.0 ms, 6 -> 25.8 k at 4.3-4.9 ms).
-        args.depth = 18 if args.beam == 1 else (6 if args.streams <= 64 else 5)
+        # 5 -> 25.4-26.0 k at 3.7 ms, 6 -> 27.2-27.7 k at 4.2 ms p50 / 6.9 ms p95: round 6 G); 6 keeps the p50 under 5 ms.
+        args.depth = 18 if args.beam == 1 else 6
     rank, world, local = dist_env()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))

@@ -119,8 +119,10 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     }
     // groups launched by the pump thread (see pump_main): greedy 2 iterations (f32 52.1-52.6 k at 2, 51.7-52.1 at 3, 51.8 at 4 against
     // 51.8-51.9 without the pump; bf16 96.0 / 93.4 / 93.1 against 92.6: profiles/r04/r04_pump_ab.txt); beam: the group size of
-    // round 3's wait path
-    c->pump_G = c->W > 1 ? c->wait_n : 2;
+    // round 3's wait path for short rounds (configs[2]: 4; re-checked in round 6: 2 / 4 / 6 / 8 within 1 %), 2 for long ones under
+    // the pump (configs[4], 5 / 6 steps in flight: G = 1 25.4 / 27.2 k, 2 26.0 / 27.6 k, 3 25.8 / 27.7 k, 4 25.2 / 26.9 k:
+    // profiles/r06/r06_experiments.txt G)
+    c->pump_G = c->W > 1 ? std::max(2, c->wait_n) : 2;
     if (getenv("LASR_PUMP_G")) c->pump_G = std::max(1, std::min(8, atoi(getenv("LASR_PUMP_G"))));
     {   // The pump thread spins on its group's flag by design (one host core per context).  When several engine processes share the
         // host (one rank per GPU: the launcher's LOCAL_WORLD_SIZE / WORLD_SIZE say so) it instead sleeps through 75 % of a group's
