@@ -959,8 +959,6 @@ __global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restr
     }
     __shared__ double cand_sc[WT][WT];
     __shared__ int cand_ord[WT][WT];
-    __shared__ double sel_sc[WT];
-    __shared__ int sel_ord[WT];
     // (the table starts empty: a wave that looks at it while others are still writing -- the pruning below -- sees "no candidate")
     if (tid < WT * WT) { cand_sc[tid / WT][tid % WT] = -INFINITY; cand_ord[tid / WT][tid % WT] = 0x7fffffff; }
     __syncthreads();
@@ -1075,75 +1073,70 @@ __global__ __launch_bounds__(64 * WT) void k_beam_select_rw(const float* __restr
         }
     }
     __syncthreads();
-    if (tid != 0) return;
+    if (w != 0) return;
     if (dbg) s.dbg[9] = wall_clock64();
+    // ---- the ordered top-W of the WT x WT candidate table, by wave 0 (round 6; one thread before: W passes over W list heads + W
+    // slots of bookkeeping = 3.1 us of 7.6 at W = 4, 7.6 of 13.3 at W = 8).  Lane l holds candidate (row l / WT, position l % WT); its
+    // rank = the number of candidates that come before it in the total order (score descending, ordinal ascending: ordinals are
+    // unique, so ranks are distinct) -- the same ordered list the W-way merge of the sorted rows produced, whatever the rows' order.
+    double my_sc = -INFINITY;
+    int my_ord = 0x7fffffff;
+    if (lane < WT * WT) { my_sc = cand_sc[lane / WT][lane % WT]; my_ord = cand_ord[lane / WT][lane % WT]; }
+    const bool valid = my_sc > -INFINITY;
+    int rank = 0;
     {
-        // WT sorted lists (a row's candidates come out best first under the total order: score descending, ordinal ascending) ->
-        // the ordered top-W by a W-way merge of their heads, one thread: W passes of W comparisons instead of W wave-wide f64
-        // argmax reductions (4.3 us at W = 8)
-        double hv[WT];
-        int ho[WT], hi[WT];
+        const int my_hi = __double2hiint(my_sc), my_lo = __double2loint(my_sc);
 #pragma unroll
-        for (int r = 0; r < WT; ++r) { hv[r] = cand_sc[r][0]; ho[r] = cand_ord[r][0]; hi[r] = 0; }
-        for (int jj = 0; jj < W; ++jj) {
-            double best = -INFINITY;
-            int bord = 0x7fffffff, br = -1;
-#pragma unroll
-            for (int r = 0; r < WT; ++r)
-                if ((hv[r] > -INFINITY) && (hv[r] > best || (hv[r] == best && ho[r] < bord))) { best = hv[r]; bord = ho[r]; br = r; }
-            sel_sc[jj] = best; sel_ord[jj] = bord;
-            if (br < 0) {                            // candidates exhausted: the remaining slots are dead
-                for (int k = jj + 1; k < W; ++k) { sel_sc[k] = -INFINITY; sel_ord[k] = 0x7fffffff; }
-                break;
-            }
-#pragma unroll
-            for (int r = 0; r < WT; ++r)
-                if (r == br) {
-                    hi[r] += 1;
-                    hv[r] = hi[r] < WT ? cand_sc[r][hi[r]] : -INFINITY;
-                    ho[r] = hi[r] < WT ? cand_ord[r][hi[r]] : 0x7fffffff;
-                }
+        for (int c2 = 0; c2 < WT * WT; ++c2) {                  // candidate c2 broadcast from its lane (v_readlane: scalar operands, no LDS round trip)
+            const double osc = __hiloint2double(__builtin_amdgcn_readlane(my_hi, c2), __builtin_amdgcn_readlane(my_lo, c2));
+            const int oord = __builtin_amdgcn_readlane(my_ord, c2);
+            rank += (osc > -INFINITY && (osc > my_sc || (osc == my_sc && oord < my_ord))) ? 1 : 0;
         }
+    }
+    // slot j (lane j < W) takes the candidate of rank j
+    double sel = -INFINITY;
+    int sord = 0x7fffffff;
+    for (int jj = 0; jj < W; ++jj) {
+        const unsigned long long m = __ballot(valid && rank == jj);
+        if (!m) break;                                        // candidates exhausted: the remaining slots are dead (wave-uniform)
+        const int src = __builtin_ctzll(m);
+        const double v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_sc), src), __builtin_amdgcn_readlane(__double2loint(my_sc), src));
+        const int o = __builtin_amdgcn_readlane(my_ord, src);
+        if (lane == jj) { sel = v; sord = o; }
     }
     if (dbg) s.dbg[3] = wall_clock64();
     const int round = s.iters[q] + 1;
-    bool all_b = true;
-    int nib[WT];
-    for (int j = 0; j < W; ++j) {
-        const int r = r0 + j;
-        nib[j] = 1;
-        if (!(sel_sc[j] > -INFINITY)) {
-            s.alive[r] = 0; s.emit[r] = 0; s.parent[r] = j; s.score[r] = -INFINITY; tre[j] = -2;
-            continue;
+    const bool slot = lane < W, live = slot && sel > -INFINITY;
+    int inb = 1;
+    if (slot) {
+        const int r = r0 + lane;
+        if (!live) {
+            s.alive[r] = 0; s.emit[r] = 0; s.parent[r] = lane; s.score[r] = -INFINITY; tre[lane] = -2;
+        } else {
+            const int pb = sord / (V + 1), k = sord - pb * (V + 1);
+            s.alive[r] = 1; s.parent[r] = pb; s.score[r] = sel;
+            int em = 0;
+            if (k > 0 && k - 1 != s.blank) {
+                em = 1;
+                s.token[r] = k - 1;
+                inb = round >= s.max_iters ? 1 : 0;
+            }
+            s.emit[r] = em;
+            tre[lane] = (pb << 16) | (em ? k : 0);
         }
-        const int pb = sel_ord[j] / (V + 1), k = sel_ord[j] - pb * (V + 1);
-        s.alive[r] = 1; s.parent[r] = pb; s.score[r] = sel_sc[j];
-        int em = 0, inb = 1;
-        if (k > 0 && k - 1 != s.blank) {
-            em = 1;
-            s.token[r] = k - 1;
-            inb = round >= s.max_iters ? 1 : 0;
-        }
-        s.emit[r] = em;
-        nib[j] = inb;
-        tre[j] = (pb << 16) | (em ? k : 0);
-        all_b = all_b && inb;
     }
+    const bool all_b = __ballot(slot && !inb) == 0ull;
+    const int am = (int)(__ballot(live) & ((1ull << W) - 1ull));
     int tn = t, rn = round;
     if (all_b) { tn = t + 1; rn = 0; }
-    for (int j = 0; j < W; ++j) s.inB[r0 + j] = all_b ? 0 : (sel_sc[j] > -INFINITY ? nib[j] : 0);
+    if (slot) s.inB[r0 + lane] = all_b ? 0 : (live ? inb : 0);
+    if (s.cont && all_b && tn % s.step_T == 0 && slot)      // the stream just finished one of its model steps: scores for the host
+        s.end_score[((size_t)q * s.end_slots + ((tn / s.step_T - 1) % s.end_slots)) * W + lane] = sel;
+    if (lane != 0) return;
     s.t_idx[q] = tn; s.iters[q] = rn;
     if (s.cont) {
         s.frame_done[(size_t)(iter_no % s.tring) * gridDim.x + q] = all_b ? 1 : 0;
-        if (all_b && tn % s.step_T == 0) {           // the stream just finished one of its model steps: scores for the host
-            const int es = (tn / s.step_T - 1) % s.end_slots;
-            int am = 0;
-            for (int j = 0; j < W; ++j) {
-                s.end_score[((size_t)q * s.end_slots + es) * W + j] = sel_sc[j];
-                if (sel_sc[j] > -INFINITY) am |= 1 << j;
-            }
-            s.end_alive[(size_t)q * s.end_slots + es] = am;
-        }
+        if (all_b && tn % s.step_T == 0) s.end_alive[(size_t)q * s.end_slots + ((tn / s.step_T - 1) % s.end_slots)] = am;
         if (s.host_flag) s.host_cur[q] = tn;
     }
     if (tn < Tr) atomicAdd(&s.unfinished[uslot], 1);
