@@ -29,13 +29,32 @@ int lasr_debug_timing(lasr_ctx* c, unsigned long long* out);
  *        6: the PCM ring                                                       [M][(n_window + n_buffer - 1) * chunk]
  *        7: pending log-mel frames (Buffer)                                    [M][n_buffer * n_stack * n_mels]
  *        8: last encoder layer's BatchNorm'ed output, frame `index`            [M][hidden]
+ *       10: (LASR_DBG_ENCLOG + LASR_DBG_PENDLOG=1) the pending log-mel frames as they were behind logged step `index`
  *        9: integers as floats [8][M]: device ring position, host mirror, chunks pushed, frames pending, frames of the
  *           last step, frame cursor, last token, emitted flag
  * M = max_streams rounded up to 64.  LASR_EFULL if cap is too small (*rows / *cols are set). */
 int lasr_debug_read(lasr_ctx* c, int what, int index, float* out, size_t cap, int* rows, int* cols);
 
+/* Race detector for the two-stream protocols (LASR_DBG_ENCLOG=N at create): behind the encoder cells of each of the first N model
+ * steps one extra launch on the main stream stores, per row, exact checksums (sum of the element bit patterns mod 2^32) of the
+ * step's LayerNorm'ed input frames, every layer's c and h, and the last layer's output frames: out[step][32][M] with entries
+ * 0..T-1 input frames, T..T+L-1 c, T+L..T+2L-1 h, T+2L..2T+2L-1 output frames, then the pending log-mel frames and the PCM ring
+ * (T = n_buffer, L = enc_layers).  The encoder does
+ * not depend on the decode stream, so the log of a pipelined run must equal the log of a synchronous run of the same input word
+ * for word (tools/r06/enc_racelog.py).  *steps = steps logged; the log restarts after the call. */
+int lasr_debug_enclog(lasr_ctx* c, unsigned* out, size_t cap, int* steps);
+
+/* Interference probe (needs an idle engine whose PCM ring holds audio): `iters` back-to-back launches of the streaming log-mel
+ * kernel on the main stream over the SAME ring contents, a per-row checksum of the output behind each, while the decode stream
+ * runs `per_iter` launches per iteration of aggressor 0 nothing, 1 the vocabulary GEMM over all hypothesis rows, 2 a predictor pass,
+ * 3 the joint half.  lds_pad = unused dynamic LDS of the log-mel launches in bytes (-1: what the engine uses, see
+ * lasr_ctx::fe_lds_pad; 0: none -- the round-6 interference shows up beside aggressor 1 with bf16 operands and >= 512 hypothesis
+ * rows).  The first launch runs alone and is the reference: *bad_launches / *bad_rows = launches / (launch, row) pairs whose
+ * output differs from it.  With the engine's setting both must be 0: the two streams share no data. */
+int lasr_debug_fe_race(lasr_ctx* c, int iters, int aggressor, int per_iter, int lds_pad, int* bad_launches, int* bad_rows);
+
 /* Engine configuration as resolved at lasr_create (defaults + LASR_* environment switches): *value = the integer behind `key`.
- * Keys: "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "la_offline", "cell_nw", "use_graphs", "M".  LASR_EINVAL for an unknown key.  bench.py records these beside every line. */
+ * Keys: "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "la_offline", "cell_nw", "use_graphs", "M", "fe_lds_pad".  LASR_EINVAL for an unknown key.  bench.py records these beside every line. */
 int lasr_debug_config(lasr_ctx* c, const char* key, int* value);
 
 /* Roofline micro-benchmark of the dominant kernel (one encoder LSTM-cell launch: all rows active,

@@ -96,6 +96,8 @@ SYMBOLS = [
 DEBUG_SYMBOLS = [
     ("lasr_debug_timing", C.c_int, [_P, _P]),
     ("lasr_debug_read", C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("lasr_debug_enclog", C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_int)]),
+    ("lasr_debug_fe_race", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("lasr_bench_cell", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("lasr_overlap_probe", C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     ("lasr_bench_neighbour", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),

@@ -56,7 +56,6 @@ struct lasr_ctx {
                                     // H / 12 * M / 64 >= 256 workgroups; LASR_ENC_U12 overrides
     int dec_prio = 1, cell_prio = 0;   // s_setprio of the decode-stream GEMMs (+4 % at 6 steps in flight, round 2) / of everything else
     int logits_mt = 2;              // m-tiles per workgroup of the logits GEMM (la x 64 rows must not re-read W2 per 16-row tile)
-    int dec_nw_mask = 0;            // bit 1 predictor cells, bit 2 PPJ, bit 4 linear (logits, pe) run with 4 waves: 7 for f32, 0 for bf16
     // beam search: c, BN(h) and pp ping-pong like h (every slot may be re-parented each round):
     // parity 0 = pred_c / pred_y / pp, parity 1 = the *1 buffers; all follow pred_par
     std::vector<float*> pred_c1;
@@ -86,6 +85,17 @@ struct lasr_ctx {
     void *cvt_a = nullptr, *cvt_b = nullptr;   // [M][H] element-typed staging of f32 op-level inputs
     bool dbg_gate = true;           // decode kernels record timestamps only in the first iteration of a step
     unsigned long long* dbg = nullptr;   // LASR_DBG_TIMING: [5 kinds][4096 blocks][16] phase timestamps
+    // Unused dynamic LDS given to the streaming log-mel launch (k_fe_mel: 46 592 B of its own) so that its workgroups never share a
+    // CU with a workgroup of the wide decode tilings (EpiLSTMw / EpiNBRCw / EpiLinearT<4>: 66-72 KB of LDS each, launched for
+    // >= 256 hypothesis rows or >= 512 logits rows): 98 304 B in total, and 98 304 + 65 536 > 160 KB.  Next to those kernels (bf16
+    // operands, beam search over >= 512 rows) a few waves of the log-mel kernel per thousand returned wrong spectra -- one 16-lane
+    // LDS read pass each, no shared data, cause not understood -- and configs[4] was not reproducible run to run; with the CU to
+    // themselves: never (profiles/r06/r06_experiments.txt R; detectors: lasr_debug_enclog, lasr_debug_fe_race, tests/test_gpu_race.py).
+    // 0 where no such kernel can run (configs[1]); LASR_FE_LDS_PAD overrides (bytes).
+    int fe_lds_pad = 0;
+    unsigned* enclog = nullptr;     // LASR_DBG_ENCLOG=N: per model step and row, exact checksums (sum of the element bit patterns) of the
+    float* pendlog = nullptr;       // LASR_DBG_PENDLOG=1 (with LASR_DBG_ENCLOG): a copy of the pending log-mel frames per logged step
+    int enclog_cap = 0, enclog_n = 0;   // encoder's inputs and state behind that step: [N][2 T + 2 L][M], see lasr_debug_enclog
     std::vector<unsigned long long> tile_masks;   // per step t: m-tiles with an active row (from the host's T_row)
     float *pp = nullptr, *logits = nullptr;
     void* ja = nullptr;             // joint activation, fragment-major, element-typed

@@ -157,6 +157,23 @@ void run_encoder(lasr_ctx* c, int T_max) {
     if (!replayed) enqueue_cells();
     if (cp_slot >= 0) { (void)hipEventRecord(c->cp_ev[cp_slot][1], c->stream); c->cp_n++; }
     tr_mark(c, 4, c->stream);
+    if (c->enclog && c->enclog_n < c->enclog_cap && 2 * T_max + 2 * L + 2 <= 32) {       // LASR_DBG_ENCLOG: checksums behind this step's cells
+        RowSumArgs ra{};
+        int e = 0;
+        for (int t = 0; t < T_max; ++t) ra.s[e++] = RowSumSrc{c->x0, 0, mt_total, t * c->MT, c->d.feat};
+        for (int l = 0; l < L; ++l) ra.s[e++] = RowSumSrc{c->enc_c[l], 1, 0, 0, c->d.hidden};
+        for (int l = 0; l < L; ++l) ra.s[e++] = RowSumSrc{c->enc_h[c->enc_par][l], 0, c->MT, 0, c->d.hidden};
+        for (int t = 0; t < T_max; ++t) ra.s[e++] = RowSumSrc{c->ybuf[(L - 1) & 1], 0, mt_total, t * c->MT, c->d.hidden};
+        ra.s[e++] = RowSumSrc{c->pend, 2, 0, 0, c->d.n_buffer * c->d.n_stack * c->d.n_mels};
+        ra.s[e++] = RowSumSrc{c->win, 2, 0, 0, c->ring_chunks * c->d.chunk};
+        hipLaunchKernelGGL(k_dbg_rowsum, dim3(c->M, e), dim3(256), 0, c->stream, ra, c->M, c->bf,
+                           c->enclog + (size_t)c->enclog_n * 32 * c->M);
+        if (c->pendlog) {
+            const size_t n = (size_t)c->M * c->d.n_buffer * c->d.n_stack * c->d.n_mels;
+            (void)hipMemcpyAsync(c->pendlog + (size_t)c->enclog_n * n, c->pend, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream);
+        }
+        c->enclog_n++;
+    }
     // encoder half of the joint for all frames: pe[t][r] = W1e * enc[t][r]
     const int H = c->d.hidden, J = c->d.joint;
     GemmArgs g{};

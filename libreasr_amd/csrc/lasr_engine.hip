@@ -152,12 +152,20 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         //  128 streams, greedy / beam 8: 46.8 / 14.6 k against 45.9 / 14.4 k as a wavefront, profiles/r04/r04_cell_tiling_d.txt)
         if (c->enc_u12) c->enc_wave = 0;
         if (getenv("LASR_ENC_WAVE")) c->enc_wave = atoi(getenv("LASR_ENC_WAVE"));
-        // decode-stream GEMMs (predictor cells, PPJ, logits): 4 waves per workgroup with f32 operands (next to the encoder cells
-        // of the main stream fewer waves per CU interfere less: whole job +5 %), 8 with bf16 (4: -3 %)
-        c->dec_nw_mask = c->bf ? 0 : 7;
+        // decode-stream GEMMs (predictor cells, PPJ, logits): 8 waves per workgroup with either operand type.  (Rounds 2-5 ran them on
+        // 4 waves with f32 operands: +5 % whole job when the decode loop had slack; with the loop the binding stream -- 18 steps in
+        // flight, 92 % busy -- 8 waves win: 53.5-53.6 -> 54.2-54.6 k timed, 57.3-57.5 -> 57.6-58.3 k sustained, same box, 4 runs each:
+        // profiles/r06/r06_experiments.txt T)
         if (getenv("LASR_DBG_TIMING")) {
             RC(dalloc(c, &c->dbg, (size_t)5 * 4096 * 16));
             HIPCHK(c, hipMemset(c->dbg, 0, sizeof(unsigned long long) * 5 * 4096 * 16));
+        }
+        if (getenv("LASR_DBG_ENCLOG") && atoi(getenv("LASR_DBG_ENCLOG")) > 0) {
+            c->enclog_cap = atoi(getenv("LASR_DBG_ENCLOG"));
+            RC(dalloc(c, &c->enclog, (size_t)c->enclog_cap * 32 * c->M));
+            HIPCHK(c, hipMemset(c->enclog, 0, sizeof(unsigned) * (size_t)c->enclog_cap * 32 * c->M));
+            if (getenv("LASR_DBG_PENDLOG") && atoi(getenv("LASR_DBG_PENDLOG")) > 0)
+                RC(dalloc(c, &c->pendlog, (size_t)c->enclog_cap * c->M * d.n_buffer * d.n_stack * d.n_mels));
         }
     }
 
@@ -312,6 +320,12 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     HIPCHK(c, hipMemset(c->T_row_main, 0, sizeof(int) * M));
     // measured (profiles/r03/r03_experiments.txt I): host time per model step 66 -> 45 us, but the replay starts its first cell ~6 us
     // later than a plain launch does: f32 -2 % (52.8 against 54.0 k audio-s/s), bf16 +0.5 %  =>  on for bf16, off for f32
+    {   // see lasr_ctx::fe_lds_pad
+        const bool wide_decode = c->Md >= 256 || lasr_ctx::LA_MAX * M >= 512;
+        c->fe_lds_pad = wide_decode ? 98304 - 46592 : 0;
+        if (getenv("LASR_FE_LDS_PAD")) c->fe_lds_pad = std::max(0, std::min(160 * 1024 - 46592, atoi(getenv("LASR_FE_LDS_PAD"))));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_fe_mel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 46592));
+    }
     c->main_graph = c->bf != 0;
     if (getenv("LASR_MAIN_GRAPH")) c->main_graph = atoi(getenv("LASR_MAIN_GRAPH")) != 0;
     c->T_row_dev = c->zero_rows;
@@ -913,7 +927,9 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
                 m.age_pk[s] = (unsigned short)pk;
             }
             hipStream_t fe_st = c->stream;
-            hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * d.n_buffer, c->M), dim3(320), 0, fe_st, m);
+            // c->fe_lds_pad bytes of unused dynamic LDS: the workgroup then shares its CU with no workgroup of the wide decode tilings
+            // (see lasr_ctx::fe_lds_pad)
+            hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * d.n_buffer, c->M), dim3(320), c->fe_lds_pad, fe_st, m);
             if (fused_done) *fused_done = fused != nullptr;
             if (with_lazy) { c->lazy_taken++; RC(lazy_consumed(c)); }
             RC(commit_T_rows(c, Tm, /*fixed_copy=*/c->pe != c->pe_ring, trow_home));    // the continuous loop reads its own frame counters
@@ -2447,6 +2463,81 @@ int lasr_debug_timing(lasr_ctx* c, unsigned long long* out /*[5*4096*8]*/) {
     return LASR_OK;
 }
 
+// debug (LASR_DBG_ENCLOG=N at create): the checksum log of the first N model steps since create or the last read; see lasr_debug.h
+int lasr_debug_enclog(lasr_ctx* c, unsigned* out, size_t cap, int* steps) {
+    if (!c || !steps) return LASR_EINVAL;
+    if (!c->enclog) return fail(c, LASR_ESTATE, "set LASR_DBG_ENCLOG=<steps> before lasr_create");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->enclog_n * 32 * c->M;
+    *steps = c->enclog_n;
+    if (n > cap) return fail(c, LASR_EFULL, "checksum log needs %zu words", n);
+    if (n && out) HIPCHK(c, hipMemcpy(out, c->enclog, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    c->enclog_n = 0;
+    return LASR_OK;
+}
+
+// debug: see lasr_debug.h.  The streaming front-end's log-mel launch (k_fe_mel) back to back on the main stream over the resident PCM
+// ring, each launch followed by per-row checksums of its output, while the decode stream runs `aggressor` in a loop.
+int lasr_debug_fe_race(lasr_ctx* c, int iters, int aggressor, int per_iter, int lds_pad, int* bad_launches, int* bad_rows) {
+    if (!c || !bad_launches || !bad_rows || iters < 1) return LASR_EINVAL;
+    *bad_launches = *bad_rows = 0;
+    if (lds_pad < 0) lds_pad = c->fe_lds_pad;
+    if (lds_pad > 160 * 1024 - 46592) return fail(c, LASR_EINVAL, "lds_pad too large");
+    RC(flush_lazy(c));
+    RC(require_idle(c));
+    if (!c->fe_fused || !c->stream_dec || c->M > 512) return fail(c, LASR_ESTATE, "the race probe needs the fused front-end and the decode stream");
+    HIPCHK(c, hipSetDevice(c->device));
+    const lasr_model_desc& d = c->d;
+    int nf = 0;
+    const int a0 = stream_frame0(c, &nf);
+    FeMelArgs m{};
+    m.window = c->window; m.tw512 = c->tw512; m.tw1024 = c->tw1024; m.fb_start = c->fb_start; m.fb_off = c->fb_off; m.fb_w = c->fb_w;
+    m.n_mels = d.n_mels; m.hop = d.hop; m.fb_nnz = c->fb_nnz; m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win;
+    m.pcm = c->win; m.ring_pos = c->ring_pos; m.chunk = d.chunk; m.n_window = d.n_window; m.ring_chunks = c->ring_chunks; m.frame0 = a0;
+    m.pend = c->pend; m.pend_frames = d.n_buffer * d.n_stack; m.trow_out = c->T_row_main;
+    for (int r = 0; r < 512; ++r) { m.idx[r] = -1; m.tp_pk[r] = 0; m.age_pk[r] = 0; }
+    for (int r = 0; r < c->M; ++r) {
+        m.tp_pk[r] = (unsigned char)((c->h_ring_pos[r] << 4) | d.n_buffer);
+        unsigned pk = 0;
+        for (int j = 0; j < d.n_buffer; ++j) pk |= (unsigned)(d.n_buffer - 1 - j) << (4 * j);
+        m.age_pk[r] = (unsigned short)pk;
+    }
+    unsigned* log = nullptr;
+    RC(dalloc(c, &log, (size_t)(iters + 1) * c->M));
+    RowSumArgs ra{};
+    ra.s[0] = RowSumSrc{c->pend, 2, 0, 0, d.n_buffer * d.n_stack * d.n_mels};
+    hipStream_t keep = c->stream;
+    auto aggress = [&]() {
+        c->stream = c->stream_dec;
+        if (aggressor == 1) launch_logits(c, c->logits, c->Md, false);
+        else if (aggressor == 2) launch_predictor(c, c->W > 1);
+        else if (aggressor == 3) launch_ppj(c, c->W > 1);
+        c->stream = keep;
+    };
+    const int pp0 = c->pred_par;
+    for (int i = 0; i <= iters; ++i) {
+        if (i > 0) for (int q = 0; q < per_iter; ++q) aggress();
+        hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * d.n_buffer, c->M), dim3(320), lds_pad, c->stream, m);
+        hipLaunchKernelGGL(k_dbg_rowsum, dim3(c->M, 1), dim3(256), 0, c->stream, ra, c->M, c->bf, log + (size_t)i * c->M);
+        if (i == 0) HIPCHK(c, hipStreamSynchronize(c->stream));       // the reference launch runs alone
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream_dec));
+    c->pred_par = pp0;
+    std::vector<unsigned> h((size_t)(iters + 1) * c->M);
+    hipError_t e = hipMemcpy(h.data(), log, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost);
+    dfree(c, log);
+    if (e != hipSuccess) return fail(c, LASR_EHIP, "race probe copy failed: %s", hipGetErrorString(e));
+    for (int i = 1; i <= iters; ++i) {
+        int nb = 0;
+        for (int r = 0; r < c->M; ++r) nb += h[(size_t)i * c->M + r] != h[r];
+        *bad_rows += nb;
+        *bad_launches += nb != 0;
+    }
+    return LASR_OK;
+}
+
 // In-job timing of the dominant kernel: while on, every model step's encoder-cell sequence (enc_layers x frames
 // back-to-back launches of k_gemm<EpiLSTM>) is bracketed by a HIP-event pair on the ctx stream.  lasr_cell_prof_read
 // drains the outstanding pairs and returns the accumulated microseconds / cell launches since the last on-switch.
@@ -2586,6 +2677,8 @@ int lasr_debug_read(lasr_ctx* c, int what, int index, float* out, size_t cap, in
         case 8: if (index < 0 || index >= c->Tcap) return fail(c, LASR_EINVAL, "frame out of range");
                 kind = FRAG; src = c->ybuf[(d.enc_layers - 1) & 1]; K = H; frag_mt_total = mt_total; frag_mt_off = index * c->MT; break;
         case 9: kind = INTS; R = 8; K = M; break;
+        case 10: if (!c->pendlog || index < 0 || index >= c->enclog_cap) return fail(c, LASR_EINVAL, "no pending-frame log (LASR_DBG_ENCLOG + LASR_DBG_PENDLOG) or step out of range");
+                kind = ROWMAJ_F32; K = d.n_buffer * d.n_stack * d.n_mels; src = c->pendlog + (size_t)index * M * K; break;
         default: return fail(c, LASR_EINVAL, "unknown debug read %d", what);
     }
     if (rows) *rows = R;
@@ -2724,6 +2817,7 @@ int lasr_debug_config(lasr_ctx* c, const char* key, int* value) {
         {"pump_G", c->pump_G}, {"la_stream", c->la_stream}, {"la_offline", c->la_offline},
         {"cell_nw", c->cell_nw ? c->cell_nw : (c->bf ? 8 : 4)}, {"use_graphs", (int)c->use_graphs}, {"M", c->M},
         {"push_lazy", (int)c->lazy_on}, {"pump_nap_pct", c->pump_nap_pct}, {"lazy_taken", c->lazy_taken}, {"lazy_flushed", c->lazy_flushed},
+        {"fe_lds_pad", c->fe_lds_pad},
     };
     for (const auto& e : tab)
         if (!strcmp(e.k, key)) { *value = e.v; return LASR_OK; }

@@ -100,6 +100,29 @@ inline __global__ void k_c_to_rows(const float* __restrict__ c, int M, float* __
     dst[idx] = c[(size_t)u * M + r];
 }
 
+// LASR_DBG_ENCLOG: out[e][r] = sum over k of the bit pattern of element (r, k) of source e (mod 2^32: exact, order-free).
+// kind 0: fragment-major activations (element type by bf), kind 1: unit-major f32 state c[k][M], kind 2: row-major f32 [M][K].
+// grid (M, entries), 256 threads.
+struct RowSumSrc { const void* p; int kind, mt_total, mt_off, K; };
+struct RowSumArgs { RowSumSrc s[32]; };
+inline __global__ void k_dbg_rowsum(const RowSumArgs a, int M, int bf, unsigned* __restrict__ out) {
+    __shared__ unsigned acc;
+    const RowSumSrc s = a.s[blockIdx.y];
+    const int r = blockIdx.x;
+    if (threadIdx.x == 0) acc = 0u;
+    __syncthreads();
+    unsigned v = 0u;
+    for (int k = threadIdx.x; k < s.K; k += blockDim.x) {
+        if (s.kind == 1) v += __float_as_uint(((const float*)s.p)[(size_t)k * M + r]);
+        else if (s.kind == 2) v += __float_as_uint(((const float*)s.p)[(size_t)r * s.K + k]);
+        else if (bf) v += ((const unsigned short*)s.p)[OpsBF16::aoff(r + 16 * s.mt_off, k, s.mt_total)];
+        else v += __float_as_uint(((const float*)s.p)[OpsF32::aoff(r + 16 * s.mt_off, k, s.mt_total)]);
+    }
+    atomicAdd(&acc, v);
+    __syncthreads();
+    if (threadIdx.x == 0) out[(size_t)blockIdx.y * M + r] = acc;
+}
+
 // encoder output of the last layer: fragment-major rows (t*M + b) -> out[b][t][H]
 inline __global__ void k_enc_out(const void* __restrict__ y, int mt_total, int M, float* __restrict__ out, int B, int T, int H, int bf) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

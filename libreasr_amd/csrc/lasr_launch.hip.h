@@ -104,8 +104,8 @@ inline void launch_lm(lasr_ctx* c, bool beam = false, int l0 = 0, int l1 = -1, b
 }
 // Pair launches of the greedy loop with an fp32 / bf16 LM (cont_enqueue): stage `kind` of the predictor / joint chain (0, 1: NBRC
 // layers 0, 1; 2: joint half; 3: the next iteration's logits GEMM), recorded in A, with LM layer l (0: through the token table),
-// recorded in B.  The kinds the templates name are the ones configs[1] runs (2 x NBRC predictor, decode GEMMs on 4 waves with f32
-// operands and 8 with bf16); anything else is issued one after the other.
+// recorded in B.  The kinds the templates name are the ones configs[1] runs (2 x NBRC predictor, decode GEMMs on 8 waves);
+// anything else is issued one after the other.
 inline void launch_pair(lasr_ctx* c, int kind, bool lm_first, lasr_ctx::Captured& A, lasr_ctx::Captured& B) {
     const bool ok = c->bf ? launch_pair_ops<OpsBF16>(c, kind, lm_first, A, B) : launch_pair_ops<OpsF32>(c, kind, lm_first, A, B);
     if (!ok) { replay_captured(c, A); replay_captured(c, B); }

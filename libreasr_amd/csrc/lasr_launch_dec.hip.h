@@ -50,8 +50,7 @@ static void launch_gemm_carry(lasr_ctx* c, int n_groups, int m_groups, const Gem
 template <class Ops, bool AROW, int D>
 void launch_linear_ops(lasr_ctx* c, int n_groups, int m_groups, GemmArgs g, int K, const EpiLinear::Args& ea) {
     g.KC[0] = K / Ops::KCH;
-    if (c->dec_nw_mask & 4) launch_gemm<Ops, EpiLinear, 1, AROW, D, 4>(c, n_groups, m_groups, g, ea);
-    else launch_gemm<Ops, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
+    launch_gemm<Ops, EpiLinear, 1, AROW, D>(c, n_groups, m_groups, g, ea);
 }
 
 // vocabulary projection of the joint for n_rows rows of ja.  m-tiles per workgroup (c->logits_mt): 1 = a 16-row x
@@ -62,8 +61,7 @@ static void launch_logits_t(lasr_ctx* c, const GemmArgs& g0, int n_rows, int K, 
     GemmArgs g = g0;
     g.KC[0] = K / Ops::KCH;
     const int ng = c->d.vocab / 16, mg = (n_rows + 16 * MTL - 1) / (16 * MTL);
-    if (c->dec_nw_mask & 4) launch_gemm<Ops, EpiLinear, MTL, false, -1, 4>(c, ng, mg, g, ea);
-    else launch_gemm<Ops, EpiLinear, MTL, false, -1>(c, ng, mg, g, ea);
+    launch_gemm<Ops, EpiLinear, MTL, false, -1>(c, ng, mg, g, ea);
 }
 template <class Ops>
 void launch_logits_ops(lasr_ctx* c, float* out, int n_rows, bool gated) {
@@ -132,14 +130,14 @@ void launch_predictor_t(lasr_ctx* c, bool beam, int l0, int l1) {
             if (l == 0) {
                 if (wide8) launch_gemm<Ops, EpiLSTMw<Ops, true, 2>, MTA, true, -1>(c, H / 8, mgroups, g, ea);
                 else if (wide) launch_gemm<Ops, EpiLSTMw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
-                else if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1, 4>(c, H / 4, mgroups, g, ea); else launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
+                else launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 typename EpiLSTM<Ops, true, false, 4>::Args eb{};
                 static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
                 if (wide8) launch_gemm<Ops, EpiLSTMw<Ops, false, 2>, MTA, true, -1>(c, H / 8, mgroups, g, eb);
                 else if (wide) launch_gemm<Ops, EpiLSTMw<Ops, false>, MTA, true, -1, 4>(c, H / 16, mgroups, g, eb);
-                else if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1, 4>(c, H / 4, mgroups, g, eb); else launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
+                else launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         } else {
             typename EpiNBRC<Ops, true>::Args ea{};
@@ -151,14 +149,14 @@ void launch_predictor_t(lasr_ctx* c, bool beam, int l0, int l1) {
             if (l == 0) {
                 if (wide8) launch_gemm<Ops, EpiNBRCw<Ops, true, 2>, MTA, true, -1>(c, H / 8, mgroups, g, ea);
                 else if (wide) launch_gemm<Ops, EpiNBRCw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
-                else if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1, 4>(c, H / 4, mgroups, g, ea); else launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
+                else launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 typename EpiNBRC<Ops, false>::Args eb{};
                 static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
                 if (wide8) launch_gemm<Ops, EpiNBRCw<Ops, false, 2>, MTA, true, -1>(c, H / 8, mgroups, g, eb);
                 else if (wide) launch_gemm<Ops, EpiNBRCw<Ops, false>, MTA, true, -1, 4>(c, H / 16, mgroups, g, eb);
-                else if (c->dec_nw_mask & 1) launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1, 4>(c, H / 4, mgroups, g, eb); else launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
+                else launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         }
     }
@@ -181,11 +179,10 @@ void launch_ppj_t(lasr_ctx* c, bool beam) {
                                                              // 19.9 against 14.3 us at 1024 rows, round 4)
     if (beam && beam_carry_mode() == 2) {      // the round's carry as extra workgroups of this launch
         if (ppj_wide) launch_gemm_carry<Ops, EpiPPJ<Ops>, 4, true, -1, 4>(c, J / 16, c->MTd / 4, g, ea);
-        else if (c->dec_nw_mask & 2) launch_gemm_carry<Ops, EpiPPJ<Ops>, 1, true, -1, 4>(c, J / 16, c->MTd, g, ea);
         else launch_gemm_carry<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
     } else
     if (ppj_wide) launch_gemm<Ops, EpiPPJ<Ops>, 4, true, -1, 4>(c, J / 16, c->MTd / 4, g, ea);
-    else if (c->dec_nw_mask & 2) launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1, 4>(c, J / 16, c->MTd, g, ea); else launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
+    else launch_gemm<Ops, EpiPPJ<Ops>, 1, true, -1>(c, J / 16, c->MTd, g, ea);
     if (beam) c->pred_par ^= 1;
 }
 // LMFuser.advance (lm.py:49-53) for the rows with emit != 0: LM step on the token just emitted, then
@@ -237,7 +234,7 @@ void launch_lm_t(lasr_ctx* c, bool beam, int l0, int l1, bool tail) {
 // the pair kinds of one operand type (see launch_pair): false = not a kind the templates name
 template <class Ops>
 bool launch_pair_ops(lasr_ctx* c, int kind, bool lm_first, lasr_ctx::Captured& A, lasr_ctx::Captured& B) {
-    constexpr int NWD = Ops::BF ? NW : 4;           // decode GEMMs: 4 waves with f32 operands, 8 with bf16 (c->dec_nw_mask)
+    constexpr int NWD = NW;                         // decode GEMMs: 8 waves with either operand type (round 6: T)
     using LT = EpiLSTM<Ops, true, true, 4>; using LF = EpiLSTM<Ops, true, false, 4>;
     if (kind == 0 && lm_first) return launch_pair_t<Ops, EpiNBRC<Ops, true>, MTA, NWD, true, -1, LT, MTA, NW, true, -1>(c, A, B);
     if (kind == 1 && !lm_first) return launch_pair_t<Ops, EpiNBRC<Ops, false>, MTA, NWD, true, -1, LF, MTA, NW, true, -1>(c, A, B);

@@ -395,7 +395,7 @@ class Engine:
     def sync(self):
         self._chk(self.lib.lasr_sync(self.ctx))
 
-    DEBUG_READS = dict(x0=0, enc_h=1, enc_c=2, pe=3, pp=4, pred_h=5, ring=6, pend=7, enc_out=8, ints=9)
+    DEBUG_READS = dict(x0=0, enc_h=1, enc_c=2, pe=3, pp=4, pred_h=5, ring=6, pend=7, enc_out=8, ints=9, pendlog=10)
 
     def debug_read(self, what, index=0):
         """Resident state as a [rows, cols] float32 array (lasr_debug_read; tests and the soak tool)."""
@@ -408,6 +408,24 @@ class Engine:
         out = np.empty((r.value, k.value), dtype=np.float32)
         self._chk(self.lib.lasr_debug_read(self.ctx, w, int(index), out.ctypes.data_as(C.c_void_p), out.size, C.byref(r), C.byref(k)))
         return out
+
+    def debug_enclog(self):
+        """lasr_debug_enclog (LASR_DBG_ENCLOG=N): [steps, 32, M] uint32 checksums of the encoder's inputs and state behind each step."""
+        n = C.c_int(0)
+        rc = self.lib.lasr_debug_enclog(self.ctx, None, 0, C.byref(n))
+        if rc != N.LASR_EFULL:
+            self._chk(rc)
+            return np.zeros((0, 32, self.config("M")), dtype=np.uint32)
+        M = self.config("M")
+        out = np.empty((n.value, 32, M), dtype=np.uint32)
+        self._chk(self.lib.lasr_debug_enclog(self.ctx, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
+        return out
+
+    def debug_fe_race(self, iters, aggressor, per_iter=4, lds_pad=-1):
+        """lasr_debug_fe_race: (launches, (launch, row) pairs) of the log-mel kernel whose output changed beside the aggressor."""
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.lasr_debug_fe_race(self.ctx, int(iters), int(aggressor), int(per_iter), int(lds_pad), C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def config(self, key):
         """lasr_debug_config: the engine's resolved configuration (defaults + LASR_* switches), e.g. "enc_wave", "pump_G", "la_stream"."""
