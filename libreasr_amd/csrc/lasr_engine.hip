@@ -325,6 +325,7 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
         c->fe_lds_pad = wide_decode ? 98304 - 46592 : 0;
         if (getenv("LASR_FE_LDS_PAD")) c->fe_lds_pad = std::max(0, std::min(160 * 1024 - 46592, atoi(getenv("LASR_FE_LDS_PAD"))));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_fe_mel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 46592));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_logmel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 40352));
     }
     c->main_graph = c->bf != 0;
     if (getenv("LASR_MAIN_GRAPH")) c->main_graph = atoi(getenv("LASR_MAIN_GRAPH")) != 0;
@@ -613,6 +614,10 @@ static int stream_frame0(lasr_ctx* c, int* nf_out) {
 // Fused front-end, irregular clients: a slot that is about to be pushed again although it still has a pending frame whose
 // window the ring would lose (more than one chunk pushed per lasr_step_* call) gets that frame computed NOW into `pend`
 // (the per-chunk log-mel kernel, window selected by its age); the step's k_fe_mel launch then skips it (age 15).
+// the per-chunk log-mel kernel of the streaming protocols (more than 512 slots, non-standard front-end shapes, irregular clients) runs
+// beside the decode stream like k_fe_mel: the same CU exclusion against the wide decode tilings (lasr_ctx::fe_lds_pad; k_logmel
+// holds 40 352 B of its own)
+static int logmel_lds_pad(lasr_ctx* c) { return c->fe_lds_pad ? 98304 - 40352 : 0; }
 static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
     const lasr_model_desc& d = c->d;
     const int slack = c->ring_chunks - d.n_window;
@@ -636,7 +641,7 @@ static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
         m.n_window = d.n_window; m.ring_chunks = c->ring_chunks; m.frame0 = stream_frame0(c, nullptr);
         m.frames_per_row = d.n_stack; m.out = c->pend; m.out_frames = d.n_buffer * d.n_stack;
         m.by_value = 1; m.trow_out = nullptr;
-        hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), 0, c->stream, m);
+        hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), logmel_lds_pad(c), c->stream, m);
     }
     return LASR_OK;
 }
@@ -986,7 +991,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
             m.trow_out = model_rows.empty() ? nullptr : c->dc.T_row;
             for (int r = 0; r < c->M; ++r) { m.sel_v[r] = (short)c->hc.feat_sel[r]; m.trow_v[r] = (unsigned char)c->hc.T_row[r]; }
         }
-        hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), 0, c->stream, m);
+        hipLaunchKernelGGL(k_logmel, dim3((d.n_stack + 3) / 4, c->M), dim3(256), logmel_lds_pad(c), c->stream, m);
     }
     if (model_rows.empty()) return LASR_OK;
     RC(ensure_T(c, Tm));

@@ -1,0 +1,24 @@
+#!/bin/bash
+# same-box A/B of two builds of the library (LASR_LIB): usage ab_lib.sh <old.so> <new.so> <out_dir> <rounds>
+OLD=$1; NEW=$2; OUT=$3; N=${4:-3}
+mkdir -p $OUT
+COMMON="--no-cpu-baseline --other-configs 0 --no-extras"
+for i in $(seq 1 $N); do
+  for tag in old new; do
+    lib=$OLD; [ $tag = new ] && lib=$NEW
+    LASR_LIB=$lib timeout 300 python bench.py $COMMON 2>/dev/null | tail -1 > $OUT/f32_${tag}_$i.json
+    LASR_LIB=$lib timeout 300 python bench.py $COMMON --model cfg5 --dtype bf16 --beam 8 --streams 128 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/cfg5b8_${tag}_$i.json
+    LASR_LIB=$lib timeout 300 python bench.py $COMMON --model cfg2 --dtype bf16 --beam 4 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/cfg2b4_${tag}_$i.json
+  done
+done
+python - <<PY
+import json,glob,os
+for cfg in ("f32","cfg5b8","cfg2b4"):
+    for tag in ("old","new"):
+        v=[]
+        for f in sorted(glob.glob("$OUT/%s_%s_*.json"%(cfg,tag))):
+            try:
+                j=json.loads(open(f).read()); v.append((round(j["value"]), round(j.get("sustained",{}).get("value",0)), j.get("latency_ms",{}).get("p50")))
+            except Exception as e: v.append(("?",str(e)[:40]))
+        print(cfg,tag,v)
+PY
