@@ -947,11 +947,13 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
                 t.pend = c->pend; t.pend_frames = d.n_buffer * d.n_stack; t.T_row = c->T_row_dev; t.ln_w = c->ln_w; t.ln_b = c->ln_b;
                 t.x0 = c->x0; t.MT = c->MT; t.mt_total = c->Tcap * c->MT; t.bf = c->bf;
                 static bool attr = false;
-                if (!attr) { (void)hipFuncSetAttribute((const void*)k_ln_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1284 * 4); attr = true; }
+                if (!attr) { (void)hipFuncSetAttribute((const void*)k_ln_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); attr = true; }
                 // store phase of the tile kernel on 4 z-slices (8 -> 32 workgroups; bit-identical): f32 52.5-52.7 -> 52.6-53.3 k, bf16
                 // 92.8 -> 95.4 k (profiles/r04/r04_lnz_ab.txt)
                 constexpr int ln_z = 4;
-                hipLaunchKernelGGL(k_ln_tile, dim3(c->MT, Tm, ln_z), dim3(1024), 16 * 1284 * 4, fe_st, t);
+                // (with wide decode tilings around: 98 304 B instead of the 82 176 the tile needs -- the same CU exclusion as the log-mel
+                //  launch's; this kernel reads its tile back with wide LDS reads as well and has never been seen wrong)
+                hipLaunchKernelGGL(k_ln_tile, dim3(c->MT, Tm, ln_z), dim3(1024), c->fe_lds_pad ? 98304 : 16 * 1284 * 4, fe_st, t);
             } else {
                 LAUNCH_STACK_LN( dim3((Tm + 3) / 4, c->M), dim3(256), 0, fe_st, a);
             }
