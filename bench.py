@@ -558,7 +558,7 @@ def main():
     if args.lm != "none":
         eng.attach_lm(synth.synth_lm_state_dict("lm768"), int8=args.lm == "int8")
     eng_cfg = {}
-    for key in ("enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "cell_nw", "push_lazy", "pump_nap_pct"):
+    for key in ("enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "cell_nw", "push_lazy", "pump_nap_pct", "fe_lds_pad"):
         try:
             eng_cfg[key] = eng.config(key)
         except Exception:

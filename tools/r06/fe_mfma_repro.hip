@@ -1,0 +1,89 @@
+// fe_mfma_repro.hip -- stand-alone reproducer of round 6's R, built from the engine's two REAL kernels (no engine, no Python):
+//   victim     k_fe_mel<10>   streaming log-mel front-end (radix-8 FFT in LDS, 5 waves, 46 592 B of LDS) over a fixed PCM ring,
+//                             launched back to back on stream A, a per-row checksum of its output behind every launch;
+//   neighbour  k_gemm<OpsBF16, EpiLinearT<4>, 4, 4, false, D>   the 64 x 64 vocabulary GEMM of the beam search (1024 x 2048 x 1536,
+//                             bf16 MFMA, 4 waves, 66 560 B of LDS) in a loop on stream B.
+// The two share no byte of memory.  Every victim launch must reproduce the first one (which runs alone) bit for bit.
+//   ./fe_mfma_repro [launches = 1000] [lds_pad_bytes = 0] [neighbour launches per victim launch = 4]
+// lds_pad_bytes = unused dynamic LDS of the victim: 51712 (98 304 B in total) keeps its workgroups off every CU that holds a
+// workgroup of the neighbour (98 304 + 66 560 > 160 KB) -- the engine's fix (lasr_ctx::fe_lds_pad).
+// build (from the repository root): hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/r06/fe_mfma_repro tools/r06/fe_mfma_repro.hip
+#include "../../libreasr_amd/csrc/lasr_kernels.hip.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace lasr;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+template <class T> static T* up(const std::vector<T>& v) { T* d = nullptr; if (hipMalloc((void**)&d, v.size() * sizeof(T)) != hipSuccess) return nullptr; (void)hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return d; }
+static unsigned rng_state = 12345u;
+static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xffff) / 65536.0f - 0.5f; }
+
+template <int D>
+static int run(int launches, int lds_pad, int per) {
+    const int M = 128, NM = 128, NFFT = 1024, HOP = 160, WIN = 400, CHUNK = 1280, NW_ = 3, NB = 2, NR = NW_ + NB - 1;
+    // ---- the victim's constants: Hann window, twiddles, a triangular filterbank (any valid sparse filterbank will do)
+    std::vector<float> win(NFFT, 0.f);
+    for (int i = 0; i < WIN; ++i) win[(NFFT - WIN) / 2 + i] = 0.5f - 0.5f * cosf(2.0f * 3.14159265358979f * i / WIN);
+    std::vector<float2> tw512(512), tw1024(513);
+    for (int i = 0; i < 512; ++i) tw512[i] = float2{cosf(-2.f * 3.14159265358979f * i / 512), sinf(-2.f * 3.14159265358979f * i / 512)};
+    for (int i = 0; i <= 512; ++i) tw1024[i] = float2{cosf(-2.f * 3.14159265358979f * i / 1024), sinf(-2.f * 3.14159265358979f * i / 1024)};
+    std::vector<int> fb_start(NM), fb_off(NM + 1, 0); std::vector<float> fb_w;
+    for (int m = 0; m < NM; ++m) {
+        const int lo = 1 + 3 * m, width = 3 + m / 12;       // 3 .. 13 bins, ascending
+        fb_start[m] = lo; fb_off[m] = (int)fb_w.size();
+        for (int k = 0; k < width && lo + k <= 512; ++k) fb_w.push_back(1.0f - fabsf((k + 0.5f) / width * 2.f - 1.f));
+    }
+    fb_off[NM] = (int)fb_w.size();
+    if (fb_w.size() > 1536) { printf("filterbank too large\n"); return 1; }
+    std::vector<float> ring((size_t)M * NR * CHUNK);
+    for (auto& x : ring) x = frand();
+    FeMelArgs m{};
+    m.window = up(win); m.tw512 = up(tw512); m.tw1024 = up(tw1024); m.fb_start = up(fb_start); m.fb_off = up(fb_off); m.fb_w = up(fb_w);
+    m.n_mels = NM; m.hop = HOP; m.fb_nnz = (int)fb_w.size(); m.win_off = (NFFT - WIN) / 2; m.win_len = WIN;
+    m.pcm = up(ring); m.chunk = CHUNK; m.n_window = NW_; m.ring_chunks = NR; m.frame0 = 9;          // (the reference geometry: T // 3 + 1)
+    float* pend = nullptr; int* trow = nullptr; int* rpos = nullptr;
+    CHECK(hipMalloc((void**)&pend, sizeof(float) * M * NB * 10 * NM)); CHECK(hipMalloc((void**)&trow, 4 * M)); CHECK(hipMalloc((void**)&rpos, 4 * M));
+    CHECK(hipMemset(pend, 0, sizeof(float) * M * NB * 10 * NM));
+    m.pend = pend; m.pend_frames = NB * 10; m.trow_out = trow; m.ring_pos = rpos;
+    for (int r = 0; r < 512; ++r) { m.idx[r] = -1; m.tp_pk[r] = 0; m.age_pk[r] = 0; }
+    for (int r = 0; r < M; ++r) { m.tp_pk[r] = (unsigned char)(((r % NR) << 4) | NB); m.age_pk[r] = (unsigned short)((NB - 1) | (0 << 4)); }
+    // ---- the neighbour's operands: random bf16 bit patterns with small exponents
+    const int K = 1536, V = 2048, ROWS = 1024, KC = K / 32;
+    std::vector<unsigned short> a((size_t)KC * (ROWS / 16) * 64 * 8), w((size_t)(V / 64) * 4 * KC * 64 * 8);
+    for (auto& x : a) x = (unsigned short)(0x3c00 + (int)(frand() * 512.f) + (frand() > 0 ? 0x8000 : 0));
+    for (auto& x : w) x = (unsigned short)(0x3c00 + (int)(frand() * 512.f) + (frand() > 0 ? 0x8000 : 0));
+    GemmArgs g{};
+    g.A[0] = up(a); g.a_mt_total[0] = ROWS / 16; g.a_mt_off[0] = 0; g.KC[0] = KC; g.W[0] = up(w); g.M = ROWS; g.prio = 1;
+    EpiLinearT<4>::Args e{};
+    float* logits = nullptr; CHECK(hipMalloc((void**)&logits, sizeof(float) * ROWS * V));
+    std::vector<float> bias(V, 0.25f);
+    e.bias = up(bias); e.out = logits; e.ldo = V; e.n_rows = ROWS; e.t_idx = nullptr; e.T_row = nullptr; e.M = M; e.W = 8;
+    hipStream_t sa, sb;
+    CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    CHECK(hipFuncSetAttribute((const void*)k_fe_mel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 46592));
+    unsigned* log = nullptr; CHECK(hipMalloc((void**)&log, sizeof(unsigned) * (size_t)(launches + 1) * M));
+    RowSumArgs ra{}; ra.s[0] = RowSumSrc{pend, 2, 0, 0, NB * 10 * NM};
+    for (int i = 0; i <= launches; ++i) {
+        if (i > 0) for (int q = 0; q < per; ++q) hipLaunchKernelGGL((k_gemm<OpsBF16, EpiLinearT<4>, 4, 4, false, D>), dim3(V / 64, ROWS / 64), dim3(256), 0, sb, g, e);
+        hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * NB, M), dim3(320), lds_pad, sa, m);
+        hipLaunchKernelGGL(k_dbg_rowsum, dim3(M, 1), dim3(256), 0, sa, ra, M, 1, log + (size_t)i * M);
+        if (i == 0) CHECK(hipStreamSynchronize(sa));
+    }
+    CHECK(hipDeviceSynchronize());
+    std::vector<unsigned> h((size_t)(launches + 1) * M);
+    CHECK(hipMemcpy(h.data(), log, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost));
+    int bad_l = 0, bad_r = 0; unsigned any = 0;
+    for (int r = 0; r < M; ++r) any |= h[r];
+    for (int i = 1; i <= launches; ++i) { int nb = 0; for (int r = 0; r < M; ++r) nb += h[(size_t)i * M + r] != h[r]; bad_r += nb; bad_l += nb != 0; }
+    printf("operand ring depth %2d, victim LDS pad %6d B, %d neighbour launches per victim launch: %d of %d log-mel launches differ from the first (%d rows)%s\n",
+           D, lds_pad, per, bad_l, launches, bad_r, any ? "" : "  [reference output is all zero?]");
+    return 0;
+}
+int main(int argc, char** argv) {
+    const int launches = argc > 1 ? atoi(argv[1]) : 1000, pad = argc > 2 ? atoi(argv[2]) : 0, per = argc > 3 ? atoi(argv[3]) : 4;
+    if (run<-1>(launches, pad, per)) return 1;          // the ring depth the engine uses (3 for this shape)
+    if (run<2>(launches, pad, per)) return 1;           // a shallower ring: the neighbour that disturbs most
+    return 0;
+}
