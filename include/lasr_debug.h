@@ -50,7 +50,9 @@ int lasr_debug_enclog(lasr_ctx* c, unsigned* out, size_t cap, int* steps);
  * 3 the joint half.  lds_pad = unused dynamic LDS of the log-mel launches in bytes (-1: what the engine uses, see
  * lasr_ctx::fe_lds_pad; 0: none -- the round-6 interference shows up beside aggressor 1 with bf16 operands and >= 512 hypothesis
  * rows).  The first launch runs alone and is the reference: *bad_launches / *bad_rows = launches / (launch, row) pairs whose
- * output differs from it.  With the engine's setting both must be 0: the two streams share no data. */
+ * output differs from it.  With the engine's setting both must be 0: the two streams share no data.  The log-mel launches write to
+ * scratch buffers (the slots' pending frames stay); aggressors 2 and 3 overwrite the slots' predictor / joint state: reset the slots
+ * before streaming through them again. */
 int lasr_debug_fe_race(lasr_ctx* c, int iters, int aggressor, int per_iter, int lds_pad, int* bad_launches, int* bad_rows);
 
 /* Engine configuration as resolved at lasr_create (defaults + LASR_* environment switches): *value = the integer behind `key`.

@@ -2502,7 +2502,12 @@ int lasr_debug_fe_race(lasr_ctx* c, int iters, int aggressor, int per_iter, int 
     m.window = c->window; m.tw512 = c->tw512; m.tw1024 = c->tw1024; m.fb_start = c->fb_start; m.fb_off = c->fb_off; m.fb_w = c->fb_w;
     m.n_mels = d.n_mels; m.hop = d.hop; m.fb_nnz = c->fb_nnz; m.win_off = (d.n_fft - d.win) / 2; m.win_len = d.win;
     m.pcm = c->win; m.ring_pos = c->ring_pos; m.chunk = d.chunk; m.n_window = d.n_window; m.ring_chunks = c->ring_chunks; m.frame0 = a0;
-    m.pend = c->pend; m.pend_frames = d.n_buffer * d.n_stack; m.trow_out = c->T_row_main;
+    // (outputs go to scratch buffers: the slots' pending frames and the step's frame counts stay as they are)
+    const size_t n_pend = (size_t)c->M * d.n_buffer * d.n_stack * d.n_mels;
+    float* pend_x = nullptr; int* trow_x = nullptr;
+    RC(dalloc(c, &pend_x, n_pend));
+    RC(dalloc(c, &trow_x, (size_t)c->M));
+    m.pend = pend_x; m.pend_frames = d.n_buffer * d.n_stack; m.trow_out = trow_x;
     for (int r = 0; r < 512; ++r) { m.idx[r] = -1; m.tp_pk[r] = 0; m.age_pk[r] = 0; }
     for (int r = 0; r < c->M; ++r) {
         m.tp_pk[r] = (unsigned char)((c->h_ring_pos[r] << 4) | d.n_buffer);
@@ -2513,7 +2518,7 @@ int lasr_debug_fe_race(lasr_ctx* c, int iters, int aggressor, int per_iter, int 
     unsigned* log = nullptr;
     RC(dalloc(c, &log, (size_t)(iters + 1) * c->M));
     RowSumArgs ra{};
-    ra.s[0] = RowSumSrc{c->pend, 2, 0, 0, d.n_buffer * d.n_stack * d.n_mels};
+    ra.s[0] = RowSumSrc{pend_x, 2, 0, 0, d.n_buffer * d.n_stack * d.n_mels};
     hipStream_t keep = c->stream;
     auto aggress = [&]() {
         c->stream = c->stream_dec;
@@ -2534,7 +2539,7 @@ int lasr_debug_fe_race(lasr_ctx* c, int iters, int aggressor, int per_iter, int 
     c->pred_par = pp0;
     std::vector<unsigned> h((size_t)(iters + 1) * c->M);
     hipError_t e = hipMemcpy(h.data(), log, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost);
-    dfree(c, log);
+    dfree(c, log); dfree(c, pend_x); dfree(c, trow_x);
     if (e != hipSuccess) return fail(c, LASR_EHIP, "race probe copy failed: %s", hipGetErrorString(e));
     for (int i = 1; i <= iters; ++i) {
         int nb = 0;

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from libreasr_amd import synth
 from libreasr_amd.engine import Engine
-name, W, B, n_chunks = sys.argv[1] if len(sys.argv) > 1 else "cfg5", int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(sys.argv[3]) if len(sys.argv) > 3 else 128, 48
+name, W, B = sys.argv[1] if len(sys.argv) > 1 else "cfg5", int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(sys.argv[3]) if len(sys.argv) > 3 else 128
+n_chunks = int(os.environ.get("CHUNKS", "48"))
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 MODE = os.environ.get("MODE", "pipe"); DEPTH = int(os.environ.get("DEPTH", "6"))
 cfg = synth.model_cfg(name); sd = synth.synth_state_dict(cfg, seed=0)
