@@ -56,7 +56,7 @@ int lasr_debug_enclog(lasr_ctx* c, unsigned* out, size_t cap, int* steps);
 int lasr_debug_fe_race(lasr_ctx* c, int iters, int aggressor, int per_iter, int lds_pad, int* bad_launches, int* bad_rows);
 
 /* Engine configuration as resolved at lasr_create (defaults + LASR_* environment switches): *value = the integer behind `key`.
- * Keys: "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "la_offline", "cell_nw", "use_graphs", "M", "fe_lds_pad".  LASR_EINVAL for an unknown key.  bench.py records these beside every line. */
+ * Keys: "enc_wave", "enc_u12", "main_graph", "pump_G", "la_stream", "la_offline", "cell_nw", "use_graphs", "M", "fe_lds_pad", "roctx" (1: LASR_ROCTX found the marker library).  LASR_EINVAL for an unknown key.  bench.py records these beside every line. */
 int lasr_debug_config(lasr_ctx* c, const char* key, int* value);
 
 /* Roofline micro-benchmark of the dominant kernel (one encoder LSTM-cell launch: all rows active,

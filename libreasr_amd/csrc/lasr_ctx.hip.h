@@ -1,6 +1,7 @@
 // lasr_ctx.hip.h -- the engine context (lasr_ctx), error / allocation helpers, operand packing, description checks
 // Included through lasr_host.hip.h by every translation unit of the library.
 #pragma once
+#include <dlfcn.h>
 
 constexpr int NW = 8;          // waves per GEMM workgroup (K split)
 constexpr int NCMD = 64;       // ring of host->device command blocks
@@ -352,6 +353,37 @@ int fail(lasr_ctx* c, int code, const char* fmt, ...) {
         if (e_ != hipSuccess)                                                                    \
             return fail(c, LASR_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// roctx ranges (tracing): LASR_ROCTX=1 resolves roctxRangePushA / roctxRangePop from the profiler's marker library
+// at the first lasr_create (no link-time dependency; silently off when the library is absent) and the protocol's host phases push
+// named ranges -- "lasr_push_submit", "lasr frontend+encoder", "lasr encoder cells", "lasr decode group", "lasr_step_wait",
+// "lasr_step_stream", "lasr_transcribe" -- which `rocprofv3 --marker-trace --kernel-trace` lays over the kernels of both streams.
+struct lasr_roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+};
+inline lasr_roctx& roctx_state() { static lasr_roctx r; return r; }      // (per translation unit: every range is pushed from lasr_engine.hip)
+inline void roctx_init() {
+    lasr_roctx& r = roctx_state();
+    if (r.tried) return;
+    r.tried = true;
+    if (!getenv("LASR_ROCTX") || atoi(getenv("LASR_ROCTX")) == 0) return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        auto push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        auto pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) { r.push = push; r.pop = pop; return; }
+    }
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(roctx_state().push != nullptr) { if (on) roctx_state().push(name); }
+    ~RoctxRange() { if (on) roctx_state().pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
 
 template <class T>
 int dalloc(lasr_ctx* c, T** p, size_t n) {

@@ -72,6 +72,7 @@ void cell_prof_harvest(lasr_ctx* c, bool all) {
 // ---------------------------------------------------------------------------- encoder + decode
 // Encoder over T_max frames for rows with T_row > 0 (x0 already holds LayerNorm'ed features).
 void run_encoder(lasr_ctx* c, int T_max) {
+    RoctxRange roctx_range_("lasr encoder cells");
     const int L = c->d.enc_layers;
     const int mt_total = c->Tcap * c->MT;
     const int par0 = c->enc_par;

@@ -99,6 +99,7 @@ const char* lasr_last_error(const lasr_ctx* c) { return c ? c->err.c_str() : "nu
 static int overlap_probe_impl(lasr_ctx* c, int delay_us, double* ratio, hipStream_t sa = nullptr, hipStream_t sb = nullptr);
 
 static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
+    roctx_init();
     const lasr_model_desc& d = c->d;
     const int F = d.feat, H = d.hidden, E = d.embed, V = d.vocab, J = d.joint;
     c->M = (d.max_streams + 16 * MTA - 1) / (16 * MTA) * (16 * MTA);   // whole "A"-tiling row groups
@@ -865,6 +866,7 @@ int lasr_push_consumed(lasr_ctx* c, long long ticket) {
 // slots[i]); the front-end launch appends it to the PCM ring itself.  *fused_done tells the caller whether that happened.
 static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::vector<int>& model_rows, int& Tm,
                                     const PushSrc* fused = nullptr, bool* fused_done = nullptr) {
+    RoctxRange roctx_range_("lasr frontend+encoder");
     const lasr_model_desc& d = c->d;
     // window geometry (api-server.py:95-102 + TransformTime + StreamPostprocess)
     const long long N = (long long)d.n_window * d.chunk;
@@ -1013,6 +1015,7 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
 
 int lasr_step_stream(lasr_ctx* c, const int* slots, int n, int* n_ran) {
     if (!c) return LASR_EINVAL;
+    RoctxRange roctx_range_("lasr_step_stream");
     if (n_ran) *n_ran = 0;
     RC(check_slots(c, slots, n, true));
     RC(flush_lazy(c));
@@ -1079,6 +1082,7 @@ int lasr_push_submit_rows(lasr_ctx* c, const int* slots, int n, const float* con
     return push_submit_impl(c, slots, n, n > 0 ? rows[0] : nullptr, 0, ticket, rows);
 }
 static int push_submit_impl(lasr_ctx* c, const int* slots, int n, const float* pcm, int flags, long long* ticket, const float* const* rows) {
+    RoctxRange roctx_range_("lasr_push_submit");
     if (ticket) *ticket = -1;
     RC(check_slots(c, slots, n, true));
     if (n == 0) return LASR_OK;
@@ -1505,7 +1509,7 @@ static int cont_launch_group(lasr_ctx* c, int G, bool from_pump = false) {
     tr_mark(c, 11 + 100 * G + (admitted_any ? 1000 : 0), sd);
     __atomic_store_n(flag, -1, __ATOMIC_RELEASE);      // before the launch that will overwrite it
     if (graphs) {
-        HIPCHK(c, hipGraphLaunch(ex, sd));
+        { RoctxRange roctx_range_("lasr decode group"); HIPCHK(c, hipGraphLaunch(ex, sd)); }
         if (G & 1) { c->pred_par ^= 1; if (c->lm.on) c->lm.par ^= 1; }
     } else {
         c->la = c->la_stream;
@@ -1687,6 +1691,7 @@ static bool cont_step_done(const lasr_ctx* c, const lasr_ctx::PendingStep& P) {
 
 int lasr_step_wait(lasr_ctx* c, int* n_ran) {
     if (!c) return LASR_EINVAL;
+    RoctxRange roctx_range_("lasr_step_wait");
     if (n_ran) *n_ran = 0;
     {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -1783,6 +1788,7 @@ static int transcribe_common(lasr_ctx* c, const int* slots, int n, int T_max) {
 }
 
 int lasr_transcribe_pcm(lasr_ctx* c, const int* slots, int n, const float* pcm, const int64_t* n_samples) {
+    RoctxRange roctx_range_("lasr_transcribe");
     if (!c) return LASR_EINVAL;
     RC(flush_lazy(c));
     RC(require_idle(c));
@@ -2829,7 +2835,7 @@ int lasr_debug_config(lasr_ctx* c, const char* key, int* value) {
         {"pump_G", c->pump_G}, {"la_stream", c->la_stream}, {"la_offline", c->la_offline},
         {"cell_nw", c->cell_nw ? c->cell_nw : (c->bf ? 8 : 4)}, {"use_graphs", (int)c->use_graphs}, {"M", c->M},
         {"push_lazy", (int)c->lazy_on}, {"pump_nap_pct", c->pump_nap_pct}, {"lazy_taken", c->lazy_taken}, {"lazy_flushed", c->lazy_flushed},
-        {"fe_lds_pad", c->fe_lds_pad},
+        {"fe_lds_pad", c->fe_lds_pad}, {"roctx", roctx_state().push != nullptr ? 1 : 0},
     };
     for (const auto& e : tab)
         if (!strcmp(e.k, key)) { *value = e.v; return LASR_OK; }

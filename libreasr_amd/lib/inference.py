@@ -11,7 +11,7 @@ import torch
 from .. import synth
 from ..engine import Engine
 from ..weights import infer_cfg
-from .config import apply_overrides, model_cfg_from_conf, open_config, stream_settings
+from .config import apply_overrides, engine_settings, model_cfg_from_conf, open_config, stream_settings
 from .language import get_language
 from .model_utils import extract_tars, load_lm_state_dict as _load_lm_sd, load_model_state_dict
 from .models import Transducer
@@ -39,12 +39,16 @@ def load_lm_state_dict(conf, synthetic_lm=None):
         return None
 
 
-def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_streams=16, device=0,
-               synthetic_lm=None, dtype="f32", beam=1, lm_int8=True):
+def load_stuff(lang, config_path="./config/testing.yaml", synthetic=None, max_streams=None, device=None,
+               synthetic_lm=None, dtype=None, beam=None, lm_int8=None):
+    """max_streams / device / dtype / beam / lm_int8: None = the YAML's `engine:` section, else its defaults (16, 0, "f32", 1, True:
+    config.engine_settings)."""
     torch.set_num_threads(2)                # inference.py:21
     conf, cfg, sd = {}, None, None
     if os.path.exists(config_path):
         conf = apply_overrides(open_config(config_path), inference=True, lang=lang)
+    es = engine_settings(conf, max_streams=max_streams, device=device, dtype=dtype, beam=beam, lm_int8=lm_int8)
+    max_streams, device, dtype, beam, lm_int8 = es["max_streams"], es["device"], es["dtype"], es["beam"], es["lm_int8"]
     if synthetic is not None:
         cfg = synth.model_cfg(synthetic)
         sd = synth.synth_state_dict(cfg, seed=0)

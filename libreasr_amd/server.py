@@ -965,11 +965,15 @@ class NativeASRServicer(apg.ASRServicer):
                 eng.close_slot(slot)
 
 
-def serve(lang="en", port=None, block=True, depth=12, front="python", **load_kw):
+def serve(lang="en", port=None, block=True, depth=None, front=None, **load_kw):
     """Start the gRPC server (api-server.py:138-145).  Returns (server, scheduler, port).  front="native": the library's front
-    thread instead of the Python scheduler (the returned object is the NativeFront; `shutdown()` works on both)."""
+    thread instead of the Python scheduler (the returned object is the NativeFront; `shutdown()` works on both).  depth / front:
+    None = the YAML's `engine:` section, else 12 / "python" (lib/config.py:engine_settings)."""
+    from .lib.config import engine_settings
     from .lib.inference import load_stuff
     conf, language, model, _, _ = load_stuff(lang, **load_kw)
+    es = engine_settings(conf, depth=depth, front=front)
+    depth, front = int(es["depth"]), es["front"]
     server = grpc.server(futures.ThreadPoolExecutor(max_workers=WORKERS))
     if front == "native":
         from .front import NativeFront

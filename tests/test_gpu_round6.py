@@ -402,3 +402,40 @@ def test_bf16_decision_agreement_under_teacher_forcing(name, n_streams, golden_d
     PR.record(f"{name}_bf16_teacher_forced_decisions", decisions=n_dec, agree=n_agree, rate=round(rate, 5),
               fp32_margins_at_disagreements=sorted(round(m, 4) for m in margins), max_abs_logit_difference=round(worst, 4))
     assert rate >= 0.97 and (not margins or max(margins) < 0.25), (rate, margins)
+
+
+def test_roctx_ranges_switch():
+    """LASR_ROCTX=1 (tracing): the marker library is found, the ranges are pushed around the protocol's host phases
+    and the results do not change.  The switch is read at the first lasr_create of a process: a child process per setting."""
+    import subprocess
+    import sys
+    prog = r'''
+import sys, zlib
+sys.path.insert(0, %r)
+import numpy as np
+from libreasr_amd import synth
+from libreasr_amd.engine import Engine
+cfg = synth.model_cfg("tiny"); sd = synth.synth_state_dict(cfg, seed=0)
+eng = Engine(sd, cfg, max_streams=4)
+slots = [eng.open() for _ in range(4)]
+pcm = np.stack([synth.synth_pcm(1, 24 * 1280, seed=7 + s)[0] for s in range(4)])
+out = []
+for k in range(24):
+    eng.push_submit(slots, pcm[:, k * 1280:(k + 1) * 1280])
+    while eng.pending() >= 4:
+        if eng.wait(): out.append(eng.fetch_many(slots, 64))
+while eng.pending():
+    if eng.wait(): out.append(eng.fetch_many(slots, 64))
+eng.transcribe_pcm(slots[:1], [pcm[0]])
+print("RESULT", eng.config("roctx"), zlib.crc32(repr(out).encode()), len(out))
+''' % ROOT
+    res = {}
+    for on in ("0", "1"):
+        env = dict(os.environ, LASR_ROCTX=on)
+        p = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+        res[on] = (int(line[1]), line[2], int(line[3]))
+    print(res)
+    assert res["0"][0] == 0 and res["1"][0] == 1          # the image ships the profiler's marker library
+    assert res["0"][1:] == res["1"][1:] and res["0"][2] > 8

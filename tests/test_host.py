@@ -46,6 +46,24 @@ def test_reference_yaml_and_overrides():
                      pred_layers=2, pred_cell="NBRC")                    # testing.yaml:202-229
 
 
+def test_engine_section_of_the_yaml(tmp_path):
+    """`engine:` (new-build stance): defaults < file < per-language override < explicit argument; unknown keys and
+    bad values are refused before anything is loaded."""
+    import yaml
+    conf = {"engine": {"max_streams": 64, "dtype": "bf16", "depth": 18},
+            "overrides": {"inference": {"engine": {"front": "native"}}, "languages": {"de": {"engine": {"beam": 4, "max_streams": 32}}}}}
+    p = tmp_path / "c.yaml"
+    p.write_text(yaml.safe_dump(conf))
+    en = cfgmod.engine_settings(cfgmod.apply_overrides(cfgmod.open_config(str(p)), inference=True, lang="en"))
+    assert en == dict(max_streams=64, device=0, dtype="bf16", beam=1, lm_int8=True, depth=18, front="native")
+    de = cfgmod.engine_settings(cfgmod.apply_overrides(cfgmod.open_config(str(p)), inference=True, lang="de"), dtype="f32", beam=None)
+    assert (de["max_streams"], de["beam"], de["dtype"], de["front"]) == (32, 4, "f32", "native")
+    assert cfgmod.engine_settings({}) == cfgmod.ENGINE_DEFAULTS and cfgmod.engine_settings(None, beam=8)["beam"] == 8
+    for bad in ({"engine": {"streams": 4}}, {"engine": {"dtype": "fp16"}}, {"engine": {"front": "rust"}}, {"engine": {"beam": 0}}):
+        with pytest.raises(ValueError):
+            cfgmod.engine_settings(bad)
+
+
 def test_update_is_recursive():
     d = {"a": {"b": 1, "c": 2}, "x": 1}
     cfgmod.update(d, {"a": {"b": 5}, "y": 2})
