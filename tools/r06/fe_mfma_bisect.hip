@@ -91,6 +91,8 @@ __global__ __launch_bounds__(320) void k_fe_var(const FeMelArgs a) {
     __shared__ int s_fbs[128], s_fbo[129];
     __shared__ float2 s_tw512[512], s_tw1024[513];
     const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
+    if constexpr (VAR & 128) asm volatile("" ::: "v127");           // 128: the victim declares 128 registers
+    if constexpr (VAR & 256) asm volatile("" ::: "v199");           // 256: ... 200
     const int tp = blockIdx.x >> 1, half = blockIdx.x & 1, row = blockIdx.y;
     const int pos = a.tp_pk[row] >> 4;
     const int NR = a.ring_chunks;
@@ -165,7 +167,7 @@ static int run(int launches, int lds_pad, int per) {
     for (auto& x : a) x = (unsigned short)(0x3c00 + (int)(frand() * 512.f) + (frand() > 0 ? 0x8000 : 0));
     for (auto& x : w) x = (unsigned short)(0x3c00 + (int)(frand() * 512.f) + (frand() > 0 ? 0x8000 : 0));
     GemmArgs g{};
-    g.A[0] = up(a); g.a_mt_total[0] = ROWS / 16; g.a_mt_off[0] = 0; g.KC[0] = KC; g.W[0] = up(w); g.M = ROWS; g.prio = 1;
+    g.A[0] = up(a); g.a_mt_total[0] = ROWS / 16; g.a_mt_off[0] = 0; g.KC[0] = KC; g.W[0] = up(w); g.M = ROWS; g.prio = getenv("PRIO") ? atoi(getenv("PRIO")) : 1;
     EpiLinearT<4>::Args e{};
     float* logits = nullptr; CHECK(hipMalloc((void**)&logits, sizeof(float) * ROWS * V));
     std::vector<float> bias(V, 0.25f);
@@ -193,10 +195,10 @@ static int run(int launches, int lds_pad, int per) {
 }
 int main(int argc, char** argv) {
     const int launches = argc > 1 ? atoi(argv[1]) : 1000, pad = argc > 2 ? atoi(argv[2]) : 0, per = argc > 3 ? atoi(argv[3]) : 4;
-    if (run<37, 7>(launches, pad, per)) return 1;              // minimal so far: formula samples, dft8, one LDS round trip, divergent P loop
-    if (run<37, 7 + 32>(launches, pad, per)) return 1;         // uniform P loop
-    if (run<37, 7 + 64>(launches, pad, per)) return 1;         // no dft8
-    if (run<37, 7 + 32 + 64>(launches, pad, per)) return 1;
-    if (run<37, 7>(launches, 51712, per)) return 1;            // with the pad
+    printf("neighbour wave priority %s\n", getenv("PRIO") ? getenv("PRIO") : "1");
+    if (run<37, 7>(launches, pad, per)) return 1;              // the smallest failing victim
+    if (run<37 + 128, 7>(launches, pad, per)) return 1;        // ... declaring 128 registers
+    if (run<37 + 256, 7>(launches, pad, per)) return 1;        // ... 200 registers
+    if (run<0>(launches, pad, per)) return 1;                  // the whole kernel's compute part
     return 0;
 }
