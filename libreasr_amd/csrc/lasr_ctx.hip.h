@@ -93,7 +93,7 @@ struct lasr_ctx {
     // LDS read pass each, no shared data, cause not understood -- and configs[4] was not reproducible run to run; with the CU to
     // themselves: never (profiles/r06/r06_experiments.txt R; detectors: lasr_debug_enclog, lasr_debug_fe_race, tests/test_gpu_race.py).
     // 0 where no such kernel can run (configs[1]); LASR_FE_LDS_PAD overrides (bytes).
-    int fe_lds_pad = 0;
+    int fe_lds_pad = 0, logmel_lds_pad = 0;       // (k_fe_mel / the per-chunk k_logmel: 98 304 B minus the kernel's own LDS)
     unsigned* enclog = nullptr;     // LASR_DBG_ENCLOG=N: per model step and row, exact checksums (sum of the element bit patterns) of the
     float* pendlog = nullptr;       // LASR_DBG_PENDLOG=1 (with LASR_DBG_ENCLOG): a copy of the pending log-mel frames per logged step
     int enclog_cap = 0, enclog_n = 0;   // encoder's inputs and state behind that step: [N][2 T + 2 L][M], see lasr_debug_enclog

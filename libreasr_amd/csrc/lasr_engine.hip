@@ -321,12 +321,17 @@ static int create_impl(lasr_ctx* c, const float* weights, size_t n_weights) {
     HIPCHK(c, hipMemset(c->T_row_main, 0, sizeof(int) * M));
     // measured (profiles/r03/r03_experiments.txt I): host time per model step 66 -> 45 us, but the replay starts its first cell ~6 us
     // later than a plain launch does: f32 -2 % (52.8 against 54.0 k audio-s/s), bf16 +0.5 %  =>  on for bf16, off for f32
-    {   // see lasr_ctx::fe_lds_pad
+    {   // see lasr_ctx::fe_lds_pad.  The kernels' own (static) LDS is asked of the runtime, not assumed
+        hipFuncAttributes fa{}, la_{};
+        HIPCHK(c, hipFuncGetAttributes(&fa, (const void*)k_fe_mel<10>));
+        HIPCHK(c, hipFuncGetAttributes(&la_, (const void*)k_logmel));
+        const int lds_cu = 160 * 1024, excl = 98304;             // 98 304 + 65 536 > 160 KB
         const bool wide_decode = c->Md >= 256 || lasr_ctx::LA_MAX * M >= 512;
-        c->fe_lds_pad = wide_decode ? 98304 - 46592 : 0;
-        if (getenv("LASR_FE_LDS_PAD")) c->fe_lds_pad = std::max(0, std::min(160 * 1024 - 46592, atoi(getenv("LASR_FE_LDS_PAD"))));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_fe_mel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 46592));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_logmel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 40352));
+        c->fe_lds_pad = wide_decode ? std::max(0, excl - (int)fa.sharedSizeBytes) : 0;
+        if (getenv("LASR_FE_LDS_PAD")) c->fe_lds_pad = std::max(0, std::min(lds_cu - (int)fa.sharedSizeBytes, atoi(getenv("LASR_FE_LDS_PAD"))));
+        c->logmel_lds_pad = c->fe_lds_pad ? std::max(0, excl - (int)la_.sharedSizeBytes) : 0;
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_fe_mel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cu - (int)fa.sharedSizeBytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_logmel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cu - (int)la_.sharedSizeBytes));
     }
     c->main_graph = c->bf != 0;
     if (getenv("LASR_MAIN_GRAPH")) c->main_graph = atoi(getenv("LASR_MAIN_GRAPH")) != 0;
@@ -616,9 +621,8 @@ static int stream_frame0(lasr_ctx* c, int* nf_out) {
 // window the ring would lose (more than one chunk pushed per lasr_step_* call) gets that frame computed NOW into `pend`
 // (the per-chunk log-mel kernel, window selected by its age); the step's k_fe_mel launch then skips it (age 15).
 // the per-chunk log-mel kernel of the streaming protocols (more than 512 slots, non-standard front-end shapes, irregular clients) runs
-// beside the decode stream like k_fe_mel: the same CU exclusion against the wide decode tilings (lasr_ctx::fe_lds_pad; k_logmel
-// holds 40 352 B of its own)
-static int logmel_lds_pad(lasr_ctx* c) { return c->fe_lds_pad ? 98304 - 40352 : 0; }
+// beside the decode stream like k_fe_mel: the same CU exclusion against the wide decode tilings (lasr_ctx::fe_lds_pad)
+static int logmel_lds_pad(lasr_ctx* c) { return c->logmel_lds_pad; }
 static int materialize_pending(lasr_ctx* c, const int* slots, int n) {
     const lasr_model_desc& d = c->d;
     const int slack = c->ring_chunks - d.n_window;
@@ -2496,7 +2500,7 @@ int lasr_debug_fe_race(lasr_ctx* c, int iters, int aggressor, int per_iter, int 
     if (!c || !bad_launches || !bad_rows || iters < 1) return LASR_EINVAL;
     *bad_launches = *bad_rows = 0;
     if (lds_pad < 0) lds_pad = c->fe_lds_pad;
-    if (lds_pad > 160 * 1024 - 46592) return fail(c, LASR_EINVAL, "lds_pad too large");
+    if (lds_pad > 160 * 1024 - 48 * 1024) return fail(c, LASR_EINVAL, "lds_pad too large");
     RC(flush_lazy(c));
     RC(require_idle(c));
     if (!c->fe_fused || !c->stream_dec || c->M > 512) return fail(c, LASR_ESTATE, "the race probe needs the fused front-end and the decode stream");
