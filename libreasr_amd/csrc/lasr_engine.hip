@@ -769,15 +769,23 @@ static int push_prepare(lasr_ctx* c, const int* slots, int n, const float* pcm, 
         float* dst = c->push_stage_dev + (size_t)ps.ev_i * c->M * CH;
         HIPCHK(c, hipMemcpyAsync(dst, host_src, sizeof(float) * (size_t)n * CH, hipMemcpyHostToDevice, c->stream_copy));
         HIPCHK(c, hipEventRecord(c->push_copied[ps.ev_i], c->stream_copy));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->push_copied[ps.ev_i], 0));
+        // (the ctx stream waits for the copy where the first kernel that reads `dst` is launched: wait_copied.  A chunk whose append is
+        //  deferred is read by the NEXT call's front-end launch, behind that call's own copy on the same in-order copy stream: one
+        //  cross-stream wait per model step instead of one per chunk)
         ps.src = dst;
         ps.dma = true;
     }
     return LASR_OK;
 }
+// the ctx stream waits until the DMA of host push `ev_i` has landed in its device staging entry
+static int wait_copied(lasr_ctx* c, const PushSrc& ps) {
+    if (ps.dma && ps.ev_i >= 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->push_copied[ps.ev_i], 0));
+    return LASR_OK;
+}
 // the plain ring append (one launch)
 static int push_append_launch(lasr_ctx* c, const int* slots, int n, const PushSrc& ps) {
     const int CH = c->d.chunk;
+    RC(wait_copied(c, ps));
     if (c->M <= 512) {      // slot -> staging-row map by value: no command-block copy for a push
         PushIdx pi;
         for (int r = 0; r < 512; ++r) pi.idx[r] = -1;
@@ -808,7 +816,7 @@ static int flush_lazy(lasr_ctx* c) {
     if (!c->lazy.on) return LASR_OK;
     HIPCHK(c, hipSetDevice(c->device));
     PushSrc ps;
-    ps.src = c->lazy.src;
+    ps.src = c->lazy.src; ps.ev_i = c->lazy.ev_i; ps.dma = c->lazy.dma;
     const std::vector<int> slots = c->lazy.slots;
     RC(push_append_launch(c, slots.data(), (int)slots.size(), ps));
     c->lazy_flushed++;
@@ -938,6 +946,10 @@ static int enqueue_frontend_encoder(lasr_ctx* c, const int* slots, int n, std::v
                 m.age_pk[s] = (unsigned short)pk;
             }
             hipStream_t fe_st = c->stream;
+            if (fused) {
+                RC(wait_copied(c, *fused));
+                if (with_lazy && c->lazy.dma && !fused->dma) { PushSrc lz; lz.ev_i = c->lazy.ev_i; lz.dma = true; RC(wait_copied(c, lz)); }
+            }
             // c->fe_lds_pad bytes of unused dynamic LDS: the workgroup then shares its CU with no workgroup of the wide decode tilings
             // (see lasr_ctx::fe_lds_pad)
             hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * d.n_buffer, c->M), dim3(320), c->fe_lds_pad, fe_st, m);
