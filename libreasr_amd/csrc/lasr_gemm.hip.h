@@ -393,6 +393,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
             LASR_TRY(5, 4)       // K = 1280 / 1024  (encoder layer 0)
             LASR_TRY(6, 6)       // K = 1536 / 1536
             LASR_TRY(5, 6)       // K = 1280 / 1536
+            LASR_TRY(12, 12)     // K = 1536 / 1536 on 4 waves (the wide decode tilings of configs[4])
+            LASR_TRY(8, 8)       // K = 1024 / 1024 on 4 waves
         } else {
             LASR_TRY(4, 4)       // (16-wave K split)
             LASR_TRY(5, 4)
