@@ -20,7 +20,7 @@ template <class T> static T* up(const std::vector<T>& v) { T* d = nullptr; if (h
 static unsigned rng_state = 12345u;
 static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xffff) / 65536.0f - 0.5f; }
 
-template <int D>
+template <int D, class OPS = OpsBF16>
 static int run(int launches, int lds_pad, int per) {
     const int M = 128, NM = 128, NFFT = 1024, HOP = 160, WIN = 400, CHUNK = 1280, NW_ = 3, NB = 2, NR = NW_ + NB - 1;
     // ---- the victim's constants: Hann window, twiddles, a triangular filterbank (any valid sparse filterbank will do)
@@ -50,7 +50,7 @@ static int run(int launches, int lds_pad, int per) {
     for (int r = 0; r < 512; ++r) { m.idx[r] = -1; m.tp_pk[r] = 0; m.age_pk[r] = 0; }
     for (int r = 0; r < M; ++r) { m.tp_pk[r] = (unsigned char)(((r % NR) << 4) | NB); m.age_pk[r] = (unsigned short)((NB - 1) | (0 << 4)); }
     // ---- the neighbour's operands: random bf16 bit patterns with small exponents
-    const int K = 1536, V = 2048, ROWS = 1024, KC = K / 32;
+    const int K = 1536, V = 2048, ROWS = 1024, KC = K / OPS::KCH;       // (f32 operands: the same bytes read as floats, 16-k chunks)
     std::vector<unsigned short> a((size_t)KC * (ROWS / 16) * 64 * 8), w((size_t)(V / 64) * 4 * KC * 64 * 8);
     for (auto& x : a) x = (unsigned short)(0x3c00 + (int)(frand() * 512.f) + (frand() > 0 ? 0x8000 : 0));
     for (auto& x : w) x = (unsigned short)(0x3c00 + (int)(frand() * 512.f) + (frand() > 0 ? 0x8000 : 0));
@@ -66,7 +66,7 @@ static int run(int launches, int lds_pad, int per) {
     unsigned* log = nullptr; CHECK(hipMalloc((void**)&log, sizeof(unsigned) * (size_t)(launches + 1) * M));
     RowSumArgs ra{}; ra.s[0] = RowSumSrc{pend, 2, 0, 0, NB * 10 * NM};
     for (int i = 0; i <= launches; ++i) {
-        if (i > 0) for (int q = 0; q < per; ++q) hipLaunchKernelGGL((k_gemm<OpsBF16, EpiLinearT<4>, 4, 4, false, D>), dim3(V / 64, ROWS / 64), dim3(256), 0, sb, g, e);
+        if (i > 0) for (int q = 0; q < per; ++q) hipLaunchKernelGGL((k_gemm<OPS, EpiLinearT<4>, 4, 4, false, D>), dim3(V / 64, ROWS / 64), dim3(256), 0, sb, g, e);
         hipLaunchKernelGGL((k_fe_mel<10>), dim3(2 * NB, M), dim3(320), lds_pad, sa, m);
         hipLaunchKernelGGL(k_dbg_rowsum, dim3(M, 1), dim3(256), 0, sa, ra, M, 1, log + (size_t)i * M);
         if (i == 0) CHECK(hipStreamSynchronize(sa));
@@ -77,13 +77,15 @@ static int run(int launches, int lds_pad, int per) {
     int bad_l = 0, bad_r = 0; unsigned any = 0;
     for (int r = 0; r < M; ++r) any |= h[r];
     for (int i = 1; i <= launches; ++i) { int nb = 0; for (int r = 0; r < M; ++r) nb += h[(size_t)i * M + r] != h[r]; bad_r += nb; bad_l += nb != 0; }
-    printf("operand ring depth %2d, victim LDS pad %6d B, %d neighbour launches per victim launch: %d of %d log-mel launches differ from the first (%d rows)%s\n",
-           D, lds_pad, per, bad_l, launches, bad_r, any ? "" : "  [reference output is all zero?]");
+    printf("%s operands, operand ring depth %2d, victim LDS pad %6d B, %d neighbour launches per victim launch: %d of %d log-mel launches differ from the first (%d rows)%s\n",
+           OPS::BF ? "bf16" : "f32 ", D, lds_pad, per, bad_l, launches, bad_r, any ? "" : "  [reference output is all zero?]");
     return 0;
 }
 int main(int argc, char** argv) {
     const int launches = argc > 1 ? atoi(argv[1]) : 1000, pad = argc > 2 ? atoi(argv[2]) : 0, per = argc > 3 ? atoi(argv[3]) : 4;
     if (run<-1>(launches, pad, per)) return 1;          // the ring depth the engine uses (3 for this shape)
     if (run<2>(launches, pad, per)) return 1;           // a shallower ring: the neighbour that disturbs most
+    if (run<-1, OpsF32>(launches, pad, per)) return 1;  // the same tiling on v_mfma_f32_16x16x4_f32
+    if (run<2, OpsF32>(launches, pad, per)) return 1;
     return 0;
 }
