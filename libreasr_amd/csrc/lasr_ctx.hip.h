@@ -92,7 +92,9 @@ struct lasr_ctx {
     // operands, beam search over >= 512 rows) a few waves of the log-mel kernel per thousand returned wrong spectra -- one 16-lane
     // LDS read pass each, no shared data, cause not understood -- and configs[4] was not reproducible run to run; with the CU to
     // themselves: never (profiles/r06/r06_experiments.txt R; detectors: lasr_debug_enclog, lasr_debug_fe_race, tests/test_gpu_race.py).
-    // 0 where no such kernel can run (configs[1]); LASR_FE_LDS_PAD overrides (bytes).
+    // 0 where no such kernel can run (configs[1]); LASR_FE_LDS_PAD overrides (bytes).  Since the same round the wide tilings run on
+    // the older matrix instruction (OpsBF16k16: the neighbour that disturbed was v_mfma_f32_16x16x32_bf16 at their density, and only
+    // it), after which the probe and the race log are clean WITHOUT the pad as well: the pad is the second line of defence.
     int fe_lds_pad = 0, logmel_lds_pad = 0;       // (k_fe_mel / the per-chunk k_logmel: 98 304 B minus the kernel's own LDS)
     unsigned* enclog = nullptr;     // LASR_DBG_ENCLOG=N: per model step and row, exact checksums (sum of the element bit patterns) of the
     float* pendlog = nullptr;       // LASR_DBG_PENDLOG=1 (with LASR_DBG_ENCLOG): a copy of the pending log-mel frames per logged step

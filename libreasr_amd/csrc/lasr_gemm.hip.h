@@ -72,6 +72,24 @@ struct OpsBF16 {
     __device__ static __forceinline__ float ld(const void* p, size_t i) { return bf16_to_f32(((const unsigned short*)p)[i]); }
     __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((unsigned short*)p)[i] = f32_to_bf16(v); }
 };
+// The same bf16 operands through the OLDER matrix instruction: two v_mfma_f32_16x16x16_bf16 per fragment pair (elements 0-3 and 4-7 of
+// both fragments: the k pairing of A and B is the same, only the summation is split in two).  Used by the WIDE decode tilings (64 x 64
+// outputs per workgroup: 16 MFMAs per 8 fragment loads): beside a workgroup that streams operands into v_mfma_f32_16x16x32_bf16 at
+// that density, waves of OTHER kernels on the same CU computed wrong results (round 6, R: DESIGN 5a); with this instruction in the
+// same kernel: never (tools/r06/fe_mfma_repro.hip: 0 of 1 000 against 37 / 619).  These kernels wait for L2, not for the matrix pipe.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct OpsBF16k16 : OpsBF16 {
+    __device__ static __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) {
+        const s16x8 a8 = __builtin_bit_cast(s16x8, a), b8 = __builtin_bit_cast(s16x8, b);
+        const s16x4 a0 = {a8[0], a8[1], a8[2], a8[3]}, a1 = {a8[4], a8[5], a8[6], a8[7]};
+        const s16x4 b0 = {b8[0], b8[1], b8[2], b8[3]}, b1 = {b8[4], b8[5], b8[6], b8[7]};
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, b1, acc, 0, 0, 0);
+    }
+};
+template <class Ops> struct WideOps { typedef Ops type; };
+template <> struct WideOps<OpsBF16> { typedef OpsBF16k16 type; };
+
 // runtime-typed access for the small kernels (is_bf16 flag)
 __device__ __forceinline__ size_t act_off(int bf, int r, int k, int mt_total) {
     return bf ? OpsBF16::aoff(r, k, mt_total) : OpsF32::aoff(r, k, mt_total);

@@ -78,12 +78,22 @@ void launch_logits_ops(lasr_ctx* c, float* out, int n_rows, bool gated) {
         EpiLinearT<4>::Args e4{};
         static_assert(sizeof(e4) == sizeof(ea), "same Args layout");
         memcpy((void*)&e4, (const void*)&ea, sizeof(e4));
-        launch_gemm<Ops, EpiLinearT<4>, 4, false, -1, 4>(c, V / 64, (n_rows + 63) / 64, g4, e4);
+        launch_gemm<typename WideOps<Ops>::type, EpiLinearT<4>, 4, false, -1, 4>(c, V / 64, (n_rows + 63) / 64, g4, e4);
         return;
     }
     if (c->logits_mt == 4 || (c->logits_mt == 2 && n_rows >= 512)) { launch_logits_t<Ops, 4>(c, g, n_rows, J, ea); return; }
     if (c->logits_mt == 2) { launch_logits_t<Ops, 2>(c, g, n_rows, J, ea); return; }
     launch_linear_ops<Ops, false, -1>(c, V / 16, (n_rows + 15) / 16, g, J, ea);
+}
+
+// launch of a wide tiling through its own operand type (WideOps): the epilogue's Args are the same struct under another template
+// argument -- copied bit for bit
+template <class OW, class Epi, class ArgsIn>
+static void launch_wide(lasr_ctx* c, int n_groups, int m_groups, const GemmArgs& g, const ArgsIn& ea_in) {
+    typename Epi::Args ea;
+    static_assert(sizeof(ea) == sizeof(ea_in), "same Args layout");
+    memcpy((void*)&ea, (const void*)&ea_in, sizeof(ea));
+    launch_gemm<OW, Epi, MTA, true, -1, 4>(c, n_groups, m_groups, g, ea);
 }
 
 // one predictor pass (all layers) for rows with emit != 0 (compacted inside the kernels); predictor
@@ -98,6 +108,7 @@ void launch_predictor_t(lasr_ctx* c, bool beam, int l0, int l1) {
     // many decoder rows (beam 8 x 64+ streams, >= 512 streams): 16-unit workgroups, a quarter of the activation traffic
     // (configs[4], 1024 rows: predictor cells 135 -> ~50 us, whole job +60 %; at 256 rows: bf16 equal, f32 -22 %; at 64: -20 %)
     const bool wide = c->Md >= 512;
+    using OW = typename WideOps<Ops>::type;            // the wide tilings' matrix instruction (see OpsBF16k16)
     const bool wide8 = c->bf && c->Md >= 256 && c->Md < 512;   // 8 units per workgroup, 8 waves (configs[2]: 6.4 -> 7.2 k in round 2)
     const bool split_carry = beam && beam_carry_on();
     if (split_carry && beam_carry_mode() == 1 && l0 == 0) {      // the slots that are not extended: whole-row copies by their own launch (see k_beam_carry)
@@ -129,14 +140,14 @@ void launch_predictor_t(lasr_ctx* c, bool beam, int l0, int l1) {
             ea.no_carry = split_carry ? 1 : 0;
             if (l == 0) {
                 if (wide8) launch_gemm<Ops, EpiLSTMw<Ops, true, 2>, MTA, true, -1>(c, H / 8, mgroups, g, ea);
-                else if (wide) launch_gemm<Ops, EpiLSTMw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
+                else if (wide) launch_wide<OW, EpiLSTMw<OW, true>>(c, H / 16, mgroups, g, ea);
                 else launch_gemm<Ops, EpiLSTM<Ops, true, true, 4>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 typename EpiLSTM<Ops, true, false, 4>::Args eb{};
                 static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
                 if (wide8) launch_gemm<Ops, EpiLSTMw<Ops, false, 2>, MTA, true, -1>(c, H / 8, mgroups, g, eb);
-                else if (wide) launch_gemm<Ops, EpiLSTMw<Ops, false>, MTA, true, -1, 4>(c, H / 16, mgroups, g, eb);
+                else if (wide) launch_wide<OW, EpiLSTMw<OW, false>>(c, H / 16, mgroups, g, eb);
                 else launch_gemm<Ops, EpiLSTM<Ops, true, false, 4>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         } else {
@@ -148,14 +159,14 @@ void launch_predictor_t(lasr_ctx* c, bool beam, int l0, int l1) {
             ea.no_carry = split_carry ? 1 : 0;
             if (l == 0) {
                 if (wide8) launch_gemm<Ops, EpiNBRCw<Ops, true, 2>, MTA, true, -1>(c, H / 8, mgroups, g, ea);
-                else if (wide) launch_gemm<Ops, EpiNBRCw<Ops, true>, MTA, true, -1, 4>(c, H / 16, mgroups, g, ea);
+                else if (wide) launch_wide<OW, EpiNBRCw<OW, true>>(c, H / 16, mgroups, g, ea);
                 else launch_gemm<Ops, EpiNBRC<Ops, true>, MTA, true, -1>(c, H / 4, mgroups, g, ea);
             } else {
                 typename EpiNBRC<Ops, false>::Args eb{};
                 static_assert(sizeof(eb) == sizeof(ea), "same Args layout");
                 memcpy(&eb, &ea, sizeof(eb));
                 if (wide8) launch_gemm<Ops, EpiNBRCw<Ops, false, 2>, MTA, true, -1>(c, H / 8, mgroups, g, eb);
-                else if (wide) launch_gemm<Ops, EpiNBRCw<Ops, false>, MTA, true, -1, 4>(c, H / 16, mgroups, g, eb);
+                else if (wide) launch_wide<OW, EpiNBRCw<OW, false>>(c, H / 16, mgroups, g, eb);
                 else launch_gemm<Ops, EpiNBRC<Ops, false>, MTA, true, -1>(c, H / 4, mgroups, g, eb);
             }
         }

@@ -110,6 +110,26 @@ def test_log_mel_kernel_beside_each_decode_kernel():
         eng.close()
 
 
+def test_wide_tilings_do_not_disturb_even_without_the_lds_pad():
+    """First line of defence: the wide decode tilings run on v_mfma_f32_16x16x16_bf16 (OpsBF16k16), not on the 16x16x32 form that
+    disturbed its CU neighbours -- the probe is clean with lds_pad = 0 as well (27-37 of 1 000 launches wrong before)."""
+    eng, cfg = _engine("cfg5", 8, 128, "bf16")
+    try:
+        B = 128
+        slots = [eng.open() for _ in range(B)]
+        pcm = np.stack([synth.synth_pcm(1, 8 * 1280, seed=1234 + s)[0] for s in range(B)])
+        for k in range(8):
+            eng.push(slots, pcm[:, k * 1280:(k + 1) * 1280])
+            if eng.step(slots):
+                eng.fetch_many(slots, 8192)
+        for agg, nm in ((1, "vocabulary GEMM"), (2, "predictor pass")):
+            bl, br = eng.debug_fe_race(500, agg, 4, lds_pad=0)
+            print(f"no pad, beside {nm}: {bl} of 500 launches differ ({br} rows)")
+            assert (bl, br) == (0, 0)
+    finally:
+        eng.close()
+
+
 def test_configs1_context_keeps_the_plain_launch():
     eng, cfg = _engine("cfg2", 1, 64, "f32")
     try:

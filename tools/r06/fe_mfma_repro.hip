@@ -15,6 +15,17 @@
 #include <vector>
 using namespace lasr;
 
+// the same bf16 operands through the OLDER matrix instruction (two v_mfma_f32_16x16x16_bf16 per 32-k fragment pair)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct OpsBF16k16 : OpsBF16 {
+    __device__ static __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) {
+        const s16x8 a8 = __builtin_bit_cast(s16x8, a), b8 = __builtin_bit_cast(s16x8, b);
+        const s16x4 a0 = {a8[0], a8[1], a8[2], a8[3]}, a1 = {a8[4], a8[5], a8[6], a8[7]};
+        const s16x4 b0 = {b8[0], b8[1], b8[2], b8[3]}, b1 = {b8[4], b8[5], b8[6], b8[7]};
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, b1, acc, 0, 0, 0);
+    }
+};
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 template <class T> static T* up(const std::vector<T>& v) { T* d = nullptr; if (hipMalloc((void**)&d, v.size() * sizeof(T)) != hipSuccess) return nullptr; (void)hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return d; }
 static unsigned rng_state = 12345u;
@@ -87,5 +98,7 @@ int main(int argc, char** argv) {
     if (run<2>(launches, pad, per)) return 1;           // a shallower ring: the neighbour that disturbs most
     if (run<-1, OpsF32>(launches, pad, per)) return 1;  // the same tiling on v_mfma_f32_16x16x4_f32
     if (run<2, OpsF32>(launches, pad, per)) return 1;
+    if (run<-1, OpsBF16k16>(launches, pad, per)) return 1;   // bf16 operands through v_mfma_f32_16x16x16_bf16 (two per fragment pair)
+    if (run<2, OpsBF16k16>(launches, pad, per)) return 1;
     return 0;
 }
