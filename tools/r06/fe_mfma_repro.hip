@@ -15,15 +15,12 @@
 #include <vector>
 using namespace lasr;
 
-// the same bf16 operands through the OLDER matrix instruction (two v_mfma_f32_16x16x16_bf16 per 32-k fragment pair)
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-struct OpsBF16k16 : OpsBF16 {
+// (the older bf16 instruction: OpsBF16k16 of lasr_gemm.hip.h -- two v_mfma_f32_16x16x16_bf16 per fragment pair)
+// the same bits as f16 operands through the other double-rate form of gfx950: v_mfma_f32_16x16x32_f16
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct OpsF16x32 : OpsBF16 {
     __device__ static __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) {
-        const s16x8 a8 = __builtin_bit_cast(s16x8, a), b8 = __builtin_bit_cast(s16x8, b);
-        const s16x4 a0 = {a8[0], a8[1], a8[2], a8[3]}, a1 = {a8[4], a8[5], a8[6], a8[7]};
-        const s16x4 b0 = {b8[0], b8[1], b8[2], b8[3]}, b1 = {b8[4], b8[5], b8[6], b8[7]};
-        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
     }
 };
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -89,7 +86,7 @@ static int run(int launches, int lds_pad, int per) {
     for (int r = 0; r < M; ++r) any |= h[r];
     for (int i = 1; i <= launches; ++i) { int nb = 0; for (int r = 0; r < M; ++r) nb += h[(size_t)i * M + r] != h[r]; bad_r += nb; bad_l += nb != 0; }
     printf("%s operands, operand ring depth %2d, victim LDS pad %6d B, %d neighbour launches per victim launch: %d of %d log-mel launches differ from the first (%d rows)%s\n",
-           OPS::BF ? "bf16" : "f32 ", D, lds_pad, per, bad_l, launches, bad_r, any ? "" : "  [reference output is all zero?]");
+           std::is_same<OPS, OpsF32>::value ? "f32" : std::is_same<OPS, OpsBF16>::value ? "bf16 16x16x32" : std::is_same<OPS, OpsBF16k16>::value ? "bf16 2 x 16x16x16" : "f16 16x16x32", D, lds_pad, per, bad_l, launches, bad_r, any ? "" : "  [reference output is all zero?]");
     return 0;
 }
 int main(int argc, char** argv) {
@@ -100,5 +97,7 @@ int main(int argc, char** argv) {
     if (run<2, OpsF32>(launches, pad, per)) return 1;
     if (run<-1, OpsBF16k16>(launches, pad, per)) return 1;   // bf16 operands through v_mfma_f32_16x16x16_bf16 (two per fragment pair)
     if (run<2, OpsBF16k16>(launches, pad, per)) return 1;
+    if (run<-1, OpsF16x32>(launches, pad, per)) return 1;    // the same bits as f16 through v_mfma_f32_16x16x32_f16
+    if (run<2, OpsF16x32>(launches, pad, per)) return 1;
     return 0;
 }
